@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — audio samples/sec of the fused Sequencer->Jitter->Synthesize HIP path.
+
+Metric (BASELINE.json): audio samples/sec (whole node) at 48 kHz, batch = 65536
+utterances x 2 s (4 segments x 0.5 s, single Voice) per GPU; a "step" is one pass of
+the hot path over one batch whose inputs are already resident in HBM; output stays
+in HBM (f32, 25.2 GB per GPU).  Weak scaling: every rank renders its own 65536-utterance
+shard of the N*65536 corpus (BASELINE config 5 at N=8), no data-path collective; the
+voice table is broadcast once with RCCL before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--utts U] [--voices V]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "grail-rs_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ALG_BYTES_PER_SAMPLE = 4.01      # 4 B f32 written + <=0.01 B of segment/voice input
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz
+
+
+def cpu_baseline(n_cpu, voices, W):
+    """The oracle (a port of the reference's single-threaded CPU path) timed on this host,
+    on the first n_cpu utterances of the same synthetic corpus."""
+    import oracle_lib as O
+    ov = [O.Voice.from_buffer_copy(bytes(v)) for v in voices]
+    segs, offs, vids, seeds = W.make_batch(n_cpu, n_voices=len(voices))
+    stride = W.max_samples()
+    O.synthesize_batch(ov, segs[:8], offs[:3], vids[:2], seeds[:2], stride)  # warm
+    t0 = time.perf_counter()
+    _, out_len = O.synthesize_batch(ov, segs, offs, vids, seeds, stride)
+    dt = time.perf_counter() - t0
+    n = int(out_len.astype(np.uint64).sum())
+    return {
+        "value": n / dt, "unit": "samples/s", "cores": 1, "kind": "port",
+        "sample": f"first {n_cpu} utterances of the same corpus ({n} samples, {dt:.1f} s, "
+                  f"oracle/liboracle.so, 1 thread; host has {os.cpu_count()} logical cores)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--utts", type=int, default=65536, help="utterances per GPU")
+    ap.add_argument("--voices", type=int, default=1, help="1 = single Voice, 8 = config-4 presets")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per utterance (0 = auto)")
+    ap.add_argument("--cpu-utts", type=int, default=512, help="utterances for the CPU baseline (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world != 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    distributed = world > 1
+
+    import __graft_entry__ as ge
+    if local_rank == 0:
+        ge.build()
+    import grail_hip as G
+    from grail_hip import workload as W
+
+    dist = None
+    if distributed:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+        G.load()
+
+    ctx = G.Context(local_rank)
+    n_utt = args.utts
+    stride = W.max_samples()
+
+    # ---- voice table: rank 0 builds it, RCCL broadcasts it over xGMI ----------
+    voice_path = "local"
+    if rank == 0:
+        voices = W.single_voice() if args.voices <= 1 else W.preset_voices(args.voices)
+        ctx.set_voices(voices)
+    if distributed:
+        ids = [G.Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.comm_init(ids[0], rank, world)
+        ctx.broadcast_voices(max(args.voices, 1), root=0)   # ncclBroadcast inside the C ABI
+        voices = ctx.get_voices()
+        voice_path = "rccl ncclBroadcast"
+
+    # ---- this rank's shard of the corpus, resident in HBM ---------------------
+    first, last = G.shard_range(n_utt * world, rank, world)
+    segs, offs, vids, seeds = W.make_batch(last - first, first_utt=first, n_voices=len(voices))
+    batch = ctx.upload(segs, offs, vids, seeds)
+    ctx.set_option("lanes_per_utterance", args.lanes)
+    d_out = ctx.device_alloc(n_utt * stride * 4)
+    d_len = ctx.device_alloc(n_utt * 4)
+
+    def step():
+        batch.synthesize_async(d_out, stride, d_len)
+        ctx.sync()
+        return ctx.last_kernel_ms()
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        ctx.sync()
+        if distributed:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = [step() for _ in range(args.steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    out_len = np.zeros(n_utt, dtype=np.uint32)
+    ctx.d2h(out_len, d_len, n_utt * 4)
+    samples_per_step = int(out_len.astype(np.uint64).sum())
+
+    if distributed:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        s = torch.tensor([samples_per_step], dtype=torch.float64, device="cuda")
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        total_samples_per_step = float(s.item())
+    else:
+        total_samples_per_step = float(samples_per_step)
+
+    lanes_used = args.lanes
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = total_samples_per_step * args.steps / elapsed
+        k_ms = float(np.mean(kernel_ms))
+        achieved = samples_per_step * ALG_BYTES_PER_SAMPLE / (k_ms * 1e-3) / 1e9
+        line = {
+            "metric": "audio samples/sec (whole node) at 48 kHz, batch=65536 utterances",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"batch={n_utt} utterances x 2 s (4 segments x 0.5 s) per GPU, "
+                            f"{len(voices)} Voice preset(s), 48 kHz, f32 PCM left in HBM "
+                            f"(BASELINE config {'3' if len(voices) == 1 else '4'}"
+                            f"{'; config 5 sharding' if world > 1 else ''})",
+                "utterances_per_gpu": n_utt, "samples_per_utterance": int(out_len[0]),
+                "out_stride": stride, "lanes_per_utterance": lanes_used or "auto",
+                "voice_table": voice_path, "parity": "bit-exact vs oracle (tests/test_parity_gpu.py)",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "synth_kernel", "kernel_ms": k_ms,
+                "note": "HBM is the nominal bound (4.01 B/sample); the binding limit is VALU issue "
+                        "(~1.2e3 non-fusable f32 lane-ops/sample), see DESIGN.md",
+            },
+        }
+        if not distributed and args.cpu_utts > 0:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_utts, voices, W)
+            line["speedup_vs_cpu_1thread"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+
+    ctx.device_free(d_out)
+    ctx.device_free(d_len)
+    batch.free()
+    ctx.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,679 @@
+// grail_api.cpp — the C ABI (include/grail_hip.h) over the HIP kernels.
+// Host orchestration only: contexts, HBM-resident batches, launches, RCCL
+// broadcast of the voice table.  No arithmetic of the hot path happens here and
+// there is no CPU fallback: without a HIP device every compute call fails.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/grail_hip.h"
+#include "kernels.h"
+
+using namespace grail;
+
+static_assert(sizeof(grail_synthesis_elem) == 196, "SynthesisElem is 49 x f32");
+static_assert(sizeof(grail_phoneme_elem) == sizeof(DevSeg), "PhonemeElem uploads as-is");
+static_assert(offsetof(grail_phoneme_elem, phoneme) == offsetof(DevSeg, elem), "layout");
+static_assert(offsetof(grail_phoneme_elem, frequency) == offsetof(DevSeg, frequency), "layout");
+static_assert(sizeof(grail_voice) == 4 + 2 * 196 + 5 * 4, "Voice layout");
+static_assert(GRAIL_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int status, const std::string &msg)
+{
+    g_last_error = msg;
+    return status;
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    if (e == hipErrorOutOfMemory)
+        return fail(GRAIL_ERR_OUT_OF_MEMORY, std::string(what) + ": " + hipGetErrorString(e));
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice)
+        return fail(GRAIL_ERR_NO_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+    return fail(GRAIL_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t e_ = (expr);                        \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
+    } while (0)
+
+// RCCL is loaded on first use so the library loads (and its symbols can be
+// checked) on hosts without a GPU stack that can initialise RCCL.
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t,
+                              hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+Rccl &rccl()
+{
+    static Rccl r = [] {
+        Rccl x;
+        x.handle = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!x.handle) x.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!x.handle) return x;
+        x.GetUniqueId = (decltype(x.GetUniqueId))dlsym(x.handle, "ncclGetUniqueId");
+        x.CommInitRank = (decltype(x.CommInitRank))dlsym(x.handle, "ncclCommInitRank");
+        x.Broadcast = (decltype(x.Broadcast))dlsym(x.handle, "ncclBroadcast");
+        x.CommDestroy = (decltype(x.CommDestroy))dlsym(x.handle, "ncclCommDestroy");
+        x.GetErrorString = (decltype(x.GetErrorString))dlsym(x.handle, "ncclGetErrorString");
+        x.ok = x.GetUniqueId && x.CommInitRank && x.Broadcast && x.CommDestroy;
+        return x;
+    }();
+    return r;
+}
+
+int rccl_fail(ncclResult_t r, const char *what)
+{
+    const char *s = rccl().GetErrorString ? rccl().GetErrorString(r) : "?";
+    return fail(GRAIL_ERR_RCCL, std::string(what) + ": " + s);
+}
+
+}  // namespace
+
+struct grail_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool have_timing = false;
+    std::vector<grail_voice> voices;  // host copy of the table
+    DevVoice *d_voices = nullptr;
+    float *d_voice_elems = nullptr;   // [n_voices * NUM_VOICED][49]
+    uint32_t *d_truncated = nullptr;  // one word
+    int lanes_option = 0;             // 0 = auto
+    ncclComm_t comm = nullptr;
+    uint32_t comm_rank = 0, comm_world = 1;
+};
+
+struct grail_batch {
+    DevSeg *d_segs = nullptr;
+    uint32_t *d_offsets = nullptr;
+    uint32_t *d_voice_ids = nullptr;
+    uint32_t *d_seeds = nullptr;
+    float *d_elems = nullptr;  // elem mode only
+    uint32_t n_utt = 0;
+    uint32_t n_segs = 0;
+    uint32_t max_voice_id = 0;
+    bool phoneme_mode = true;
+};
+
+namespace {
+
+int bind(grail_ctx *ctx)
+{
+    if (!ctx) return fail(GRAIL_ERR_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return GRAIL_OK;
+}
+
+template <typename Tp>
+int upload(Tp **dst, const void *src, size_t count, hipStream_t stream)
+{
+    *dst = nullptr;
+    if (count == 0) count = 1;
+    HIP_TRY(hipMalloc((void **)dst, count * sizeof(Tp)));
+    if (src) HIP_TRY(hipMemcpyAsync(*dst, src, count * sizeof(Tp), hipMemcpyHostToDevice, stream));
+    return GRAIL_OK;
+}
+
+void free_batch_buffers(grail_batch *b)
+{
+    if (b->d_segs) (void)hipFree(b->d_segs);
+    if (b->d_offsets) (void)hipFree(b->d_offsets);
+    if (b->d_voice_ids) (void)hipFree(b->d_voice_ids);
+    if (b->d_seeds) (void)hipFree(b->d_seeds);
+    if (b->d_elems) (void)hipFree(b->d_elems);
+}
+
+int check_offsets(const uint32_t *seg_offsets, uint32_t n_utt, uint32_t *n_segs)
+{
+    if (!seg_offsets) return fail(GRAIL_ERR_INVALID_ARG, "seg_offsets is NULL");
+    for (uint32_t u = 0; u < n_utt; ++u)
+        if (seg_offsets[u + 1] < seg_offsets[u])
+            return fail(GRAIL_ERR_INVALID_ARG, "seg_offsets must be non-decreasing");
+    *n_segs = seg_offsets[n_utt];
+    return GRAIL_OK;
+}
+
+int upload_common(grail_ctx *ctx, grail_batch *b, const uint32_t *seg_offsets,
+                  const uint32_t *voice_ids, const uint32_t *jitter_seeds, uint32_t n_utt)
+{
+    int rc;
+    if ((rc = upload(&b->d_offsets, seg_offsets, (size_t)n_utt + 1, ctx->stream))) return rc;
+    b->max_voice_id = 0;
+    if (voice_ids) {
+        for (uint32_t u = 0; u < n_utt; ++u)
+            if (voice_ids[u] > b->max_voice_id) b->max_voice_id = voice_ids[u];
+        if ((rc = upload(&b->d_voice_ids, voice_ids, n_utt, ctx->stream))) return rc;
+    }
+    if (jitter_seeds)
+        if ((rc = upload(&b->d_seeds, jitter_seeds, n_utt, ctx->stream))) return rc;
+    b->n_utt = n_utt;
+    // host buffers may be freed by the caller right after we return
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GRAIL_OK;
+}
+
+int install_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices)
+{
+    if (!voices || n_voices == 0) return fail(GRAIL_ERR_INVALID_ARG, "no voices given");
+    std::vector<DevVoice> dv(n_voices);
+    std::vector<float> elems((size_t)n_voices * NUM_VOICED * ELEM_FLOATS);
+    for (uint32_t v = 0; v < n_voices; ++v) {
+        dv[v].sample_rate = voices[v].sample_rate;
+        dv[v].jitter_frequency = voices[v].jitter_frequency;
+        dv[v].jitter_delta_frequency = voices[v].jitter_delta_frequency;
+        dv[v].jitter_delta_formant_frequency = voices[v].jitter_delta_formant_frequency;
+        dv[v].jitter_delta_amplitude = voices[v].jitter_delta_amplitude;
+        dv[v].elem_base = v * NUM_VOICED;
+        dv[v].pad[0] = dv[v].pad[1] = 0;
+        std::memcpy(&elems[(size_t)v * NUM_VOICED * ELEM_FLOATS], voices[v].phonemes,
+                    sizeof(grail_synthesis_elem) * NUM_VOICED);
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // kernels may still read the old table
+    if (ctx->d_voices) (void)hipFree(ctx->d_voices);
+    if (ctx->d_voice_elems) (void)hipFree(ctx->d_voice_elems);
+    ctx->d_voices = nullptr;
+    ctx->d_voice_elems = nullptr;
+    HIP_TRY(hipMalloc((void **)&ctx->d_voices, dv.size() * sizeof(DevVoice)));
+    HIP_TRY(hipMalloc((void **)&ctx->d_voice_elems, elems.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(ctx->d_voices, dv.data(), dv.size() * sizeof(DevVoice), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_voice_elems, elems.data(), elems.size() * sizeof(float),
+                      hipMemcpyHostToDevice));
+    ctx->voices.assign(voices, voices + n_voices);
+    return GRAIL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int grail_abi_version(void) { return GRAIL_ABI_VERSION; }
+
+const char *grail_status_string(int status)
+{
+    switch (status) {
+    case GRAIL_OK: return "ok";
+    case GRAIL_ERR_INVALID_ARG: return "invalid argument";
+    case GRAIL_ERR_NO_DEVICE: return "no usable HIP device (there is no CPU fallback)";
+    case GRAIL_ERR_HIP: return "HIP runtime error";
+    case GRAIL_ERR_BUFFER_TOO_SMALL: return "an utterance did not end within out_stride samples";
+    case GRAIL_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case GRAIL_ERR_RCCL: return "RCCL error";
+    case GRAIL_ERR_NO_VOICES: return "no voice table set";
+    default: return "unknown status";
+    }
+}
+
+const char *grail_last_error(void) { return g_last_error.c_str(); }
+
+int grail_device_count(int *count)
+{
+    if (!count) return fail(GRAIL_ERR_INVALID_ARG, "count is NULL");
+    *count = 0;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDeviceCount");
+    *count = n;
+    return GRAIL_OK;
+}
+
+int grail_create(int device, grail_ctx **out)
+{
+    if (!out) return fail(GRAIL_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(GRAIL_ERR_NO_DEVICE,
+                    std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count 0"));
+    if (device < 0 || device >= n) return fail(GRAIL_ERR_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    grail_ctx *ctx = new (std::nothrow) grail_ctx();
+    if (!ctx) return fail(GRAIL_ERR_OUT_OF_MEMORY, "host allocation failed");
+    ctx->device = device;
+    hipError_t err;
+    if ((err = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (err = hipEventCreate(&ctx->ev_start)) != hipSuccess ||
+        (err = hipEventCreate(&ctx->ev_stop)) != hipSuccess ||
+        (err = hipMalloc((void **)&ctx->d_truncated, sizeof(uint32_t))) != hipSuccess ||
+        (err = hipMemset(ctx->d_truncated, 0, sizeof(uint32_t))) != hipSuccess) {
+        grail_destroy(ctx);
+        return hip_fail(err, "grail_create");
+    }
+    *out = ctx;
+    return GRAIL_OK;
+}
+
+int grail_destroy(grail_ctx *ctx)
+{
+    if (!ctx) return GRAIL_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm && rccl().ok) rccl().CommDestroy(ctx->comm);
+    if (ctx->d_voices) (void)hipFree(ctx->d_voices);
+    if (ctx->d_voice_elems) (void)hipFree(ctx->d_voice_elems);
+    if (ctx->d_truncated) (void)hipFree(ctx->d_truncated);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return GRAIL_OK;
+}
+
+int grail_set_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    return install_voices(ctx, voices, n_voices);
+}
+
+int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t *n_voices)
+{
+    if (!ctx) return fail(GRAIL_ERR_INVALID_ARG, "ctx is NULL");
+    if (n_voices) *n_voices = (uint32_t)ctx->voices.size();
+    if (voices)
+        for (uint32_t i = 0; i < cap && i < ctx->voices.size(); ++i) voices[i] = ctx->voices[i];
+    return GRAIL_OK;
+}
+
+int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
+{
+    if (!ctx || !name) return fail(GRAIL_ERR_INVALID_ARG, "NULL argument");
+    if (std::strcmp(name, "lanes_per_utterance") == 0) {
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
+            return fail(GRAIL_ERR_INVALID_ARG, "lanes_per_utterance must be 0, 1, 2, 4 or 8");
+        ctx->lanes_option = (int)value;
+        return GRAIL_OK;
+    }
+    return fail(GRAIL_ERR_INVALID_ARG, std::string("unknown option ") + name);
+}
+
+int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
+{
+    if (!ctx || !name || !value) return fail(GRAIL_ERR_INVALID_ARG, "NULL argument");
+    if (std::strcmp(name, "lanes_per_utterance") == 0) {
+        *value = ctx->lanes_option;
+        return GRAIL_OK;
+    }
+    return fail(GRAIL_ERR_INVALID_ARG, std::string("unknown option ") + name);
+}
+
+int grail_batch_upload(grail_ctx *ctx, const grail_phoneme_elem *segs, const uint32_t *seg_offsets,
+                       const uint32_t *voice_ids, const uint32_t *jitter_seeds, uint32_t n_utt,
+                       grail_batch **out)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!out) return fail(GRAIL_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    uint32_t n_segs = 0;
+    if ((rc = check_offsets(seg_offsets, n_utt, &n_segs))) return rc;
+    if (n_segs && !segs) return fail(GRAIL_ERR_INVALID_ARG, "segs is NULL");
+    for (uint32_t i = 0; i < n_segs; ++i)
+        if (segs[i].phoneme < 0 || segs[i].phoneme >= GRAIL_PH_COUNT)
+            return fail(GRAIL_ERR_INVALID_ARG, "phoneme discriminant out of range");
+    grail_batch *b = new (std::nothrow) grail_batch();
+    if (!b) return fail(GRAIL_ERR_OUT_OF_MEMORY, "host allocation failed");
+    b->phoneme_mode = true;
+    b->n_segs = n_segs;
+    if ((rc = upload(&b->d_segs, segs, n_segs, ctx->stream)) ||
+        (rc = upload_common(ctx, b, seg_offsets, voice_ids, jitter_seeds, n_utt))) {
+        free_batch_buffers(b);
+        delete b;
+        return rc;
+    }
+    *out = b;
+    return GRAIL_OK;
+}
+
+int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
+                             const uint32_t *seg_offsets, const uint32_t *voice_ids,
+                             const uint32_t *jitter_seeds, uint32_t n_utt, grail_batch **out)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!out) return fail(GRAIL_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    uint32_t n_segs = 0;
+    if ((rc = check_offsets(seg_offsets, n_utt, &n_segs))) return rc;
+    if (n_segs && !segs) return fail(GRAIL_ERR_INVALID_ARG, "segs is NULL");
+    // Split the SequenceElems into the 16-B segment records and the elem table.
+    std::vector<DevSeg> ds(n_segs);
+    std::vector<float> elems((size_t)(n_segs ? n_segs : 1) * ELEM_FLOATS);
+    for (uint32_t i = 0; i < n_segs; ++i) {
+        ds[i].elem = segs[i].has_elem ? (int32_t)i : -1;
+        ds[i].length = segs[i].length;
+        ds[i].blend_length = segs[i].blend_length;
+        ds[i].frequency = segs[i].elem.frequency;
+        std::memcpy(&elems[(size_t)i * ELEM_FLOATS], &segs[i].elem, sizeof(grail_synthesis_elem));
+    }
+    grail_batch *b = new (std::nothrow) grail_batch();
+    if (!b) return fail(GRAIL_ERR_OUT_OF_MEMORY, "host allocation failed");
+    b->phoneme_mode = false;
+    b->n_segs = n_segs;
+    if ((rc = upload(&b->d_segs, ds.data(), n_segs, ctx->stream)) ||
+        (rc = upload(&b->d_elems, elems.data(), elems.size(), ctx->stream)) ||
+        (rc = upload_common(ctx, b, seg_offsets, voice_ids, jitter_seeds, n_utt))) {
+        free_batch_buffers(b);
+        delete b;
+        return rc;
+    }
+    *out = b;
+    return GRAIL_OK;
+}
+
+int grail_batch_free(grail_ctx *ctx, grail_batch *batch)
+{
+    if (!batch) return GRAIL_OK;
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    free_batch_buffers(batch);
+    delete batch;
+    return GRAIL_OK;
+}
+
+uint32_t grail_batch_size(const grail_batch *batch) { return batch ? batch->n_utt : 0; }
+
+static int check_ready(grail_ctx *ctx, const grail_batch *batch)
+{
+    if (!batch) return fail(GRAIL_ERR_INVALID_ARG, "batch is NULL");
+    if (ctx->voices.empty()) return fail(GRAIL_ERR_NO_VOICES, "call grail_set_voices first");
+    if (batch->max_voice_id >= ctx->voices.size())
+        return fail(GRAIL_ERR_INVALID_ARG, "a voice id exceeds the voice table");
+    return GRAIL_OK;
+}
+
+int grail_batch_lengths(grail_ctx *ctx, const grail_batch *batch, uint32_t max_len,
+                        uint32_t *out_len)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if ((rc = check_ready(ctx, batch))) return rc;
+    if (!out_len && batch->n_utt) return fail(GRAIL_ERR_INVALID_ARG, "out_len is NULL");
+    if (batch->n_utt == 0) return GRAIL_OK;
+    uint32_t *d_len = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_len, (size_t)batch->n_utt * sizeof(uint32_t)));
+    LenArgs a{};
+    a.segs = batch->d_segs;
+    a.seg_offsets = batch->d_offsets;
+    a.voice_ids = batch->d_voice_ids;
+    a.voices = ctx->d_voices;
+    a.out_len = d_len;
+    a.n_utt = batch->n_utt;
+    a.n_voices = (uint32_t)ctx->voices.size();
+    a.max_len = max_len;
+    hipError_t e = launch_lengths(a, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(out_len, d_len, (size_t)batch->n_utt * sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_len);
+    if (e != hipSuccess) return hip_fail(e, "grail_batch_lengths");
+    return GRAIL_OK;
+}
+
+int grail_batch_synthesize_async(grail_ctx *ctx, const grail_batch *batch, float *out_dev,
+                                 uint64_t out_stride, uint32_t *out_len_dev)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if ((rc = check_ready(ctx, batch))) return rc;
+    if (batch->n_utt == 0) return GRAIL_OK;
+    if (!out_dev && out_stride) return fail(GRAIL_ERR_INVALID_ARG, "out_dev is NULL");
+    SynthArgs a{};
+    a.segs = batch->d_segs;
+    a.seg_offsets = batch->d_offsets;
+    a.voice_ids = batch->d_voice_ids;
+    a.seeds = batch->d_seeds;
+    a.elems = batch->phoneme_mode ? ctx->d_voice_elems : batch->d_elems;
+    a.voices = ctx->d_voices;
+    a.out = out_dev;
+    a.out_len = out_len_dev;
+    a.truncated = ctx->d_truncated;
+    a.out_stride = out_stride;
+    a.n_utt = batch->n_utt;
+    a.n_voices = (uint32_t)ctx->voices.size();
+    a.phoneme_mode = batch->phoneme_mode ? 1u : 0u;
+    const int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(batch->n_utt);
+    HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    hipError_t e = launch_synth(a, L, ctx->stream);
+    if (e != hipSuccess) return hip_fail(e, "synth kernel launch");
+    HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    ctx->have_timing = true;
+    return GRAIL_OK;
+}
+
+int grail_sync(grail_ctx *ctx)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    uint32_t flag = 0;
+    HIP_TRY(hipMemcpy(&flag, ctx->d_truncated, sizeof flag, hipMemcpyDeviceToHost));
+    if (flag) {
+        HIP_TRY(hipMemset(ctx->d_truncated, 0, sizeof flag));
+        return fail(GRAIL_ERR_BUFFER_TOO_SMALL,
+                    "at least one utterance did not end within out_stride samples");
+    }
+    return GRAIL_OK;
+}
+
+int grail_last_kernel_ms(grail_ctx *ctx, float *ms)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!ms) return fail(GRAIL_ERR_INVALID_ARG, "ms is NULL");
+    if (!ctx->have_timing) return fail(GRAIL_ERR_INVALID_ARG, "no kernel has been launched");
+    HIP_TRY(hipEventSynchronize(ctx->ev_stop));
+    HIP_TRY(hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
+    return GRAIL_OK;
+}
+
+static int run_one_call(grail_ctx *ctx, grail_batch *b, uint32_t n_utt, float *out,
+                        uint64_t out_stride, uint32_t *out_len, uint32_t flags)
+{
+    int rc = GRAIL_OK;
+    float *d_out = nullptr;
+    uint32_t *d_len = nullptr;
+    const bool dev_out = (flags & GRAIL_OUT_DEVICE) != 0;
+    const size_t out_bytes = (size_t)n_utt * out_stride * sizeof(float);
+    hipError_t e = hipSuccess;
+    if (dev_out) {
+        d_out = out;
+    } else if (out_bytes) {
+        e = hipMalloc((void **)&d_out, out_bytes);
+    }
+    if (e == hipSuccess && n_utt) e = hipMalloc((void **)&d_len, (size_t)n_utt * sizeof(uint32_t));
+    if (e != hipSuccess) rc = hip_fail(e, "output allocation");
+    if (!rc) rc = grail_batch_synthesize_async(ctx, b, d_out, out_stride, d_len);
+    int sync_rc = GRAIL_OK;
+    if (!rc) {
+        sync_rc = grail_sync(ctx);
+        if (sync_rc != GRAIL_OK && sync_rc != GRAIL_ERR_BUFFER_TOO_SMALL) rc = sync_rc;
+    }
+    if (!rc && out_len && n_utt) {
+        e = hipMemcpy(out_len, d_len, (size_t)n_utt * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "out_len copy");
+    }
+    if (!rc && !dev_out && out_bytes) {
+        e = hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "output copy");
+    }
+    if (!dev_out && d_out) (void)hipFree(d_out);
+    if (d_len) (void)hipFree(d_len);
+    return rc ? rc : sync_rc;
+}
+
+int grail_synthesize_batch(grail_ctx *ctx, const grail_phoneme_elem *segs,
+                           const uint32_t *seg_offsets, const uint32_t *voice_ids,
+                           const uint32_t *jitter_seeds, uint32_t n_utt, float *out,
+                           uint64_t out_stride, uint32_t *out_len, uint32_t flags)
+{
+    grail_batch *b = nullptr;
+    int rc = grail_batch_upload(ctx, segs, seg_offsets, voice_ids, jitter_seeds, n_utt, &b);
+    if (rc) return rc;
+    rc = run_one_call(ctx, b, n_utt, out, out_stride, out_len, flags);
+    const std::string keep = g_last_error;
+    grail_batch_free(ctx, b);
+    g_last_error = keep;
+    return rc;
+}
+
+int grail_synthesize_batch_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
+                                 const uint32_t *seg_offsets, const uint32_t *voice_ids,
+                                 const uint32_t *jitter_seeds, uint32_t n_utt, float *out,
+                                 uint64_t out_stride, uint32_t *out_len, uint32_t flags)
+{
+    grail_batch *b = nullptr;
+    int rc = grail_batch_upload_elems(ctx, segs, seg_offsets, voice_ids, jitter_seeds, n_utt, &b);
+    if (rc) return rc;
+    rc = run_one_call(ctx, b, n_utt, out, out_stride, out_len, flags);
+    const std::string keep = g_last_error;
+    grail_batch_free(ctx, b);
+    g_last_error = keep;
+    return rc;
+}
+
+int grail_device_alloc(grail_ctx *ctx, size_t bytes, void **out)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!out) return fail(GRAIL_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+    return GRAIL_OK;
+}
+
+int grail_device_free(grail_ctx *ctx, void *ptr)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (ptr) HIP_TRY(hipFree(ptr));
+    return GRAIL_OK;
+}
+
+int grail_memcpy_d2h(grail_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GRAIL_OK;
+}
+
+int grail_memcpy_h2d(grail_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GRAIL_OK;
+}
+
+int grail_memset_d(grail_ctx *ctx, void *dst_dev, int value, size_t bytes)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GRAIL_OK;
+}
+
+int grail_comm_unique_id(uint8_t id[GRAIL_UNIQUE_ID_BYTES])
+{
+    if (!id) return fail(GRAIL_ERR_INVALID_ARG, "id is NULL");
+    if (!rccl().ok) return fail(GRAIL_ERR_RCCL, "librccl.so could not be loaded");
+    ncclUniqueId uid;
+    ncclResult_t r = rccl().GetUniqueId(&uid);
+    if (r != ncclSuccess) return rccl_fail(r, "ncclGetUniqueId");
+    std::memcpy(id, uid.internal, GRAIL_UNIQUE_ID_BYTES);
+    return GRAIL_OK;
+}
+
+int grail_comm_init(grail_ctx *ctx, const uint8_t id[GRAIL_UNIQUE_ID_BYTES], uint32_t rank,
+                    uint32_t world)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!id || world == 0 || rank >= world) return fail(GRAIL_ERR_INVALID_ARG, "bad rank/world/id");
+    if (!rccl().ok) return fail(GRAIL_ERR_RCCL, "librccl.so could not be loaded");
+    if (ctx->comm) {
+        rccl().CommDestroy(ctx->comm);
+        ctx->comm = nullptr;
+    }
+    ncclUniqueId uid;
+    std::memcpy(uid.internal, id, GRAIL_UNIQUE_ID_BYTES);
+    ncclResult_t r = rccl().CommInitRank(&ctx->comm, (int)world, uid, (int)rank);
+    if (r != ncclSuccess) {
+        ctx->comm = nullptr;
+        return rccl_fail(r, "ncclCommInitRank");
+    }
+    ctx->comm_rank = rank;
+    ctx->comm_world = world;
+    return GRAIL_OK;
+}
+
+int grail_broadcast_voices(grail_ctx *ctx, uint32_t n_voices, uint32_t root)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!ctx->comm) return fail(GRAIL_ERR_RCCL, "call grail_comm_init first");
+    if (n_voices == 0 || root >= ctx->comm_world) return fail(GRAIL_ERR_INVALID_ARG, "bad n_voices/root");
+    if (ctx->comm_rank == root && ctx->voices.size() != n_voices)
+        return fail(GRAIL_ERR_INVALID_ARG, "root's voice table does not hold n_voices voices");
+    const size_t bytes = (size_t)n_voices * sizeof(grail_voice);
+    void *d_blob = nullptr;
+    HIP_TRY(hipMalloc(&d_blob, bytes));
+    hipError_t e = hipSuccess;
+    if (ctx->comm_rank == root)
+        e = hipMemcpyAsync(d_blob, ctx->voices.data(), bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(d_blob);
+        return hip_fail(e, "voice blob upload");
+    }
+    // one ncclBroadcast over xGMI: root's HBM -> every rank's HBM
+    ncclResult_t r = rccl().Broadcast(d_blob, d_blob, bytes, ncclUint8, (int)root, ctx->comm, ctx->stream);
+    if (r != ncclSuccess) {
+        (void)hipFree(d_blob);
+        return rccl_fail(r, "ncclBroadcast");
+    }
+    std::vector<grail_voice> got(n_voices);
+    e = hipMemcpyAsync(got.data(), d_blob, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_blob);
+    if (e != hipSuccess) return hip_fail(e, "voice blob download");
+    if (ctx->comm_rank == root) return GRAIL_OK;  // already installed
+    return install_voices(ctx, got.data(), n_voices);
+}
+
+int grail_comm_destroy(grail_ctx *ctx)
+{
+    if (!ctx) return fail(GRAIL_ERR_INVALID_ARG, "ctx is NULL");
+    if (ctx->comm && rccl().ok) rccl().CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_world = 1;
+    ctx->comm_rank = 0;
+    return GRAIL_OK;
+}
+
+}  // extern "C"

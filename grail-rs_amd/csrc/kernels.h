@@ -1,0 +1,76 @@
+// kernels.h — device-side data layout and launcher prototypes (internal).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace grail {
+
+constexpr int NF = 8;            // NUM_FORMANTS, reference src/lib.rs:24
+constexpr int ELEM_FLOATS = 49;  // SynthesisElem, reference src/lib.rs:316-337
+constexpr int NUM_VOICED = 2;    // VoiceStorage {a, e}, reference src/lib.rs:653-659
+constexpr int PH_FIRST_VOICED = 3;
+
+// field offsets inside a 49-float SynthesisElem (declared order)
+constexpr int F_FREQ = 1, F_BW = 9, F_SMOOTH = 17, F_BREATH = 25, F_TURB = 33, F_AMP = 41;
+
+// One segment as the kernel reads it: 16 B, one dwordx4 load.
+// Phoneme mode: bit-identical to grail_phoneme_elem (PhonemeElem, src/lib.rs:961-973),
+//   `elem` holds the Phoneme discriminant and the Selector runs on the device.
+// Elem mode: `elem` is the row of the batch's elem table, or -1 for None
+//   (SequenceElem.elem, src/lib.rs:817), `frequency` repeats the elem's own.
+struct DevSeg {
+    int32_t elem;
+    float length;
+    float blend_length;
+    float frequency;
+};
+static_assert(sizeof(DevSeg) == 16, "DevSeg must be one dwordx4");
+
+// Per-voice scalars (Voice, src/lib.rs:696-717) + where its phoneme elems sit
+// in the elem table. 32 B.
+struct DevVoice {
+    float sample_rate;
+    float jitter_frequency;
+    float jitter_delta_frequency;
+    float jitter_delta_formant_frequency;
+    float jitter_delta_amplitude;
+    uint32_t elem_base;  // row of phonemes.a in the voice elem table
+    uint32_t pad[2];
+};
+static_assert(sizeof(DevVoice) == 32, "DevVoice layout");
+
+struct SynthArgs {
+    const DevSeg *segs;
+    const uint32_t *seg_offsets;  // [n_utt + 1]
+    const uint32_t *voice_ids;    // [n_utt] or nullptr (voice 0)
+    const uint32_t *seeds;        // [n_utt] or nullptr (seed 0)
+    const float *elems;           // phoneme mode: voice elem table; elem mode: batch elem table
+    const DevVoice *voices;
+    float *out;
+    uint32_t *out_len;            // may be nullptr
+    uint32_t *truncated;          // one word, set to 1 when an utterance is cut at out_stride
+    uint64_t out_stride;
+    uint32_t n_utt;
+    uint32_t n_voices;
+    uint32_t phoneme_mode;        // 1: run the Selector on the device
+};
+
+struct LenArgs {
+    const DevSeg *segs;
+    const uint32_t *seg_offsets;
+    const uint32_t *voice_ids;
+    const DevVoice *voices;
+    uint32_t *out_len;
+    uint32_t n_utt;
+    uint32_t n_voices;
+    uint32_t max_len;
+};
+
+// lanes_per_utt in {1, 2, 4, 8}; returns hipSuccess or the launch error.
+hipError_t launch_synth(const SynthArgs &args, int lanes_per_utt, hipStream_t stream);
+hipError_t launch_lengths(const LenArgs &args, hipStream_t stream);
+// the choice made when the option is 0 (auto)
+int auto_lanes_per_utt(uint32_t n_utt);
+
+}  // namespace grail

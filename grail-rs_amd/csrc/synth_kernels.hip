@@ -1,0 +1,507 @@
+// synth_kernels.hip — the fused Selector -> Sequencer -> Jitter -> Synthesize kernel
+// for gfx950 (MI355X, CDNA4, wave64).  Hand-written HIP; no MFMA (the path is a
+// per-sample IIR recurrence, VALU-issue bound, ~4 B of HBM traffic per sample).
+//
+// Reference behaviour (file:line in the grail-rs tree):
+//   Selector::next    src/lib.rs:990-1005     Sequencer::next  src/lib.rs:859-932
+//   Jitter::next      src/lib.rs:753-777      Synthesize::next src/lib.rs:497-578
+//   ValueNoise        src/lib.rs:227-255      ArrayValueNoise  src/lib.rs:270-306
+//   random_f32 :36    tan_approx :63          exp_approx :75   Array::sum :123
+//
+// Mapping.  One wavefront renders S = 64/L utterances; the 8 formants of an
+// utterance are spread over L adjacent lanes (L in {1,2,4,8}, FPL = 8/L formants
+// per lane).  Time is serial (phase, clocks, RNG and filter states all carry
+// sample to sample, exactly as in the reference); the per-utterance scalar
+// state is recomputed identically in each of its L lanes so lanes never wait on
+// each other.  The 8-term `Array::sum` is a left fold and must stay one: it is
+// run as a chain down the L lanes with DPP row_shr:1 hand-offs.  Samples are
+// staged through LDS for T steps and flushed as 16-B-per-lane row stores, so
+// every utterance row is written in contiguous 4*T-byte runs.
+//
+// Exactness.  Built with -ffp-contract=off: every a*b+c is a v_mul_f32 then a
+// v_add_f32, divisions are hipcc's correctly rounded IEEE sequence, f32
+// denormals are kept (the kernel descriptor's default).  The result is
+// bit-identical to the reference arithmetic, whatever L is.
+#include "kernels.h"
+
+namespace grail {
+
+namespace {
+
+// random_f32, src/lib.rs:36-55
+__device__ __forceinline__ float lcg_f32(uint32_t &s)
+{
+    s = s * 16807u + 1u;
+    return (__uint_as_float((s >> 9) | 0x3F800000u) - 1.5f) * 2.0f;
+}
+
+// tan_approx, src/lib.rs:63-70 (tan(pi x), Bhaskara-style rational)
+__device__ __forceinline__ float tan_approx(float x)
+{
+    const float omx = 1.0f - x;
+    const float xph = x + 0.5f;
+    const float hmx = 0.5f - x;
+    const float num = (omx * x) * (5.0f - (4.0f * xph) * hmx);
+    const float den = (xph * (5.0f - (4.0f * omx) * x)) * hmx;
+    return num / den;
+}
+
+// exp_approx, src/lib.rs:75-82 ((1-x)^5)
+__device__ __forceinline__ float exp_approx(float x)
+{
+    const float o = 1.0f - x;
+    const float o2 = o * o;
+    return (o2 * o2) * o;
+}
+
+// lane i takes lane i-1's value (within its row of 16 lanes)
+__device__ __forceinline__ float dpp_from_lane_below(float x)
+{
+    return __int_as_float(
+        __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111 /* row_shr:1 */, 0xF, 0xF, true));
+}
+
+// LDS hand-off between lanes of ONE wave: same-wave DS operations execute in
+// order, so only compiler reordering has to be fenced.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// the FPL-formant slice of a SynthesisElem that one lane owns
+template <int FPL>
+struct Part {
+    float frequency;
+    float freq[FPL], bw[FPL], smooth[FPL], breath[FPL], turb[FPL], amp[FPL];
+};
+
+template <int FPL>
+__device__ __forceinline__ void load_part(Part<FPL> &p, const float *__restrict__ elems,
+                                          int row, int f0)
+{
+    const float *e = elems + (size_t)row * ELEM_FLOATS + f0;
+    p.frequency = elems[(size_t)row * ELEM_FLOATS];
+#pragma unroll
+    for (int i = 0; i < FPL; ++i) {
+        p.freq[i] = e[F_FREQ + i];
+        p.bw[i] = e[F_BW + i];
+        p.smooth[i] = e[F_SMOOTH + i];
+        p.breath[i] = e[F_BREATH + i];
+        p.turb[i] = e[F_TURB + i];
+        p.amp[i] = e[F_AMP + i];
+    }
+}
+
+// SynthesisElem::silent(), src/lib.rs:367-377
+template <int FPL>
+__device__ __forceinline__ void silent_part(Part<FPL> &p)
+{
+    p.frequency = 0.25f;
+#pragma unroll
+    for (int i = 0; i < FPL; ++i) {
+        p.freq[i] = 0.25f;
+        p.bw[i] = 0.25f;
+        p.smooth[i] = 0.25f;
+        p.breath[i] = 0.0f;
+        p.turb[i] = 0.0f;
+        p.amp[i] = 0.0f;
+    }
+}
+
+// Option<SequenceElem> held in registers
+struct Seg {
+    bool some;
+    int elem;  // table row, or -1 for None
+    float length, blend_length, frequency;
+};
+
+// iter.next() of the Sequencer's source.  Phoneme mode folds in Selector::next
+// (src/lib.rs:990-1005): VoiceStorage::get (:664-671) and
+// copy_with_frequency (:445-450: frequency.min(0.5)).
+__device__ __forceinline__ void fetch_seg(Seg &s, const DevSeg *__restrict__ segs,
+                                          uint32_t &pos, uint32_t end, bool phoneme_mode,
+                                          uint32_t elem_base)
+{
+    if (pos < end) {
+        const DevSeg d = segs[pos++];
+        s.some = true;
+        s.length = d.length;
+        s.blend_length = d.blend_length;
+        if (phoneme_mode) {
+            const int ph = d.elem;
+            const bool voiced = ph >= PH_FIRST_VOICED && ph < PH_FIRST_VOICED + NUM_VOICED;
+            s.elem = voiced ? (int)elem_base + (ph - PH_FIRST_VOICED) : -1;
+            s.frequency = __builtin_fminf(d.frequency, 0.5f);
+        } else {
+            s.elem = d.elem;
+            s.frequency = d.frequency;
+        }
+    } else {
+        s.some = false;
+        s.elem = -1;
+        s.length = 0.0f;
+        s.blend_length = 1.0f;
+        s.frequency = 0.0f;
+    }
+}
+
+template <int L, int T>
+__global__ __launch_bounds__(64) void synth_kernel(const SynthArgs A)
+{
+    constexpr int FPL = NF / L;   // formants per lane
+    constexpr int S = 64 / L;     // utterances per wave
+    constexpr int SP = S + 1;     // padded row of the staging tile
+    static_assert(T % 4 == 0 && (64 % (T / 4)) == 0, "T");
+
+    __shared__ float stage[T * SP];
+    __shared__ uint32_t cnt[S];
+
+    const int lane = threadIdx.x;
+    const int slot = lane / L;
+    const int j = lane % L;
+    const int f0 = j * FPL;
+    const uint32_t u0 = blockIdx.x * S;
+    const uint32_t u = u0 + slot;
+    bool done = u >= A.n_utt;
+    const uint32_t uc = done ? 0u : u;
+
+    uint32_t vid = A.voice_ids ? A.voice_ids[uc] : 0u;
+    if (vid >= A.n_voices) vid = 0u;
+    const DevVoice V = A.voices[vid];
+    const bool phoneme_mode = A.phoneme_mode != 0;
+    const float *__restrict__ elems = A.elems;
+
+    // ---- Sequencer state: IntoSequencer::sequence, src/lib.rs:941-949
+    uint32_t seg_pos = A.seg_offsets[uc];
+    const uint32_t seg_end = A.seg_offsets[uc + 1];
+    Seg cur, nxt;
+    cur.some = false; cur.elem = -1; cur.length = 0.0f; cur.blend_length = 1.0f; cur.frequency = 0.0f;
+    nxt = cur;
+    float clk = 0.0f;                        // Sequencer.time
+    const float dt = 1.0f / V.sample_rate;   // :944
+    Part<FPL> X, Y;                          // emitted elem = X*(1-alpha) + Y*alpha
+    silent_part(X);
+    silent_part(Y);
+    float blend_length = 1.0f;
+    bool silent_pair = true;
+
+    // ---- Jitter state: IntoJitter::jitter, src/lib.rs:786-797.  One seed is
+    // threaded through the three constructors (2 + 16 + 16 draws), each noise
+    // then keeps its own copy of the state.  The three noises share one phase
+    // sequence (same start, same increment), kept once.
+    uint32_t seed = A.seeds ? A.seeds[uc] : 0u;
+    float fn_cur = lcg_f32(seed);            // ValueNoise::new :228-229
+    float fn_next = lcg_f32(seed);
+    uint32_t fn_state = seed;
+    float ff_cur[FPL], ff_next[FPL], fa_cur[FPL], fa_next[FPL];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {           // ArrayValueNoise::new :275-278
+        const float c = lcg_f32(seed);
+        const float n = lcg_f32(seed);
+#pragma unroll
+        for (int k = 0; k < FPL; ++k)
+            if (i == f0 + k) { ff_cur[k] = c; ff_next[k] = n; }
+    }
+    uint32_t ff_state = seed;
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        const float c = lcg_f32(seed);
+        const float n = lcg_f32(seed);
+#pragma unroll
+        for (int k = 0; k < FPL; ++k)
+            if (i == f0 + k) { fa_cur[k] = c; fa_next[k] = n; }
+    }
+    uint32_t fa_state = seed;
+    float jphase = 0.0f;
+    const float jinc = V.jitter_frequency;
+    const float d_freq = V.jitter_delta_frequency;
+    const float d_ffreq = V.jitter_delta_formant_frequency;
+    const float amp_scale = 0.5f * V.jitter_delta_amplitude;   // :769
+
+    // ---- Synthesize state: IntoSynthesize::synthesize, src/lib.rs:587-596
+    float phase = 0.0f;
+    float st_a[FPL], st_b[FPL], st_c[FPL];
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) { st_a[k] = 0.0f; st_b[k] = 0.0f; st_c[k] = 0.0f; }
+    uint32_t noise_seed = 0u;                // :594
+
+    const uint64_t cap = A.out_stride;
+    uint32_t n_out = 0;
+    bool truncated = false;
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(A.out) & 15u) == 0) && ((cap & 3u) == 0);
+
+    for (uint32_t base = 0;; base += T) {
+        for (int t = 0; t < T; ++t) {
+            if (done) continue;
+
+            // ================= Sequencer::next, src/lib.rs:859-932
+            clk -= dt;                                            // :861
+            if (clk < 0.0f) {                                     // :864
+                if (cur.some && nxt.some) {                       // :868
+                    cur = nxt;
+                    fetch_seg(nxt, A.segs, seg_pos, seg_end, phoneme_mode, V.elem_base);
+                    clk += cur.length;                            // :873
+                } else if (!cur.some && !nxt.some) {              // :876
+                    fetch_seg(cur, A.segs, seg_pos, seg_end, phoneme_mode, V.elem_base);
+                    fetch_seg(nxt, A.segs, seg_pos, seg_end, phoneme_mode, V.elem_base);
+                    if (cur.some) clk += cur.length;              // :881-883
+                } else {
+                    done = true;                                  // :886
+                }
+                if (!done && cur.some) {
+                    // the match at :891-931, resolved once per segment pair
+                    const bool has_b = cur.elem >= 0;
+                    const bool has_c = nxt.some && nxt.elem >= 0;
+                    blend_length = cur.blend_length;
+                    silent_pair = !has_b && !has_c;
+                    if (has_b && has_c) {          // c.blend(b, alpha)  :897-903
+                        load_part(X, elems, nxt.elem, f0);
+                        load_part(Y, elems, cur.elem, f0);
+                        X.frequency = nxt.frequency;
+                        Y.frequency = cur.frequency;
+                    } else if (has_b) {            // b.copy_silent().blend(b, alpha)  :906-912
+                        load_part(Y, elems, cur.elem, f0);
+                        Y.frequency = cur.frequency;
+                        X = Y;
+#pragma unroll
+                        for (int k = 0; k < FPL; ++k) X.amp[k] = 0.0f;
+                    } else if (has_c) {            // c.blend(c.copy_silent(), alpha)  :915-921
+                        load_part(X, elems, nxt.elem, f0);
+                        X.frequency = nxt.frequency;
+                        Y = X;
+#pragma unroll
+                        for (int k = 0; k < FPL; ++k) Y.amp[k] = 0.0f;
+                    } else {                       // SynthesisElem::silent()  :924-927
+                        silent_part(X);
+                        silent_part(Y);
+                    }
+                }
+            }
+            if (!cur.some) done = true;                           // :930
+            if (done) continue;
+            if (n_out >= cap) {   // the chain would yield another sample: row is full
+                truncated = true;
+                done = true;
+                continue;
+            }
+
+            // alpha = (time / blend_length).min(1.0)  :899/:908/:917.  A both-silent
+            // pair emits silent() itself (:926): alpha = 1 selects Y = silent() exactly
+            // (X*0 + Y*1 with finite X).
+            float alpha = __builtin_fminf(clk / blend_length, 1.0f);
+            alpha = silent_pair ? 1.0f : alpha;
+            const float oma = 1.0f - alpha;
+
+            // SynthesisElem::blend, src/lib.rs:404-414
+            float frequency = X.frequency * oma + Y.frequency * alpha;
+            float e_freq[FPL], e_bw[FPL], e_smooth[FPL], e_breath[FPL], e_turb[FPL], e_amp[FPL];
+#pragma unroll
+            for (int k = 0; k < FPL; ++k) {
+                e_freq[k] = X.freq[k] * oma + Y.freq[k] * alpha;
+                e_smooth[k] = X.smooth[k] * oma + Y.smooth[k] * alpha;
+                e_bw[k] = X.bw[k] * oma + Y.bw[k] * alpha;
+                e_turb[k] = X.turb[k] * oma + Y.turb[k] * alpha;
+                e_breath[k] = X.breath[k] * oma + Y.breath[k] * alpha;
+                e_amp[k] = X.amp[k] * oma + Y.amp[k] * alpha;
+            }
+
+            // ================= Jitter::next, src/lib.rs:753-777
+            jphase += jinc;                                       // :242 / :291
+            if (jphase > 1.0f) {                                  // :245 / :294
+                jphase -= 1.0f;
+                fn_cur = fn_next;                                 // :249-250
+                fn_next = lcg_f32(fn_state);
+                uint32_t s1 = ff_state, s2 = fa_state;
+#pragma unroll
+                for (int k = 0; k < FPL; ++k) { ff_cur[k] = ff_next[k]; fa_cur[k] = fa_next[k]; }
+#pragma unroll
+                for (int i = 0; i < NF; ++i) {                    // from_func order :301
+                    const float r1 = lcg_f32(s1);
+                    const float r2 = lcg_f32(s2);
+#pragma unroll
+                    for (int k = 0; k < FPL; ++k)
+                        if (i == f0 + k) { ff_next[k] = r1; fa_next[k] = r2; }
+                }
+                ff_state = s1;
+                fa_state = s2;
+            }
+            const float jomp = 1.0f - jphase;
+            const float n_freq = fn_cur * jomp + fn_next * jphase;         // :254
+            frequency = frequency + n_freq * d_freq;                       // :763
+#pragma unroll
+            for (int k = 0; k < FPL; ++k) {
+                const float n_ff = ff_cur[k] * jomp + ff_next[k] * jphase; // :305
+                const float n_fa = fa_cur[k] * jomp + fa_next[k] * jphase;
+                e_freq[k] = e_freq[k] + n_ff * d_ffreq;                    // :764
+                const float delta = (n_fa + 1.0f) * amp_scale;             // :768-769
+                const float mul = 1.0f - delta;                            // :772
+                e_amp[k] = e_amp[k] * mul;                                 // :773
+            }
+
+            // ================= Synthesize::next, src/lib.rs:497-578
+            // polyBLEP saw: both branches divide by the jittered frequency  :503-514
+            const bool head = phase < frequency;
+            const bool tail = phase > (1.0f - frequency);
+            float polyblep = 0.0f;
+            if (head || tail) {
+                const float tt = (head ? phase : (phase - 1.0f)) / frequency;
+                polyblep = head ? ((2.0f * tt - (tt * tt)) - 1.0f)
+                                : (((tt * tt) + 2.0f * tt) + 1.0f);
+            }
+            const float saw = (2.0f * phase - 1.0f) - polyblep;            // :517
+            phase += frequency;                                            // :520
+            if (phase >= 1.0f) phase -= 1.0f;                              // :523-525
+            const float noise = lcg_f32(noise_seed);                       // :528
+
+            float v1[FPL];
+#pragma unroll
+            for (int k = 0; k < FPL; ++k) {
+                const float nw = saw * (1.0f - e_breath[k]) + noise * e_breath[k];   // :531
+                const float lp = exp_approx(e_smooth[k]);                            // :535
+                st_a[k] = st_a[k] + (1.0f - lp) * (nw - st_a[k]);                    // :538
+                const float tw = st_a[k] * (1.0f * (1.0f - e_turb[k]) + noise * e_turb[k]); // :544-545
+                const float v0 = tw * e_amp[k];                                      // :550
+                const float g = tan_approx(e_freq[k]);                               // :555
+                const float kq = e_bw[k] / e_freq[k];                                // :558
+                const float a1 = 1.0f / (1.0f + g * (g + kq));                       // :560
+                const float a2 = g * a1;                                             // :561
+                const float a3 = g * a2;                                             // :562
+                const float v3 = v0 - st_c[k];                                       // :565
+                const float w1 = a1 * st_b[k] + a2 * v3;                             // :566
+                const float w2 = (st_c[k] + a2 * st_b[k]) + a3 * v3;                 // :567
+                st_b[k] = 2.0f * w1 - st_b[k];                                       // :570
+                st_c[k] = 2.0f * w2 - st_c[k];                                       // :571
+                v1[k] = w1;
+            }
+
+            // v1.sum() * 0.5: a left fold from 0.0 over formants 0..7  :574, :123-125,
+            // carried down the utterance's L lanes.
+            float acc = 0.0f;
+#pragma unroll
+            for (int step = 0; step < L; ++step) {
+                float run = (step == 0) ? 0.0f : dpp_from_lane_below(acc);
+#pragma unroll
+                for (int k = 0; k < FPL; ++k) run = run + v1[k];
+                acc = (j == step) ? run : acc;
+            }
+            if (j == L - 1) stage[t * SP + slot] = acc * 0.5f;
+            ++n_out;
+        }
+
+        // ---- flush the staged tile: row `slot` holds samples [base, base+T)
+        if (j == L - 1) cnt[slot] = n_out > base ? n_out - base : 0u;
+        wave_lds_sync();
+        constexpr int ROW_LANES = T / 4;
+        constexpr int ROWS_PER_IT = 64 / ROW_LANES;
+        const int rl = lane % ROW_LANES;
+        const int rr = lane / ROW_LANES;
+#pragma unroll 1
+        for (int r0 = 0; r0 < S; r0 += ROWS_PER_IT) {
+            const int r = r0 + rr;
+            if (ROWS_PER_IT > S && r >= S) continue;
+            const uint32_t c = cnt[r];
+            const int t0 = rl * 4;
+            if ((uint32_t)t0 < c) {
+                float *dst = A.out + (uint64_t)(u0 + r) * cap + base + t0;
+                const float s0 = stage[(t0 + 0) * SP + r];
+                const float s1 = stage[(t0 + 1) * SP + r];
+                const float s2 = stage[(t0 + 2) * SP + r];
+                const float s3 = stage[(t0 + 3) * SP + r];
+                if (vec_ok && (uint32_t)(t0 + 4) <= c) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(s0, s1, s2, s3);
+                } else {
+                    dst[0] = s0;
+                    if ((uint32_t)(t0 + 1) < c) dst[1] = s1;
+                    if ((uint32_t)(t0 + 2) < c) dst[2] = s2;
+                    if ((uint32_t)(t0 + 3) < c) dst[3] = s3;
+                }
+            }
+        }
+        wave_lds_sync();
+        if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+    }
+
+    if (j == L - 1 && u < A.n_utt) {
+        if (A.out_len) A.out_len[u] = n_out;
+        if (truncated) atomicOr(A.truncated, 1u);
+    }
+}
+
+// Sequencer clock only (src/lib.rs:861-888, :930): how many elems the
+// Sequencer yields, one utterance per lane.
+__global__ __launch_bounds__(64) void lengths_kernel(const LenArgs A)
+{
+    const uint32_t u = blockIdx.x * 64u + threadIdx.x;
+    if (u >= A.n_utt) return;
+    uint32_t vid = A.voice_ids ? A.voice_ids[u] : 0u;
+    if (vid >= A.n_voices) vid = 0u;
+    const float dt = 1.0f / A.voices[vid].sample_rate;
+    uint32_t pos = A.seg_offsets[u];
+    const uint32_t end = A.seg_offsets[u + 1];
+    bool cur_some = false, nxt_some = false;
+    float cur_len = 0.0f, nxt_len = 0.0f;
+    float clk = 0.0f;
+    uint32_t n = 0;
+    while (n < A.max_len) {
+        clk -= dt;
+        if (clk < 0.0f) {
+            if (cur_some && nxt_some) {
+                cur_len = nxt_len;
+                nxt_some = pos < end;
+                if (nxt_some) nxt_len = A.segs[pos++].length;
+                clk += cur_len;
+            } else if (!cur_some && !nxt_some) {
+                cur_some = pos < end;
+                if (cur_some) cur_len = A.segs[pos++].length;
+                nxt_some = pos < end;
+                if (nxt_some) nxt_len = A.segs[pos++].length;
+                if (cur_some) clk += cur_len;
+            } else {
+                break;
+            }
+        }
+        if (!cur_some) break;
+        ++n;
+    }
+    A.out_len[u] = n;
+}
+
+}  // namespace
+
+int auto_lanes_per_utt(uint32_t n_utt)
+{
+    // The VALU saturates at >= 2 waves per SIMD: 256 CUs x 4 SIMDs x 2 = 2048
+    // waves.  Fewer lanes per utterance = less redundant per-utterance scalar
+    // work, so take the smallest L that still reaches that many waves.
+    const uint64_t want_waves = 2048;
+    for (int L = 1; L < 8; L *= 2)
+        if (((uint64_t)n_utt * L + 63) / 64 >= want_waves) return L;
+    return 8;
+}
+
+hipError_t launch_synth(const SynthArgs &args, int L, hipStream_t stream)
+{
+    if (args.n_utt == 0) return hipSuccess;
+    const uint32_t S = 64u / (uint32_t)L;
+    const dim3 grid((args.n_utt + S - 1) / S), block(64);
+    switch (L) {
+    case 1: hipLaunchKernelGGL((synth_kernel<1, 32>), grid, block, 0, stream, args); break;
+    case 2: hipLaunchKernelGGL((synth_kernel<2, 64>), grid, block, 0, stream, args); break;
+    case 4: hipLaunchKernelGGL((synth_kernel<4, 64>), grid, block, 0, stream, args); break;
+    case 8: hipLaunchKernelGGL((synth_kernel<8, 64>), grid, block, 0, stream, args); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_lengths(const LenArgs &args, hipStream_t stream)
+{
+    if (args.n_utt == 0) return hipSuccess;
+    const dim3 grid((args.n_utt + 63) / 64), block(64);
+    hipLaunchKernelGGL(lengths_kernel, grid, block, 0, stream, args);
+    return hipGetLastError();
+}
+
+}  // namespace grail

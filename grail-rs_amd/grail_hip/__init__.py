@@ -1,0 +1,432 @@
+"""ctypes binding of libgrail_hip.so — the C ABI declared in include/grail_hip.h.
+
+This is plumbing for tests and bench.py (the reference's own host language,
+Rust, is not in this image; INTEGRATION.md has the Rust binding).  It holds no
+arithmetic: every sample comes from the HIP kernels behind the C ABI, and
+anything that needs the GPU raises GrailError when the library or a device is
+missing — there is no CPU fallback.
+
+Reference API mirrored (reference file:line):
+  Voice src/lib.rs:696, SynthesisElem :316, PhonemeElem :961, SequenceElem :814,
+  Phoneme :632, voices::generic() src/voices/generic.rs:5,
+  .select().sequence().jitter().synthesize() src/lib.rs:1013/941/786/587.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+NUM_FORMANTS = 8
+DEFAULT_SAMPLE_RATE = 44100.0
+
+PH_SILENCE, PH_STOP, PH_GLIDE, PH_A, PH_E = range(5)
+PH_COUNT = 5
+NUM_VOICED = 2
+
+OK = 0
+ERR_INVALID_ARG = -1
+ERR_NO_DEVICE = -2
+ERR_HIP = -3
+ERR_BUFFER_TOO_SMALL = -4
+ERR_OUT_OF_MEMORY = -5
+ERR_RCCL = -6
+ERR_NO_VOICES = -7
+
+OUT_HOST = 0
+OUT_DEVICE = 1
+UNIQUE_ID_BYTES = 128
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgrail_hip.so")
+
+# every symbol include/grail_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "grail_abi_version", "grail_status_string", "grail_last_error",
+    "grail_elem_silent", "grail_elem_new_phoneme", "grail_elem_new", "grail_elem_resample",
+    "grail_elem_blend", "grail_voice_generic", "grail_voice_generic_at", "grail_voice_get",
+    "grail_create", "grail_destroy", "grail_device_count", "grail_set_voices",
+    "grail_get_voices", "grail_set_option", "grail_get_option",
+    "grail_batch_upload", "grail_batch_upload_elems", "grail_batch_free", "grail_batch_size",
+    "grail_batch_lengths", "grail_batch_synthesize_async", "grail_sync",
+    "grail_last_kernel_ms", "grail_synthesize_batch", "grail_synthesize_batch_elems",
+    "grail_device_alloc", "grail_device_free", "grail_memcpy_d2h", "grail_memcpy_h2d",
+    "grail_memset_d", "grail_shard_range", "grail_comm_unique_id", "grail_comm_init",
+    "grail_broadcast_voices", "grail_comm_destroy",
+]
+
+
+class GrailError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"grail_hip status {status}: {message}")
+        self.status = status
+
+
+class SynthesisElem(C.Structure):
+    _fields_ = [
+        ("frequency", C.c_float),
+        ("formant_freq", C.c_float * NUM_FORMANTS),
+        ("formant_bw", C.c_float * NUM_FORMANTS),
+        ("formant_smooth", C.c_float * NUM_FORMANTS),
+        ("formant_breath", C.c_float * NUM_FORMANTS),
+        ("formant_turb", C.c_float * NUM_FORMANTS),
+        ("formant_amp", C.c_float * NUM_FORMANTS),
+    ]
+
+    def as_np(self):
+        return np.frombuffer(bytes(self), dtype=np.float32).copy()
+
+    @classmethod
+    def from_np(cls, a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        assert a.size == 49
+        return cls.from_buffer_copy(a.tobytes())
+
+
+class Voice(C.Structure):
+    _fields_ = [
+        ("sample_rate", C.c_float),
+        ("phonemes", SynthesisElem * NUM_VOICED),
+        ("center_frequency", C.c_float),
+        ("jitter_frequency", C.c_float),
+        ("jitter_delta_frequency", C.c_float),
+        ("jitter_delta_formant_frequency", C.c_float),
+        ("jitter_delta_amplitude", C.c_float),
+    ]
+
+    def copy(self):
+        return Voice.from_buffer_copy(bytes(self))
+
+
+class PhonemeElem(C.Structure):
+    _fields_ = [
+        ("phoneme", C.c_int32),
+        ("length", C.c_float),
+        ("blend_length", C.c_float),
+        ("frequency", C.c_float),
+    ]
+
+
+class SequenceElem(C.Structure):
+    _fields_ = [
+        ("has_elem", C.c_int32),
+        ("elem", SynthesisElem),
+        ("length", C.c_float),
+        ("blend_length", C.c_float),
+    ]
+
+
+PHONEME_DTYPE = np.dtype(
+    [("phoneme", "<i4"), ("length", "<f4"), ("blend_length", "<f4"), ("frequency", "<f4")]
+)
+
+_lib = None
+
+
+def lib_exists():
+    return os.path.exists(LIB_PATH)
+
+
+def load():
+    """Load libgrail_hip.so; fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GrailError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: run __graft_entry__.build() "
+                                        "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, u32p, u64 = C.c_void_p, C.POINTER(C.c_uint32), C.c_uint64
+    L.grail_abi_version.restype = C.c_int
+    L.grail_status_string.restype = C.c_char_p
+    L.grail_status_string.argtypes = [C.c_int]
+    L.grail_last_error.restype = C.c_char_p
+    L.grail_elem_silent.restype = None
+    L.grail_elem_silent.argtypes = [C.POINTER(SynthesisElem)]
+    fp = C.POINTER(C.c_float)
+    L.grail_elem_new_phoneme.restype = None
+    L.grail_elem_new_phoneme.argtypes = [C.POINTER(SynthesisElem)] + [fp] * 6
+    L.grail_elem_new.restype = None
+    L.grail_elem_new.argtypes = [C.POINTER(SynthesisElem), C.c_float, C.c_float] + [fp] * 6
+    L.grail_elem_resample.restype = None
+    L.grail_elem_resample.argtypes = [C.POINTER(SynthesisElem), C.c_float, C.c_float]
+    L.grail_elem_blend.restype = None
+    L.grail_elem_blend.argtypes = [C.POINTER(SynthesisElem)] * 3 + [C.c_float]
+    L.grail_voice_generic.restype = None
+    L.grail_voice_generic.argtypes = [C.POINTER(Voice)]
+    L.grail_voice_generic_at.restype = None
+    L.grail_voice_generic_at.argtypes = [C.POINTER(Voice), C.c_float]
+    L.grail_voice_get.argtypes = [C.POINTER(Voice), C.c_int32, C.POINTER(SynthesisElem)]
+    L.grail_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.grail_destroy.argtypes = [vp]
+    L.grail_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.grail_set_voices.argtypes = [vp, vp, C.c_uint32]
+    L.grail_get_voices.argtypes = [vp, vp, C.c_uint32, u32p]
+    L.grail_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.grail_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
+    L.grail_batch_upload.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.POINTER(vp)]
+    L.grail_batch_upload_elems.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.POINTER(vp)]
+    L.grail_batch_free.argtypes = [vp, vp]
+    L.grail_batch_size.restype = C.c_uint32
+    L.grail_batch_size.argtypes = [vp]
+    L.grail_batch_lengths.argtypes = [vp, vp, C.c_uint32, vp]
+    L.grail_batch_synthesize_async.argtypes = [vp, vp, vp, u64, vp]
+    L.grail_sync.argtypes = [vp]
+    L.grail_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.grail_synthesize_batch.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, u64, vp, C.c_uint32]
+    L.grail_synthesize_batch_elems.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, u64, vp,
+                                               C.c_uint32]
+    L.grail_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.grail_device_free.argtypes = [vp, vp]
+    L.grail_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    L.grail_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    L.grail_memset_d.argtypes = [vp, vp, C.c_int, C.c_size_t]
+    L.grail_shard_range.restype = None
+    L.grail_shard_range.argtypes = [u64, C.c_uint32, C.c_uint32, C.POINTER(u64), C.POINTER(u64)]
+    L.grail_comm_unique_id.argtypes = [vp]
+    L.grail_comm_init.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
+    L.grail_broadcast_voices.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.grail_comm_destroy.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def _check(status):
+    if status != OK:
+        raise GrailError(status, load().grail_last_error().decode() or
+                         load().grail_status_string(status).decode())
+
+
+# ---- host-side parameter algebra -------------------------------------------
+def voice_generic(sample_rate=None):
+    """voices::generic() (src/voices/generic.rs:5); sample_rate != None gives the
+    resampled variant of SURVEY.md §8d."""
+    v = Voice()
+    if sample_rate is None:
+        load().grail_voice_generic(C.byref(v))
+    else:
+        load().grail_voice_generic_at(C.byref(v), C.c_float(sample_rate))
+    return v
+
+
+def elem_new_phoneme(freq, bw, smooth, turb, breath, amp):
+    """SynthesisElem::new_phoneme == MKPHON (src/lib.rs:381, src/voices/mod.rs:7)."""
+    e = SynthesisElem()
+    arrs = [(C.c_float * NUM_FORMANTS)(*[float(x) for x in a])
+            for a in (freq, bw, smooth, turb, breath, amp)]
+    load().grail_elem_new_phoneme(C.byref(e), *arrs)
+    return e
+
+
+def elem_resample(elem, old_rate, new_rate):
+    e = SynthesisElem.from_buffer_copy(bytes(elem))
+    load().grail_elem_resample(C.byref(e), C.c_float(old_rate), C.c_float(new_rate))
+    return e
+
+
+def elem_silent():
+    e = SynthesisElem()
+    load().grail_elem_silent(C.byref(e))
+    return e
+
+
+def elem_blend(a, b, alpha):
+    e = SynthesisElem()
+    load().grail_elem_blend(C.byref(e), C.byref(a), C.byref(b), C.c_float(alpha))
+    return e
+
+
+def shard_range(n_utt, rank, world):
+    b, e = C.c_uint64(), C.c_uint64()
+    load().grail_shard_range(n_utt, rank, world, C.byref(b), C.byref(e))
+    return b.value, e.value
+
+
+def voices_blob(voices):
+    """The broadcast payload: the raw grail_voice[] bytes."""
+    return b"".join(bytes(v) for v in voices)
+
+
+def voices_from_blob(blob):
+    n = len(blob) // C.sizeof(Voice)
+    assert n * C.sizeof(Voice) == len(blob)
+    return [Voice.from_buffer_copy(blob[i * C.sizeof(Voice):(i + 1) * C.sizeof(Voice)])
+            for i in range(n)]
+
+
+def segments(seq):
+    a = np.zeros(len(seq), dtype=PHONEME_DTYPE)
+    for i, s in enumerate(seq):
+        a[i] = tuple(s)
+    return a
+
+
+def device_count():
+    n = C.c_int(0)
+    st = load().grail_device_count(C.byref(n))
+    return n.value if st == OK else 0
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class Batch:
+    def __init__(self, ctx, handle, n_utt):
+        self.ctx, self.handle, self.n_utt = ctx, handle, n_utt
+
+    def lengths(self, max_len=0xFFFFFFFF):
+        out = np.zeros(max(self.n_utt, 1), dtype=np.uint32)
+        _check(load().grail_batch_lengths(self.ctx.handle, self.handle, max_len, out.ctypes.data))
+        return out[: self.n_utt]
+
+    def synthesize_async(self, out_dev, out_stride, out_len_dev=None):
+        _check(load().grail_batch_synthesize_async(self.ctx.handle, self.handle, out_dev,
+                                                   out_stride, out_len_dev))
+
+    def free(self):
+        if self.handle:
+            load().grail_batch_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+
+class Context:
+    """grail_ctx: one per (process, GPU)."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        _check(load().grail_create(device, C.byref(h)))
+        self.handle = h
+        self.device = device
+
+    def close(self):
+        if self.handle:
+            load().grail_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_voices(self, voices):
+        arr = (Voice * len(voices))(*[v.copy() for v in voices])
+        _check(load().grail_set_voices(self.handle, C.cast(arr, C.c_void_p), len(voices)))
+
+    def get_voices(self):
+        n = C.c_uint32()
+        _check(load().grail_get_voices(self.handle, None, 0, C.byref(n)))
+        arr = (Voice * max(n.value, 1))()
+        _check(load().grail_get_voices(self.handle, C.cast(arr, C.c_void_p), n.value, C.byref(n)))
+        return [arr[i].copy() for i in range(n.value)]
+
+    def set_option(self, name, value):
+        _check(load().grail_set_option(self.handle, name.encode(), value))
+
+    def get_option(self, name):
+        v = C.c_int64()
+        _check(load().grail_get_option(self.handle, name.encode(), C.byref(v)))
+        return v.value
+
+    @staticmethod
+    def _prep(segs_dtype, segs, seg_offsets, voice_ids, jitter_seeds):
+        seg_offsets = np.ascontiguousarray(seg_offsets, dtype=np.uint32)
+        n_utt = len(seg_offsets) - 1
+        if voice_ids is not None:
+            voice_ids = np.ascontiguousarray(voice_ids, dtype=np.uint32)
+            assert len(voice_ids) == n_utt
+        if jitter_seeds is not None:
+            jitter_seeds = np.ascontiguousarray(jitter_seeds, dtype=np.uint32)
+            assert len(jitter_seeds) == n_utt
+        return seg_offsets, n_utt, voice_ids, jitter_seeds
+
+    def upload(self, segs, seg_offsets, voice_ids=None, jitter_seeds=None):
+        segs = np.ascontiguousarray(segs, dtype=PHONEME_DTYPE)
+        seg_offsets, n_utt, voice_ids, jitter_seeds = self._prep(None, segs, seg_offsets,
+                                                                 voice_ids, jitter_seeds)
+        h = C.c_void_p()
+        _check(load().grail_batch_upload(self.handle, segs.ctypes.data, seg_offsets.ctypes.data,
+                                         _ptr(voice_ids), _ptr(jitter_seeds), n_utt, C.byref(h)))
+        return Batch(self, h, n_utt)
+
+    def upload_elems(self, seq_elems, seg_offsets, voice_ids=None, jitter_seeds=None):
+        arr = (SequenceElem * max(len(seq_elems), 1))(*seq_elems)
+        seg_offsets, n_utt, voice_ids, jitter_seeds = self._prep(None, None, seg_offsets,
+                                                                 voice_ids, jitter_seeds)
+        h = C.c_void_p()
+        _check(load().grail_batch_upload_elems(self.handle, C.cast(arr, C.c_void_p),
+                                               seg_offsets.ctypes.data, _ptr(voice_ids),
+                                               _ptr(jitter_seeds), n_utt, C.byref(h)))
+        return Batch(self, h, n_utt)
+
+    def synthesize(self, segs, seg_offsets, voice_ids=None, jitter_seeds=None, out_stride=None,
+                   allow_truncation=False):
+        """One-call form over host buffers.  Returns (out[n_utt, out_stride], out_len)."""
+        segs = np.ascontiguousarray(segs, dtype=PHONEME_DTYPE)
+        seg_offsets, n_utt, voice_ids, jitter_seeds = self._prep(None, segs, seg_offsets,
+                                                                 voice_ids, jitter_seeds)
+        if out_stride is None:
+            b = self.upload(segs, seg_offsets, voice_ids, jitter_seeds)
+            try:
+                lens = b.lengths()
+            finally:
+                b.free()
+            out_stride = int((max(int(lens.max()) if n_utt else 0, 1) + 3) // 4 * 4)
+        out = np.zeros((max(n_utt, 1), out_stride), dtype=np.float32)
+        out_len = np.zeros(max(n_utt, 1), dtype=np.uint32)
+        st = load().grail_synthesize_batch(self.handle, segs.ctypes.data, seg_offsets.ctypes.data,
+                                           _ptr(voice_ids), _ptr(jitter_seeds), n_utt,
+                                           out.ctypes.data, out_stride, out_len.ctypes.data,
+                                           OUT_HOST)
+        if not (allow_truncation and st == ERR_BUFFER_TOO_SMALL):
+            _check(st)
+        return out[:n_utt], out_len[:n_utt]
+
+    def synthesize_elems(self, seq_elems, seg_offsets, voice_ids=None, jitter_seeds=None,
+                         out_stride=4096):
+        arr = (SequenceElem * max(len(seq_elems), 1))(*seq_elems)
+        seg_offsets, n_utt, voice_ids, jitter_seeds = self._prep(None, None, seg_offsets,
+                                                                 voice_ids, jitter_seeds)
+        out = np.zeros((max(n_utt, 1), out_stride), dtype=np.float32)
+        out_len = np.zeros(max(n_utt, 1), dtype=np.uint32)
+        _check(load().grail_synthesize_batch_elems(
+            self.handle, C.cast(arr, C.c_void_p), seg_offsets.ctypes.data, _ptr(voice_ids),
+            _ptr(jitter_seeds), n_utt, out.ctypes.data, out_stride, out_len.ctypes.data, OUT_HOST))
+        return out[:n_utt], out_len[:n_utt]
+
+    def sync(self):
+        _check(load().grail_sync(self.handle))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        _check(load().grail_last_kernel_ms(self.handle, C.byref(ms)))
+        return ms.value
+
+    def device_alloc(self, nbytes):
+        p = C.c_void_p()
+        _check(load().grail_device_alloc(self.handle, nbytes, C.byref(p)))
+        return p
+
+    def device_free(self, p):
+        _check(load().grail_device_free(self.handle, p))
+
+    def d2h(self, dst, src_dev, nbytes, offset=0):
+        src = C.c_void_p(src_dev.value + offset)
+        _check(load().grail_memcpy_d2h(self.handle, dst.ctypes.data, src, nbytes))
+
+    def memset(self, dst_dev, value, nbytes):
+        _check(load().grail_memset_d(self.handle, dst_dev, value, nbytes))
+
+    # RCCL
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_uint8 * UNIQUE_ID_BYTES)()
+        _check(load().grail_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        buf = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        _check(load().grail_comm_init(self.handle, buf, rank, world))
+
+    def broadcast_voices(self, n_voices, root=0):
+        _check(load().grail_broadcast_voices(self.handle, n_voices, root))

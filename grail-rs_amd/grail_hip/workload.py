@@ -1,0 +1,102 @@
+"""Deterministic synthetic workloads of SURVEY.md §8d / BASELINE.json configs.
+
+Inputs only (segment lists, seeds, voice presets) — no synthesis arithmetic.
+Used by bench.py and the parity tests so both sides see identical inputs.
+"""
+import numpy as np
+
+from . import (NUM_FORMANTS, PH_A, PH_E, PH_SILENCE, PHONEME_DTYPE, elem_new_phoneme,
+               elem_resample, voice_generic)
+
+SAMPLE_RATE = 48000.0
+SEGMENTS_PER_UTT = 4
+
+
+def _lcg(s):
+    # the crate's own generator state update, reference src/lib.rs:40
+    return (s * np.uint32(16807) + np.uint32(1)).astype(np.uint32)
+
+
+def make_batch(n_utt, first_utt=0, n_voices=1, segments=SEGMENTS_PER_UTT, sample_rate=SAMPLE_RATE,
+               length=0.5, blend_length=0.5):
+    """Utterances [first_utt, first_utt + n_utt) of the synthetic corpus.
+
+    Utterance u: `segments` segments; segment 0 is Silence (what .transcribe()
+    always emits first, reference src/lib.rs:1201), the others draw from
+    (A, E, Silence); length/blend_length are the Intonator's constants
+    (src/lib.rs:1070-1071); pitch 100..200 Hz; jitter seed = u; voice = u mod n_voices.
+    Returns (segs, seg_offsets, voice_ids, jitter_seeds).
+    """
+    with np.errstate(over="ignore"):
+        u = (np.arange(n_utt, dtype=np.uint64) + np.uint64(first_utt)).astype(np.uint32)
+        s = (u ^ np.uint32(0x9E3779B9)).astype(np.uint32)
+        segs = np.zeros((n_utt, segments), dtype=PHONEME_DTYPE)
+        choices = np.array([PH_A, PH_E, PH_SILENCE], dtype=np.int32)
+        for i in range(segments):
+            s = _lcg(s)
+            ph = choices[(s >> np.uint32(16)) % np.uint32(3)]
+            if i == 0:
+                ph = np.full(n_utt, PH_SILENCE, dtype=np.int32)
+            s = _lcg(s)
+            hz = (np.uint32(100) + (s >> np.uint32(16)) % np.uint32(101)).astype(np.float32)
+            segs["phoneme"][:, i] = ph
+            segs["length"][:, i] = np.float32(length)
+            segs["blend_length"][:, i] = np.float32(blend_length)
+            segs["frequency"][:, i] = hz / np.float32(sample_rate)
+    seg_offsets = (np.arange(n_utt + 1, dtype=np.uint64) * segments).astype(np.uint32)
+    voice_ids = (u % np.uint32(max(n_voices, 1))).astype(np.uint32)
+    jitter_seeds = u.copy()
+    return segs.reshape(-1), seg_offsets, voice_ids, jitter_seeds
+
+
+# BASELINE.json config 4: 8 presets with divergent formant coefficients.  The
+# reference ships one voice (src/voices/mod.rs:17-20); these are the build's own:
+# generic()'s phoneme tables with the formant frequencies scaled (vocal-tract
+# length), a different centre pitch, and all eight formant amplitudes live.
+PRESET_FREQ_SCALE = [0.80, 0.87, 0.94, 1.00, 1.07, 1.14, 1.21, 1.28]
+PRESET_PITCH_HZ = [90.0, 110.0, 120.0, 140.0, 165.0, 190.0, 220.0, 250.0]
+PRESET_AMP = [0.3, 0.25, 0.15, 0.1, 0.08, 0.06, 0.04, 0.02]
+
+# src/voices/generic.rs:9-32 raw tables (Hz), MKPHON order freq, bw, smooth, turb, breath
+_GENERIC_RAW = {
+    "a": dict(freq=[910.0, 1271.0, 2851.0, 3213.0, 1200.0, 2000.0, 3000.0, 4000.0],
+              bw=[60.0, 160.0, 180.0, 200.0, 100.0, 100.0, 100.0, 100.0],
+              smooth=[1600.0] * 8,
+              turb=[0.2, 0.2, 0.1, 0.0, 0.0, 0.0, 0.0, 0.0],
+              breath=[0.5, 0.2, 0.05, 0.0, 0.0, 0.0, 0.0, 0.0]),
+    "e": dict(freq=[910.0, 1871.0, 2851.0, 3213.0, 1200.0, 2000.0, 3000.0, 4000.0],
+              bw=[80.0, 180.0, 180.0, 200.0, 100.0, 100.0, 100.0, 100.0],
+              smooth=[1600.0] * 8,
+              turb=[0.2, 0.4, 0.4, 0.4, 0.4, 0.4, 0.4, 0.4],
+              breath=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.1, 0.1]),
+}
+
+
+def preset_voices(n=8, sample_rate=SAMPLE_RATE):
+    voices = []
+    for k in range(n):
+        v = voice_generic(sample_rate)
+        scale = np.float32(PRESET_FREQ_SCALE[k % 8])
+        for p, name in enumerate(("a", "e")):
+            raw = _GENERIC_RAW[name]
+            freq = (np.array(raw["freq"], dtype=np.float32) * scale).astype(np.float32)
+            e = elem_new_phoneme(freq, raw["bw"], raw["smooth"], raw["turb"], raw["breath"],
+                                 PRESET_AMP)
+            v.phonemes[p] = elem_resample(e, 44100.0, sample_rate)
+        v.center_frequency = float(np.float32(PRESET_PITCH_HZ[k % 8]) / np.float32(sample_rate))
+        voices.append(v)
+    return voices
+
+
+def single_voice(sample_rate=SAMPLE_RATE):
+    return [voice_generic(sample_rate)]
+
+
+def max_samples(segments=SEGMENTS_PER_UTT, length=0.5, sample_rate=SAMPLE_RATE):
+    """A safe out_stride (multiple of 4) for make_batch's utterances: the f32
+    Sequencer clock yields a few samples more than length*rate per segment."""
+    n = int(np.ceil(segments * length * sample_rate)) + 4 * segments + 8
+    return (n + 3) // 4 * 4
+
+
+assert NUM_FORMANTS == 8

@@ -1,0 +1,247 @@
+/*
+ * grail_hip.h — C ABI of the MI355X-native (gfx950) batched implementation of
+ * the grail-rs per-sample synthesis hot path.
+ *
+ * What it replaces.  grail-rs has no FFI layer; its boundary for this path is
+ * the iterator-adapter API (reference = /root/reference):
+ *
+ *     phoneme_elems.into_iter()
+ *         .select(voice)          // src/lib.rs:1013  Selector::next   :990
+ *         .sequence(voice)        // src/lib.rs:941   Sequencer::next  :859
+ *         .jitter(seed, voice)    // src/lib.rs:786   Jitter::next     :753
+ *         .synthesize()           // src/lib.rs:587   Synthesize::next :497
+ *         .collect::<Vec<f32>>()
+ *
+ * grail_synthesize_batch() is that expression evaluated for N independent
+ * utterances at once on one GPU; every entry point below cites the reference
+ * item it stands for.  INTEGRATION.md shows the Rust `extern "C"` block and
+ * the IntoSynthesizeBatch trait shim a maintainer would add.
+ *
+ * Types are plain-old-data with the reference's declared field order; no
+ * torch / HIP types appear in any signature (device memory is `void *`).
+ *
+ * Determinism contract: the samples of utterance u are a pure
+ * function of (its segments, its voice, its jitter seed) — independent of the
+ * batch size, its position in the batch, the lane mapping and the GPU count —
+ * and are bit-identical to the reference's IEEE-754 binary32 arithmetic
+ * (no FMA contraction, correctly rounded division, denormals kept).
+ *
+ * There is no CPU fallback: every compute entry point fails with
+ * GRAIL_ERR_NO_DEVICE when no gfx950-capable HIP device is usable.
+ */
+#ifndef GRAIL_HIP_H
+#define GRAIL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRAIL_ABI_VERSION 1
+
+/* src/lib.rs:24  NUM_FORMANTS, src/lib.rs:21 DEFAULT_SAMPLE_RATE */
+#define GRAIL_NUM_FORMANTS 8
+#define GRAIL_DEFAULT_SAMPLE_RATE 44100.0f
+
+/* Phoneme: src/lib.rs:632-649 with make_phonemes!(A a test, E e test) :686-689.
+ * Discriminants follow the declaration order of the Rust enum. */
+typedef enum grail_phoneme {
+    GRAIL_PH_SILENCE = 0, /* src/lib.rs:635 */
+    GRAIL_PH_STOP    = 1, /* src/lib.rs:640 */
+    GRAIL_PH_GLIDE   = 2, /* src/lib.rs:643 */
+    GRAIL_PH_A       = 3,
+    GRAIL_PH_E       = 4,
+    GRAIL_PH_COUNT   = 5
+} grail_phoneme;
+/* number of VoiceStorage fields (src/lib.rs:653-659): a, e */
+#define GRAIL_NUM_VOICED 2
+#define GRAIL_PH_FIRST_VOICED GRAIL_PH_A
+
+typedef enum grail_status {
+    GRAIL_OK                   = 0,
+    GRAIL_ERR_INVALID_ARG      = -1,
+    GRAIL_ERR_NO_DEVICE        = -2, /* no usable HIP device: there is NO CPU fallback */
+    GRAIL_ERR_HIP              = -3, /* a hip* call failed; see grail_last_error() */
+    GRAIL_ERR_BUFFER_TOO_SMALL = -4, /* >=1 utterance did not end within out_stride samples */
+    GRAIL_ERR_OUT_OF_MEMORY    = -5,
+    GRAIL_ERR_RCCL             = -6,
+    GRAIL_ERR_NO_VOICES        = -7  /* grail_set_voices() has not been called */
+} grail_status;
+
+/* SynthesisElem: src/lib.rs:316-337, 49 x f32 in declared order.
+ * `Array` (src/lib.rs:88) is float[8]. */
+typedef struct grail_synthesis_elem {
+    float frequency;
+    float formant_freq[GRAIL_NUM_FORMANTS];
+    float formant_bw[GRAIL_NUM_FORMANTS];
+    float formant_smooth[GRAIL_NUM_FORMANTS];
+    float formant_breath[GRAIL_NUM_FORMANTS];
+    float formant_turb[GRAIL_NUM_FORMANTS];
+    float formant_amp[GRAIL_NUM_FORMANTS];
+} grail_synthesis_elem;
+
+/* Voice: src/lib.rs:696-717; `phonemes` is VoiceStorage {a, e} (src/lib.rs:653-659). */
+typedef struct grail_voice {
+    float                sample_rate;
+    grail_synthesis_elem phonemes[GRAIL_NUM_VOICED];
+    float                center_frequency;
+    float                jitter_frequency;
+    float                jitter_delta_frequency;
+    float                jitter_delta_formant_frequency;
+    float                jitter_delta_amplitude;
+} grail_voice;
+
+/* PhonemeElem: src/lib.rs:961-973 (the Selector's input item). */
+typedef struct grail_phoneme_elem {
+    int32_t phoneme;      /* grail_phoneme */
+    float   length;       /* seconds */
+    float   blend_length; /* seconds */
+    float   frequency;    /* normalised to the sample rate */
+} grail_phoneme_elem;
+
+/* SequenceElem: src/lib.rs:814-824 (the Sequencer's input item);
+ * Option<SynthesisElem> is (has_elem, elem). */
+typedef struct grail_sequence_elem {
+    int32_t              has_elem;
+    grail_synthesis_elem elem;
+    float                length;
+    float                blend_length;
+} grail_sequence_elem;
+
+typedef struct grail_ctx   grail_ctx;   /* one per (process, GPU); owns a HIP stream */
+typedef struct grail_batch grail_batch; /* inputs of one batch, resident in HBM */
+
+/* flags of grail_synthesize_batch*() */
+#define GRAIL_OUT_HOST   0u /* `out` is host memory (pageable or pinned) */
+#define GRAIL_OUT_DEVICE 1u /* `out` is device memory of ctx's GPU; no copy is made */
+
+/* ---- library ----------------------------------------------------------- */
+int         grail_abi_version(void);
+const char *grail_status_string(int status);
+/* text of the last failure on this thread ("" if none) */
+const char *grail_last_error(void);
+
+/* ---- host-side parameter algebra (per voice / per phoneme, once) ------- */
+/* SynthesisElem::silent()  src/lib.rs:367-377 */
+void grail_elem_silent(grail_synthesis_elem *out);
+/* SynthesisElem::new_phoneme(freq, bw, smooth, turb, breath, amp)  src/lib.rs:381-401
+ * (== voices::MKPHON, src/voices/mod.rs:7-14); each argument is float[8]. */
+void grail_elem_new_phoneme(grail_synthesis_elem *out, const float *formant_freq,
+                            const float *formant_bw, const float *formant_smooth,
+                            const float *formant_turb, const float *formant_breath,
+                            const float *formant_amp);
+/* SynthesisElem::new(sample_rate, frequency, freq, smooth, bw, breath, turb, amp)
+ * src/lib.rs:343-364 — note the argument order differs from new_phoneme. */
+void grail_elem_new(grail_synthesis_elem *out, float sample_rate, float frequency,
+                    const float *formant_freq, const float *formant_smooth,
+                    const float *formant_bw, const float *formant_breath,
+                    const float *formant_turb, const float *formant_amp);
+/* SynthesisElem::resample(old, new) in place  src/lib.rs:418-440 */
+void grail_elem_resample(grail_synthesis_elem *elem, float old_sample_rate,
+                         float new_sample_rate);
+/* SynthesisElem::blend(self, other, alpha)  src/lib.rs:404-414 */
+void grail_elem_blend(grail_synthesis_elem *out, const grail_synthesis_elem *self,
+                      const grail_synthesis_elem *other, float alpha);
+/* voices::generic()  src/voices/generic.rs:5-40 */
+void grail_voice_generic(grail_voice *out);
+/* generic() carried to another sample rate (the reference ships 44.1 kHz only):
+ * every phoneme .resample(44100, rate) (src/lib.rs:418 through for_all :674),
+ * sample_rate = rate, scalars 120/rate, 16/rate, 6/rate, 6/rate, 0.2
+ * (cf. src/voices/generic.rs:34-38).  SURVEY.md §8d "48 kHz voice". */
+void grail_voice_generic_at(grail_voice *out, float sample_rate);
+/* VoiceStorage::get(phoneme)  src/lib.rs:664-671; returns 1 and fills *out for a
+ * voiced phoneme, 0 for Silence/Stop/Glide (None). */
+int grail_voice_get(const grail_voice *voice, int32_t phoneme, grail_synthesis_elem *out);
+
+/* ---- context ----------------------------------------------------------- */
+/* Binds to HIP device `device` (>= 0) and creates a stream.
+ * GRAIL_ERR_NO_DEVICE when HIP reports no such device. */
+int grail_create(int device, grail_ctx **out);
+int grail_destroy(grail_ctx *ctx);
+int grail_device_count(int *count);
+/* Uploads the voice table (the `voice` argument of .select/.sequence/.jitter,
+ * src/lib.rs:1013, 941, 786) to HBM.  Utterances refer to it by voice id. */
+int grail_set_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices);
+int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t *n_voices);
+/* Tuning knobs. name = "lanes_per_utterance": 0 = auto, or 1/2/4/8 — how many
+ * wavefront lanes share one utterance's 8 formants.  Never changes results. */
+int grail_set_option(grail_ctx *ctx, const char *name, int64_t value);
+int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value);
+
+/* ---- batches ----------------------------------------------------------- */
+/* Uploads the inputs of n_utt utterances: utterance u is
+ *   segs[seg_offsets[u] .. seg_offsets[u+1]).into_iter()
+ *       .select(v).sequence(v).jitter(jitter_seeds[u], v).synthesize()
+ * with v = voices[voice_ids[u]].  voice_ids == NULL means voice 0 for all,
+ * jitter_seeds == NULL means seed 0 for all (examples/cli.rs:182). */
+int grail_batch_upload(grail_ctx *ctx, const grail_phoneme_elem *segs,
+                       const uint32_t *seg_offsets, const uint32_t *voice_ids,
+                       const uint32_t *jitter_seeds, uint32_t n_utt, grail_batch **out);
+/* Same, for callers that build SequenceElems themselves (skips the Selector):
+ *   segs[..].into_iter().sequence(v).jitter(seed, v).synthesize() */
+int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
+                             const uint32_t *seg_offsets, const uint32_t *voice_ids,
+                             const uint32_t *jitter_seeds, uint32_t n_utt,
+                             grail_batch **out);
+int grail_batch_free(grail_ctx *ctx, grail_batch *batch);
+uint32_t grail_batch_size(const grail_batch *batch);
+
+/* Sequencer clock pre-pass (src/lib.rs:861-888 only): the number of samples
+ * each utterance yields, capped at max_len.  out_len is host memory [n_utt]. */
+int grail_batch_lengths(grail_ctx *ctx, const grail_batch *batch, uint32_t max_len,
+                        uint32_t *out_len);
+
+/* Enqueue the fused Sequencer->Jitter->Synthesize kernel on ctx's stream.
+ * out_dev: device memory, utterance u written at out_dev + u*out_stride,
+ * samples past its end are left untouched.  out_len_dev: device memory [n_utt]
+ * (samples written, <= out_stride) or NULL.  Returns without waiting. */
+int grail_batch_synthesize_async(grail_ctx *ctx, const grail_batch *batch, float *out_dev,
+                                 uint64_t out_stride, uint32_t *out_len_dev);
+/* Wait for ctx's stream.  Returns GRAIL_ERR_BUFFER_TOO_SMALL if any utterance
+ * of a kernel enqueued since the last sync was cut at out_stride. */
+int grail_sync(grail_ctx *ctx);
+/* HIP-event time (ms) of the most recent synthesis kernel on ctx's stream
+ * (events recorded on the stream the kernel is launched on).  Syncs. */
+int grail_last_kernel_ms(grail_ctx *ctx, float *ms);
+
+/* One-call forms: upload, synthesize, copy back (GRAIL_OUT_HOST) or leave in
+ * place (GRAIL_OUT_DEVICE), wait.  out_len is host memory [n_utt] or NULL. */
+int grail_synthesize_batch(grail_ctx *ctx, const grail_phoneme_elem *segs,
+                           const uint32_t *seg_offsets, const uint32_t *voice_ids,
+                           const uint32_t *jitter_seeds, uint32_t n_utt, float *out,
+                           uint64_t out_stride, uint32_t *out_len, uint32_t flags);
+int grail_synthesize_batch_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
+                                 const uint32_t *seg_offsets, const uint32_t *voice_ids,
+                                 const uint32_t *jitter_seeds, uint32_t n_utt, float *out,
+                                 uint64_t out_stride, uint32_t *out_len, uint32_t flags);
+
+/* ---- device memory plumbing ------------------------------------------- */
+int grail_device_alloc(grail_ctx *ctx, size_t bytes, void **out);
+int grail_device_free(grail_ctx *ctx, void *ptr);
+int grail_memcpy_d2h(grail_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int grail_memcpy_h2d(grail_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int grail_memset_d(grail_ctx *ctx, void *dst_dev, int value, size_t bytes);
+
+/* ---- multi-GPU: utterance sharding + voice-table broadcast ------------- */
+/* Contiguous utterance range of `rank` out of `world`:
+ * [rank*n/world, (rank+1)*n/world) in 64-bit arithmetic. */
+void grail_shard_range(uint64_t n_utt, uint32_t rank, uint32_t world, uint64_t *begin,
+                       uint64_t *end);
+/* RCCL path (one process per GPU).  grail_comm_unique_id fills a 128-byte id
+ * on rank 0 that the launcher hands to every rank out of band;
+ * grail_comm_init joins the communicator; grail_broadcast_voices sends rank
+ * `root`'s voice table (grail_set_voices) to every rank's HBM with one
+ * ncclBroadcast on ctx's stream and installs it there. */
+#define GRAIL_UNIQUE_ID_BYTES 128
+int grail_comm_unique_id(uint8_t id[GRAIL_UNIQUE_ID_BYTES]);
+int grail_comm_init(grail_ctx *ctx, const uint8_t id[GRAIL_UNIQUE_ID_BYTES], uint32_t rank,
+                    uint32_t world);
+int grail_broadcast_voices(grail_ctx *ctx, uint32_t n_voices, uint32_t root);
+int grail_comm_destroy(grail_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAIL_HIP_H */
