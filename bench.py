@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--utts", type=int, default=65536, help="utterances per GPU")
     ap.add_argument("--voices", type=int, default=1, help="1 = single Voice, 8 = config-4 presets")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per utterance (0 = auto)")
+    ap.add_argument("--variant", type=int, default=0, help="kernel instantiation (experiments)")
     ap.add_argument("--cpu-utts", type=int, default=512, help="utterances for the CPU baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -104,6 +105,7 @@ def main():
     segs, offs, vids, seeds = W.make_batch(last - first, first_utt=first, n_voices=len(voices))
     batch = ctx.upload(segs, offs, vids, seeds)
     ctx.set_option("lanes_per_utterance", args.lanes)
+    ctx.set_option("kernel_variant", args.variant)
     d_out = ctx.device_alloc(n_utt * stride * 4)
     d_len = ctx.device_alloc(n_utt * 4)
 

@@ -99,6 +99,7 @@ struct grail_ctx {
     float *d_voice_elems = nullptr;   // [n_voices * NUM_VOICED][49]
     uint32_t *d_truncated = nullptr;  // one word
     int lanes_option = 0;             // 0 = auto
+    int variant_option = 0;           // experiments: explicit kernel instantiation
     ncclComm_t comm = nullptr;
     uint32_t comm_rank = 0, comm_world = 1;
 };
@@ -304,6 +305,11 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         ctx->lanes_option = (int)value;
         return GRAIL_OK;
     }
+    if (std::strcmp(name, "kernel_variant") == 0) {
+        if (value < 0 || value > 8) return fail(GRAIL_ERR_INVALID_ARG, "kernel_variant out of range");
+        ctx->variant_option = (int)value;
+        return GRAIL_OK;
+    }
     return fail(GRAIL_ERR_INVALID_ARG, std::string("unknown option ") + name);
 }
 
@@ -312,6 +318,10 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
     if (!ctx || !name || !value) return fail(GRAIL_ERR_INVALID_ARG, "NULL argument");
     if (std::strcmp(name, "lanes_per_utterance") == 0) {
         *value = ctx->lanes_option;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "kernel_variant") == 0) {
+        *value = ctx->variant_option;
         return GRAIL_OK;
     }
     return fail(GRAIL_ERR_INVALID_ARG, std::string("unknown option ") + name);
@@ -456,7 +466,7 @@ int grail_batch_synthesize_async(grail_ctx *ctx, const grail_batch *batch, float
     a.phoneme_mode = batch->phoneme_mode ? 1u : 0u;
     const int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(batch->n_utt);
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
-    hipError_t e = launch_synth(a, L, ctx->stream);
+    hipError_t e = launch_synth(a, L, ctx->variant_option, ctx->stream);
     if (e != hipSuccess) return hip_fail(e, "synth kernel launch");
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->have_timing = true;
@@ -502,6 +512,8 @@ static int run_one_call(grail_ctx *ctx, grail_batch *b, uint32_t n_utt, float *o
         d_out = out;
     } else if (out_bytes) {
         e = hipMalloc((void **)&d_out, out_bytes);
+        // the whole block is copied back: rows end in zeros, not stale HBM
+        if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, out_bytes, ctx->stream);
     }
     if (e == hipSuccess && n_utt) e = hipMalloc((void **)&d_len, (size_t)n_utt * sizeof(uint32_t));
     if (e != hipSuccess) rc = hip_fail(e, "output allocation");

@@ -68,7 +68,7 @@ struct LenArgs {
 };
 
 // lanes_per_utt in {1, 2, 4, 8}; returns hipSuccess or the launch error.
-hipError_t launch_synth(const SynthArgs &args, int lanes_per_utt, hipStream_t stream);
+hipError_t launch_synth(const SynthArgs &args, int lanes_per_utt, int variant, hipStream_t stream);
 hipError_t launch_lengths(const LenArgs &args, hipStream_t stream);
 // the choice made when the option is 0 (auto)
 int auto_lanes_per_utt(uint32_t n_utt);

@@ -147,22 +147,27 @@ __device__ __forceinline__ void fetch_seg(Seg &s, const DevSeg *__restrict__ seg
     }
 }
 
-template <int L, int T>
-__global__ __launch_bounds__(64) void synth_kernel(const SynthArgs A)
+template <int L, int T, int WAVES, int MIN_WAVES_PER_SIMD>
+__global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(const SynthArgs A)
 {
     constexpr int FPL = NF / L;   // formants per lane
     constexpr int S = 64 / L;     // utterances per wave
     constexpr int SP = S + 1;     // padded row of the staging tile
     static_assert(T % 4 == 0 && (64 % (T / 4)) == 0, "T");
 
-    __shared__ float stage[T * SP];
-    __shared__ uint32_t cnt[S];
+    // every wave of the block works alone on its own S utterances and its own
+    // slice of LDS: there is no inter-wave communication and no block barrier
+    __shared__ float stage_all[WAVES][T * SP];
+    __shared__ uint32_t cnt_all[WAVES][S];
+    const int wave = threadIdx.x / 64;
+    float *stage = stage_all[wave];
+    uint32_t *cnt = cnt_all[wave];
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x % 64;
     const int slot = lane / L;
     const int j = lane % L;
     const int f0 = j * FPL;
-    const uint32_t u0 = blockIdx.x * S;
+    const uint32_t u0 = (blockIdx.x * WAVES + wave) * S;
     const uint32_t u = u0 + slot;
     bool done = u >= A.n_utt;
     const uint32_t uc = done ? 0u : u;
@@ -481,16 +486,37 @@ int auto_lanes_per_utt(uint32_t n_utt)
     return 8;
 }
 
-hipError_t launch_synth(const SynthArgs &args, int L, hipStream_t stream)
+template <int L, int T, int WAVES, int MINW>
+static void launch_one(const SynthArgs &args, hipStream_t stream)
+{
+    const uint32_t per_block = (64u / L) * WAVES;
+    const dim3 grid((args.n_utt + per_block - 1) / per_block), block(64 * WAVES);
+    hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW>), grid, block, 0, stream, args);
+}
+
+hipError_t launch_synth(const SynthArgs &args, int L, int variant, hipStream_t stream)
 {
     if (args.n_utt == 0) return hipSuccess;
-    const uint32_t S = 64u / (uint32_t)L;
-    const dim3 grid((args.n_utt + S - 1) / S), block(64);
+    // 64-thread workgroups are admitted 8 per CU (2 waves per SIMD, measured); the
+    // mappings that want more resident waves use 256-thread workgroups.
+    // `variant` (tuning/experiments only) picks another <L, T, WAVES, MIN_WAVES_PER_SIMD>.
+    switch (variant) {
+    case 0: break;
+    case 1: launch_one<2, 64, 4, 2>(args, stream); return hipGetLastError();
+    case 2: launch_one<2, 64, 4, 3>(args, stream); return hipGetLastError();
+    case 3: launch_one<2, 64, 4, 4>(args, stream); return hipGetLastError();
+    case 4: launch_one<4, 64, 1, 4>(args, stream); return hipGetLastError();
+    case 5: launch_one<4, 64, 4, 5>(args, stream); return hipGetLastError();
+    case 6: launch_one<1, 32, 4, 2>(args, stream); return hipGetLastError();
+    case 7: launch_one<8, 64, 4, 6>(args, stream); return hipGetLastError();
+    case 8: launch_one<4, 64, 8, 4>(args, stream); return hipGetLastError();
+    default: return hipErrorInvalidValue;
+    }
     switch (L) {
-    case 1: hipLaunchKernelGGL((synth_kernel<1, 32>), grid, block, 0, stream, args); break;
-    case 2: hipLaunchKernelGGL((synth_kernel<2, 64>), grid, block, 0, stream, args); break;
-    case 4: hipLaunchKernelGGL((synth_kernel<4, 64>), grid, block, 0, stream, args); break;
-    case 8: hipLaunchKernelGGL((synth_kernel<8, 64>), grid, block, 0, stream, args); break;
+    case 1: launch_one<1, 32, 1, 1>(args, stream); break;
+    case 2: launch_one<2, 64, 1, 2>(args, stream); break;
+    case 4: launch_one<4, 64, 4, 4>(args, stream); break;
+    case 8: launch_one<8, 64, 4, 4>(args, stream); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -37,7 +37,8 @@ OUT_DEVICE = 1
 UNIQUE_ID_BYTES = 128
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgrail_hip.so")
+LIB_PATH = os.environ.get("GRAIL_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib",
+                                                         "libgrail_hip.so")
 
 # every symbol include/grail_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [

@@ -207,7 +207,9 @@ int grail_sync(grail_ctx *ctx);
 int grail_last_kernel_ms(grail_ctx *ctx, float *ms);
 
 /* One-call forms: upload, synthesize, copy back (GRAIL_OUT_HOST) or leave in
- * place (GRAIL_OUT_DEVICE), wait.  out_len is host memory [n_utt] or NULL. */
+ * place (GRAIL_OUT_DEVICE), wait.  out_len is host memory [n_utt] or NULL.
+ * GRAIL_OUT_HOST overwrites all n_utt*out_stride floats: each row is its
+ * samples followed by zeros.  GRAIL_OUT_DEVICE leaves the tail untouched. */
 int grail_synthesize_batch(grail_ctx *ctx, const grail_phoneme_elem *segs,
                            const uint32_t *seg_offsets, const uint32_t *voice_ids,
                            const uint32_t *jitter_seeds, uint32_t n_utt, float *out,

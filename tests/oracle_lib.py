@@ -192,6 +192,10 @@ def trace_elems(voice, segs, jitter_seed, stage):
     return out[:n]
 
 
+def _zeros_if_none(a, n):
+    return np.zeros(n, dtype=np.uint32) if a is None else a
+
+
 def synthesize_batch(voices, segs, seg_offsets, voice_ids, jitter_seeds, out_stride):
     """voices: list of Voice.  Returns (out[n_utt, out_stride], out_len[n_utt])."""
     L = lib()
@@ -199,8 +203,8 @@ def synthesize_batch(voices, segs, seg_offsets, voice_ids, jitter_seeds, out_str
     segs = np.ascontiguousarray(segs, dtype=PHONEME_DTYPE)
     seg_offsets = np.ascontiguousarray(seg_offsets, dtype=np.uint32)
     n_utt = len(seg_offsets) - 1
-    voice_ids = np.ascontiguousarray(voice_ids, dtype=np.uint32)
-    jitter_seeds = np.ascontiguousarray(jitter_seeds, dtype=np.uint32)
+    voice_ids = np.ascontiguousarray(_zeros_if_none(voice_ids, n_utt), dtype=np.uint32)
+    jitter_seeds = np.ascontiguousarray(_zeros_if_none(jitter_seeds, n_utt), dtype=np.uint32)
     out = np.zeros((n_utt, out_stride), dtype=np.float32)
     out_len = np.zeros(n_utt, dtype=np.uint32)
     L.orc_synthesize_batch(C.cast(varr, C.c_void_p), len(voices), segs.ctypes.data,
@@ -216,8 +220,8 @@ def count_batch(voices, segs, seg_offsets, voice_ids, jitter_seeds):
     segs = np.ascontiguousarray(segs, dtype=PHONEME_DTYPE)
     seg_offsets = np.ascontiguousarray(seg_offsets, dtype=np.uint32)
     n_utt = len(seg_offsets) - 1
-    voice_ids = np.ascontiguousarray(voice_ids, dtype=np.uint32)
-    jitter_seeds = np.ascontiguousarray(jitter_seeds, dtype=np.uint32)
+    voice_ids = np.ascontiguousarray(_zeros_if_none(voice_ids, n_utt), dtype=np.uint32)
+    jitter_seeds = np.ascontiguousarray(_zeros_if_none(jitter_seeds, n_utt), dtype=np.uint32)
     out_len = np.zeros(n_utt, dtype=np.uint32)
     L.orc_synthesize_batch(C.cast(varr, C.c_void_p), len(voices), segs.ctypes.data,
                            seg_offsets.ctypes.data, voice_ids.ctypes.data,
