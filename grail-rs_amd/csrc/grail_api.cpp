@@ -97,7 +97,8 @@ struct grail_ctx {
     std::vector<grail_voice> voices;  // host copy of the table
     DevVoice *d_voices = nullptr;
     float *d_voice_elems = nullptr;   // [n_voices * NUM_VOICED][49]
-    uint32_t *d_truncated = nullptr;  // one word
+    uint32_t *d_truncated = nullptr;  // [0] truncation flag, [1] slow-path wave-steps
+    uint64_t slow_steps = 0;          // of the kernels synced so far
     int lanes_option = 0;             // 0 = auto
     int variant_option = 0;           // experiments: explicit kernel instantiation
     ncclComm_t comm = nullptr;
@@ -255,8 +256,8 @@ int grail_create(int device, grail_ctx **out)
     if ((err = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (err = hipEventCreate(&ctx->ev_start)) != hipSuccess ||
         (err = hipEventCreate(&ctx->ev_stop)) != hipSuccess ||
-        (err = hipMalloc((void **)&ctx->d_truncated, sizeof(uint32_t))) != hipSuccess ||
-        (err = hipMemset(ctx->d_truncated, 0, sizeof(uint32_t))) != hipSuccess) {
+        (err = hipMalloc((void **)&ctx->d_truncated, 2 * sizeof(uint32_t))) != hipSuccess ||
+        (err = hipMemset(ctx->d_truncated, 0, 2 * sizeof(uint32_t))) != hipSuccess) {
         grail_destroy(ctx);
         return hip_fail(err, "grail_create");
     }
@@ -322,6 +323,10 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
     }
     if (std::strcmp(name, "kernel_variant") == 0) {
         *value = ctx->variant_option;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "slow_division_wave_steps") == 0) {  // read-only statistic
+        *value = (int64_t)ctx->slow_steps;
         return GRAIL_OK;
     }
     return fail(GRAIL_ERR_INVALID_ARG, std::string("unknown option ") + name);
@@ -478,10 +483,12 @@ int grail_sync(grail_ctx *ctx)
     int rc = bind(ctx);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    uint32_t flag = 0;
-    HIP_TRY(hipMemcpy(&flag, ctx->d_truncated, sizeof flag, hipMemcpyDeviceToHost));
+    uint32_t flags[2] = {0, 0};
+    HIP_TRY(hipMemcpy(flags, ctx->d_truncated, sizeof flags, hipMemcpyDeviceToHost));
+    const uint32_t flag = flags[0];
+    if (flags[0] || flags[1]) HIP_TRY(hipMemset(ctx->d_truncated, 0, sizeof flags));
+    ctx->slow_steps += flags[1];
     if (flag) {
-        HIP_TRY(hipMemset(ctx->d_truncated, 0, sizeof flag));
         return fail(GRAIL_ERR_BUFFER_TOO_SMALL,
                     "at least one utterance did not end within out_stride samples");
     }

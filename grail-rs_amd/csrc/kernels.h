@@ -49,7 +49,8 @@ struct SynthArgs {
     const DevVoice *voices;
     float *out;
     uint32_t *out_len;            // may be nullptr
-    uint32_t *truncated;          // one word, set to 1 when an utterance is cut at out_stride
+    uint32_t *truncated;          // [0]: set to 1 when an utterance is cut at out_stride;
+                                  // [1]: += wave-steps that ran the IEEE-division body
     uint64_t out_stride;
     uint32_t n_utt;
     uint32_t n_voices;

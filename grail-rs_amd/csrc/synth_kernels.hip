@@ -35,7 +35,45 @@ __device__ __forceinline__ float lcg_f32(uint32_t &s)
     return (__uint_as_float((s >> 9) | 0x3F800000u) - 1.5f) * 2.0f;
 }
 
+// Correctly rounded f32 division without the v_div_scale / v_div_fmas / v_div_fixup
+// wrapper.  SAFE = true requires both operands finite, normal and within
+// [2^-60, 2^60] in magnitude (then no intermediate can over- or underflow and the
+// rounding depends on the significands only).  For that window the sequence is
+// PROVEN equal to IEEE division by exhaustion over all 2^46 significand pairs with
+// an exact integer remainder check (tools/div_exhaustive.hip,
+// profiles/r01_div_exhaustive.txt), so the result is bit-identical to `a / b`.
+template <bool SAFE>
+__device__ __forceinline__ float div_exact(float a, float b)
+{
+    if constexpr (SAFE) {
+        float y = __builtin_amdgcn_rcpf(b);
+        const float e = __builtin_fmaf(-b, y, 1.0f);
+        y = __builtin_fmaf(e, y, y);               // RN(1/b)
+        const float q = a * y;
+        const float r = __builtin_fmaf(-b, q, a);  // exact remainder
+        return __builtin_fmaf(r, y, q);
+    } else {
+        return a / b;                              // hipcc's IEEE sequence
+    }
+}
+
+// 1/x: v_rcp_f32 + one Newton step equals the correctly rounded reciprocal for every
+// float with |x| in [2^-60, 2^61) (exhaustive, tools/div_check.hip,
+// profiles/r01_div_check.txt).
+template <bool SAFE>
+__device__ __forceinline__ float rcp_exact(float x)
+{
+    if constexpr (SAFE) {
+        const float y = __builtin_amdgcn_rcpf(x);
+        const float e = __builtin_fmaf(-x, y, 1.0f);
+        return __builtin_fmaf(e, y, y);
+    } else {
+        return 1.0f / x;
+    }
+}
+
 // tan_approx, src/lib.rs:63-70 (tan(pi x), Bhaskara-style rational)
+template <bool SAFE>
 __device__ __forceinline__ float tan_approx(float x)
 {
     const float omx = 1.0f - x;
@@ -43,7 +81,7 @@ __device__ __forceinline__ float tan_approx(float x)
     const float hmx = 0.5f - x;
     const float num = (omx * x) * (5.0f - (4.0f * xph) * hmx);
     const float den = (xph * (5.0f - (4.0f * omx) * x)) * hmx;
-    return num / den;
+    return div_exact<SAFE>(num, den);
 }
 
 // exp_approx, src/lib.rs:75-82 ((1-x)^5)
@@ -147,6 +185,65 @@ __device__ __forceinline__ void fetch_seg(Seg &s, const DevSeg *__restrict__ seg
     }
 }
 
+// The eight parallel formant filters of Synthesize::next, src/lib.rs:531-571, for the
+// FPL formants one lane owns.  SAFE selects the division flavour (same bits either way).
+template <bool SAFE, int FPL>
+__device__ __forceinline__ void formant_filters(const float saw, const float noise,
+                                                const float (&e_freq)[FPL], const float (&e_bw)[FPL],
+                                                const float (&e_smooth)[FPL],
+                                                const float (&e_breath)[FPL],
+                                                const float (&e_turb)[FPL], const float (&e_amp)[FPL],
+                                                float (&st_a)[FPL], float (&st_b)[FPL],
+                                                float (&st_c)[FPL], float (&v1)[FPL])
+{
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) {
+        const float nw = saw * (1.0f - e_breath[k]) + noise * e_breath[k];   // :531
+        const float lp = exp_approx(e_smooth[k]);                            // :535
+        st_a[k] = st_a[k] + (1.0f - lp) * (nw - st_a[k]);                    // :538
+        const float tw = st_a[k] * (1.0f * (1.0f - e_turb[k]) + noise * e_turb[k]); // :544-545
+        const float v0 = tw * e_amp[k];                                      // :550
+        const float g = tan_approx<SAFE>(e_freq[k]);                         // :555
+        const float kq = div_exact<SAFE>(e_bw[k], e_freq[k]);                // :558
+        const float a1 = rcp_exact<SAFE>(1.0f + g * (g + kq));               // :560
+        const float a2 = g * a1;                                             // :561
+        const float a3 = g * a2;                                             // :562
+        const float v3 = v0 - st_c[k];                                       // :565
+        const float w1 = a1 * st_b[k] + a2 * v3;                             // :566
+        const float w2 = (st_c[k] + a2 * st_b[k]) + a3 * v3;                 // :567
+        st_b[k] = 2.0f * w1 - st_b[k];                                       // :570
+        st_c[k] = 2.0f * w2 - st_c[k];                                       // :571
+        v1[k] = w1;
+    }
+}
+
+// Can every division of the coming segment pair take the SAFE path?  Bounds every
+// divisor/dividend over the pair: alpha in [0,1] (clk >= 0 for the whole pair once it
+// is >= 0 at its first sample, blend_length > 0), the jitter noises in [-1,1] (0 <=
+// jitter_frequency <= 1 keeps the noise phase in (0,1]), so that
+//   x = formant_freq  in [2^-20, 1/2 - 2^-20]  =>  tan_approx num in [2^-18, 1.25], den in [2^-19, 5]
+//   w = formant_bw    in [2^-40, 2^10]         =>  w/x in [2^-39, 2^30],  1+g(g+w/x) in [1, 2^52]
+// all inside the proven [2^-60, 2^60] window.  Any NaN fails a comparison => false.
+template <int FPL>
+__device__ __forceinline__ bool pair_is_safe(const Part<FPL> &X, const Part<FPL> &Y, float clk,
+                                             float blend_length, float jinc, float d_ffreq)
+{
+    constexpr float X_LO = 9.5367431640625e-07f;        // 2^-20
+    constexpr float X_HI = 0.5f - 9.5367431640625e-07f;
+    constexpr float W_LO = 1.8189894035458565e-12f;     // 2^-39 (2x margin over 2^-40)
+    constexpr float W_HI = 512.0f;                      // 2^9   (2x margin under 2^10)
+    const float jm = 1.002f * __builtin_fabsf(d_ffreq);
+    bool ok = (clk >= 0.0f) && (blend_length > 0.0f) && (jinc >= 0.0f) && (jinc <= 1.0f) &&
+              (jm <= 1.0f);
+#pragma unroll
+    for (int k = 0; k < FPL; ++k) {
+        ok = ok && (X.freq[k] * 0.999f - jm >= X_LO) && (Y.freq[k] * 0.999f - jm >= X_LO) &&
+             (X.freq[k] * 1.001f + jm <= X_HI) && (Y.freq[k] * 1.001f + jm <= X_HI) &&
+             (X.bw[k] >= W_LO) && (Y.bw[k] >= W_LO) && (X.bw[k] <= W_HI) && (Y.bw[k] <= W_HI);
+    }
+    return ok;
+}
+
 template <int L, int T, int WAVES, int MIN_WAVES_PER_SIMD>
 __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(const SynthArgs A)
 {
@@ -190,7 +287,10 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     silent_part(X);
     silent_part(Y);
     float blend_length = 1.0f;
+    float inv_blend_length = 1.0f;           // exact when blend_length is +-2^k
+    bool blend_pow2 = true;
     bool silent_pair = true;
+    bool pair_safe = false;                  // every division of this pair may use div_exact<true>
 
     // ---- Jitter state: IntoJitter::jitter, src/lib.rs:786-797.  One seed is
     // threaded through the three constructors (2 + 16 + 16 draws), each noise
@@ -234,6 +334,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 
     const uint64_t cap = A.out_stride;
     uint32_t n_out = 0;
+    uint32_t slow_steps = 0;                 // wave-steps that took the IEEE-division body
     bool truncated = false;
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(A.out) & 15u) == 0) && ((cap & 3u) == 0);
 
@@ -282,6 +383,12 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                         silent_part(X);
                         silent_part(Y);
                     }
+                    // clk / 2^k == clk * 2^-k for every clk (same real number, same rounding)
+                    const uint32_t blb = __float_as_uint(blend_length);
+                    const uint32_t ble = (blb >> 23) & 0xFFu;
+                    blend_pow2 = ((blb & 0x7FFFFFu) == 0u) && ble >= 1u && ble <= 253u;
+                    inv_blend_length = 1.0f / blend_length;
+                    pair_safe = pair_is_safe(X, Y, clk, blend_length, jinc, d_ffreq);
                 }
             }
             if (!cur.some) done = true;                           // :930
@@ -295,7 +402,10 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             // alpha = (time / blend_length).min(1.0)  :899/:908/:917.  A both-silent
             // pair emits silent() itself (:926): alpha = 1 selects Y = silent() exactly
             // (X*0 + Y*1 with finite X).
-            float alpha = __builtin_fminf(clk / blend_length, 1.0f);
+            float ratio;
+            if (__builtin_amdgcn_ballot_w64(!blend_pow2) == 0) ratio = clk * inv_blend_length;
+            else ratio = blend_pow2 ? clk * inv_blend_length : clk / blend_length;
+            float alpha = __builtin_fminf(ratio, 1.0f);
             alpha = silent_pair ? 1.0f : alpha;
             const float oma = 1.0f - alpha;
 
@@ -361,24 +471,13 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             const float noise = lcg_f32(noise_seed);                       // :528
 
             float v1[FPL];
-#pragma unroll
-            for (int k = 0; k < FPL; ++k) {
-                const float nw = saw * (1.0f - e_breath[k]) + noise * e_breath[k];   // :531
-                const float lp = exp_approx(e_smooth[k]);                            // :535
-                st_a[k] = st_a[k] + (1.0f - lp) * (nw - st_a[k]);                    // :538
-                const float tw = st_a[k] * (1.0f * (1.0f - e_turb[k]) + noise * e_turb[k]); // :544-545
-                const float v0 = tw * e_amp[k];                                      // :550
-                const float g = tan_approx(e_freq[k]);                               // :555
-                const float kq = e_bw[k] / e_freq[k];                                // :558
-                const float a1 = 1.0f / (1.0f + g * (g + kq));                       // :560
-                const float a2 = g * a1;                                             // :561
-                const float a3 = g * a2;                                             // :562
-                const float v3 = v0 - st_c[k];                                       // :565
-                const float w1 = a1 * st_b[k] + a2 * v3;                             // :566
-                const float w2 = (st_c[k] + a2 * st_b[k]) + a3 * v3;                 // :567
-                st_b[k] = 2.0f * w1 - st_b[k];                                       // :570
-                st_c[k] = 2.0f * w2 - st_c[k];                                       // :571
-                v1[k] = w1;
+            if (__builtin_amdgcn_ballot_w64(!pair_safe) == 0) {  // wave-uniform choice, same bits
+                formant_filters<true, FPL>(saw, noise, e_freq, e_bw, e_smooth, e_breath, e_turb, e_amp,
+                                           st_a, st_b, st_c, v1);
+            } else {
+                formant_filters<false, FPL>(saw, noise, e_freq, e_bw, e_smooth, e_breath, e_turb, e_amp,
+                                            st_a, st_b, st_c, v1);
+                ++slow_steps;
             }
 
             // v1.sum() * 0.5: a left fold from 0.0 over formants 0..7  :574, :123-125,
@@ -432,6 +531,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         if (A.out_len) A.out_len[u] = n_out;
         if (truncated) atomicOr(A.truncated, 1u);
     }
+    if (lane == 0 && slow_steps) atomicAdd(A.truncated + 1, slow_steps);
 }
 
 // Sequencer clock only (src/lib.rs:861-888, :930): how many elems the
@@ -515,7 +615,7 @@ hipError_t launch_synth(const SynthArgs &args, int L, int variant, hipStream_t s
     switch (L) {
     case 1: launch_one<1, 32, 1, 1>(args, stream); break;
     case 2: launch_one<2, 64, 1, 2>(args, stream); break;
-    case 4: launch_one<4, 64, 4, 4>(args, stream); break;
+    case 4: launch_one<4, 64, 4, 3>(args, stream); break;
     case 8: launch_one<8, 64, 4, 4>(args, stream); break;
     default: return hipErrorInvalidValue;
     }
