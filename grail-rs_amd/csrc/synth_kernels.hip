@@ -18,15 +18,47 @@
 // staged through LDS for T steps and flushed as 16-B-per-lane row stores, so
 // every utterance row is written in contiguous 4*T-byte runs.
 //
-// Exactness.  Built with -ffp-contract=off: every a*b+c is a v_mul_f32 then a
-// v_add_f32, divisions are hipcc's correctly rounded IEEE sequence, f32
-// denormals are kept (the kernel descriptor's default).  The result is
-// bit-identical to the reference arithmetic, whatever L is.
+// Exactness.  Built with -ffp-contract=off: every a*b+c is a multiply then an add
+// (never a fused multiply-add), divisions are correctly rounded (hipcc's IEEE
+// sequence, or the proven-equal short sequence div_exact<true>), f32 denormals are
+// kept (the kernel descriptor's default).  The result is bit-identical to the
+// reference arithmetic, whatever L is.
+//
+// Packed math.  On gfx950 only v_{add,mul,fma}_f32 issue at 2 cycles per wave64;
+// one wave issues at most one VALU instruction every ~5 cycles, so with the two
+// waves per SIMD this register budget allows the scarce resource is issue slots.
+// The per-formant arithmetic is therefore written on float2 values, which hipcc
+// lowers to v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two formants per issue
+// slot, each component still an individually rounded IEEE operation.
 #include "kernels.h"
 
 namespace grail {
 
 namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// ---- scalar / packed helpers: V is float (1 formant) or f2 (2 formants) --------
+template <int W> struct VecOf;
+template <> struct VecOf<1> { typedef float type; };
+template <> struct VecOf<2> { typedef f2 type; };
+
+__device__ __forceinline__ float vfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ f2 vfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float vrcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ f2 vrcp(f2 x)
+{
+    f2 r;
+    r.x = __builtin_amdgcn_rcpf(x.x);
+    r.y = __builtin_amdgcn_rcpf(x.y);
+    return r;
+}
+__device__ __forceinline__ float vsplat(float x, float) { return x; }
+__device__ __forceinline__ f2 vsplat(float x, f2) { f2 r; r.x = x; r.y = x; return r; }
+__device__ __forceinline__ float vget(float v, int) { return v; }
+__device__ __forceinline__ float vget(f2 v, int c) { return c == 0 ? v.x : v.y; }
+__device__ __forceinline__ void vset(float &v, int, float x) { v = x; }
+__device__ __forceinline__ void vset(f2 &v, int c, float x) { if (c == 0) v.x = x; else v.y = x; }
 
 // random_f32, src/lib.rs:36-55
 __device__ __forceinline__ float lcg_f32(uint32_t &s)
@@ -42,53 +74,56 @@ __device__ __forceinline__ float lcg_f32(uint32_t &s)
 // PROVEN equal to IEEE division by exhaustion over all 2^46 significand pairs with
 // an exact integer remainder check (tools/div_exhaustive.hip,
 // profiles/r01_div_exhaustive.txt), so the result is bit-identical to `a / b`.
-template <bool SAFE>
-__device__ __forceinline__ float div_exact(float a, float b)
+template <bool SAFE, typename V>
+__device__ __forceinline__ V div_exact(V a, V b)
 {
     if constexpr (SAFE) {
-        float y = __builtin_amdgcn_rcpf(b);
-        const float e = __builtin_fmaf(-b, y, 1.0f);
-        y = __builtin_fmaf(e, y, y);               // RN(1/b)
-        const float q = a * y;
-        const float r = __builtin_fmaf(-b, q, a);  // exact remainder
-        return __builtin_fmaf(r, y, q);
+        const V one = vsplat(1.0f, a);
+        V y = vrcp(b);
+        const V e = vfma(-b, y, one);
+        y = vfma(e, y, y);               // RN(1/b)
+        const V q = a * y;
+        const V r = vfma(-b, q, a);      // exact remainder
+        return vfma(r, y, q);
     } else {
-        return a / b;                              // hipcc's IEEE sequence
+        return a / b;                    // hipcc's IEEE sequence, per component
     }
 }
 
 // 1/x: v_rcp_f32 + one Newton step equals the correctly rounded reciprocal for every
 // float with |x| in [2^-60, 2^61) (exhaustive, tools/div_check.hip,
 // profiles/r01_div_check.txt).
-template <bool SAFE>
-__device__ __forceinline__ float rcp_exact(float x)
+template <bool SAFE, typename V>
+__device__ __forceinline__ V rcp_exact(V x)
 {
+    const V one = vsplat(1.0f, x);
     if constexpr (SAFE) {
-        const float y = __builtin_amdgcn_rcpf(x);
-        const float e = __builtin_fmaf(-x, y, 1.0f);
-        return __builtin_fmaf(e, y, y);
+        const V y = vrcp(x);
+        const V e = vfma(-x, y, one);
+        return vfma(e, y, y);
     } else {
-        return 1.0f / x;
+        return one / x;
     }
 }
 
 // tan_approx, src/lib.rs:63-70 (tan(pi x), Bhaskara-style rational)
-template <bool SAFE>
-__device__ __forceinline__ float tan_approx(float x)
+template <bool SAFE, typename V>
+__device__ __forceinline__ V tan_approx(V x)
 {
-    const float omx = 1.0f - x;
-    const float xph = x + 0.5f;
-    const float hmx = 0.5f - x;
-    const float num = (omx * x) * (5.0f - (4.0f * xph) * hmx);
-    const float den = (xph * (5.0f - (4.0f * omx) * x)) * hmx;
+    const V omx = 1.0f - x;
+    const V xph = x + 0.5f;
+    const V hmx = 0.5f - x;
+    const V num = (omx * x) * (5.0f - (4.0f * xph) * hmx);
+    const V den = (xph * (5.0f - (4.0f * omx) * x)) * hmx;
     return div_exact<SAFE>(num, den);
 }
 
 // exp_approx, src/lib.rs:75-82 ((1-x)^5)
-__device__ __forceinline__ float exp_approx(float x)
+template <typename V>
+__device__ __forceinline__ V exp_approx(V x)
 {
-    const float o = 1.0f - x;
-    const float o2 = o * o;
+    const V o = 1.0f - x;
+    const V o2 = o * o;
     return (o2 * o2) * o;
 }
 
@@ -108,43 +143,47 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// the FPL-formant slice of a SynthesisElem that one lane owns
-template <int FPL>
+// the slice of a SynthesisElem that one lane owns: NV vectors of W formants
+template <int NV, typename V>
 struct Part {
     float frequency;
-    float freq[FPL], bw[FPL], smooth[FPL], breath[FPL], turb[FPL], amp[FPL];
+    V freq[NV], bw[NV], smooth[NV], breath[NV], turb[NV], amp[NV];
 };
 
-template <int FPL>
-__device__ __forceinline__ void load_part(Part<FPL> &p, const float *__restrict__ elems,
+template <int NV, int W, typename V>
+__device__ __forceinline__ void load_part(Part<NV, V> &p, const float *__restrict__ elems,
                                           int row, int f0)
 {
     const float *e = elems + (size_t)row * ELEM_FLOATS + f0;
     p.frequency = elems[(size_t)row * ELEM_FLOATS];
 #pragma unroll
-    for (int i = 0; i < FPL; ++i) {
-        p.freq[i] = e[F_FREQ + i];
-        p.bw[i] = e[F_BW + i];
-        p.smooth[i] = e[F_SMOOTH + i];
-        p.breath[i] = e[F_BREATH + i];
-        p.turb[i] = e[F_TURB + i];
-        p.amp[i] = e[F_AMP + i];
+    for (int k = 0; k < NV; ++k) {
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            const int i = k * W + c;
+            vset(p.freq[k], c, e[F_FREQ + i]);
+            vset(p.bw[k], c, e[F_BW + i]);
+            vset(p.smooth[k], c, e[F_SMOOTH + i]);
+            vset(p.breath[k], c, e[F_BREATH + i]);
+            vset(p.turb[k], c, e[F_TURB + i]);
+            vset(p.amp[k], c, e[F_AMP + i]);
+        }
     }
 }
 
 // SynthesisElem::silent(), src/lib.rs:367-377
-template <int FPL>
-__device__ __forceinline__ void silent_part(Part<FPL> &p)
+template <int NV, typename V>
+__device__ __forceinline__ void silent_part(Part<NV, V> &p)
 {
     p.frequency = 0.25f;
 #pragma unroll
-    for (int i = 0; i < FPL; ++i) {
-        p.freq[i] = 0.25f;
-        p.bw[i] = 0.25f;
-        p.smooth[i] = 0.25f;
-        p.breath[i] = 0.0f;
-        p.turb[i] = 0.0f;
-        p.amp[i] = 0.0f;
+    for (int k = 0; k < NV; ++k) {
+        p.freq[k] = vsplat(0.25f, p.freq[k]);
+        p.bw[k] = vsplat(0.25f, p.bw[k]);
+        p.smooth[k] = vsplat(0.25f, p.smooth[k]);
+        p.breath[k] = vsplat(0.0f, p.breath[k]);
+        p.turb[k] = vsplat(0.0f, p.turb[k]);
+        p.amp[k] = vsplat(0.0f, p.amp[k]);
     }
 }
 
@@ -185,37 +224,67 @@ __device__ __forceinline__ void fetch_seg(Seg &s, const DevSeg *__restrict__ seg
     }
 }
 
-// The eight parallel formant filters of Synthesize::next, src/lib.rs:531-571, for the
-// FPL formants one lane owns.  SAFE selects the division flavour (same bits either way).
-template <bool SAFE, int FPL>
+// The parallel formant filters of Synthesize::next, src/lib.rs:531-571, for the NV
+// formant vectors one lane owns.  SAFE selects the division flavour (same bits).
+// Written breadth-first (each step for every k before the next step) so that the NV
+// independent dependency chains interleave and hide each other's VALU latency.
+#define FOR_K _Pragma("unroll") for (int k = 0; k < NV; ++k)
+template <bool SAFE, int NV, typename V>
 __device__ __forceinline__ void formant_filters(const float saw, const float noise,
-                                                const float (&e_freq)[FPL], const float (&e_bw)[FPL],
-                                                const float (&e_smooth)[FPL],
-                                                const float (&e_breath)[FPL],
-                                                const float (&e_turb)[FPL], const float (&e_amp)[FPL],
-                                                float (&st_a)[FPL], float (&st_b)[FPL],
-                                                float (&st_c)[FPL], float (&v1)[FPL])
+                                                const V (&e_freq)[NV], const V (&e_bw)[NV],
+                                                const V (&e_smooth)[NV], const V (&e_breath)[NV],
+                                                const V (&e_turb)[NV], const V (&e_amp)[NV],
+                                                V (&st_a)[NV], V (&st_b)[NV], V (&st_c)[NV],
+                                                V (&v1)[NV])
 {
-#pragma unroll
-    for (int k = 0; k < FPL; ++k) {
-        const float nw = saw * (1.0f - e_breath[k]) + noise * e_breath[k];   // :531
-        const float lp = exp_approx(e_smooth[k]);                            // :535
-        st_a[k] = st_a[k] + (1.0f - lp) * (nw - st_a[k]);                    // :538
-        const float tw = st_a[k] * (1.0f * (1.0f - e_turb[k]) + noise * e_turb[k]); // :544-545
-        const float v0 = tw * e_amp[k];                                      // :550
-        const float g = tan_approx<SAFE>(e_freq[k]);                         // :555
-        const float kq = div_exact<SAFE>(e_bw[k], e_freq[k]);                // :558
-        const float a1 = rcp_exact<SAFE>(1.0f + g * (g + kq));               // :560
-        const float a2 = g * a1;                                             // :561
-        const float a3 = g * a2;                                             // :562
-        const float v3 = v0 - st_c[k];                                       // :565
-        const float w1 = a1 * st_b[k] + a2 * v3;                             // :566
-        const float w2 = (st_c[k] + a2 * st_b[k]) + a3 * v3;                 // :567
-        st_b[k] = 2.0f * w1 - st_b[k];                                       // :570
-        st_c[k] = 2.0f * w2 - st_c[k];                                       // :571
-        v1[k] = w1;
+    V num[NV], den[NV], g[NV], kq[NV], a1[NV], y[NV], e[NV], q[NV], r[NV], d3[NV];
+    // tan_approx numerator / denominator, src/lib.rs:63-70
+    FOR_K {
+        const V x = e_freq[k];
+        const V omx = 1.0f - x;
+        const V xph = x + 0.5f;
+        const V hmx = 0.5f - x;
+        num[k] = (omx * x) * (5.0f - (4.0f * xph) * hmx);
+        den[k] = (xph * (5.0f - (4.0f * omx) * x)) * hmx;
     }
+    if constexpr (SAFE) {
+        // g = num/den and kq = bw/freq by div_exact<true>, a1 = 1/d3 by rcp_exact<true>,
+        // spelled out step by step across k
+        const V one = vsplat(1.0f, num[0]);
+        V y2[NV], e2[NV], q2[NV], r2[NV];
+        FOR_K { y[k] = vrcp(den[k]); y2[k] = vrcp(e_freq[k]); }
+        FOR_K { e[k] = vfma(-den[k], y[k], one); e2[k] = vfma(-e_freq[k], y2[k], one); }
+        FOR_K { y[k] = vfma(e[k], y[k], y[k]); y2[k] = vfma(e2[k], y2[k], y2[k]); }
+        FOR_K { q[k] = num[k] * y[k]; q2[k] = e_bw[k] * y2[k]; }
+        FOR_K { r[k] = vfma(-den[k], q[k], num[k]); r2[k] = vfma(-e_freq[k], q2[k], e_bw[k]); }
+        FOR_K { g[k] = vfma(r[k], y[k], q[k]); kq[k] = vfma(r2[k], y2[k], q2[k]); }   // :555, :558
+        FOR_K d3[k] = 1.0f + g[k] * (g[k] + kq[k]);                                   // :560
+        FOR_K y[k] = vrcp(d3[k]);
+        FOR_K e[k] = vfma(-d3[k], y[k], one);
+        FOR_K a1[k] = vfma(e[k], y[k], y[k]);
+    } else {
+        FOR_K g[k] = num[k] / den[k];                                                 // :555
+        FOR_K kq[k] = e_bw[k] / e_freq[k];                                            // :558
+        FOR_K d3[k] = 1.0f + g[k] * (g[k] + kq[k]);
+        FOR_K a1[k] = vsplat(1.0f, d3[k]) / d3[k];                                    // :560
+    }
+    V nw[NV], lp[NV], tw[NV], v0[NV], a2[NV], a3[NV], v3[NV], w1[NV], w2[NV];
+    FOR_K nw[k] = saw * (1.0f - e_breath[k]) + noise * e_breath[k];                   // :531
+    FOR_K lp[k] = exp_approx(e_smooth[k]);                                            // :535
+    FOR_K st_a[k] = st_a[k] + (1.0f - lp[k]) * (nw[k] - st_a[k]);                     // :538
+    // :544-545  1.0*(1-turb) + noise*turb; the multiply by 1.0 is exact and dropped
+    FOR_K tw[k] = st_a[k] * ((1.0f - e_turb[k]) + noise * e_turb[k]);
+    FOR_K v0[k] = tw[k] * e_amp[k];                                                   // :550
+    FOR_K a2[k] = g[k] * a1[k];                                                       // :561
+    FOR_K a3[k] = g[k] * a2[k];                                                       // :562
+    FOR_K v3[k] = v0[k] - st_c[k];                                                    // :565
+    FOR_K w1[k] = a1[k] * st_b[k] + a2[k] * v3[k];                                    // :566
+    FOR_K w2[k] = (st_c[k] + a2[k] * st_b[k]) + a3[k] * v3[k];                        // :567
+    FOR_K st_b[k] = 2.0f * w1[k] - st_b[k];                                           // :570
+    FOR_K st_c[k] = 2.0f * w2[k] - st_c[k];                                           // :571
+    FOR_K v1[k] = w1[k];
 }
+#undef FOR_K
 
 // Can every division of the coming segment pair take the SAFE path?  Bounds every
 // divisor/dividend over the pair: alpha in [0,1] (clk >= 0 for the whole pair once it
@@ -224,8 +293,8 @@ __device__ __forceinline__ void formant_filters(const float saw, const float noi
 //   x = formant_freq  in [2^-20, 1/2 - 2^-20]  =>  tan_approx num in [2^-18, 1.25], den in [2^-19, 5]
 //   w = formant_bw    in [2^-40, 2^10]         =>  w/x in [2^-39, 2^30],  1+g(g+w/x) in [1, 2^52]
 // all inside the proven [2^-60, 2^60] window.  Any NaN fails a comparison => false.
-template <int FPL>
-__device__ __forceinline__ bool pair_is_safe(const Part<FPL> &X, const Part<FPL> &Y, float clk,
+template <int NV, int W, typename V>
+__device__ __forceinline__ bool pair_is_safe(const Part<NV, V> &X, const Part<NV, V> &Y, float clk,
                                              float blend_length, float jinc, float d_ffreq)
 {
     constexpr float X_LO = 9.5367431640625e-07f;        // 2^-20
@@ -236,10 +305,15 @@ __device__ __forceinline__ bool pair_is_safe(const Part<FPL> &X, const Part<FPL>
     bool ok = (clk >= 0.0f) && (blend_length > 0.0f) && (jinc >= 0.0f) && (jinc <= 1.0f) &&
               (jm <= 1.0f);
 #pragma unroll
-    for (int k = 0; k < FPL; ++k) {
-        ok = ok && (X.freq[k] * 0.999f - jm >= X_LO) && (Y.freq[k] * 0.999f - jm >= X_LO) &&
-             (X.freq[k] * 1.001f + jm <= X_HI) && (Y.freq[k] * 1.001f + jm <= X_HI) &&
-             (X.bw[k] >= W_LO) && (Y.bw[k] >= W_LO) && (X.bw[k] <= W_HI) && (Y.bw[k] <= W_HI);
+    for (int k = 0; k < NV; ++k) {
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            const float xf = vget(X.freq[k], c), yf = vget(Y.freq[k], c);
+            const float xb = vget(X.bw[k], c), yb = vget(Y.bw[k], c);
+            ok = ok && (xf * 0.999f - jm >= X_LO) && (yf * 0.999f - jm >= X_LO) &&
+                 (xf * 1.001f + jm <= X_HI) && (yf * 1.001f + jm <= X_HI) &&
+                 (xb >= W_LO) && (yb >= W_LO) && (xb <= W_HI) && (yb <= W_HI);
+        }
     }
     return ok;
 }
@@ -247,9 +321,12 @@ __device__ __forceinline__ bool pair_is_safe(const Part<FPL> &X, const Part<FPL>
 template <int L, int T, int WAVES, int MIN_WAVES_PER_SIMD>
 __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(const SynthArgs A)
 {
-    constexpr int FPL = NF / L;   // formants per lane
-    constexpr int S = 64 / L;     // utterances per wave
-    constexpr int SP = S + 1;     // padded row of the staging tile
+    constexpr int FPL = NF / L;          // formants per lane
+    constexpr int W = FPL >= 2 ? 2 : 1;  // formants per packed value
+    constexpr int NV = FPL / W;          // packed values per lane and field
+    typedef typename VecOf<W>::type V;
+    constexpr int S = 64 / L;            // utterances per wave
+    constexpr int SP = S + 1;            // padded row of the staging tile
     static_assert(T % 4 == 0 && (64 % (T / 4)) == 0, "T");
 
     // every wave of the block works alone on its own S utterances and its own
@@ -271,7 +348,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 
     uint32_t vid = A.voice_ids ? A.voice_ids[uc] : 0u;
     if (vid >= A.n_voices) vid = 0u;
-    const DevVoice V = A.voices[vid];
+    const DevVoice VO = A.voices[vid];
     const bool phoneme_mode = A.phoneme_mode != 0;
     const float *__restrict__ elems = A.elems;
 
@@ -282,8 +359,8 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     cur.some = false; cur.elem = -1; cur.length = 0.0f; cur.blend_length = 1.0f; cur.frequency = 0.0f;
     nxt = cur;
     float clk = 0.0f;                        // Sequencer.time
-    const float dt = 1.0f / V.sample_rate;   // :944
-    Part<FPL> X, Y;                          // emitted elem = X*(1-alpha) + Y*alpha
+    const float dt = 1.0f / VO.sample_rate;  // :944
+    Part<NV, V> X, Y;                        // emitted elem = X*(1-alpha) + Y*alpha
     silent_part(X);
     silent_part(Y);
     float blend_length = 1.0f;
@@ -300,36 +377,49 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     float fn_cur = lcg_f32(seed);            // ValueNoise::new :228-229
     float fn_next = lcg_f32(seed);
     uint32_t fn_state = seed;
-    float ff_cur[FPL], ff_next[FPL], fa_cur[FPL], fa_next[FPL];
+    V ff_cur[NV], ff_next[NV], fa_cur[NV], fa_next[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        ff_cur[k] = vsplat(0.0f, ff_cur[k]); ff_next[k] = ff_cur[k];
+        fa_cur[k] = ff_cur[k]; fa_next[k] = ff_cur[k];
+    }
 #pragma unroll
     for (int i = 0; i < NF; ++i) {           // ArrayValueNoise::new :275-278
-        const float c = lcg_f32(seed);
-        const float n = lcg_f32(seed);
+        const float c0 = lcg_f32(seed);
+        const float n0 = lcg_f32(seed);
 #pragma unroll
-        for (int k = 0; k < FPL; ++k)
-            if (i == f0 + k) { ff_cur[k] = c; ff_next[k] = n; }
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int c = 0; c < W; ++c)
+                if (i == f0 + k * W + c) { vset(ff_cur[k], c, c0); vset(ff_next[k], c, n0); }
     }
     uint32_t ff_state = seed;
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
-        const float c = lcg_f32(seed);
-        const float n = lcg_f32(seed);
+        const float c0 = lcg_f32(seed);
+        const float n0 = lcg_f32(seed);
 #pragma unroll
-        for (int k = 0; k < FPL; ++k)
-            if (i == f0 + k) { fa_cur[k] = c; fa_next[k] = n; }
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int c = 0; c < W; ++c)
+                if (i == f0 + k * W + c) { vset(fa_cur[k], c, c0); vset(fa_next[k], c, n0); }
     }
     uint32_t fa_state = seed;
     float jphase = 0.0f;
-    const float jinc = V.jitter_frequency;
-    const float d_freq = V.jitter_delta_frequency;
-    const float d_ffreq = V.jitter_delta_formant_frequency;
-    const float amp_scale = 0.5f * V.jitter_delta_amplitude;   // :769
+    const float jinc = VO.jitter_frequency;
+    const float d_freq = VO.jitter_delta_frequency;
+    const float d_ffreq = VO.jitter_delta_formant_frequency;
+    const float amp_scale = 0.5f * VO.jitter_delta_amplitude;   // :769
 
     // ---- Synthesize state: IntoSynthesize::synthesize, src/lib.rs:587-596
     float phase = 0.0f;
-    float st_a[FPL], st_b[FPL], st_c[FPL];
+    V st_a[NV], st_b[NV], st_c[NV];
 #pragma unroll
-    for (int k = 0; k < FPL; ++k) { st_a[k] = 0.0f; st_b[k] = 0.0f; st_c[k] = 0.0f; }
+    for (int k = 0; k < NV; ++k) {
+        st_a[k] = vsplat(0.0f, st_a[k]);
+        st_b[k] = st_a[k];
+        st_c[k] = st_a[k];
+    }
     uint32_t noise_seed = 0u;                // :594
 
     const uint64_t cap = A.out_stride;
@@ -344,14 +434,14 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 
             // ================= Sequencer::next, src/lib.rs:859-932
             clk -= dt;                                            // :861
-            if (clk < 0.0f) {                                     // :864
+            if (__builtin_expect(clk < 0.0f, 0)) {                // :864
                 if (cur.some && nxt.some) {                       // :868
                     cur = nxt;
-                    fetch_seg(nxt, A.segs, seg_pos, seg_end, phoneme_mode, V.elem_base);
+                    fetch_seg(nxt, A.segs, seg_pos, seg_end, phoneme_mode, VO.elem_base);
                     clk += cur.length;                            // :873
                 } else if (!cur.some && !nxt.some) {              // :876
-                    fetch_seg(cur, A.segs, seg_pos, seg_end, phoneme_mode, V.elem_base);
-                    fetch_seg(nxt, A.segs, seg_pos, seg_end, phoneme_mode, V.elem_base);
+                    fetch_seg(cur, A.segs, seg_pos, seg_end, phoneme_mode, VO.elem_base);
+                    fetch_seg(nxt, A.segs, seg_pos, seg_end, phoneme_mode, VO.elem_base);
                     if (cur.some) clk += cur.length;              // :881-883
                 } else {
                     done = true;                                  // :886
@@ -363,22 +453,22 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     blend_length = cur.blend_length;
                     silent_pair = !has_b && !has_c;
                     if (has_b && has_c) {          // c.blend(b, alpha)  :897-903
-                        load_part(X, elems, nxt.elem, f0);
-                        load_part(Y, elems, cur.elem, f0);
+                        load_part<NV, W>(X, elems, nxt.elem, f0);
+                        load_part<NV, W>(Y, elems, cur.elem, f0);
                         X.frequency = nxt.frequency;
                         Y.frequency = cur.frequency;
                     } else if (has_b) {            // b.copy_silent().blend(b, alpha)  :906-912
-                        load_part(Y, elems, cur.elem, f0);
+                        load_part<NV, W>(Y, elems, cur.elem, f0);
                         Y.frequency = cur.frequency;
                         X = Y;
 #pragma unroll
-                        for (int k = 0; k < FPL; ++k) X.amp[k] = 0.0f;
+                        for (int k = 0; k < NV; ++k) X.amp[k] = vsplat(0.0f, X.amp[k]);
                     } else if (has_c) {            // c.blend(c.copy_silent(), alpha)  :915-921
-                        load_part(X, elems, nxt.elem, f0);
+                        load_part<NV, W>(X, elems, nxt.elem, f0);
                         X.frequency = nxt.frequency;
                         Y = X;
 #pragma unroll
-                        for (int k = 0; k < FPL; ++k) Y.amp[k] = 0.0f;
+                        for (int k = 0; k < NV; ++k) Y.amp[k] = vsplat(0.0f, Y.amp[k]);
                     } else {                       // SynthesisElem::silent()  :924-927
                         silent_part(X);
                         silent_part(Y);
@@ -388,12 +478,12 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     const uint32_t ble = (blb >> 23) & 0xFFu;
                     blend_pow2 = ((blb & 0x7FFFFFu) == 0u) && ble >= 1u && ble <= 253u;
                     inv_blend_length = 1.0f / blend_length;
-                    pair_safe = pair_is_safe(X, Y, clk, blend_length, jinc, d_ffreq);
+                    pair_safe = pair_is_safe<NV, W>(X, Y, clk, blend_length, jinc, d_ffreq);
                 }
             }
             if (!cur.some) done = true;                           // :930
             if (done) continue;
-            if (n_out >= cap) {   // the chain would yield another sample: row is full
+            if (__builtin_expect(n_out >= cap, 0)) {   // the chain would yield another sample: row is full
                 truncated = true;
                 done = true;
                 continue;
@@ -403,17 +493,19 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             // pair emits silent() itself (:926): alpha = 1 selects Y = silent() exactly
             // (X*0 + Y*1 with finite X).
             float ratio;
-            if (__builtin_amdgcn_ballot_w64(!blend_pow2) == 0) ratio = clk * inv_blend_length;
-            else ratio = blend_pow2 ? clk * inv_blend_length : clk / blend_length;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!blend_pow2) == 0, 1))
+                ratio = clk * inv_blend_length;
+            else
+                ratio = blend_pow2 ? clk * inv_blend_length : clk / blend_length;
             float alpha = __builtin_fminf(ratio, 1.0f);
             alpha = silent_pair ? 1.0f : alpha;
             const float oma = 1.0f - alpha;
 
             // SynthesisElem::blend, src/lib.rs:404-414
             float frequency = X.frequency * oma + Y.frequency * alpha;
-            float e_freq[FPL], e_bw[FPL], e_smooth[FPL], e_breath[FPL], e_turb[FPL], e_amp[FPL];
+            V e_freq[NV], e_bw[NV], e_smooth[NV], e_breath[NV], e_turb[NV], e_amp[NV];
 #pragma unroll
-            for (int k = 0; k < FPL; ++k) {
+            for (int k = 0; k < NV; ++k) {
                 e_freq[k] = X.freq[k] * oma + Y.freq[k] * alpha;
                 e_smooth[k] = X.smooth[k] * oma + Y.smooth[k] * alpha;
                 e_bw[k] = X.bw[k] * oma + Y.bw[k] * alpha;
@@ -424,20 +516,22 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 
             // ================= Jitter::next, src/lib.rs:753-777
             jphase += jinc;                                       // :242 / :291
-            if (jphase > 1.0f) {                                  // :245 / :294
+            if (__builtin_expect(jphase > 1.0f, 0)) {             // :245 / :294
                 jphase -= 1.0f;
                 fn_cur = fn_next;                                 // :249-250
                 fn_next = lcg_f32(fn_state);
                 uint32_t s1 = ff_state, s2 = fa_state;
 #pragma unroll
-                for (int k = 0; k < FPL; ++k) { ff_cur[k] = ff_next[k]; fa_cur[k] = fa_next[k]; }
+                for (int k = 0; k < NV; ++k) { ff_cur[k] = ff_next[k]; fa_cur[k] = fa_next[k]; }
 #pragma unroll
                 for (int i = 0; i < NF; ++i) {                    // from_func order :301
                     const float r1 = lcg_f32(s1);
                     const float r2 = lcg_f32(s2);
 #pragma unroll
-                    for (int k = 0; k < FPL; ++k)
-                        if (i == f0 + k) { ff_next[k] = r1; fa_next[k] = r2; }
+                    for (int k = 0; k < NV; ++k)
+#pragma unroll
+                        for (int c = 0; c < W; ++c)
+                            if (i == f0 + k * W + c) { vset(ff_next[k], c, r1); vset(fa_next[k], c, r2); }
                 }
                 ff_state = s1;
                 fa_state = s2;
@@ -446,12 +540,12 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             const float n_freq = fn_cur * jomp + fn_next * jphase;         // :254
             frequency = frequency + n_freq * d_freq;                       // :763
 #pragma unroll
-            for (int k = 0; k < FPL; ++k) {
-                const float n_ff = ff_cur[k] * jomp + ff_next[k] * jphase; // :305
-                const float n_fa = fa_cur[k] * jomp + fa_next[k] * jphase;
+            for (int k = 0; k < NV; ++k) {
+                const V n_ff = ff_cur[k] * jomp + ff_next[k] * jphase;     // :305
+                const V n_fa = fa_cur[k] * jomp + fa_next[k] * jphase;
                 e_freq[k] = e_freq[k] + n_ff * d_ffreq;                    // :764
-                const float delta = (n_fa + 1.0f) * amp_scale;             // :768-769
-                const float mul = 1.0f - delta;                            // :772
+                const V delta = (n_fa + 1.0f) * amp_scale;                 // :768-769
+                const V mul = 1.0f - delta;                                // :772
                 e_amp[k] = e_amp[k] * mul;                                 // :773
             }
 
@@ -460,7 +554,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             const bool head = phase < frequency;
             const bool tail = phase > (1.0f - frequency);
             float polyblep = 0.0f;
-            if (head || tail) {
+            if (__builtin_expect(head || tail, 0)) {
                 const float tt = (head ? phase : (phase - 1.0f)) / frequency;
                 polyblep = head ? ((2.0f * tt - (tt * tt)) - 1.0f)
                                 : (((tt * tt) + 2.0f * tt) + 1.0f);
@@ -470,13 +564,14 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             if (phase >= 1.0f) phase -= 1.0f;                              // :523-525
             const float noise = lcg_f32(noise_seed);                       // :528
 
-            float v1[FPL];
-            if (__builtin_amdgcn_ballot_w64(!pair_safe) == 0) {  // wave-uniform choice, same bits
-                formant_filters<true, FPL>(saw, noise, e_freq, e_bw, e_smooth, e_breath, e_turb, e_amp,
-                                           st_a, st_b, st_c, v1);
+            V v1[NV];
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!pair_safe) == 0, 1)) {
+                // wave-uniform choice between two bit-identical bodies
+                formant_filters<true, NV, V>(saw, noise, e_freq, e_bw, e_smooth, e_breath, e_turb,
+                                             e_amp, st_a, st_b, st_c, v1);
             } else {
-                formant_filters<false, FPL>(saw, noise, e_freq, e_bw, e_smooth, e_breath, e_turb, e_amp,
-                                            st_a, st_b, st_c, v1);
+                formant_filters<false, NV, V>(saw, noise, e_freq, e_bw, e_smooth, e_breath, e_turb,
+                                              e_amp, st_a, st_b, st_c, v1);
                 ++slow_steps;
             }
 
@@ -487,7 +582,9 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             for (int step = 0; step < L; ++step) {
                 float run = (step == 0) ? 0.0f : dpp_from_lane_below(acc);
 #pragma unroll
-                for (int k = 0; k < FPL; ++k) run = run + v1[k];
+                for (int k = 0; k < NV; ++k)
+#pragma unroll
+                    for (int c = 0; c < W; ++c) run = run + vget(v1[k], c);
                 acc = (j == step) ? run : acc;
             }
             if (j == L - 1) stage[t * SP + slot] = acc * 0.5f;
