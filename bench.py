@@ -2,16 +2,18 @@
 """bench.py — audio samples/sec of the fused Sequencer->Jitter->Synthesize HIP path.
 
 Metric (BASELINE.json): audio samples/sec (whole node) at 48 kHz, batch = 65536
-utterances x 2 s (4 segments x 0.5 s, single Voice) per GPU; a "step" is one pass of
-the hot path over one batch whose inputs are already resident in HBM; output stays
-in HBM (f32, 25.2 GB per GPU).  Weak scaling: every rank renders its own 65536-utterance
-shard of the N*65536 corpus (BASELINE config 5 at N=8), no data-path collective; the
-voice table is broadcast once with RCCL before the timed region.
+utterances x 2 s (4 segments x 0.5 s, single Voice) per GPU — BASELINE config 3 at N=1.
+A "step" is one pass of the hot path over one batch whose inputs already sit in HBM; the
+f32 PCM stays in HBM (25.2 GB per GPU).  Weak scaling: every rank renders its own
+65536-utterance shard of the N*65536 corpus (config 5 at N=8) with no data-path
+collective; the voice table is broadcast once (RCCL ncclBroadcast inside the C ABI) before
+the timed region.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--utts U] [--voices V]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -25,14 +27,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-ALG_BYTES_PER_SAMPLE = 4.01      # 4 B f32 written + <=0.01 B of segment/voice input
-VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+ALG_BYTES_PER_SAMPLE = 4.01  # 4 B f32 written + <= 0.01 B of segment/voice input
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
 
 
 def cpu_baseline(n_cpu, voices, W):
-    """The oracle (a port of the reference's single-threaded CPU path) timed on this host,
-    on the first n_cpu utterances of the same synthetic corpus."""
+    """The oracle (a C port of the reference's single-threaded CPU path, oracle/) timed on this
+    host on the first n_cpu utterances of the same corpus.  Checker code, never the product."""
     import oracle_lib as O
     ov = [O.Voice.from_buffer_copy(bytes(v)) for v in voices]
     segs, offs, vids, seeds = W.make_batch(n_cpu, n_voices=len(voices))
@@ -44,9 +46,20 @@ def cpu_baseline(n_cpu, voices, W):
     n = int(out_len.astype(np.uint64).sum())
     return {
         "value": n / dt, "unit": "samples/s", "cores": 1, "kind": "port",
-        "sample": f"first {n_cpu} utterances of the same corpus ({n} samples, {dt:.1f} s, "
-                  f"oracle/liboracle.so, 1 thread; host has {os.cpu_count()} logical cores)",
+        "sample": f"first {n_cpu} utterances of the same corpus ({n} samples, {dt:.1f} s of "
+                  f"oracle/liboracle.so on 1 thread; host has {os.cpu_count()} logical cores; "
+                  f"the reference itself is single-threaded)",
     }
+
+
+def committed_traffic(workload_key):
+    """HBM bytes per launch measured with rocprofv3 --pmc (separate WRITE_SIZE / FETCH_SIZE
+    passes, gfx950 corrections applied) for the same command; see profiles/README.md."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            return json.load(f).get(workload_key)
+    except OSError:
+        return None
 
 
 def main():
@@ -58,7 +71,8 @@ def main():
     ap.add_argument("--voices", type=int, default=1, help="1 = single Voice, 8 = config-4 presets")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per utterance (0 = auto)")
     ap.add_argument("--variant", type=int, default=0, help="kernel instantiation (experiments)")
-    ap.add_argument("--cpu-utts", type=int, default=512, help="utterances for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-utts", type=int, default=1536,
+                    help="utterances for the CPU baseline (0 = skip); 1536 is ~12-25 s of CPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -71,38 +85,48 @@ def main():
     import __graft_entry__ as ge
     if local_rank == 0:
         ge.build()
-    import grail_hip as G
-    from grail_hip import workload as W
 
-    dist = None
+    dist = torch = None
     if distributed:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dist.barrier()
-        G.load()
+        dist.barrier()  # rank 0 has finished building
+
+    import grail_hip as G
+    from grail_hip import dist as D
+    from grail_hip import workload as W
+    G.load()
 
     ctx = G.Context(local_rank)
     n_utt = args.utts
+    n_voices = max(args.voices, 1)
     stride = W.max_samples()
 
-    # ---- voice table: rank 0 builds it, RCCL broadcasts it over xGMI ----------
+    # ---- voice table: rank 0 builds it; one RCCL broadcast puts it in every GPU's HBM ----
     voice_path = "local"
+    voices = None
     if rank == 0:
-        voices = W.single_voice() if args.voices <= 1 else W.preset_voices(args.voices)
+        voices = W.single_voice() if n_voices == 1 else W.preset_voices(n_voices)
         ctx.set_voices(voices)
     if distributed:
-        ids = [G.Context.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ctx.comm_init(ids[0], rank, world)
-        ctx.broadcast_voices(max(args.voices, 1), root=0)   # ncclBroadcast inside the C ABI
-        voices = ctx.get_voices()
-        voice_path = "rccl ncclBroadcast"
+        try:
+            ids = [G.Context.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            ctx.comm_init(ids[0], rank, world)
+            ctx.broadcast_voices(n_voices, root=0)   # ncclBroadcast over xGMI inside the C ABI
+            voices = ctx.get_voices()
+            voice_path = "rccl ncclBroadcast (grail_broadcast_voices)"
+        except G.GrailError as e:                    # same hand-off through torch's RCCL
+            print(f"[rank {rank}] native RCCL broadcast failed ({e}); using torch.distributed",
+                  file=sys.stderr)
+            voices = D.broadcast_voices_torch(voices, n_voices, dist, device="cuda")
+            ctx.set_voices(voices)
+            voice_path = "rccl via torch.distributed.broadcast"
 
-    # ---- this rank's shard of the corpus, resident in HBM ---------------------
-    first, last = G.shard_range(n_utt * world, rank, world)
-    segs, offs, vids, seeds = W.make_batch(last - first, first_utt=first, n_voices=len(voices))
+    # ---- this rank's shard of the corpus, resident in HBM ---------------------------------
+    first, last, segs, offs, vids, seeds = D.shard_inputs(n_utt, rank, world, len(voices))
     batch = ctx.upload(segs, offs, vids, seeds)
     ctx.set_option("lanes_per_utterance", args.lanes)
     ctx.set_option("kernel_variant", args.variant)
@@ -112,7 +136,7 @@ def main():
     def step():
         batch.synthesize_async(d_out, stride, d_len)
         ctx.sync()
-        return ctx.last_kernel_ms()
+        return ctx.last_kernel_ms()   # hipEvents on the kernel's own stream
 
     for _ in range(args.warmup):
         step()
@@ -120,7 +144,6 @@ def main():
     def barrier():
         ctx.sync()
         if distributed:
-            import torch
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -133,24 +156,21 @@ def main():
     out_len = np.zeros(n_utt, dtype=np.uint32)
     ctx.d2h(out_len, d_len, n_utt * 4)
     samples_per_step = int(out_len.astype(np.uint64).sum())
+    slow = ctx.get_option("slow_division_wave_steps")
 
     if distributed:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        s = torch.tensor([samples_per_step], dtype=torch.float64, device="cuda")
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        total_samples_per_step = float(s.item())
+        elapsed, total_samples_per_step = D.reduce_step_stats(elapsed, samples_per_step, dist, "cuda")
     else:
         total_samples_per_step = float(samples_per_step)
 
-    lanes_used = args.lanes
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = total_samples_per_step * args.steps / elapsed
         k_ms = float(np.mean(kernel_ms))
-        achieved = samples_per_step * ALG_BYTES_PER_SAMPLE / (k_ms * 1e-3) / 1e9
+        alg_bytes = samples_per_step * ALG_BYTES_PER_SAMPLE
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        cfg = "3" if len(voices) == 1 else "4"
+        wl_key = f"config{cfg}_utts{n_utt}"
         line = {
             "metric": "audio samples/sec (whole node) at 48 kHz, batch=65536 utterances",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
@@ -159,18 +179,21 @@ def main():
             "config": {
                 "workload": f"batch={n_utt} utterances x 2 s (4 segments x 0.5 s) per GPU, "
                             f"{len(voices)} Voice preset(s), 48 kHz, f32 PCM left in HBM "
-                            f"(BASELINE config {'3' if len(voices) == 1 else '4'}"
-                            f"{'; config 5 sharding' if world > 1 else ''})",
+                            f"(BASELINE config {cfg}{'; config 5 sharding' if world > 1 else ''})",
                 "utterances_per_gpu": n_utt, "samples_per_utterance": int(out_len[0]),
-                "out_stride": stride, "lanes_per_utterance": lanes_used or "auto",
-                "voice_table": voice_path, "parity": "bit-exact vs oracle (tests/test_parity_gpu.py)",
+                "samples_per_step_per_gpu": samples_per_step, "out_stride": stride,
+                "lanes_per_utterance": args.lanes or "auto", "voice_table": voice_path,
+                "parity": "bit-exact vs oracle (tests/test_parity_gpu.py); "
+                          f"IEEE-division fallback wave-steps this run: {slow}",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "synth_kernel", "kernel_ms": k_ms,
-                "note": "HBM is the nominal bound (4.01 B/sample); the binding limit is VALU issue "
-                        "(~1.2e3 non-fusable f32 lane-ops/sample), see DESIGN.md",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": committed_traffic(wl_key),
+                "kernel": "grail::synth_kernel", "kernel_ms": k_ms,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "note": "HBM is the nominal bound north_star names (4.01 B/sample); the binding "
+                        "limit is f32 VALU issue (~660 unfusable flops + 25 IEEE divisions per "
+                        "sample, SURVEY.md §8d) — see DESIGN.md §Roofline",
             },
         }
         if not distributed and args.cpu_utts > 0:

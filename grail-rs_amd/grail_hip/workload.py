@@ -93,10 +93,11 @@ def single_voice(sample_rate=SAMPLE_RATE):
 
 
 def max_samples(segments=SEGMENTS_PER_UTT, length=0.5, sample_rate=SAMPLE_RATE):
-    """A safe out_stride (multiple of 4) for make_batch's utterances: the f32
-    Sequencer clock yields a few samples more than length*rate per segment."""
+    """A safe out_stride for make_batch's utterances: the f32 Sequencer clock yields a few
+    samples more than length*rate per segment.  Rounded up to 64 samples (256 B) so every
+    64-sample tile the kernel flushes is one aligned 256-B run in HBM (no partial lines)."""
     n = int(np.ceil(segments * length * sample_rate)) + 4 * segments + 8
-    return (n + 3) // 4 * 4
+    return (n + 63) // 64 * 64
 
 
 assert NUM_FORMANTS == 8

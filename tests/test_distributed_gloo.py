@@ -1,0 +1,79 @@
+"""The N>1 path on CPU: two gloo ranks shard the corpus, broadcast the voice table and reduce
+the timing exactly as bench.py does on RCCL.  No synthesis runs here (no GPU, no CPU fallback);
+the oracle checks that rank shards are slices of the global job (batch invariance of inputs)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "grail-rs_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    import grail_hip as G
+    import oracle_lib as O
+    from grail_hip import dist as D
+    from grail_hip import workload as W
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_voices, per_rank = 8, 24
+        voices = W.preset_voices(n_voices) if rank == 0 else None
+        got = D.broadcast_voices_torch(voices, n_voices, dist)
+        want = W.preset_voices(n_voices)
+        assert all(bytes(a) == bytes(b) for a, b in zip(got, want)), "voice table differs"
+
+        first, last, segs, offs, vids, seeds = D.shard_inputs(per_rank, rank, world, n_voices,
+                                                              length=0.004, blend_length=0.004)
+        assert (first, last) == (rank * per_rank, (rank + 1) * per_rank)
+        # every rank's shard is the matching slice of the one global corpus
+        gsegs, goffs, gvids, gseeds = W.make_batch(per_rank * world, n_voices=n_voices,
+                                                   length=0.004, blend_length=0.004)
+        assert np.array_equal(segs, gsegs[goffs[first]:goffs[last]])
+        assert np.array_equal(vids, gvids[first:last]) and np.array_equal(seeds, gseeds[first:last])
+
+        # the oracle stands in for the device here: per-rank lengths gathered == global lengths
+        ov = [O.Voice.from_buffer_copy(bytes(v)) for v in got]
+        lens = O.count_batch(ov, segs, offs, vids, seeds)
+        all_lens = np.concatenate(D.gather_uint32(lens, dist))
+        glens = O.count_batch(ov, gsegs, goffs, gvids, gseeds)
+        assert np.array_equal(all_lens, glens)
+
+        t, s = D.reduce_step_stats(0.5 + rank, int(lens.sum()), dist)
+        assert t == 0.5 + (world - 1) and s == float(glens.sum())
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gloo_shard_broadcast_reduce(built):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(results) == [(0, "ok"), (1, "ok")], results
