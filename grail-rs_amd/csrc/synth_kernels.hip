@@ -237,6 +237,28 @@ __device__ __forceinline__ void formant_filters(const float saw, const float noi
                                                 V (&st_a)[NV], V (&st_b)[NV], V (&st_c)[NV],
                                                 V (&v1)[NV])
 {
+    if constexpr (!SAFE) {
+        // the rare IEEE-division flavour, one formant vector at a time (fewest live registers)
+        FOR_K {
+            const V nw = saw * (1.0f - e_breath[k]) + noise * e_breath[k];      // :531
+            const V lp = exp_approx(e_smooth[k]);                               // :535
+            st_a[k] = st_a[k] + (1.0f - lp) * (nw - st_a[k]);                   // :538
+            const V tw = st_a[k] * ((1.0f - e_turb[k]) + noise * e_turb[k]);    // :544-545
+            const V v0 = tw * e_amp[k];                                         // :550
+            const V g = tan_approx<false>(e_freq[k]);                           // :555
+            const V kq = e_bw[k] / e_freq[k];                                   // :558
+            const V a1 = vsplat(1.0f, g) / (1.0f + g * (g + kq));               // :560
+            const V a2 = g * a1;                                                // :561
+            const V a3 = g * a2;                                                // :562
+            const V v3 = v0 - st_c[k];                                          // :565
+            const V w1 = a1 * st_b[k] + a2 * v3;                                // :566
+            const V w2 = (st_c[k] + a2 * st_b[k]) + a3 * v3;                    // :567
+            st_b[k] = 2.0f * w1 - st_b[k];                                      // :570
+            st_c[k] = 2.0f * w2 - st_c[k];                                      // :571
+            v1[k] = w1;
+        }
+        return;
+    }
     V num[NV], den[NV], g[NV], kq[NV], a1[NV], y[NV], e[NV], q[NV], r[NV], d3[NV];
     // tan_approx numerator / denominator, src/lib.rs:63-70
     FOR_K {
@@ -295,15 +317,21 @@ __device__ __forceinline__ void formant_filters(const float saw, const float noi
 // all inside the proven [2^-60, 2^60] window.  Any NaN fails a comparison => false.
 template <int NV, int W, typename V>
 __device__ __forceinline__ bool pair_is_safe(const Part<NV, V> &X, const Part<NV, V> &Y, float clk,
-                                             float blend_length, float jinc, float d_ffreq)
+                                             float blend_length, float jinc, float d_ffreq,
+                                             float d_freq)
 {
     constexpr float X_LO = 9.5367431640625e-07f;        // 2^-20
     constexpr float X_HI = 0.5f - 9.5367431640625e-07f;
     constexpr float W_LO = 1.8189894035458565e-12f;     // 2^-39 (2x margin over 2^-40)
     constexpr float W_HI = 512.0f;                      // 2^9   (2x margin under 2^10)
     const float jm = 1.002f * __builtin_fabsf(d_ffreq);
+    // carrier frequency (the polyBLEP divisor, src/lib.rs:505/509): in [2^-20, 1]; the
+    // dividend is the phase or phase-1, a sum of such frequencies: 0 or >= 2^-24 in magnitude
+    const float jf = 1.002f * __builtin_fabsf(d_freq);
     bool ok = (clk >= 0.0f) && (blend_length > 0.0f) && (jinc >= 0.0f) && (jinc <= 1.0f) &&
-              (jm <= 1.0f);
+              (jm <= 1.0f) && (jf <= 1.0f) &&
+              (X.frequency * 0.999f - jf >= X_LO) && (Y.frequency * 0.999f - jf >= X_LO) &&
+              (X.frequency * 1.001f + jf <= 1.0f) && (Y.frequency * 1.001f + jf <= 1.0f);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
 #pragma unroll
@@ -428,167 +456,242 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     bool truncated = false;
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(A.out) & 15u) == 0) && ((cap & 3u) == 0);
 
-    for (uint32_t base = 0;; base += T) {
-        for (int t = 0; t < T; ++t) {
-            if (done) continue;
+    // false while the lane's segment pair needs the IEEE-division body or has a blend
+    // length that is not a power of two: such lanes always take the general step
+    bool quiet_ok = false;
 
-            // ================= Sequencer::next, src/lib.rs:859-932
-            clk -= dt;                                            // :861
-            if (__builtin_expect(clk < 0.0f, 0)) {                // :864
-                if (cur.some && nxt.some) {                       // :868
-                    cur = nxt;
-                    fetch_seg(nxt, A.segs, seg_pos, seg_end, phoneme_mode, VO.elem_base);
-                    clk += cur.length;                            // :873
-                } else if (!cur.some && !nxt.some) {              // :876
-                    fetch_seg(cur, A.segs, seg_pos, seg_end, phoneme_mode, VO.elem_base);
-                    fetch_seg(nxt, A.segs, seg_pos, seg_end, phoneme_mode, VO.elem_base);
-                    if (cur.some) clk += cur.length;              // :881-883
-                } else {
-                    done = true;                                  // :886
-                }
-                if (!done && cur.some) {
-                    // the match at :891-931, resolved once per segment pair
-                    const bool has_b = cur.elem >= 0;
-                    const bool has_c = nxt.some && nxt.elem >= 0;
-                    blend_length = cur.blend_length;
-                    silent_pair = !has_b && !has_c;
-                    if (has_b && has_c) {          // c.blend(b, alpha)  :897-903
-                        load_part<NV, W>(X, elems, nxt.elem, f0);
-                        load_part<NV, W>(Y, elems, cur.elem, f0);
-                        X.frequency = nxt.frequency;
-                        Y.frequency = cur.frequency;
-                    } else if (has_b) {            // b.copy_silent().blend(b, alpha)  :906-912
-                        load_part<NV, W>(Y, elems, cur.elem, f0);
-                        Y.frequency = cur.frequency;
-                        X = Y;
-#pragma unroll
-                        for (int k = 0; k < NV; ++k) X.amp[k] = vsplat(0.0f, X.amp[k]);
-                    } else if (has_c) {            // c.blend(c.copy_silent(), alpha)  :915-921
-                        load_part<NV, W>(X, elems, nxt.elem, f0);
-                        X.frequency = nxt.frequency;
-                        Y = X;
-#pragma unroll
-                        for (int k = 0; k < NV; ++k) Y.amp[k] = vsplat(0.0f, Y.amp[k]);
-                    } else {                       // SynthesisElem::silent()  :924-927
-                        silent_part(X);
-                        silent_part(Y);
-                    }
-                    // clk / 2^k == clk * 2^-k for every clk (same real number, same rounding)
-                    const uint32_t blb = __float_as_uint(blend_length);
-                    const uint32_t ble = (blb >> 23) & 0xFFu;
-                    blend_pow2 = ((blb & 0x7FFFFFu) == 0u) && ble >= 1u && ble <= 253u;
-                    inv_blend_length = 1.0f / blend_length;
-                    pair_safe = pair_is_safe<NV, W>(X, Y, clk, blend_length, jinc, d_ffreq);
-                }
-            }
-            if (!cur.some) done = true;                           // :930
-            if (done) continue;
-            if (__builtin_expect(n_out >= cap, 0)) {   // the chain would yield another sample: row is full
-                truncated = true;
-                done = true;
-                continue;
-            }
+    // ---- the general sample step: any lane may be finished, advance a segment, wrap its
+    // jitter noise, hit the row capacity, or need the IEEE-division body.
+    auto general_step = [&](const int t) __attribute__((always_inline)) {
+        if (done) return;
 
-            // alpha = (time / blend_length).min(1.0)  :899/:908/:917.  A both-silent
-            // pair emits silent() itself (:926): alpha = 1 selects Y = silent() exactly
-            // (X*0 + Y*1 with finite X).
-            float ratio;
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!blend_pow2) == 0, 1))
-                ratio = clk * inv_blend_length;
-            else
-                ratio = blend_pow2 ? clk * inv_blend_length : clk / blend_length;
-            float alpha = __builtin_fminf(ratio, 1.0f);
-            alpha = silent_pair ? 1.0f : alpha;
-            const float oma = 1.0f - alpha;
-
-            // SynthesisElem::blend, src/lib.rs:404-414
-            float frequency = X.frequency * oma + Y.frequency * alpha;
-            V e_freq[NV], e_bw[NV], e_smooth[NV], e_breath[NV], e_turb[NV], e_amp[NV];
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                e_freq[k] = X.freq[k] * oma + Y.freq[k] * alpha;
-                e_smooth[k] = X.smooth[k] * oma + Y.smooth[k] * alpha;
-                e_bw[k] = X.bw[k] * oma + Y.bw[k] * alpha;
-                e_turb[k] = X.turb[k] * oma + Y.turb[k] * alpha;
-                e_breath[k] = X.breath[k] * oma + Y.breath[k] * alpha;
-                e_amp[k] = X.amp[k] * oma + Y.amp[k] * alpha;
-            }
-
-            // ================= Jitter::next, src/lib.rs:753-777
-            jphase += jinc;                                       // :242 / :291
-            if (__builtin_expect(jphase > 1.0f, 0)) {             // :245 / :294
-                jphase -= 1.0f;
-                fn_cur = fn_next;                                 // :249-250
-                fn_next = lcg_f32(fn_state);
-                uint32_t s1 = ff_state, s2 = fa_state;
-#pragma unroll
-                for (int k = 0; k < NV; ++k) { ff_cur[k] = ff_next[k]; fa_cur[k] = fa_next[k]; }
-#pragma unroll
-                for (int i = 0; i < NF; ++i) {                    // from_func order :301
-                    const float r1 = lcg_f32(s1);
-                    const float r2 = lcg_f32(s2);
-#pragma unroll
-                    for (int k = 0; k < NV; ++k)
-#pragma unroll
-                        for (int c = 0; c < W; ++c)
-                            if (i == f0 + k * W + c) { vset(ff_next[k], c, r1); vset(fa_next[k], c, r2); }
-                }
-                ff_state = s1;
-                fa_state = s2;
-            }
-            const float jomp = 1.0f - jphase;
-            const float n_freq = fn_cur * jomp + fn_next * jphase;         // :254
-            frequency = frequency + n_freq * d_freq;                       // :763
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                const V n_ff = ff_cur[k] * jomp + ff_next[k] * jphase;     // :305
-                const V n_fa = fa_cur[k] * jomp + fa_next[k] * jphase;
-                e_freq[k] = e_freq[k] + n_ff * d_ffreq;                    // :764
-                const V delta = (n_fa + 1.0f) * amp_scale;                 // :768-769
-                const V mul = 1.0f - delta;                                // :772
-                e_amp[k] = e_amp[k] * mul;                                 // :773
-            }
-
-            // ================= Synthesize::next, src/lib.rs:497-578
-            // polyBLEP saw: both branches divide by the jittered frequency  :503-514
-            const bool head = phase < frequency;
-            const bool tail = phase > (1.0f - frequency);
-            float polyblep = 0.0f;
-            if (__builtin_expect(head || tail, 0)) {
-                const float tt = (head ? phase : (phase - 1.0f)) / frequency;
-                polyblep = head ? ((2.0f * tt - (tt * tt)) - 1.0f)
-                                : (((tt * tt) + 2.0f * tt) + 1.0f);
-            }
-            const float saw = (2.0f * phase - 1.0f) - polyblep;            // :517
-            phase += frequency;                                            // :520
-            if (phase >= 1.0f) phase -= 1.0f;                              // :523-525
-            const float noise = lcg_f32(noise_seed);                       // :528
-
-            V v1[NV];
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!pair_safe) == 0, 1)) {
-                // wave-uniform choice between two bit-identical bodies
-                formant_filters<true, NV, V>(saw, noise, e_freq, e_bw, e_smooth, e_breath, e_turb,
-                                             e_amp, st_a, st_b, st_c, v1);
+        // ================= Sequencer::next, src/lib.rs:859-932
+        clk -= dt;                                            // :861
+        if (__builtin_expect(clk < 0.0f, 0)) {                // :864
+            if (cur.some && nxt.some) {                       // :868
+                cur = nxt;
+                fetch_seg(nxt, A.segs, seg_pos, seg_end, phoneme_mode, VO.elem_base);
+                clk += cur.length;                            // :873
+            } else if (!cur.some && !nxt.some) {              // :876
+                fetch_seg(cur, A.segs, seg_pos, seg_end, phoneme_mode, VO.elem_base);
+                fetch_seg(nxt, A.segs, seg_pos, seg_end, phoneme_mode, VO.elem_base);
+                if (cur.some) clk += cur.length;              // :881-883
             } else {
-                formant_filters<false, NV, V>(saw, noise, e_freq, e_bw, e_smooth, e_breath, e_turb,
-                                              e_amp, st_a, st_b, st_c, v1);
-                ++slow_steps;
+                done = true;                                  // :886
             }
-
-            // v1.sum() * 0.5: a left fold from 0.0 over formants 0..7  :574, :123-125,
-            // carried down the utterance's L lanes.
-            float acc = 0.0f;
+            if (!done && cur.some) {
+                // the match at :891-931, resolved once per segment pair
+                const bool has_b = cur.elem >= 0;
+                const bool has_c = nxt.some && nxt.elem >= 0;
+                blend_length = cur.blend_length;
+                silent_pair = !has_b && !has_c;
+                if (has_b && has_c) {          // c.blend(b, alpha)  :897-903
+                    load_part<NV, W>(X, elems, nxt.elem, f0);
+                    load_part<NV, W>(Y, elems, cur.elem, f0);
+                    X.frequency = nxt.frequency;
+                    Y.frequency = cur.frequency;
+                } else if (has_b) {            // b.copy_silent().blend(b, alpha)  :906-912
+                    load_part<NV, W>(Y, elems, cur.elem, f0);
+                    Y.frequency = cur.frequency;
+                    X = Y;
 #pragma unroll
-            for (int step = 0; step < L; ++step) {
-                float run = (step == 0) ? 0.0f : dpp_from_lane_below(acc);
+                    for (int k = 0; k < NV; ++k) X.amp[k] = vsplat(0.0f, X.amp[k]);
+                } else if (has_c) {            // c.blend(c.copy_silent(), alpha)  :915-921
+                    load_part<NV, W>(X, elems, nxt.elem, f0);
+                    X.frequency = nxt.frequency;
+                    Y = X;
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) Y.amp[k] = vsplat(0.0f, Y.amp[k]);
+                } else {                       // SynthesisElem::silent()  :924-927
+                    silent_part(X);
+                    silent_part(Y);
+                }
+                // clk / 2^k == clk * 2^-k for every clk (same real number, same rounding)
+                const uint32_t blb = __float_as_uint(blend_length);
+                const uint32_t ble = (blb >> 23) & 0xFFu;
+                blend_pow2 = ((blb & 0x7FFFFFu) == 0u) && ble >= 1u && ble <= 253u;
+                inv_blend_length = 1.0f / blend_length;
+                pair_safe = pair_is_safe<NV, W>(X, Y, clk, blend_length, jinc, d_ffreq, d_freq);
+            }
+        }
+        if (!cur.some) done = true;                           // :930
+        if (done) return;
+        if (__builtin_expect(n_out >= cap, 0)) {   // the chain would yield another sample: row is full
+            truncated = true;
+            done = true;
+            return;
+        }
+
+        // alpha = (time / blend_length).min(1.0)  :899/:908/:917.  A both-silent
+        // pair emits silent() itself (:926): alpha = 1 selects Y = silent() exactly
+        // (X*0 + Y*1 with finite X).
+        float ratio;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!blend_pow2) == 0, 1))
+            ratio = clk * inv_blend_length;
+        else
+            ratio = blend_pow2 ? clk * inv_blend_length : clk / blend_length;
+        float alpha = __builtin_fminf(ratio, 1.0f);
+        alpha = silent_pair ? 1.0f : alpha;
+        const float oma = 1.0f - alpha;
+
+        // SynthesisElem::blend, src/lib.rs:404-414
+        float frequency = X.frequency * oma + Y.frequency * alpha;
+        V e_freq[NV], e_bw[NV], e_smooth[NV], e_breath[NV], e_turb[NV], e_amp[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            e_freq[k] = X.freq[k] * oma + Y.freq[k] * alpha;
+            e_smooth[k] = X.smooth[k] * oma + Y.smooth[k] * alpha;
+            e_bw[k] = X.bw[k] * oma + Y.bw[k] * alpha;
+            e_turb[k] = X.turb[k] * oma + Y.turb[k] * alpha;
+            e_breath[k] = X.breath[k] * oma + Y.breath[k] * alpha;
+            e_amp[k] = X.amp[k] * oma + Y.amp[k] * alpha;
+        }
+
+        // ================= Jitter::next, src/lib.rs:753-777
+        jphase += jinc;                                       // :242 / :291
+        if (__builtin_expect(jphase > 1.0f, 0)) {             // :245 / :294
+            jphase -= 1.0f;
+            fn_cur = fn_next;                                 // :249-250
+            fn_next = lcg_f32(fn_state);
+            uint32_t s1 = ff_state, s2 = fa_state;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) { ff_cur[k] = ff_next[k]; fa_cur[k] = fa_next[k]; }
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {                    // from_func order :301
+                const float r1 = lcg_f32(s1);
+                const float r2 = lcg_f32(s2);
 #pragma unroll
                 for (int k = 0; k < NV; ++k)
 #pragma unroll
-                    for (int c = 0; c < W; ++c) run = run + vget(v1[k], c);
-                acc = (j == step) ? run : acc;
+                    for (int c = 0; c < W; ++c)
+                        if (i == f0 + k * W + c) { vset(ff_next[k], c, r1); vset(fa_next[k], c, r2); }
             }
-            if (j == L - 1) stage[t * SP + slot] = acc * 0.5f;
-            ++n_out;
+            ff_state = s1;
+            fa_state = s2;
+        }
+        const float jomp = 1.0f - jphase;
+        const float n_freq = fn_cur * jomp + fn_next * jphase;         // :254
+        frequency = frequency + n_freq * d_freq;                       // :763
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const V n_ff = ff_cur[k] * jomp + ff_next[k] * jphase;     // :305
+            const V n_fa = fa_cur[k] * jomp + fa_next[k] * jphase;
+            e_freq[k] = e_freq[k] + n_ff * d_ffreq;                    // :764
+            const V delta = (n_fa + 1.0f) * amp_scale;                 // :768-769
+            const V mul = 1.0f - delta;                                // :772
+            e_amp[k] = e_amp[k] * mul;                                 // :773
+        }
+
+        // ================= Synthesize::next, src/lib.rs:497-578
+        // polyBLEP saw: both branches divide by the jittered frequency  :503-514
+        const bool head = phase < frequency;
+        const bool tail = phase > (1.0f - frequency);
+        float polyblep = 0.0f;
+        if (__builtin_expect(head || tail, 0)) {
+            const float tt = (head ? phase : (phase - 1.0f)) / frequency;
+            polyblep = head ? ((2.0f * tt - (tt * tt)) - 1.0f)
+                            : (((tt * tt) + 2.0f * tt) + 1.0f);
+        }
+        const float saw = (2.0f * phase - 1.0f) - polyblep;            // :517
+        phase += frequency;                                            // :520
+        if (phase >= 1.0f) phase -= 1.0f;                              // :523-525
+        const float noise = lcg_f32(noise_seed);                       // :528
+
+        // events are rare: this step always takes the IEEE-division body (same bits)
+        V v1[NV];
+        formant_filters<false, NV, V>(saw, noise, e_freq, e_bw, e_smooth, e_breath, e_turb, e_amp,
+                                      st_a, st_b, st_c, v1);
+        if (!pair_safe) ++slow_steps;
+
+        // v1.sum() * 0.5: a left fold from 0.0 over formants 0..7  :574, :123-125,
+        // carried down the utterance's L lanes.
+        float acc = 0.0f;
+#pragma unroll
+        for (int step = 0; step < L; ++step) {
+            float run = (step == 0) ? 0.0f : dpp_from_lane_below(acc);
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+#pragma unroll
+                for (int c = 0; c < W; ++c) run = run + vget(v1[k], c);
+            acc = (j == step) ? run : acc;
+        }
+        if (j == L - 1) stage[t * SP + slot] = acc * 0.5f;
+        ++n_out;
+    };
+
+    // ---- the quiet sample step: taken when a single ballot shows that NO lane of the wave
+    // has any of those events at this sample.  Same arithmetic, straight-line: the polyBLEP
+    // quotient is evaluated unconditionally with div_exact<true> and selected afterwards.
+    auto quiet_step = [&](const int t, const float clk_next, const float jphase_next)
+                          __attribute__((always_inline)) {
+        if (done) return;                                                  // finished lanes sit out
+        clk = clk_next;                                                    // :861
+        float alpha = __builtin_fminf(clk * inv_blend_length, 1.0f);       // :899/:908/:917
+        alpha = silent_pair ? 1.0f : alpha;
+        const float oma = 1.0f - alpha;
+        float frequency = X.frequency * oma + Y.frequency * alpha;         // :404-414
+        V e_freq[NV], e_bw[NV], e_smooth[NV], e_breath[NV], e_turb[NV], e_amp[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            e_freq[k] = X.freq[k] * oma + Y.freq[k] * alpha;
+            e_smooth[k] = X.smooth[k] * oma + Y.smooth[k] * alpha;
+            e_bw[k] = X.bw[k] * oma + Y.bw[k] * alpha;
+            e_turb[k] = X.turb[k] * oma + Y.turb[k] * alpha;
+            e_breath[k] = X.breath[k] * oma + Y.breath[k] * alpha;
+            e_amp[k] = X.amp[k] * oma + Y.amp[k] * alpha;
+        }
+        jphase = jphase_next;                                              // :242 / :291, no wrap
+        const float jomp = 1.0f - jphase;
+        const float n_freq = fn_cur * jomp + fn_next * jphase;             // :254
+        frequency = frequency + n_freq * d_freq;                           // :763
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const V n_ff = ff_cur[k] * jomp + ff_next[k] * jphase;         // :305
+            const V n_fa = fa_cur[k] * jomp + fa_next[k] * jphase;
+            e_freq[k] = e_freq[k] + n_ff * d_ffreq;                        // :764
+            const V delta = (n_fa + 1.0f) * amp_scale;                     // :768-769
+            const V mul = 1.0f - delta;                                    // :772
+            e_amp[k] = e_amp[k] * mul;                                     // :773
+        }
+        const bool head = phase < frequency;                               // :503
+        const bool tail = phase > (1.0f - frequency);                      // :507
+        const float tt = div_exact<true>(head ? phase : (phase - 1.0f), frequency);
+        const float pb_head = (2.0f * tt - (tt * tt)) - 1.0f;              // :506
+        const float pb_tail = ((tt * tt) + 2.0f * tt) + 1.0f;              // :510
+        const float polyblep = head ? pb_head : (tail ? pb_tail : 0.0f);
+        const float saw = (2.0f * phase - 1.0f) - polyblep;                // :517
+        phase += frequency;                                                // :520
+        phase = (phase >= 1.0f) ? phase - 1.0f : phase;                    // :523-525
+        const float noise = lcg_f32(noise_seed);                           // :528
+        V v1[NV];
+        formant_filters<true, NV, V>(saw, noise, e_freq, e_bw, e_smooth, e_breath, e_turb, e_amp,
+                                     st_a, st_b, st_c, v1);
+        float acc = 0.0f;
+#pragma unroll
+        for (int step = 0; step < L; ++step) {
+            float run = (step == 0) ? 0.0f : dpp_from_lane_below(acc);
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+#pragma unroll
+                for (int c = 0; c < W; ++c) run = run + vget(v1[k], c);
+            acc = (j == step) ? run : acc;
+        }
+        if (j == L - 1) stage[t * SP + slot] = acc * 0.5f;
+        ++n_out;
+    };
+
+    for (uint32_t base = 0;; base += T) {
+        for (int t = 0; t < T; ++t) {
+            const float clk_next = clk - dt;
+            const float jphase_next = jphase + jinc;
+            const bool eventful = !done && (!quiet_ok || (clk_next < 0.0f) ||
+                                            (jphase_next > 1.0f) || (n_out >= cap));
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(eventful) == 0, 1)) {
+                quiet_step(t, clk_next, jphase_next);
+            } else {
+                general_step(t);
+                quiet_ok = pair_safe && blend_pow2;
+            }
         }
 
         // ---- flush the staged tile: row `slot` holds samples [base, base+T)
