@@ -451,6 +451,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     uint32_t noise_seed = 0u;                // :594
 
     const uint64_t cap = A.out_stride;
+    const uint32_t cap32 = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;   // n_out is 32-bit
     uint32_t n_out = 0;
     uint32_t slow_steps = 0;                 // wave-steps that took the IEEE-division body
     bool truncated = false;
@@ -681,16 +682,23 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     };
 
     for (uint32_t base = 0;; base += T) {
-        for (int t = 0; t < T; ++t) {
-            const float clk_next = clk - dt;
-            const float jphase_next = jphase + jinc;
-            const bool eventful = !done && (!quiet_ok || (clk_next < 0.0f) ||
-                                            (jphase_next > 1.0f) || (n_out >= cap));
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(eventful) == 0, 1)) {
+        int t = 0;
+        while (t < T) {
+            // a run of quiet steps: a tight inner loop, so the loop-carried state keeps its
+            // registers from one sample to the next
+            for (; t < T; ++t) {
+                const float clk_next = clk - dt;
+                const float jphase_next = jphase + jinc;
+                // bitwise on purpose: no short-circuit, so no exec-mask regions
+                const bool eventful = !done & (!quiet_ok | (clk_next < 0.0f) |
+                                               (jphase_next > 1.0f) | (n_out >= cap32));
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(eventful) != 0, 0)) break;
                 quiet_step(t, clk_next, jphase_next);
-            } else {
+            }
+            if (t < T) {
                 general_step(t);
                 quiet_ok = pair_safe && blend_pow2;
+                ++t;
             }
         }
 
@@ -777,13 +785,14 @@ __global__ __launch_bounds__(64) void lengths_kernel(const LenArgs A)
 
 int auto_lanes_per_utt(uint32_t n_utt)
 {
-    // The VALU saturates at >= 2 waves per SIMD: 256 CUs x 4 SIMDs x 2 = 2048
-    // waves.  Fewer lanes per utterance = less redundant per-utterance scalar
-    // work, so take the smallest L that still reaches that many waves.
-    const uint64_t want_waves = 2048;
-    for (int L = 1; L < 8; L *= 2)
-        if (((uint64_t)n_utt * L + 63) / 64 >= want_waves) return L;
-    return 8;
+    // Measured (profiles/r02_lanes_sweep.txt): a wave alone on its SIMD renders 2 s of audio
+    // in 92 / 60 / 42 / 38 ms for L = 1 / 2 / 4 / 8, and a second wave on the same SIMD costs
+    // more than it brings (the packed-f32 stream of one wave already keeps the VALU ~80 %
+    // busy).  So: the widest mapping that still fits one wave per SIMD (256 CUs x 4 SIMDs).
+    const uint64_t simds = 1024;
+    for (int L = 8; L > 1; L /= 2)
+        if (((uint64_t)n_utt * L + 63) / 64 <= simds) return L;
+    return 1;
 }
 
 template <int L, int T, int WAVES, int MINW>
