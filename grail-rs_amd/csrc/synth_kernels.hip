@@ -785,7 +785,7 @@ __global__ __launch_bounds__(64) void lengths_kernel(const LenArgs A)
 
 int auto_lanes_per_utt(uint32_t n_utt)
 {
-    // Measured (profiles/r02_lanes_sweep.txt): a wave alone on its SIMD renders 2 s of audio
+    // Measured (profiles/r01_lanes_sweep.txt): a wave alone on its SIMD renders 2 s of audio
     // in 92 / 60 / 42 / 38 ms for L = 1 / 2 / 4 / 8, and a second wave on the same SIMD costs
     // more than it brings (the packed-f32 stream of one wave already keeps the VALU ~80 %
     // busy).  So: the widest mapping that still fits one wave per SIMD (256 CUs x 4 SIMDs).
