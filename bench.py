@@ -62,6 +62,21 @@ def committed_traffic(workload_key):
         return None
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on fd 1 while a communicator forms; stdout must carry only
+    the one JSON line, so fd 1 points at fd 2 for the duration."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,6 +86,8 @@ def main():
     ap.add_argument("--voices", type=int, default=1, help="1 = single Voice, 8 = config-4 presets")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per utterance (0 = auto)")
     ap.add_argument("--variant", type=int, default=0, help="kernel instantiation (experiments)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-rank code path even with one rank (testing)")
     ap.add_argument("--cpu-utts", type=int, default=1536,
                     help="utterances for the CPU baseline (0 = skip); 1536 is ~12-25 s of CPU")
     args = ap.parse_args()
@@ -80,19 +97,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world != 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
+    if args.force_dist and "MASTER_ADDR" not in os.environ:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
 
     import __graft_entry__ as ge
     if local_rank == 0:
         ge.build()
 
-    dist = torch = None
+    group = None
     if distributed:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dist.barrier()  # rank 0 has finished building
+        # Control plane (barriers, unique-id hand-off, max/sum of two scalars): files in /tmp,
+        # see grail_hip/rendezvous.py for why PyTorch stays out of the bench processes.  All
+        # device-side exchange — the RCCL broadcast of the voice table — is in libgrail_hip.so.
+        sys.path.insert(0, os.path.join(ROOT, "grail-rs_amd"))
+        from grail_hip.rendezvous import FileGroup
+        group = FileGroup(rank, world)
+        group.barrier()  # local rank 0 has finished building
 
     import grail_hip as G
     from grail_hip import dist as D
@@ -112,18 +133,19 @@ def main():
         ctx.set_voices(voices)
     if distributed:
         try:
-            ids = [G.Context.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            ctx.comm_init(ids[0], rank, world)
-            ctx.broadcast_voices(n_voices, root=0)   # ncclBroadcast over xGMI inside the C ABI
+            with stdout_to_stderr():
+                uid = group.broadcast_bytes(G.Context.comm_unique_id() if rank == 0 else None)
+                ctx.comm_init(uid, rank, world)
+                ctx.broadcast_voices(n_voices, root=0)   # ncclBroadcast over xGMI inside the C ABI
             voices = ctx.get_voices()
             voice_path = "rccl ncclBroadcast (grail_broadcast_voices)"
-        except G.GrailError as e:                    # same hand-off through torch's RCCL
-            print(f"[rank {rank}] native RCCL broadcast failed ({e}); using torch.distributed",
+        except G.GrailError as e:      # keep the job alive: hand the same bytes over through /tmp
+            print(f"[rank {rank}] native RCCL broadcast failed ({e}); using the file rendezvous",
                   file=sys.stderr)
-            voices = D.broadcast_voices_torch(voices, n_voices, dist, device="cuda")
+            blob = group.broadcast_bytes(G.voices_blob(voices) if rank == 0 else None)
+            voices = G.voices_from_blob(blob)
             ctx.set_voices(voices)
-            voice_path = "rccl via torch.distributed.broadcast"
+            voice_path = "file rendezvous (native RCCL failed)"
 
     # ---- this rank's shard of the corpus, resident in HBM ---------------------------------
     first, last, segs, offs, vids, seeds = D.shard_inputs(n_utt, rank, world, len(voices))
@@ -142,10 +164,9 @@ def main():
         step()
 
     def barrier():
-        ctx.sync()
+        ctx.sync()              # hipStreamSynchronize on the stream every kernel ran on
         if distributed:
-            dist.barrier()
-            torch.cuda.synchronize()
+            group.barrier()
 
     barrier()
     t0 = time.perf_counter()
@@ -159,7 +180,9 @@ def main():
     slow = ctx.get_option("slow_division_wave_steps")
 
     if distributed:
-        elapsed, total_samples_per_step = D.reduce_step_stats(elapsed, samples_per_step, dist, "cuda")
+        stats = group.gather_doubles((elapsed, float(samples_per_step)))
+        elapsed = max(e for e, _ in stats)                  # MAX over ranks
+        total_samples_per_step = sum(n for _, n in stats)   # whole-job samples per step
     else:
         total_samples_per_step = float(samples_per_step)
 
@@ -196,7 +219,7 @@ def main():
                         "sample, SURVEY.md §8d) — see DESIGN.md §Roofline",
             },
         }
-        if not distributed and args.cpu_utts > 0:
+        if world == 1 and args.cpu_utts > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_utts, voices, W)
             line["speedup_vs_cpu_1thread"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
@@ -206,8 +229,7 @@ def main():
     batch.free()
     ctx.close()
     if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+        group.close()
 
 
 if __name__ == "__main__":

@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -67,8 +68,14 @@ Rccl &rccl()
 {
     static Rccl r = [] {
         Rccl x;
-        x.handle = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        // The ROCm installation's RCCL by absolute path first: a bare "librccl.so" would be
+        // satisfied by any copy the host process already holds (PyTorch wheels bundle one that
+        // is bound to their own private HIP runtime, not to the one this library links).
+        const char *env = getenv("GRAIL_RCCL_PATH");
+        if (env && *env) x.handle = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+        if (!x.handle) x.handle = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
         if (!x.handle) x.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!x.handle) x.handle = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!x.handle) return x;
         x.GetUniqueId = (decltype(x.GetUniqueId))dlsym(x.handle, "ncclGetUniqueId");
         x.CommInitRank = (decltype(x.CommInitRank))dlsym(x.handle, "ncclCommInitRank");

@@ -77,3 +77,40 @@ def test_two_rank_gloo_shard_broadcast_reduce(built):
     for p in procs:
         p.join(60)
     assert sorted(results) == [(0, "ok"), (1, "ok")], results
+
+
+def _fg_worker(rank, world, key, q):
+    sys.path.insert(0, os.path.join(ROOT, "grail-rs_amd"))
+    from grail_hip.rendezvous import FileGroup
+    try:
+        g = FileGroup(rank, world, key=key, timeout=60)
+        g.barrier()
+        blob = g.broadcast_bytes(bytes(range(128)) if rank == 0 else None)
+        assert blob == bytes(range(128))
+        stats = g.gather_doubles((0.25 * (rank + 1), 1000.0 + rank))
+        assert [s[0] for s in stats] == [0.25 * (r + 1) for r in range(world)]
+        assert max(s[0] for s in stats) == 0.25 * world
+        assert sum(s[1] for s in stats) == sum(1000.0 + r for r in range(world))
+        for _ in range(20):
+            g.barrier()
+        g.close()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+
+
+def test_file_rendezvous_three_ranks():
+    """bench.py's torch-free control plane: barrier, byte broadcast (the RCCL unique id),
+    scalar gather (max elapsed / sum samples)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    key = f"pytest_{os.getpid()}"
+    procs = [ctx.Process(target=_fg_worker, args=(r, 3, key, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert sorted(results) == [(0, "ok"), (1, "ok"), (2, "ok")], results
+    assert not os.path.exists(os.path.join("/tmp", f"grail_rdzv_{key}"))

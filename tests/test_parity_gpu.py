@@ -241,3 +241,19 @@ def test_config2_full_size_properties_and_sampled_parity(gpu_ctx):
     sub_offs = np.arange(len(pick) + 1, dtype=np.uint32) * 4
     ref, ref_len = O.synthesize_batch(ovoices(voices), sub, sub_offs, vids[pick], seeds[pick], stride)
     assert_bit_identical(out[pick], out_len[pick], ref, ref_len, "config 2 sample")
+
+
+def test_rccl_voice_broadcast_single_rank(gpu_ctx):
+    """grail_comm_* / grail_broadcast_voices on a 1-rank communicator: the RCCL library loads,
+    the communicator forms, ncclBroadcast runs on the context's stream and the table survives."""
+    voices = W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    uid = G.Context.comm_unique_id()
+    assert len(uid) == G.UNIQUE_ID_BYTES
+    gpu_ctx.comm_init(uid, 0, 1)
+    gpu_ctx.broadcast_voices(8, root=0)
+    got = gpu_ctx.get_voices()
+    assert all(bytes(a) == bytes(b) for a, b in zip(got, voices))
+    with pytest.raises(G.GrailError):
+        gpu_ctx.broadcast_voices(3, root=0)   # root's table holds 8 voices, not 3
+    G._check(G.load().grail_comm_destroy(gpu_ctx.handle))
