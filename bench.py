@@ -72,7 +72,9 @@ class stdout_to_stderr:
         os.dup2(2, 1)
 
     def __exit__(self, *exc):
+        import ctypes
         sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)   # RCCL used C stdio: empty its buffer while fd 1 is fd 2
         os.dup2(self.saved, 1)
         os.close(self.saved)
 
