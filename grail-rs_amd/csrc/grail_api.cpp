@@ -580,6 +580,44 @@ int grail_synthesize_batch_elems(grail_ctx *ctx, const grail_sequence_elem *segs
     return rc;
 }
 
+int grail_pcm16_async(grail_ctx *ctx, const float *in_dev, uint64_t in_stride,
+                      const uint32_t *len_dev, uint32_t n_utt, uint32_t max_len, int16_t *out_dev,
+                      uint64_t out_stride)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (n_utt && (!in_dev || !len_dev || !out_dev)) return fail(GRAIL_ERR_INVALID_ARG, "NULL buffer");
+    hipError_t e = launch_pcm16(in_dev, in_stride, len_dev, n_utt, max_len, out_dev, out_stride,
+                                ctx->stream);
+    if (e != hipSuccess) return hip_fail(e, "pcm16 kernel launch");
+    return GRAIL_OK;
+}
+
+int grail_say_batch(grail_ctx *ctx, const char *const *texts_utf8, uint32_t n_texts,
+                    const uint32_t *voice_ids, const uint32_t *jitter_seeds, float *out,
+                    uint64_t out_stride, uint32_t *out_len, uint32_t flags)
+{
+    if (!ctx) return fail(GRAIL_ERR_INVALID_ARG, "ctx is NULL");
+    if (ctx->voices.empty()) return fail(GRAIL_ERR_NO_VOICES, "call grail_set_voices first");
+    if (n_texts && !texts_utf8) return fail(GRAIL_ERR_INVALID_ARG, "texts is NULL");
+    std::vector<grail_phoneme_elem> segs;
+    std::vector<uint32_t> offs(1, 0u);
+    for (uint32_t i = 0; i < n_texts; ++i) {
+        const uint32_t vid = voice_ids ? voice_ids[i] : 0u;
+        if (vid >= ctx->voices.size()) return fail(GRAIL_ERR_INVALID_ARG, "voice id out of range");
+        if (!texts_utf8[i]) return fail(GRAIL_ERR_INVALID_ARG, "a text is NULL");
+        uint32_t n = 0;
+        grail_text_to_phoneme_elems(&ctx->voices[vid], texts_utf8[i], nullptr, 0, &n);
+        const size_t base = segs.size();
+        segs.resize(base + n);
+        int rc = grail_text_to_phoneme_elems(&ctx->voices[vid], texts_utf8[i], segs.data() + base, n, &n);
+        if (rc) return fail(rc, "transcription failed");
+        offs.push_back((uint32_t)segs.size());
+    }
+    return grail_synthesize_batch(ctx, segs.data(), offs.data(), voice_ids, jitter_seeds, n_texts, out,
+                                  out_stride, out_len, flags);
+}
+
 int grail_device_alloc(grail_ctx *ctx, size_t bytes, void **out)
 {
     int rc = bind(ctx);

@@ -50,6 +50,8 @@ EXPORTS = [
     "grail_batch_upload", "grail_batch_upload_elems", "grail_batch_free", "grail_batch_size",
     "grail_batch_lengths", "grail_batch_synthesize_async", "grail_sync",
     "grail_last_kernel_ms", "grail_synthesize_batch", "grail_synthesize_batch_elems",
+    "grail_language_generic", "grail_transcribe", "grail_intonate", "grail_text_to_phoneme_elems",
+    "grail_say_batch", "grail_pcm16_async", "grail_wav_write_i16",
     "grail_device_alloc", "grail_device_free", "grail_memcpy_d2h", "grail_memcpy_h2d",
     "grail_memset_d", "grail_shard_range", "grail_comm_unique_id", "grail_comm_init",
     "grail_broadcast_voices", "grail_comm_destroy",
@@ -116,6 +118,15 @@ class SequenceElem(C.Structure):
     ]
 
 
+class Rule(C.Structure):
+    _fields_ = [
+        ("string", C.POINTER(C.c_uint32)),
+        ("string_len", C.c_uint32),
+        ("phonemes", C.POINTER(C.c_int32)),
+        ("n_phonemes", C.c_uint32),
+    ]
+
+
 PHONEME_DTYPE = np.dtype(
     [("phoneme", "<i4"), ("length", "<f4"), ("blend_length", "<f4"), ("frequency", "<f4")]
 )
@@ -176,6 +187,16 @@ def load():
     L.grail_synthesize_batch.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, u64, vp, C.c_uint32]
     L.grail_synthesize_batch_elems.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, u64, vp,
                                                C.c_uint32]
+    L.grail_language_generic.restype = C.c_uint32
+    L.grail_language_generic.argtypes = [C.POINTER(C.POINTER(Rule)), C.POINTER(C.c_int)]
+    L.grail_transcribe.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(Rule), C.c_uint32,
+                                   C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_uint32, u32p]
+    L.grail_intonate.argtypes = [C.POINTER(Voice), C.POINTER(C.c_int32), C.c_uint32, vp]
+    L.grail_text_to_phoneme_elems.argtypes = [C.POINTER(Voice), C.c_char_p, vp, C.c_uint32, u32p]
+    L.grail_say_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.c_uint32, vp, vp, vp, u64, vp,
+                                  C.c_uint32]
+    L.grail_pcm16_async.argtypes = [vp, vp, u64, vp, C.c_uint32, C.c_uint32, vp, u64]
+    L.grail_wav_write_i16.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
     L.grail_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.grail_device_free.argtypes = [vp, vp]
     L.grail_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
@@ -259,6 +280,62 @@ def segments(seq):
     for i, s in enumerate(seq):
         a[i] = tuple(s)
     return a
+
+
+# ---- text front half ---------------------------------------------------------
+def make_rules(rule_list):
+    """[(string, [phonemes...]), ...] -> (Rule array, keepalive list)."""
+    keep = []
+    arr = (Rule * len(rule_list))()
+    for i, (st, ph) in enumerate(rule_list):
+        cps = (C.c_uint32 * max(len(st), 1))(*[ord(ch) for ch in st])
+        pp = (C.c_int32 * max(len(ph), 1))(*ph)
+        keep += [cps, pp]
+        arr[i].string = C.cast(cps, C.POINTER(C.c_uint32))
+        arr[i].string_len = len(st)
+        arr[i].phonemes = C.cast(pp, C.POINTER(C.c_int32))
+        arr[i].n_phonemes = len(ph)
+    return arr, keep
+
+
+def transcribe(text, rule_list, case_sensitive=False, leading_silence=False):
+    """Transcriber (src/lib.rs:1116); leading_silence=True is .transcribe() (:1201)."""
+    arr, keep = make_rules(rule_list)
+    cps = (C.c_uint32 * max(len(text), 1))(*[ord(ch) for ch in text])
+    cap = 4 * len(text) + 8
+    out = (C.c_int32 * cap)()
+    n = C.c_uint32()
+    _check(load().grail_transcribe(cps, len(text), arr, len(rule_list), int(case_sensitive),
+                                   int(leading_silence), out, cap, C.byref(n)))
+    return list(out[: n.value])
+
+
+def language_generic():
+    """languages::generic() as [(string, [phonemes])], case_sensitive."""
+    rules = C.POINTER(Rule)()
+    cs = C.c_int()
+    n = load().grail_language_generic(C.byref(rules), C.byref(cs))
+    out = []
+    for i in range(n):
+        r = rules[i]
+        out.append(("".join(chr(r.string[k]) for k in range(r.string_len)),
+                    [r.phonemes[k] for k in range(r.n_phonemes)]))
+    return out, bool(cs.value)
+
+
+def text_to_phoneme_elems(voice, text):
+    n = C.c_uint32()
+    _check(load().grail_text_to_phoneme_elems(C.byref(voice), text.encode("utf-8"), None, 0,
+                                              C.byref(n)))
+    a = np.zeros(max(n.value, 1), dtype=PHONEME_DTYPE)
+    _check(load().grail_text_to_phoneme_elems(C.byref(voice), text.encode("utf-8"), a.ctypes.data,
+                                              n.value, C.byref(n)))
+    return a[: n.value]
+
+
+def wav_write_i16(path, pcm, sample_rate):
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    _check(load().grail_wav_write_i16(path.encode(), pcm.ctypes.data, len(pcm), int(sample_rate)))
 
 
 def device_count():
@@ -394,6 +471,31 @@ class Context:
             self.handle, C.cast(arr, C.c_void_p), seg_offsets.ctypes.data, _ptr(voice_ids),
             _ptr(jitter_seeds), n_utt, out.ctypes.data, out_stride, out_len.ctypes.data, OUT_HOST))
         return out[:n_utt], out_len[:n_utt]
+
+    def say(self, texts, voice_ids=None, jitter_seeds=None, out_stride=None, seconds_per_char=1.6):
+        """examples/cli.rs:175-184 for a list of texts. Returns (out[n, stride], out_len)."""
+        n = len(texts)
+        arr = (C.c_char_p * max(n, 1))(*[t.encode("utf-8") for t in texts])
+        if voice_ids is not None:
+            voice_ids = np.ascontiguousarray(voice_ids, dtype=np.uint32)
+        if jitter_seeds is not None:
+            jitter_seeds = np.ascontiguousarray(jitter_seeds, dtype=np.uint32)
+        if out_stride is None:
+            rate = max(v.sample_rate for v in self.get_voices())
+            longest = max([len(t) for t in texts] + [1])
+            out_stride = (int((longest * seconds_per_char + 1.0) * rate) + 63) // 64 * 64
+        out = np.zeros((max(n, 1), out_stride), dtype=np.float32)
+        out_len = np.zeros(max(n, 1), dtype=np.uint32)
+        _check(load().grail_say_batch(self.handle, arr, n, _ptr(voice_ids), _ptr(jitter_seeds),
+                                      out.ctypes.data, out_stride, out_len.ctypes.data, OUT_HOST))
+        return out[:n], out_len[:n]
+
+    def pcm16(self, in_dev, in_stride, len_dev, n_utt, max_len, out_dev, out_stride):
+        _check(load().grail_pcm16_async(self.handle, in_dev, in_stride, len_dev, n_utt, max_len,
+                                        out_dev, out_stride))
+
+    def h2d(self, dst_dev, src, nbytes):
+        _check(load().grail_memcpy_h2d(self.handle, dst_dev, src.ctypes.data, nbytes))
 
     def sync(self):
         _check(load().grail_sync(self.handle))

@@ -219,6 +219,42 @@ int grail_synthesize_batch_elems(grail_ctx *ctx, const grail_sequence_elem *segs
                                  const uint32_t *jitter_seeds, uint32_t n_utt, float *out,
                                  uint64_t out_stride, uint32_t *out_len, uint32_t flags);
 
+/* ---- text front half + PCM sink ------------------ */
+/* TranscriptionRule  src/lib.rs:1030-1036; strings are Unicode scalar values (str::chars). */
+typedef struct grail_rule {
+    const uint32_t *string;
+    uint32_t        string_len;
+    const int32_t  *phonemes;   /* grail_phoneme */
+    uint32_t        n_phonemes;
+} grail_rule;
+/* languages::generic()  src/languages/mod.rs:4-34; returns the rule count. */
+uint32_t grail_language_generic(const grail_rule **rules, int *case_sensitive);
+/* Transcriber::next until None  src/lib.rs:1116-1191.  leading_silence != 0 is
+ * `.transcribe(language)` (buffer seeded with Silence, :1201); 0 starts with an empty buffer as
+ * the reference's own unit tests do (:1212-1225).  *n_out is the full count even when > cap. */
+int grail_transcribe(const uint32_t *text, uint32_t text_len, const grail_rule *rules,
+                     uint32_t n_rules, int case_sensitive, int leading_silence,
+                     int32_t *out_phonemes, uint32_t cap, uint32_t *n_out);
+/* Intonator::next  src/lib.rs:1057-1075 (`.intonate(language, voice)` :1081). */
+int grail_intonate(const grail_voice *voice, const int32_t *phonemes, uint32_t n,
+                   grail_phoneme_elem *out);
+/* text.chars().transcribe(languages::generic()).intonate(languages::generic(), voice)
+ * — the front of examples/cli.rs:176-179.  out == NULL only counts. */
+int grail_text_to_phoneme_elems(const grail_voice *voice, const char *text_utf8,
+                                grail_phoneme_elem *out, uint32_t cap, uint32_t *n_out);
+/* The whole chain of examples/cli.rs:175-184 for n texts: text i is spoken with
+ * voices[voice_ids[i]] (NULL: voice 0) and jitter seed seeds[i] (NULL: 0, as the CLI). */
+int grail_say_batch(grail_ctx *ctx, const char *const *texts_utf8, uint32_t n_texts,
+                    const uint32_t *voice_ids, const uint32_t *jitter_seeds, float *out,
+                    uint64_t out_stride, uint32_t *out_len, uint32_t flags);
+/* `(x * i16::MAX as f32) as i16` of examples/cli.rs:49 on the device: rows of f32 -> rows of
+ * i16, first len_dev[u] samples of each row; all pointers are device memory. Asynchronous. */
+int grail_pcm16_async(grail_ctx *ctx, const float *in_dev, uint64_t in_stride,
+                      const uint32_t *len_dev, uint32_t n_utt, uint32_t max_len,
+                      int16_t *out_dev, uint64_t out_stride);
+/* save_wav  examples/cli.rs:28-67: 44-byte RIFF header (PCM, mono, 16 bit) + samples. */
+int grail_wav_write_i16(const char *path, const int16_t *pcm, uint32_t n, uint32_t sample_rate);
+
 /* ---- device memory plumbing ------------------------------------------- */
 int grail_device_alloc(grail_ctx *ctx, size_t bytes, void **out);
 int grail_device_free(grail_ctx *ctx, void *ptr);

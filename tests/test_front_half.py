@@ -1,0 +1,121 @@
+"""The host front half of the product (csrc/text_front.cpp): Transcriber, Intonator,
+languages::generic(), the RIFF writer — against the reference's six literal Transcriber tests
+(src/lib.rs:1210-1358), against the oracle on random inputs, and the header spec of
+examples/cli.rs:28-67."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import grail_hip as G
+import oracle_lib as O
+
+A, E, SIL = G.PH_A, G.PH_E, G.PH_SILENCE
+
+REFERENCE_TESTS = [   # (name, text, rules, expected) — literal from the reference
+    ("transcribe_unique", "abc", [("ab", [A]), ("c", [E])], [A, E]),                       # :1210
+    ("transcribe_same_start", "abacab", [("ab", [A]), ("ac", [E])], [A, E, A]),            # :1233
+    ("transcribe_same_char_different_length", "aaa", [("a", [A]), ("aa", [E])], [E, A]),   # :1257
+    ("transcribe_same_char_different_length_cutoff", "ae",
+     [("a", [A]), ("aa", [E]), ("e", [E])], [A, E]),                                        # :1282
+    ("transcribe_skip_no_matches", "abuac", [("ab", [A]), ("ac", [E])], [A, SIL, E]),      # :1310
+    ("transcribe_skip_partial_match_at_end", "abaca", [("ab", [A]), ("ac", [E])], [A, E, SIL]),  # :1335
+]
+
+
+@pytest.mark.parametrize("name,text,rules,want", REFERENCE_TESTS, ids=[t[0] for t in REFERENCE_TESTS])
+def test_reference_transcriber_tests(built, name, text, rules, want):
+    assert G.transcribe(text, rules) == want
+
+
+def test_language_generic_table(built):
+    rules, cs = G.language_generic()
+    assert cs is False
+    assert rules == [("a", [A]), ("e", [E]), ("i", [A]), ("ii", [E, A]), ("oui", [A, E, A]),
+                     ("p", [SIL])]
+    assert [r[0] for r in rules] == sorted(r[0] for r in rules)  # binary search needs sorted rules
+
+
+def test_transcriber_matches_oracle_on_random_text(built):
+    rng = np.random.default_rng(3)
+    rules, _ = G.language_generic()
+    extra = [("ab", [A]), ("abc", [E, E]), ("b", [SIL]), ("ba", [A, E]), ("c", [E]), ("cab", [A])]
+    for rs in (rules, sorted(extra)):
+        for _ in range(300):
+            n = int(rng.integers(0, 12))
+            text = "".join(rng.choice(list("aeioupbcAEI x"), n))
+            for lead in (False, True):
+                got = G.transcribe(text, rs, leading_silence=lead)
+                want = O.transcribe(text, rs, leading_silence=lead)
+                assert got == want, (text, lead, got, want)
+
+
+def test_text_to_phoneme_elems_is_transcribe_then_intonate(built):
+    v = G.voice_generic()
+    pe = G.text_to_phoneme_elems(v, "aEi oui")
+    rules, _ = G.language_generic()
+    want = G.transcribe("aEi oui", rules, leading_silence=True)
+    assert list(pe["phoneme"]) == want and want[0] == SIL          # src/lib.rs:1201
+    assert np.all(pe["length"] == np.float32(0.5)) and np.all(pe["blend_length"] == np.float32(0.5))
+    assert np.all(pe["frequency"] == np.float32(v.center_frequency))  # src/lib.rs:1068-1073
+    assert len(G.text_to_phoneme_elems(v, "")) == 1                # just the leading Silence
+    assert list(G.text_to_phoneme_elems(v, "éa")["phoneme"]) == [SIL, SIL, A]  # non-ASCII char: no rule
+
+
+def test_wav_header_matches_cli_save_wav(built, tmp_path):
+    pcm = np.array([0, 1, -1, 32767, -32768, 1234], dtype=np.int16)
+    path = str(tmp_path / "t.wav")
+    G.wav_write_i16(path, pcm, 44100)
+    raw = open(path, "rb").read()
+    assert len(raw) == 44 + 2 * len(pcm)
+    assert raw[:4] == b"RIFF" and raw[8:16] == b"WAVEfmt " and raw[36:40] == b"data"
+    size, = struct.unpack("<I", raw[4:8])
+    fmt_len, fmt, ch, rate, brate, align, bits = struct.unpack("<IHHIIHH", raw[16:36])
+    dlen, = struct.unpack("<I", raw[40:44])
+    assert (size, fmt_len, fmt, ch, rate, brate, align, bits, dlen) == (
+        36 + 2 * len(pcm), 16, 1, 1, 44100, 88200, 2, 16, 2 * len(pcm))
+    assert np.array_equal(np.frombuffer(raw[44:], dtype="<i2"), pcm)
+
+
+@pytest.mark.gpu
+def test_say_batch_equals_the_cli_chain(gpu_ctx):
+    """text -> PCM through the C ABI == the oracle's examples/cli.rs:175-184 chain."""
+    v = G.voice_generic()
+    gpu_ctx.set_voices([v])
+    texts = ["a", "ae", "", "oui", "xyz"]
+    out, out_len = gpu_ctx.say(texts)
+    ov = O.voice_generic()
+    for i, t in enumerate(texts):
+        ref = O.say(ov, t)
+        assert out_len[i] == len(ref), (t, out_len[i], len(ref))
+        assert np.array_equal(out[i, :len(ref)].view(np.uint32), ref.view(np.uint32)), t
+
+
+@pytest.mark.gpu
+def test_pcm16_kernel_matches_rust_as_cast(gpu_ctx):
+    rng = np.random.default_rng(9)
+    n_utt, stride = 5, 4104
+    x = (rng.standard_normal((n_utt, stride)) * 0.6).astype(np.float32)
+    x[0, :12] = [0.0, -0.0, 1.0, -1.0, 2.0, -2.0, np.nan, np.inf, -np.inf, 0.99999, 1e-9, -3e-5]
+    lens = np.array([4104, 4097, 1, 0, 2049], dtype=np.uint32)
+    d_in = gpu_ctx.device_alloc(x.nbytes)
+    d_len = gpu_ctx.device_alloc(lens.nbytes)
+    d_out = gpu_ctx.device_alloc(n_utt * stride * 2)
+    try:
+        gpu_ctx.h2d(d_in, x, x.nbytes)
+        gpu_ctx.h2d(d_len, lens, lens.nbytes)
+        gpu_ctx.memset(d_out, 0x55, n_utt * stride * 2)
+        gpu_ctx.pcm16(d_in, stride, d_len, n_utt, int(lens.max()), d_out, stride)
+        gpu_ctx.sync()
+        got = np.zeros((n_utt, stride), dtype=np.int16)
+        gpu_ctx.d2h(got, d_out, got.nbytes)
+    finally:
+        for p in (d_in, d_len, d_out):
+            gpu_ctx.device_free(p)
+    L = O.lib()
+    for u in range(n_utt):
+        want = np.array([L.orc_pcm16(float(v)) if not np.isnan(v) else 0 for v in x[u, :lens[u]]],
+                        dtype=np.int16)
+        assert np.array_equal(got[u, :lens[u]], want), u
+        assert np.all(got[u, lens[u]:] == 0x5555)   # beyond the row's length: untouched
