@@ -112,6 +112,15 @@ struct grail_ctx {
     uint32_t comm_rank = 0, comm_world = 1;
 };
 
+struct grail_stream {
+    const grail_batch *batch = nullptr;
+    uint32_t *d_state = nullptr;   // [state_words(L)][lanes]
+    uint64_t lanes = 0;
+    int L = 1;
+    int variant = 0;
+    bool started = false;
+};
+
 struct grail_batch {
     DevSeg *d_segs = nullptr;
     uint32_t *d_offsets = nullptr;
@@ -314,7 +323,7 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         return GRAIL_OK;
     }
     if (std::strcmp(name, "kernel_variant") == 0) {
-        if (value < 0 || value > 8) return fail(GRAIL_ERR_INVALID_ARG, "kernel_variant out of range");
+        if (value < 0 || value > 1) return fail(GRAIL_ERR_INVALID_ARG, "kernel_variant out of range");
         ctx->variant_option = (int)value;
         return GRAIL_OK;
     }
@@ -473,6 +482,7 @@ int grail_batch_synthesize_async(grail_ctx *ctx, const grail_batch *batch, float
     a.out_len = out_len_dev;
     a.truncated = ctx->d_truncated;
     a.out_stride = out_stride;
+    a.cap = out_stride;
     a.n_utt = batch->n_utt;
     a.n_voices = (uint32_t)ctx->voices.size();
     a.phoneme_mode = batch->phoneme_mode ? 1u : 0u;
@@ -482,6 +492,78 @@ int grail_batch_synthesize_async(grail_ctx *ctx, const grail_batch *batch, float
     if (e != hipSuccess) return hip_fail(e, "synth kernel launch");
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->have_timing = true;
+    return GRAIL_OK;
+}
+
+int grail_stream_open(grail_ctx *ctx, const grail_batch *batch, grail_stream **out)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!out) return fail(GRAIL_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if ((rc = check_ready(ctx, batch))) return rc;
+    grail_stream *s = new (std::nothrow) grail_stream();
+    if (!s) return fail(GRAIL_ERR_OUT_OF_MEMORY, "host allocation failed");
+    s->batch = batch;
+    s->L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(batch->n_utt);
+    s->variant = ctx->variant_option;
+    s->lanes = state_lanes(batch->n_utt, s->L, s->variant);
+    const size_t bytes = (size_t)state_words(s->L) * s->lanes * sizeof(uint32_t);
+    hipError_t e = hipMalloc((void **)&s->d_state, bytes ? bytes : 4);
+    if (e != hipSuccess) {
+        delete s;
+        return hip_fail(e, "stream state allocation");
+    }
+    *out = s;
+    return GRAIL_OK;
+}
+
+int grail_stream_next_async(grail_ctx *ctx, grail_stream *stream, uint32_t max_samples,
+                            float *out_dev, uint64_t out_stride, uint32_t *out_len_dev)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!stream) return fail(GRAIL_ERR_INVALID_ARG, "stream is NULL");
+    const grail_batch *batch = stream->batch;
+    if ((rc = check_ready(ctx, batch))) return rc;
+    if (max_samples > out_stride) return fail(GRAIL_ERR_INVALID_ARG, "max_samples exceeds out_stride");
+    if (batch->n_utt == 0) return GRAIL_OK;
+    if (!out_dev && max_samples) return fail(GRAIL_ERR_INVALID_ARG, "out_dev is NULL");
+    SynthArgs a{};
+    a.segs = batch->d_segs;
+    a.seg_offsets = batch->d_offsets;
+    a.voice_ids = batch->d_voice_ids;
+    a.seeds = batch->d_seeds;
+    a.elems = batch->phoneme_mode ? ctx->d_voice_elems : batch->d_elems;
+    a.voices = ctx->d_voices;
+    a.out = out_dev;
+    a.out_len = out_len_dev;
+    a.truncated = ctx->d_truncated;
+    a.out_stride = out_stride;
+    a.cap = max_samples;
+    a.n_utt = batch->n_utt;
+    a.n_voices = (uint32_t)ctx->voices.size();
+    a.phoneme_mode = batch->phoneme_mode ? 1u : 0u;
+    a.state = stream->d_state;
+    a.state_stride = stream->lanes;
+    a.resume = stream->started ? 1u : 0u;
+    HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    hipError_t e = launch_synth(a, stream->L, stream->variant, ctx->stream);
+    if (e != hipSuccess) return hip_fail(e, "synth kernel launch");
+    HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    ctx->have_timing = true;
+    stream->started = true;
+    return GRAIL_OK;
+}
+
+int grail_stream_close(grail_ctx *ctx, grail_stream *stream)
+{
+    if (!stream) return GRAIL_OK;
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (stream->d_state) (void)hipFree(stream->d_state);
+    delete stream;
     return GRAIL_OK;
 }
 

@@ -51,10 +51,14 @@ struct SynthArgs {
     uint32_t *out_len;            // may be nullptr
     uint32_t *truncated;          // [0]: set to 1 when an utterance is cut at out_stride;
                                   // [1]: += wave-steps that ran the IEEE-division body
-    uint64_t out_stride;
+    uint64_t out_stride;          // floats between rows
+    uint64_t cap;                 // samples a row may receive in this launch (<= out_stride)
     uint32_t n_utt;
     uint32_t n_voices;
     uint32_t phoneme_mode;        // 1: run the Selector on the device
+    uint32_t *state;              // resumable synthesis: state[word][lane] or nullptr (one-shot)
+    uint64_t state_stride;        // lanes of the launch (= state_lanes())
+    uint32_t resume;              // 1: load the state first (not the first call of a stream)
 };
 
 struct LenArgs {
@@ -74,6 +78,9 @@ hipError_t launch_lengths(const LenArgs &args, hipStream_t stream);
 // f32 rows -> i16 PCM rows (examples/cli.rs:49); only the first len[u] (<= max_len) samples of row u
 hipError_t launch_pcm16(const float *in, uint64_t in_stride, const uint32_t *len, uint32_t n_utt,
                         uint32_t max_len, int16_t *out, uint64_t out_stride, hipStream_t stream);
+// resumable synthesis: words per lane and lanes per launch of the state buffer
+uint32_t state_words(int lanes_per_utt);
+uint64_t state_lanes(uint32_t n_utt, int lanes_per_utt, int variant);
 // the choice made when the option is 0 (auto)
 int auto_lanes_per_utt(uint32_t n_utt);
 

@@ -346,7 +346,39 @@ __device__ __forceinline__ bool pair_is_safe(const Part<NV, V> &X, const Part<NV
     return ok;
 }
 
-template <int L, int T, int WAVES, int MIN_WAVES_PER_SIMD>
+// Resumable synthesis: the per-lane state that the reference keeps in
+// its Copy iterator structs (Sequencer :839-854, Jitter :724-748, Synthesize :470-488), moved
+// between registers and HBM word by word.  Layout: state[word][global lane], coalesced.
+template <bool LOAD>
+struct StateIO {
+    uint32_t *base;
+    size_t stride, lane;
+    uint32_t w = 0;
+    __device__ __forceinline__ uint32_t &slot() { return base[(size_t)(w++) * stride + lane]; }
+    __device__ __forceinline__ void operator()(uint32_t &v) { if (LOAD) v = slot(); else slot() = v; }
+    __device__ __forceinline__ void operator()(int &v)
+    {
+        if (LOAD) v = (int)slot(); else slot() = (uint32_t)v;
+    }
+    __device__ __forceinline__ void operator()(float &v)
+    {
+        if (LOAD) v = __uint_as_float(slot()); else slot() = __float_as_uint(v);
+    }
+    __device__ __forceinline__ void operator()(bool &v)
+    {
+        if (LOAD) v = slot() != 0u; else slot() = v ? 1u : 0u;
+    }
+    __device__ __forceinline__ void operator()(f2 &v)
+    {
+        float a = v.x, b = v.y;
+        (*this)(a);
+        (*this)(b);
+        v.x = a;
+        v.y = b;
+    }
+};
+
+template <int L, int T, int WAVES, int MIN_WAVES_PER_SIMD, bool STREAM>
 __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(const SynthArgs A)
 {
     constexpr int FPL = NF / L;          // formants per lane
@@ -450,21 +482,86 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     }
     uint32_t noise_seed = 0u;                // :594
 
-    const uint64_t cap = A.out_stride;
+    const uint64_t cap = A.cap;              // samples this launch may write per row (<= out_stride)
     const uint32_t cap32 = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;   // n_out is 32-bit
     uint32_t n_out = 0;
     uint32_t slow_steps = 0;                 // wave-steps that took the IEEE-division body
     bool truncated = false;
-    const bool vec_ok = ((reinterpret_cast<uintptr_t>(A.out) & 15u) == 0) && ((cap & 3u) == 0);
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(A.out) & 15u) == 0) && ((A.out_stride & 3u) == 0);
 
     // false while the lane's segment pair needs the IEEE-division body or has a blend
     // length that is not a power of two: such lanes always take the general step
     bool quiet_ok = false;
 
+    bool finished = false;   // the chain has returned None (persistent); `done` also covers pauses
+
+    // (cur, nxt) -> X, Y, blend constants: the match of Sequencer::next resolved once per pair
+    auto setup_pair = [&]() __attribute__((always_inline)) {
+        // the match at :891-931, resolved once per segment pair
+        const bool has_b = cur.elem >= 0;
+        const bool has_c = nxt.some && nxt.elem >= 0;
+        blend_length = cur.blend_length;
+        silent_pair = !has_b && !has_c;
+        if (has_b && has_c) {          // c.blend(b, alpha)  :897-903
+            load_part<NV, W>(X, elems, nxt.elem, f0);
+            load_part<NV, W>(Y, elems, cur.elem, f0);
+            X.frequency = nxt.frequency;
+            Y.frequency = cur.frequency;
+        } else if (has_b) {            // b.copy_silent().blend(b, alpha)  :906-912
+            load_part<NV, W>(Y, elems, cur.elem, f0);
+            Y.frequency = cur.frequency;
+            X = Y;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) X.amp[k] = vsplat(0.0f, X.amp[k]);
+        } else if (has_c) {            // c.blend(c.copy_silent(), alpha)  :915-921
+            load_part<NV, W>(X, elems, nxt.elem, f0);
+            X.frequency = nxt.frequency;
+            Y = X;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) Y.amp[k] = vsplat(0.0f, Y.amp[k]);
+        } else {                       // SynthesisElem::silent()  :924-927
+            silent_part(X);
+            silent_part(Y);
+        }
+        // clk / 2^k == clk * 2^-k for every clk (same real number, same rounding)
+        const uint32_t blb = __float_as_uint(blend_length);
+        const uint32_t ble = (blb >> 23) & 0xFFu;
+        blend_pow2 = ((blb & 0x7FFFFFu) == 0u) && ble >= 1u && ble <= 253u;
+        inv_blend_length = 1.0f / blend_length;
+    };
+
+    constexpr bool streaming = STREAM;       // a separate instantiation: the one-shot kernel
+                                             // carries none of the state traffic or its registers
+    const size_t state_lane = (size_t)(blockIdx.x * WAVES + wave) * 64 + lane;
+    auto visit_state = [&](auto &io) __attribute__((always_inline)) {
+        io(seg_pos);
+        io(cur.some); io(cur.elem); io(cur.length); io(cur.blend_length); io(cur.frequency);
+        io(nxt.some); io(nxt.elem); io(nxt.length); io(nxt.blend_length); io(nxt.frequency);
+        io(clk); io(pair_safe); io(finished);
+        io(fn_cur); io(fn_next); io(fn_state); io(ff_state); io(fa_state); io(jphase);
+        io(phase); io(noise_seed);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            io(ff_cur[k]); io(ff_next[k]); io(fa_cur[k]); io(fa_next[k]);
+            io(st_a[k]); io(st_b[k]); io(st_c[k]);
+        }
+    };
+    if (streaming && A.state && A.resume && u < A.n_utt) {
+        StateIO<true> io{A.state, A.state_stride, state_lane};
+        visit_state(io);
+        done = finished;
+        if (cur.some) setup_pair();
+        quiet_ok = pair_safe && blend_pow2;
+    }
+
     // ---- the general sample step: any lane may be finished, advance a segment, wrap its
     // jitter noise, hit the row capacity, or need the IEEE-division body.
     auto general_step = [&](const int t) __attribute__((always_inline)) {
         if (done) return;
+        if (streaming && n_out >= cap32) {   // this call's quota is used up: pause BEFORE advancing
+            done = true;
+            return;
+        }
 
         // ================= Sequencer::next, src/lib.rs:859-932
         clk -= dt;                                            // :861
@@ -479,43 +576,14 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 if (cur.some) clk += cur.length;              // :881-883
             } else {
                 done = true;                                  // :886
+                finished = true;
             }
             if (!done && cur.some) {
-                // the match at :891-931, resolved once per segment pair
-                const bool has_b = cur.elem >= 0;
-                const bool has_c = nxt.some && nxt.elem >= 0;
-                blend_length = cur.blend_length;
-                silent_pair = !has_b && !has_c;
-                if (has_b && has_c) {          // c.blend(b, alpha)  :897-903
-                    load_part<NV, W>(X, elems, nxt.elem, f0);
-                    load_part<NV, W>(Y, elems, cur.elem, f0);
-                    X.frequency = nxt.frequency;
-                    Y.frequency = cur.frequency;
-                } else if (has_b) {            // b.copy_silent().blend(b, alpha)  :906-912
-                    load_part<NV, W>(Y, elems, cur.elem, f0);
-                    Y.frequency = cur.frequency;
-                    X = Y;
-#pragma unroll
-                    for (int k = 0; k < NV; ++k) X.amp[k] = vsplat(0.0f, X.amp[k]);
-                } else if (has_c) {            // c.blend(c.copy_silent(), alpha)  :915-921
-                    load_part<NV, W>(X, elems, nxt.elem, f0);
-                    X.frequency = nxt.frequency;
-                    Y = X;
-#pragma unroll
-                    for (int k = 0; k < NV; ++k) Y.amp[k] = vsplat(0.0f, Y.amp[k]);
-                } else {                       // SynthesisElem::silent()  :924-927
-                    silent_part(X);
-                    silent_part(Y);
-                }
-                // clk / 2^k == clk * 2^-k for every clk (same real number, same rounding)
-                const uint32_t blb = __float_as_uint(blend_length);
-                const uint32_t ble = (blb >> 23) & 0xFFu;
-                blend_pow2 = ((blb & 0x7FFFFFu) == 0u) && ble >= 1u && ble <= 253u;
-                inv_blend_length = 1.0f / blend_length;
+                setup_pair();
                 pair_safe = pair_is_safe<NV, W>(X, Y, clk, blend_length, jinc, d_ffreq, d_freq);
             }
         }
-        if (!cur.some) done = true;                           // :930
+        if (!cur.some) { done = true; finished = true; }      // :930
         if (done) return;
         if (__builtin_expect(n_out >= cap, 0)) {   // the chain would yield another sample: row is full
             truncated = true;
@@ -716,7 +784,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             const uint32_t c = cnt[r];
             const int t0 = rl * 4;
             if ((uint32_t)t0 < c) {
-                float *dst = A.out + (uint64_t)(u0 + r) * cap + base + t0;
+                float *dst = A.out + (uint64_t)(u0 + r) * A.out_stride + base + t0;
                 const float s0 = stage[(t0 + 0) * SP + r];
                 const float s1 = stage[(t0 + 1) * SP + r];
                 const float s2 = stage[(t0 + 2) * SP + r];
@@ -738,6 +806,10 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     if (j == L - 1 && u < A.n_utt) {
         if (A.out_len) A.out_len[u] = n_out;
         if (truncated) atomicOr(A.truncated, 1u);
+    }
+    if (streaming && A.state && u < A.n_utt) {
+        StateIO<false> io{A.state, A.state_stride, state_lane};
+        visit_state(io);
     }
     if (lane == 0 && slow_steps) atomicAdd(A.truncated + 1, slow_steps);
 }
@@ -783,6 +855,28 @@ __global__ __launch_bounds__(64) void lengths_kernel(const LenArgs A)
 
 }  // namespace
 
+uint32_t state_words(int L)
+{
+    const int fpl = NF / L;
+    return 22u + 7u * (uint32_t)fpl;   // visit_state: 22 scalars + 7 values per formant
+}
+
+static void geometry(int L, int variant, uint32_t &per_block, uint32_t &threads)
+{
+    // must mirror the <L, T, WAVES, MINW> table of launch_synth
+    const int waves = (L >= 4 || variant == 1) ? 4 : 1;
+    per_block = (64u / (uint32_t)L) * (uint32_t)waves;
+    threads = 64u * (uint32_t)waves;
+}
+
+uint64_t state_lanes(uint32_t n_utt, int L, int variant)
+{
+    uint32_t per_block, threads;
+    geometry(L, variant, per_block, threads);
+    const uint64_t blocks = (n_utt + per_block - 1) / per_block;
+    return blocks * threads;
+}
+
 int auto_lanes_per_utt(uint32_t n_utt)
 {
     // Measured (profiles/r01_lanes_sweep.txt): a wave alone on its SIMD renders 2 s of audio
@@ -800,26 +894,26 @@ static void launch_one(const SynthArgs &args, hipStream_t stream)
 {
     const uint32_t per_block = (64u / L) * WAVES;
     const dim3 grid((args.n_utt + per_block - 1) / per_block), block(64 * WAVES);
-    hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW>), grid, block, 0, stream, args);
+    if (args.state)
+        hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, true>), grid, block, 0, stream, args);
+    else
+        hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, false>), grid, block, 0, stream, args);
 }
 
 hipError_t launch_synth(const SynthArgs &args, int L, int variant, hipStream_t stream)
 {
     if (args.n_utt == 0) return hipSuccess;
-    // 64-thread workgroups are admitted 8 per CU (2 waves per SIMD, measured); the
-    // mappings that want more resident waves use 256-thread workgroups.
-    // `variant` (tuning/experiments only) picks another <L, T, WAVES, MIN_WAVES_PER_SIMD>.
-    switch (variant) {
-    case 0: break;
-    case 1: launch_one<2, 64, 4, 2>(args, stream); return hipGetLastError();
-    case 2: launch_one<2, 64, 4, 3>(args, stream); return hipGetLastError();
-    case 3: launch_one<2, 64, 4, 4>(args, stream); return hipGetLastError();
-    case 4: launch_one<4, 64, 1, 4>(args, stream); return hipGetLastError();
-    case 5: launch_one<4, 64, 4, 5>(args, stream); return hipGetLastError();
-    case 6: launch_one<1, 32, 4, 2>(args, stream); return hipGetLastError();
-    case 7: launch_one<8, 64, 4, 6>(args, stream); return hipGetLastError();
-    case 8: launch_one<4, 64, 8, 4>(args, stream); return hipGetLastError();
-    default: return hipErrorInvalidValue;
+    // 64-thread workgroups are admitted 8 per CU (2 waves per SIMD, measured); L = 4 / 8 use
+    // 256-thread workgroups so that more waves can be resident.  variant 1 (experiments only):
+    // 256-thread workgroups for L = 1 / 2 as well.
+    if (variant == 1) {
+        switch (L) {
+        case 1: launch_one<1, 32, 4, 1>(args, stream); return hipGetLastError();
+        case 2: launch_one<2, 64, 4, 2>(args, stream); return hipGetLastError();
+        default: break;
+        }
+    } else if (variant != 0) {
+        return hipErrorInvalidValue;
     }
     switch (L) {
     case 1: launch_one<1, 32, 1, 1>(args, stream); break;

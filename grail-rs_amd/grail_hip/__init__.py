@@ -50,6 +50,7 @@ EXPORTS = [
     "grail_batch_upload", "grail_batch_upload_elems", "grail_batch_free", "grail_batch_size",
     "grail_batch_lengths", "grail_batch_synthesize_async", "grail_sync",
     "grail_last_kernel_ms", "grail_synthesize_batch", "grail_synthesize_batch_elems",
+    "grail_stream_open", "grail_stream_next_async", "grail_stream_close",
     "grail_language_generic", "grail_transcribe", "grail_intonate", "grail_text_to_phoneme_elems",
     "grail_say_batch", "grail_pcm16_async", "grail_wav_write_i16",
     "grail_device_alloc", "grail_device_free", "grail_memcpy_d2h", "grail_memcpy_h2d",
@@ -187,6 +188,9 @@ def load():
     L.grail_synthesize_batch.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, u64, vp, C.c_uint32]
     L.grail_synthesize_batch_elems.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, u64, vp,
                                                C.c_uint32]
+    L.grail_stream_open.argtypes = [vp, vp, C.POINTER(vp)]
+    L.grail_stream_next_async.argtypes = [vp, vp, C.c_uint32, vp, u64, vp]
+    L.grail_stream_close.argtypes = [vp, vp]
     L.grail_language_generic.restype = C.c_uint32
     L.grail_language_generic.argtypes = [C.POINTER(C.POINTER(Rule)), C.POINTER(C.c_int)]
     L.grail_transcribe.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(Rule), C.c_uint32,
@@ -364,6 +368,25 @@ class Batch:
     def free(self):
         if self.handle:
             load().grail_batch_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+
+class Stream:
+    """grail_stream: resumable synthesis of a Batch (chunks of samples per call)."""
+
+    def __init__(self, batch):
+        self.batch, self.ctx = batch, batch.ctx
+        h = C.c_void_p()
+        _check(load().grail_stream_open(self.ctx.handle, batch.handle, C.byref(h)))
+        self.handle = h
+
+    def next_async(self, max_samples, out_dev, out_stride, out_len_dev=None):
+        _check(load().grail_stream_next_async(self.ctx.handle, self.handle, max_samples, out_dev,
+                                              out_stride, out_len_dev))
+
+    def close(self):
+        if self.handle:
+            load().grail_stream_close(self.ctx.handle, self.handle)
             self.handle = None
 
 

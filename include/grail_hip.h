@@ -112,6 +112,7 @@ typedef struct grail_sequence_elem {
 
 typedef struct grail_ctx   grail_ctx;   /* one per (process, GPU); owns a HIP stream */
 typedef struct grail_batch grail_batch; /* inputs of one batch, resident in HBM */
+typedef struct grail_stream grail_stream; /* resumable synthesis of one batch */
 
 /* flags of grail_synthesize_batch*() */
 #define GRAIL_OUT_HOST   0u /* `out` is host memory (pageable or pinned) */
@@ -205,6 +206,17 @@ int grail_sync(grail_ctx *ctx);
 /* HIP-event time (ms) of the most recent synthesis kernel on ctx's stream
  * (events recorded on the stream the kernel is launched on).  Syncs. */
 int grail_last_kernel_ms(grail_ctx *ctx, float *ms);
+
+/* Resumable synthesis (the lazy-iterator use of the chain, examples/interactive.rs:31-48):
+ * the per-utterance iterator state (Sequencer :839-854, Jitter :724-748, Synthesize :470-488)
+ * lives in HBM between launches.  Each call renders the NEXT max_samples (<= out_stride)
+ * samples of every utterance to out_dev + u*out_stride (from index 0) and the count to
+ * out_len_dev[u] (0 once the utterance has ended).  Concatenating the chunks gives exactly the
+ * one-shot result, whatever the chunk sizes.  The batch must outlive the stream. */
+int grail_stream_open(grail_ctx *ctx, const grail_batch *batch, grail_stream **out);
+int grail_stream_next_async(grail_ctx *ctx, grail_stream *stream, uint32_t max_samples,
+                            float *out_dev, uint64_t out_stride, uint32_t *out_len_dev);
+int grail_stream_close(grail_ctx *ctx, grail_stream *stream);
 
 /* One-call forms: upload, synthesize, copy back (GRAIL_OUT_HOST) or leave in
  * place (GRAIL_OUT_DEVICE), wait.  out_len is host memory [n_utt] or NULL.

@@ -1,0 +1,79 @@
+"""Resumable synthesis: chunks pulled through grail_stream_* must
+concatenate to exactly the one-shot rendering — for any chunk sizes, any lane mapping, ragged
+and edge-case utterances included."""
+import numpy as np
+import pytest
+
+import grail_hip as G
+from grail_hip import workload as W
+from test_parity_gpu import edge_case_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def stream_all(ctx, batch, n_utt, chunk_sizes, stride):
+    st = G.Stream(batch)
+    d_out = ctx.device_alloc(n_utt * stride * 4)
+    d_len = ctx.device_alloc(n_utt * 4)
+    rows = [[] for _ in range(n_utt)]
+    try:
+        k = 0
+        while True:
+            q = chunk_sizes[k % len(chunk_sizes)]
+            k += 1
+            st.next_async(q, d_out, stride, d_len)
+            ctx.sync()
+            lens = np.zeros(n_utt, dtype=np.uint32)
+            ctx.d2h(lens, d_len, n_utt * 4)
+            assert lens.max(initial=0) <= q
+            if lens.max(initial=0) == 0:
+                break
+            buf = np.zeros((n_utt, stride), dtype=np.float32)
+            ctx.d2h(buf, d_out, buf.nbytes)
+            for u in range(n_utt):
+                rows[u].append(buf[u, :lens[u]].copy())
+            assert k < 10000
+    finally:
+        st.close()
+        ctx.device_free(d_out)
+        ctx.device_free(d_len)
+    return [np.concatenate(r) if r else np.zeros(0, dtype=np.float32) for r in rows]
+
+
+@pytest.mark.parametrize("lanes", [0, 1, 2, 4, 8])
+def test_chunked_stream_equals_one_shot(gpu_ctx, lanes):
+    voices = W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    gpu_ctx.set_option("lanes_per_utterance", lanes)
+    n_utt = 70
+    segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=8, length=0.03, blend_length=0.03)
+    full, full_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=W.max_samples(length=0.03))
+    b = gpu_ctx.upload(segs, offs, vids, seeds)
+    try:
+        got = stream_all(gpu_ctx, b, n_utt, [1000, 37, 2048, 64, 1], stride=2048)
+    finally:
+        b.free()
+        gpu_ctx.set_option("lanes_per_utterance", 0)
+    for u in range(n_utt):
+        assert len(got[u]) == full_len[u], (u, len(got[u]), full_len[u])
+        assert np.array_equal(got[u].view(np.uint32), full[u, :full_len[u]].view(np.uint32)), u
+
+
+@pytest.mark.parametrize("lanes", [1, 8])
+def test_stream_edge_cases_and_ragged_ends(gpu_ctx, lanes):
+    gpu_ctx.set_voices(W.single_voice())
+    gpu_ctx.set_option("lanes_per_utterance", lanes)
+    segs, offs = edge_case_batch(48000.0)
+    n_utt = len(offs) - 1
+    seeds = np.arange(n_utt, dtype=np.uint32) * 977
+    with np.errstate(all="ignore"):
+        full, full_len = gpu_ctx.synthesize(segs, offs, None, seeds, out_stride=20032)
+        b = gpu_ctx.upload(segs, offs, None, seeds)
+        try:
+            got = stream_all(gpu_ctx, b, n_utt, [333, 4096], stride=4096)
+        finally:
+            b.free()
+            gpu_ctx.set_option("lanes_per_utterance", 0)
+    for u in range(n_utt):
+        assert len(got[u]) == full_len[u], (u, len(got[u]), full_len[u])
+        assert np.array_equal(got[u].view(np.uint32), full[u, :full_len[u]].view(np.uint32)), u
