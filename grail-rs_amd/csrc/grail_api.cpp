@@ -68,6 +68,11 @@ Rccl &rccl()
 {
     static Rccl r = [] {
         Rccl x;
+        // Single-node defaults (never override the user's): the ranks of one xGMI node meet over
+        // loopback; probing InfiniBand / every network interface only costs start-up time
+        // (measured: up to 2 minutes on a box without a network).
+        setenv("NCCL_IB_DISABLE", "1", 0);
+        setenv("NCCL_SOCKET_IFNAME", "lo", 0);
         // The ROCm installation's RCCL by absolute path first: a bare "librccl.so" would be
         // satisfied by any copy the host process already holds (PyTorch wheels bundle one that
         // is bound to their own private HIP runtime, not to the one this library links).
@@ -672,6 +677,33 @@ int grail_pcm16_async(grail_ctx *ctx, const float *in_dev, uint64_t in_stride,
     hipError_t e = launch_pcm16(in_dev, in_stride, len_dev, n_utt, max_len, out_dev, out_stride,
                                 ctx->stream);
     if (e != hipSuccess) return hip_fail(e, "pcm16 kernel launch");
+    return GRAIL_OK;
+}
+
+int grail_batch_digest(grail_ctx *ctx, const float *in_dev, uint64_t in_stride,
+                       const uint32_t *len_dev, uint32_t n_utt, uint64_t *sums, float *maxabs,
+                       uint32_t *nonfinite)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (n_utt == 0) return GRAIL_OK;
+    if (!in_dev || !len_dev || !sums || !maxabs || !nonfinite)
+        return fail(GRAIL_ERR_INVALID_ARG, "NULL buffer");
+    unsigned long long *d_s = nullptr;
+    float *d_m = nullptr;
+    uint32_t *d_b = nullptr;
+    hipError_t e = hipMalloc((void **)&d_s, (size_t)n_utt * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_m, (size_t)n_utt * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_b, (size_t)n_utt * 4);
+    if (e == hipSuccess) e = launch_digest(in_dev, in_stride, len_dev, n_utt, d_s, d_m, d_b, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(sums, d_s, (size_t)n_utt * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(maxabs, d_m, (size_t)n_utt * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(nonfinite, d_b, (size_t)n_utt * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (d_s) (void)hipFree(d_s);
+    if (d_m) (void)hipFree(d_m);
+    if (d_b) (void)hipFree(d_b);
+    if (e != hipSuccess) return hip_fail(e, "grail_batch_digest");
     return GRAIL_OK;
 }
 

@@ -78,6 +78,10 @@ hipError_t launch_lengths(const LenArgs &args, hipStream_t stream);
 // f32 rows -> i16 PCM rows (examples/cli.rs:49); only the first len[u] (<= max_len) samples of row u
 hipError_t launch_pcm16(const float *in, uint64_t in_stride, const uint32_t *len, uint32_t n_utt,
                         uint32_t max_len, int16_t *out, uint64_t out_stride, hipStream_t stream);
+// per-row digest (bit-pattern sum mod 2^64, max |x|, count of NaN/Inf) of rendered rows
+hipError_t launch_digest(const float *in, uint64_t in_stride, const uint32_t *len, uint32_t n_utt,
+                         unsigned long long *sums, float *maxabs, uint32_t *nonfinite,
+                         hipStream_t stream);
 // resumable synthesis: words per lane and lanes per launch of the state buffer
 uint32_t state_words(int lanes_per_utt);
 uint64_t state_lanes(uint32_t n_utt, int lanes_per_utt, int variant);

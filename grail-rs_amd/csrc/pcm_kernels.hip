@@ -44,7 +44,61 @@ __global__ __launch_bounds__(256) void pcm16_kernel(const float *__restrict__ in
     }
 }
 
+// Per-row digest of a rendered batch: the sum of the samples' bit patterns (mod 2^64), the
+// largest magnitude, and the number of non-finite samples.  Lets a caller (and the full-size
+// tests) compare 25 GB of output on the device instead of copying it over PCIe.
+__global__ __launch_bounds__(256) void digest_kernel(const float *__restrict__ in, uint64_t in_stride,
+                                                     const uint32_t *__restrict__ len,
+                                                     unsigned long long *__restrict__ sums,
+                                                     float *__restrict__ maxabs,
+                                                     uint32_t *__restrict__ nonfinite)
+{
+    const uint32_t u = blockIdx.x;
+    const uint32_t n = len[u];
+    const float *row = in + (uint64_t)u * in_stride;
+    unsigned long long s = 0;
+    float m = 0.0f;
+    uint32_t bad = 0;
+    for (uint32_t t = threadIdx.x; t < n; t += 256u) {
+        const float x = row[t];
+        s += __float_as_uint(x);
+        const float a = __builtin_fabsf(x);
+        if (!(a <= 3.4028234663852886e38f)) ++bad;     // NaN or Inf
+        else m = a > m ? a : m;
+    }
+    __shared__ unsigned long long ss[256];
+    __shared__ float sm[256];
+    __shared__ uint32_t sb[256];
+    ss[threadIdx.x] = s;
+    sm[threadIdx.x] = m;
+    sb[threadIdx.x] = bad;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) {
+            ss[threadIdx.x] += ss[threadIdx.x + k];
+            sm[threadIdx.x] = sm[threadIdx.x] > sm[threadIdx.x + k] ? sm[threadIdx.x] : sm[threadIdx.x + k];
+            sb[threadIdx.x] += sb[threadIdx.x + k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sums[u] = ss[0];
+        maxabs[u] = sm[0];
+        nonfinite[u] = sb[0];
+    }
+}
+
 }  // namespace
+
+hipError_t launch_digest(const float *in, uint64_t in_stride, const uint32_t *len, uint32_t n_utt,
+                         unsigned long long *sums, float *maxabs, uint32_t *nonfinite,
+                         hipStream_t stream)
+{
+    if (n_utt == 0) return hipSuccess;
+    hipLaunchKernelGGL(digest_kernel, dim3(n_utt), dim3(256), 0, stream, in, in_stride, len, sums,
+                       maxabs, nonfinite);
+    return hipGetLastError();
+}
 
 hipError_t launch_pcm16(const float *in, uint64_t in_stride, const uint32_t *len, uint32_t n_utt,
                         uint32_t max_len, int16_t *out, uint64_t out_stride, hipStream_t stream)

@@ -52,7 +52,7 @@ EXPORTS = [
     "grail_last_kernel_ms", "grail_synthesize_batch", "grail_synthesize_batch_elems",
     "grail_stream_open", "grail_stream_next_async", "grail_stream_close",
     "grail_language_generic", "grail_transcribe", "grail_intonate", "grail_text_to_phoneme_elems",
-    "grail_say_batch", "grail_pcm16_async", "grail_wav_write_i16",
+    "grail_say_batch", "grail_pcm16_async", "grail_batch_digest", "grail_wav_write_i16",
     "grail_device_alloc", "grail_device_free", "grail_memcpy_d2h", "grail_memcpy_h2d",
     "grail_memset_d", "grail_shard_range", "grail_comm_unique_id", "grail_comm_init",
     "grail_broadcast_voices", "grail_comm_destroy",
@@ -200,6 +200,7 @@ def load():
     L.grail_say_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.c_uint32, vp, vp, vp, u64, vp,
                                   C.c_uint32]
     L.grail_pcm16_async.argtypes = [vp, vp, u64, vp, C.c_uint32, C.c_uint32, vp, u64]
+    L.grail_batch_digest.argtypes = [vp, vp, u64, vp, C.c_uint32, vp, vp, vp]
     L.grail_wav_write_i16.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
     L.grail_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.grail_device_free.argtypes = [vp, vp]
@@ -516,6 +517,15 @@ class Context:
     def pcm16(self, in_dev, in_stride, len_dev, n_utt, max_len, out_dev, out_stride):
         _check(load().grail_pcm16_async(self.handle, in_dev, in_stride, len_dev, n_utt, max_len,
                                         out_dev, out_stride))
+
+    def digest(self, in_dev, in_stride, len_dev, n_utt):
+        """(bit-pattern sums mod 2^64, max |x|, non-finite counts) per row, computed on the device."""
+        sums = np.zeros(max(n_utt, 1), dtype=np.uint64)
+        maxabs = np.zeros(max(n_utt, 1), dtype=np.float32)
+        bad = np.zeros(max(n_utt, 1), dtype=np.uint32)
+        _check(load().grail_batch_digest(self.handle, in_dev, in_stride, len_dev, n_utt,
+                                         sums.ctypes.data, maxabs.ctypes.data, bad.ctypes.data))
+        return sums[:n_utt], maxabs[:n_utt], bad[:n_utt]
 
     def h2d(self, dst_dev, src, nbytes):
         _check(load().grail_memcpy_h2d(self.handle, dst_dev, src.ctypes.data, nbytes))

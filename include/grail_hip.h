@@ -264,6 +264,13 @@ int grail_say_batch(grail_ctx *ctx, const char *const *texts_utf8, uint32_t n_te
 int grail_pcm16_async(grail_ctx *ctx, const float *in_dev, uint64_t in_stride,
                       const uint32_t *len_dev, uint32_t n_utt, uint32_t max_len,
                       int16_t *out_dev, uint64_t out_stride);
+/* Per-row digest of rendered rows, computed on the device (comparing a 25 GB batch over PCIe is
+ * pointless): sums[u] = sum of the samples' IEEE bit patterns mod 2^64, maxabs[u] = largest
+ * finite |x|, nonfinite[u] = count of NaN/Inf, over the first len_dev[u] samples of row u.
+ * in_dev/len_dev are device memory, the three results host memory [n_utt].  Synchronous. */
+int grail_batch_digest(grail_ctx *ctx, const float *in_dev, uint64_t in_stride,
+                       const uint32_t *len_dev, uint32_t n_utt, uint64_t *sums, float *maxabs,
+                       uint32_t *nonfinite);
 /* save_wav  examples/cli.rs:28-67: 44-byte RIFF header (PCM, mono, 16 bit) + samples. */
 int grail_wav_write_i16(const char *path, const int16_t *pcm, uint32_t n, uint32_t sample_rate);
 

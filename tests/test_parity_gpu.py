@@ -257,3 +257,45 @@ def test_rccl_voice_broadcast_single_rank(gpu_ctx):
     with pytest.raises(G.GrailError):
         gpu_ctx.broadcast_voices(3, root=0)   # root's table holds 8 voices, not 3
     G._check(G.load().grail_comm_destroy(gpu_ctx.handle))
+
+
+def test_config3_full_size_on_device_digest(gpu_ctx):
+    """BASELINE config 3 at FULL size (65536 utterances x 2 s, 25 GB of PCM left in HBM): lengths,
+    finiteness and the normalisation bound over all 6.3e9 samples via the on-device digest; a
+    checksum of checksums between two lane mappings (batch invariance at scale); bit parity of a
+    sample of utterances against the oracle through their digests."""
+    n_utt = 65536
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
+    segs, offs, vids, seeds = W.make_batch(n_utt)
+    stride = W.max_samples()
+    b = gpu_ctx.upload(segs, offs, vids, seeds)
+    d_out = gpu_ctx.device_alloc(n_utt * stride * 4)
+    d_len = gpu_ctx.device_alloc(n_utt * 4)
+    digests = {}
+    try:
+        for lanes in (0, 2):
+            gpu_ctx.set_option("lanes_per_utterance", lanes)
+            b.synthesize_async(d_out, stride, d_len)
+            gpu_ctx.sync()
+            out_len = np.zeros(n_utt, dtype=np.uint32)
+            gpu_ctx.d2h(out_len, d_len, n_utt * 4)
+            assert np.all(out_len == 96006)
+            sums, maxabs, bad = gpu_ctx.digest(d_out, stride, d_len, n_utt)
+            assert bad.sum() == 0                       # every sample finite
+            assert maxabs.max() <= 1.0                  # synthesize_normalized (src/lib.rs:602)
+            assert (maxabs > 0.01).mean() > 0.9         # (an all-Silence utterance is exactly 0)
+            digests[lanes] = sums
+    finally:
+        gpu_ctx.set_option("lanes_per_utterance", 0)
+        gpu_ctx.device_free(d_out)
+        gpu_ctx.device_free(d_len)
+        b.free()
+    assert np.array_equal(digests[0], digests[2])       # 65536 checksums agree across lane mappings
+    pick = [0, 1, 63, 64, 1023, 1024, 32767, 32768, 65534, 65535]
+    sub = np.concatenate([segs[offs[u]:offs[u + 1]] for u in pick])
+    sub_offs = np.arange(len(pick) + 1, dtype=np.uint32) * 4
+    ref, ref_len = O.synthesize_batch(ovoices(voices), sub, sub_offs, vids[pick], seeds[pick], stride)
+    for k, u in enumerate(pick):
+        want = int(ref[k, :ref_len[k]].view(np.uint32).astype(np.uint64).sum())
+        assert int(digests[0][u]) == want, u
