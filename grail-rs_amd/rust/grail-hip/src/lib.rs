@@ -1,0 +1,116 @@
+//! `utterances.synthesize_batch(&gpu)` — the batched counterpart of grail-rs's
+//! `.select(v).sequence(v).jitter(seed, v).synthesize()` (reference src/lib.rs:1013, 941, 786,
+//! 587; trait pattern of `IntoSynthesize`, src/lib.rs:582-600).  Per-utterance results are
+//! bit-identical to the CPU iterator chain.  SOURCE ONLY: not compiled in the build image.
+use grail_hip_sys as sys;
+use grail_rs::{PhonemeElem, Voice};
+use std::ffi::CStr;
+
+#[derive(Debug)]
+pub struct Error {
+    pub status: i32,
+    pub message: String,
+}
+
+fn check(status: i32) -> Result<(), Error> {
+    if status == sys::GRAIL_OK {
+        return Ok(());
+    }
+    let message = unsafe { CStr::from_ptr(sys::grail_last_error()) }.to_string_lossy().into_owned();
+    Err(Error { status, message })
+}
+
+/// One GPU + a voice table (grail_ctx).
+pub struct Gpu {
+    ctx: *mut sys::grail_ctx,
+}
+
+// grail-rs keeps its struct layouts private to Rust; convert field by field.  `Array` needs a
+// `pub fn to_array(self) -> [f32; NUM_FORMANTS]` accessor in grail-rs (one line).
+fn elem_to_c(e: &grail_rs::SynthesisElem) -> sys::grail_synthesis_elem {
+    sys::grail_synthesis_elem {
+        frequency: e.frequency,
+        formant_freq: e.formant_freq.to_array(),
+        formant_bw: e.formant_bw.to_array(),
+        formant_smooth: e.formant_smooth.to_array(),
+        formant_breath: e.formant_breath.to_array(),
+        formant_turb: e.formant_turb.to_array(),
+        formant_amp: e.formant_amp.to_array(),
+    }
+}
+
+fn voice_to_c(v: &Voice) -> sys::grail_voice {
+    sys::grail_voice {
+        sample_rate: v.sample_rate,
+        phonemes: [elem_to_c(&v.phonemes.a), elem_to_c(&v.phonemes.e)],
+        center_frequency: v.center_frequency,
+        jitter_frequency: v.jitter_frequency,
+        jitter_delta_frequency: v.jitter_delta_frequency,
+        jitter_delta_formant_frequency: v.jitter_delta_formant_frequency,
+        jitter_delta_amplitude: v.jitter_delta_amplitude,
+    }
+}
+
+impl Gpu {
+    pub fn new(device: i32, voices: &[Voice]) -> Result<Self, Error> {
+        let mut ctx = std::ptr::null_mut();
+        check(unsafe { sys::grail_create(device, &mut ctx) })?;
+        let gpu = Gpu { ctx };
+        let table: Vec<_> = voices.iter().map(voice_to_c).collect();
+        check(unsafe { sys::grail_set_voices(gpu.ctx, table.as_ptr(), table.len() as u32) })?;
+        Ok(gpu)
+    }
+}
+
+impl Drop for Gpu {
+    fn drop(&mut self) {
+        unsafe { sys::grail_destroy(self.ctx) };
+    }
+}
+
+pub struct Utterance {
+    pub phonemes: Vec<PhonemeElem>,
+    pub voice: u32,
+    pub jitter_seed: u32,
+}
+
+pub trait IntoSynthesizeBatch {
+    fn synthesize_batch(self, gpu: &Gpu) -> Result<Vec<Vec<f32>>, Error>;
+}
+
+impl<I: IntoIterator<Item = Utterance>> IntoSynthesizeBatch for I {
+    fn synthesize_batch(self, gpu: &Gpu) -> Result<Vec<Vec<f32>>, Error> {
+        let (mut segs, mut offs, mut vids, mut seeds) = (vec![], vec![0u32], vec![], vec![]);
+        for u in self {
+            segs.extend(u.phonemes.iter().map(|p| sys::grail_phoneme_elem {
+                phoneme: p.phoneme as i32, // Silence=0 Stop=1 Glide=2 A=3 E=4 (src/lib.rs:632-649)
+                length: p.length,
+                blend_length: p.blend_length,
+                frequency: p.frequency,
+            }));
+            offs.push(segs.len() as u32);
+            vids.push(u.voice);
+            seeds.push(u.jitter_seed);
+        }
+        let n = vids.len() as u32;
+        let mut lens = vec![0u32; n as usize];
+        unsafe {
+            let mut b = std::ptr::null_mut();
+            check(sys::grail_batch_upload(gpu.ctx, segs.as_ptr(), offs.as_ptr(), vids.as_ptr(),
+                                          seeds.as_ptr(), n, &mut b))?;
+            let r = check(sys::grail_batch_lengths(gpu.ctx, b, u32::MAX, lens.as_mut_ptr()));
+            sys::grail_batch_free(gpu.ctx, b);
+            r?;
+        }
+        let stride = (*lens.iter().max().unwrap_or(&0) as u64 + 63) / 64 * 64;
+        let mut out = vec![0f32; n as usize * stride as usize];
+        check(unsafe {
+            sys::grail_synthesize_batch(gpu.ctx, segs.as_ptr(), offs.as_ptr(), vids.as_ptr(),
+                                        seeds.as_ptr(), n, out.as_mut_ptr(), stride,
+                                        lens.as_mut_ptr(), sys::GRAIL_OUT_HOST)
+        })?;
+        Ok(lens.iter().enumerate()
+            .map(|(u, &l)| out[u * stride as usize..][..l as usize].to_vec())
+            .collect())
+    }
+}
