@@ -1,0 +1,150 @@
+// grail.hpp — header-only C++ facade over the C ABI (grail_hip.h) that keeps the call shape of
+// the grail-rs crate for this path:
+//
+//   Rust (reference examples/cli.rs:175-184)            C++ (this header)
+//   text.chars().transcribe(lang).intonate(lang, v)  -> grail::phoneme_elems(v, text)
+//       .select(v).sequence(v).jitter(seed, v)
+//       .synthesize().collect::<Vec<f32>>()           -> gpu.synthesize({Utterance{...}})
+//   voices::generic()                                 -> grail::voices::generic()
+//
+// No arithmetic lives here; everything forwards to libgrail_hip.so.
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "grail_hip.h"
+
+namespace grail {
+
+using SynthesisElem = grail_synthesis_elem;  // src/lib.rs:316
+using Voice = grail_voice;                   // src/lib.rs:696
+using PhonemeElem = grail_phoneme_elem;      // src/lib.rs:961
+using SequenceElem = grail_sequence_elem;    // src/lib.rs:814
+
+enum class Phoneme : int32_t {               // src/lib.rs:632-649
+    Silence = GRAIL_PH_SILENCE, Stop = GRAIL_PH_STOP, Glide = GRAIL_PH_GLIDE,
+    A = GRAIL_PH_A, E = GRAIL_PH_E,
+};
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int s, const std::string &what) : std::runtime_error(what), status(s) {}
+};
+
+inline void check(int status)
+{
+    if (status != GRAIL_OK) {
+        const char *msg = grail_last_error();
+        throw Error(status, (msg && *msg) ? msg : grail_status_string(status));
+    }
+}
+
+namespace voices {
+inline Voice generic() { Voice v; grail_voice_generic(&v); return v; }             // generic.rs:5
+inline Voice generic_at(float sample_rate) { Voice v; grail_voice_generic_at(&v, sample_rate); return v; }
+}  // namespace voices
+
+// text.chars().transcribe(languages::generic()).intonate(languages::generic(), voice)
+inline std::vector<PhonemeElem> phoneme_elems(const Voice &voice, const std::string &text_utf8)
+{
+    uint32_t n = 0;
+    check(grail_text_to_phoneme_elems(&voice, text_utf8.c_str(), nullptr, 0, &n));
+    std::vector<PhonemeElem> out(n);
+    if (n) check(grail_text_to_phoneme_elems(&voice, text_utf8.c_str(), out.data(), n, &n));
+    return out;
+}
+
+struct Utterance {
+    std::vector<PhonemeElem> phonemes;
+    uint32_t voice = 0;
+    uint32_t jitter_seed = 0;   // examples/cli.rs:182 uses 0
+};
+
+// One GPU and its voice table.
+class Gpu {
+public:
+    Gpu(int device, const std::vector<Voice> &voices) : voices_(voices)
+    {
+        check(grail_create(device, &ctx_));
+        const int rc = grail_set_voices(ctx_, voices_.data(), (uint32_t)voices_.size());
+        if (rc != GRAIL_OK) {
+            grail_destroy(ctx_);
+            check(rc);
+        }
+    }
+    ~Gpu() { grail_destroy(ctx_); }
+    Gpu(const Gpu &) = delete;
+    Gpu &operator=(const Gpu &) = delete;
+
+    grail_ctx *ctx() const { return ctx_; }
+    const std::vector<Voice> &voices() const { return voices_; }
+
+    // utterances.map(|u| u.phonemes.select(v).sequence(v).jitter(seed, v).synthesize().collect())
+    std::vector<std::vector<float>> synthesize(const std::vector<Utterance> &utts) const
+    {
+        std::vector<PhonemeElem> segs;
+        std::vector<uint32_t> offs(1, 0u), vids, seeds;
+        for (const Utterance &u : utts) {
+            segs.insert(segs.end(), u.phonemes.begin(), u.phonemes.end());
+            offs.push_back((uint32_t)segs.size());
+            vids.push_back(u.voice);
+            seeds.push_back(u.jitter_seed);
+        }
+        const uint32_t n = (uint32_t)utts.size();
+        std::vector<uint32_t> lens(n ? n : 1);
+        grail_batch *b = nullptr;
+        check(grail_batch_upload(ctx_, segs.data(), offs.data(), vids.data(), seeds.data(), n, &b));
+        const int rc = grail_batch_lengths(ctx_, b, 0xFFFFFFFFu, lens.data());
+        grail_batch_free(ctx_, b);
+        check(rc);
+        uint64_t stride = 64;
+        for (uint32_t i = 0; i < n; ++i) stride = lens[i] > stride ? lens[i] : stride;
+        stride = (stride + 63) / 64 * 64;
+        std::vector<float> flat((size_t)n * stride);
+        check(grail_synthesize_batch(ctx_, segs.data(), offs.data(), vids.data(), seeds.data(), n,
+                                     flat.data(), stride, lens.data(), GRAIL_OUT_HOST));
+        std::vector<std::vector<float>> out(n);
+        for (uint32_t i = 0; i < n; ++i)
+            out[i].assign(flat.begin() + (size_t)i * stride, flat.begin() + (size_t)i * stride + lens[i]);
+        return out;
+    }
+
+    // the whole chain of examples/cli.rs:175-184 for several texts, voice 0, seed 0
+    std::vector<std::vector<float>> say(const std::vector<std::string> &texts) const
+    {
+        std::vector<Utterance> utts;
+        for (const std::string &t : texts) utts.push_back(Utterance{phoneme_elems(voices_.at(0), t), 0, 0});
+        return synthesize(utts);
+    }
+
+    // examples/cli.rs:49 on the device, then save_wav (cli.rs:28-67)
+    void save_wav(const std::string &path, const std::vector<float> &pcm, uint32_t sample_rate) const
+    {
+        const uint32_t n = (uint32_t)pcm.size();
+        void *d_in = nullptr, *d_out = nullptr, *d_len = nullptr;
+        std::vector<int16_t> i16(n);
+        check(grail_device_alloc(ctx_, (size_t)n * 4 + 4, &d_in));
+        check(grail_device_alloc(ctx_, (size_t)n * 2 + 16, &d_out));
+        check(grail_device_alloc(ctx_, 4, &d_len));
+        int rc = grail_memcpy_h2d(ctx_, d_in, pcm.data(), (size_t)n * 4);
+        if (!rc) rc = grail_memcpy_h2d(ctx_, d_len, &n, 4);
+        if (!rc) rc = grail_pcm16_async(ctx_, (const float *)d_in, n, (const uint32_t *)d_len, 1, n,
+                                        (int16_t *)d_out, n);
+        if (!rc) rc = grail_sync(ctx_);
+        if (!rc && n) rc = grail_memcpy_d2h(ctx_, i16.data(), d_out, (size_t)n * 2);
+        grail_device_free(ctx_, d_in);
+        grail_device_free(ctx_, d_out);
+        grail_device_free(ctx_, d_len);
+        check(rc);
+        check(grail_wav_write_i16(path.c_str(), i16.data(), n, sample_rate));
+    }
+
+private:
+    grail_ctx *ctx_ = nullptr;
+    std::vector<Voice> voices_;
+};
+
+}  // namespace grail

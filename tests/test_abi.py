@@ -129,3 +129,19 @@ def test_compute_calls_fail_loudly_without_a_device(built):
     with pytest.raises(G.GrailError) as ei:
         G.Context(0)
     assert ei.value.status == G.ERR_NO_DEVICE
+
+
+def test_rust_sys_crate_mirrors_the_header():
+    """grail-hip-sys (source only: no rustc in the image) declares exactly the header's functions."""
+    src = open(os.path.join(ROOT, "grail-rs_amd", "rust", "grail-hip-sys", "src", "lib.rs")).read()
+    rust = sorted(set(re.findall(r"pub fn (grail_[a-z0-9_]+)\s*\(", src)))
+    assert rust == header_functions()
+
+
+def test_cpp_facade_example_builds(built):
+    exe = os.path.join(ROOT, "grail-rs_amd", "lib", "grail_say")
+    assert os.path.exists(exe)
+    import subprocess
+    if G.device_count() == 0:   # no CPU fallback: the example must fail loudly, not fake audio
+        r = subprocess.run([exe, "a"], capture_output=True, text=True)
+        assert r.returncode == 1 and "no HIP device" in r.stderr
