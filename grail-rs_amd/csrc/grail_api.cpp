@@ -707,6 +707,57 @@ int grail_batch_digest(grail_ctx *ctx, const float *in_dev, uint64_t in_stride,
     return GRAIL_OK;
 }
 
+int grail_synthesize_batch_pcm16(grail_ctx *ctx, const grail_phoneme_elem *segs,
+                                 const uint32_t *seg_offsets, const uint32_t *voice_ids,
+                                 const uint32_t *jitter_seeds, uint32_t n_utt, int16_t *out,
+                                 uint64_t out_stride, uint32_t *out_len, uint32_t flags)
+{
+    grail_batch *b = nullptr;
+    int rc = grail_batch_upload(ctx, segs, seg_offsets, voice_ids, jitter_seeds, n_utt, &b);
+    if (rc) return rc;
+    float *d_f32 = nullptr;
+    int16_t *d_i16 = nullptr;
+    uint32_t *d_len = nullptr;
+    const bool dev_out = (flags & GRAIL_OUT_DEVICE) != 0;
+    const size_t n_elems = (size_t)n_utt * out_stride;
+    int sync_rc = GRAIL_OK;
+    hipError_t e = hipSuccess;
+    if (n_elems) e = hipMalloc((void **)&d_f32, n_elems * sizeof(float));
+    if (e == hipSuccess && n_utt) e = hipMalloc((void **)&d_len, (size_t)n_utt * sizeof(uint32_t));
+    if (e == hipSuccess) {
+        if (dev_out) d_i16 = out;
+        else if (n_elems) {
+            e = hipMalloc((void **)&d_i16, n_elems * sizeof(int16_t));
+            if (e == hipSuccess) e = hipMemsetAsync(d_i16, 0, n_elems * sizeof(int16_t), ctx->stream);
+        }
+    }
+    if (e != hipSuccess) rc = hip_fail(e, "pcm16 output allocation");
+    if (!rc) rc = grail_batch_synthesize_async(ctx, b, d_f32, out_stride, d_len);
+    // the conversion runs behind the synthesis on the same stream; 6 B per sample of HBM traffic
+    if (!rc && n_utt)
+        rc = grail_pcm16_async(ctx, d_f32, out_stride, d_len, n_utt, (uint32_t)(out_stride > 0xFFFFFFFFull ? 0xFFFFFFFFu : out_stride),
+                               d_i16, out_stride);
+    if (!rc) {
+        sync_rc = grail_sync(ctx);
+        if (sync_rc != GRAIL_OK && sync_rc != GRAIL_ERR_BUFFER_TOO_SMALL) rc = sync_rc;
+    }
+    if (!rc && out_len && n_utt) {
+        e = hipMemcpy(out_len, d_len, (size_t)n_utt * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "out_len copy");
+    }
+    if (!rc && !dev_out && n_elems) {
+        e = hipMemcpy(out, d_i16, n_elems * sizeof(int16_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "pcm16 output copy");
+    }
+    const std::string keep = g_last_error;
+    if (d_f32) (void)hipFree(d_f32);
+    if (d_len) (void)hipFree(d_len);
+    if (!dev_out && d_i16) (void)hipFree(d_i16);
+    grail_batch_free(ctx, b);
+    g_last_error = keep;
+    return rc ? rc : sync_rc;
+}
+
 int grail_say_batch(grail_ctx *ctx, const char *const *texts_utf8, uint32_t n_texts,
                     const uint32_t *voice_ids, const uint32_t *jitter_seeds, float *out,
                     uint64_t out_stride, uint32_t *out_len, uint32_t flags)

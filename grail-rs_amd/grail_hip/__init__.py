@@ -52,7 +52,7 @@ EXPORTS = [
     "grail_last_kernel_ms", "grail_synthesize_batch", "grail_synthesize_batch_elems",
     "grail_stream_open", "grail_stream_next_async", "grail_stream_close",
     "grail_language_generic", "grail_transcribe", "grail_intonate", "grail_text_to_phoneme_elems",
-    "grail_say_batch", "grail_pcm16_async", "grail_batch_digest", "grail_wav_write_i16",
+    "grail_synthesize_batch_pcm16", "grail_say_batch", "grail_pcm16_async", "grail_batch_digest", "grail_wav_write_i16",
     "grail_device_alloc", "grail_device_free", "grail_memcpy_d2h", "grail_memcpy_h2d",
     "grail_memset_d", "grail_shard_range", "grail_comm_unique_id", "grail_comm_init",
     "grail_broadcast_voices", "grail_comm_destroy",
@@ -200,6 +200,8 @@ def load():
     L.grail_say_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.c_uint32, vp, vp, vp, u64, vp,
                                   C.c_uint32]
     L.grail_pcm16_async.argtypes = [vp, vp, u64, vp, C.c_uint32, C.c_uint32, vp, u64]
+    L.grail_synthesize_batch_pcm16.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, u64, vp,
+                                               C.c_uint32]
     L.grail_batch_digest.argtypes = [vp, vp, u64, vp, C.c_uint32, vp, vp, vp]
     L.grail_wav_write_i16.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
     L.grail_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
@@ -482,6 +484,18 @@ class Context:
                                            OUT_HOST)
         if not (allow_truncation and st == ERR_BUFFER_TOO_SMALL):
             _check(st)
+        return out[:n_utt], out_len[:n_utt]
+
+    def synthesize_pcm16(self, segs, seg_offsets, voice_ids=None, jitter_seeds=None, out_stride=4096):
+        """One-call form with i16 PCM rows (examples/cli.rs:49 on the device)."""
+        segs = np.ascontiguousarray(segs, dtype=PHONEME_DTYPE)
+        seg_offsets, n_utt, voice_ids, jitter_seeds = self._prep(None, segs, seg_offsets,
+                                                                 voice_ids, jitter_seeds)
+        out = np.zeros((max(n_utt, 1), out_stride), dtype=np.int16)
+        out_len = np.zeros(max(n_utt, 1), dtype=np.uint32)
+        _check(load().grail_synthesize_batch_pcm16(
+            self.handle, segs.ctypes.data, seg_offsets.ctypes.data, _ptr(voice_ids),
+            _ptr(jitter_seeds), n_utt, out.ctypes.data, out_stride, out_len.ctypes.data, OUT_HOST))
         return out[:n_utt], out_len[:n_utt]
 
     def synthesize_elems(self, seq_elems, seg_offsets, voice_ids=None, jitter_seeds=None,

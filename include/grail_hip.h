@@ -264,6 +264,12 @@ int grail_say_batch(grail_ctx *ctx, const char *const *texts_utf8, uint32_t n_te
 int grail_pcm16_async(grail_ctx *ctx, const float *in_dev, uint64_t in_stride,
                       const uint32_t *len_dev, uint32_t n_utt, uint32_t max_len,
                       int16_t *out_dev, uint64_t out_stride);
+/* grail_synthesize_batch() followed by the examples/cli.rs:49 conversion on the device: rows of
+ * i16 PCM (half the PCIe bytes of the f32 form).  Same flags and row semantics. */
+int grail_synthesize_batch_pcm16(grail_ctx *ctx, const grail_phoneme_elem *segs,
+                                 const uint32_t *seg_offsets, const uint32_t *voice_ids,
+                                 const uint32_t *jitter_seeds, uint32_t n_utt, int16_t *out,
+                                 uint64_t out_stride, uint32_t *out_len, uint32_t flags);
 /* Per-row digest of rendered rows, computed on the device (comparing a 25 GB batch over PCIe is
  * pointless): sums[u] = sum of the samples' IEEE bit patterns mod 2^64, maxabs[u] = largest
  * finite |x|, nonfinite[u] = count of NaN/Inf, over the first len_dev[u] samples of row u.

@@ -140,3 +140,20 @@ def test_cpp_cli_example_writes_the_reference_wav(gpu_ctx, tmp_path):
     assert len(raw) == 44 + 2 * len(want)
     assert struct.unpack("<I", raw[24:28])[0] == 44100
     assert np.array_equal(np.frombuffer(raw[44:], dtype="<i2"), want)
+
+
+@pytest.mark.gpu
+def test_one_call_pcm16_rows(gpu_ctx):
+    from grail_hip import workload as W
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
+    segs, offs, vids, seeds = W.make_batch(40, length=0.02, blend_length=0.02)
+    stride = W.max_samples(length=0.02)
+    f32, n = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+    i16, n2 = gpu_ctx.synthesize_pcm16(segs, offs, vids, seeds, out_stride=stride)
+    assert np.array_equal(n, n2)
+    L = O.lib()
+    for u in range(40):
+        want = np.array([L.orc_pcm16(float(v)) for v in f32[u, :n[u]]], dtype=np.int16)
+        assert np.array_equal(i16[u, :n[u]], want), u
+        assert np.all(i16[u, n[u]:] == 0)
