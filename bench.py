@@ -181,6 +181,14 @@ def main():
     samples_per_step = int(out_len.astype(np.uint64).sum())
     slow = ctx.get_option("slow_division_wave_steps")
 
+    # Outside the timed region, for the record: the same batch with every formant evaluated
+    # literally ("skip_silent_formants" = 0).  Same output bits; see DESIGN.md section 4.
+    literal_ms = None
+    if rank == 0 and ctx.get_option("skip_silent_formants"):
+        ctx.set_option("skip_silent_formants", 0)
+        literal_ms = float(np.mean([step() for _ in range(2)]))
+        ctx.set_option("skip_silent_formants", 1)
+
     if distributed:
         stats = group.gather_doubles((elapsed, float(samples_per_step)))
         elapsed = max(e for e, _ in stats)                  # MAX over ranks
@@ -210,6 +218,13 @@ def main():
                 "lanes_per_utterance": args.lanes or "auto", "voice_table": voice_path,
                 "parity": "bit-exact vs oracle (tests/test_parity_gpu.py); "
                           f"IEEE-division fallback wave-steps this run: {slow}",
+                "silent_formant_skip": "on: formants with amplitude exactly 0 and zero band-pass "
+                                       "state contribute exactly +0.0 and their filters are skipped "
+                                       "(voices::generic() has 4 of 8 such formants; config 4's "
+                                       "presets have none); output bits unchanged",
+                "kernel_ms_all_formants_literal": literal_ms,
+                "samples_per_s_all_formants_literal":
+                    (samples_per_step / (literal_ms * 1e-3)) if literal_ms else None,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

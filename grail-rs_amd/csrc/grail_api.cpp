@@ -113,6 +113,7 @@ struct grail_ctx {
     uint64_t slow_steps = 0;          // of the kernels synced so far
     int lanes_option = 0;             // 0 = auto
     int variant_option = 0;           // experiments: explicit kernel instantiation
+    int skip_silent_option = 1;       // skip band-pass filters of provably silent formants
     ncclComm_t comm = nullptr;
     uint32_t comm_rank = 0, comm_world = 1;
 };
@@ -327,6 +328,10 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         ctx->lanes_option = (int)value;
         return GRAIL_OK;
     }
+    if (std::strcmp(name, "skip_silent_formants") == 0) {
+        ctx->skip_silent_option = value ? 1 : 0;
+        return GRAIL_OK;
+    }
     if (std::strcmp(name, "kernel_variant") == 0) {
         if (value < 0 || value > 1) return fail(GRAIL_ERR_INVALID_ARG, "kernel_variant out of range");
         ctx->variant_option = (int)value;
@@ -344,6 +349,10 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
     }
     if (std::strcmp(name, "kernel_variant") == 0) {
         *value = ctx->variant_option;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "skip_silent_formants") == 0) {
+        *value = ctx->skip_silent_option;
         return GRAIL_OK;
     }
     if (std::strcmp(name, "slow_division_wave_steps") == 0) {  // read-only statistic
@@ -491,6 +500,7 @@ int grail_batch_synthesize_async(grail_ctx *ctx, const grail_batch *batch, float
     a.n_utt = batch->n_utt;
     a.n_voices = (uint32_t)ctx->voices.size();
     a.phoneme_mode = batch->phoneme_mode ? 1u : 0u;
+    a.skip_silent = ctx->skip_silent_option ? 1u : 0u;
     const int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(batch->n_utt);
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
     hipError_t e = launch_synth(a, L, ctx->variant_option, ctx->stream);
@@ -549,6 +559,7 @@ int grail_stream_next_async(grail_ctx *ctx, grail_stream *stream, uint32_t max_s
     a.n_utt = batch->n_utt;
     a.n_voices = (uint32_t)ctx->voices.size();
     a.phoneme_mode = batch->phoneme_mode ? 1u : 0u;
+    a.skip_silent = ctx->skip_silent_option ? 1u : 0u;
     a.state = stream->d_state;
     a.state_stride = stream->lanes;
     a.resume = stream->started ? 1u : 0u;

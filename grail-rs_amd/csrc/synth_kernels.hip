@@ -30,6 +30,8 @@
 // The per-formant arithmetic is therefore written on float2 values, which hipcc
 // lowers to v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two formants per issue
 // slot, each component still an individually rounded IEEE operation.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace grail {
@@ -228,8 +230,15 @@ __device__ __forceinline__ void fetch_seg(Seg &s, const DevSeg *__restrict__ seg
 // formant vectors one lane owns.  SAFE selects the division flavour (same bits).
 // Written breadth-first (each step for every k before the next step) so that the NV
 // independent dependency chains interleave and hide each other's VALU latency.
+//
+// NLIVE < NV (quiet step only): vectors k >= NLIVE are "silent" for the whole segment pair —
+// amplitude exactly +0 in both blended elems and band-pass state exactly +0 (see
+// upper_half_is_silent) — so their v0 is +-0, their band-pass output w1 is exactly +0 and the
+// state stays +0 (a1*(+0) + a2*(+-0) = +0, (0 + a2*0) + a3*(+-0) = +0, 2*0 - 0 = +0).  Only
+// their one-pole low-pass state (:538) still has to advance; v1 = +0 is returned for the fold.
 #define FOR_K _Pragma("unroll") for (int k = 0; k < NV; ++k)
-template <bool SAFE, int NV, typename V>
+#define FOR_L _Pragma("unroll") for (int k = 0; k < NLIVE; ++k)
+template <bool SAFE, int NV, int NLIVE, typename V>
 __device__ __forceinline__ void formant_filters(const float saw, const float noise,
                                                 const V (&e_freq)[NV], const V (&e_bw)[NV],
                                                 const V (&e_smooth)[NV], const V (&e_breath)[NV],
@@ -238,6 +247,7 @@ __device__ __forceinline__ void formant_filters(const float saw, const float noi
                                                 V (&v1)[NV])
 {
     if constexpr (!SAFE) {
+        static_assert(NLIVE == NV, "the IEEE flavour always runs every formant");
         // the rare IEEE-division flavour, one formant vector at a time (fewest live registers)
         FOR_K {
             const V nw = saw * (1.0f - e_breath[k]) + noise * e_breath[k];      // :531
@@ -258,54 +268,58 @@ __device__ __forceinline__ void formant_filters(const float saw, const float noi
             v1[k] = w1;
         }
         return;
-    }
-    V num[NV], den[NV], g[NV], kq[NV], a1[NV], y[NV], e[NV], q[NV], r[NV], d3[NV];
-    // tan_approx numerator / denominator, src/lib.rs:63-70
-    FOR_K {
-        const V x = e_freq[k];
-        const V omx = 1.0f - x;
-        const V xph = x + 0.5f;
-        const V hmx = 0.5f - x;
-        num[k] = (omx * x) * (5.0f - (4.0f * xph) * hmx);
-        den[k] = (xph * (5.0f - (4.0f * omx) * x)) * hmx;
-    }
-    if constexpr (SAFE) {
+    } else {
+        V num[NLIVE], den[NLIVE], g[NLIVE], kq[NLIVE], a1[NLIVE], y[NLIVE], e[NLIVE], q[NLIVE],
+            r[NLIVE], d3[NLIVE], y2[NLIVE], e2[NLIVE], q2[NLIVE], r2[NLIVE];
+        const V one = vsplat(1.0f, st_a[0]);
+        const V five = vsplat(5.0f, st_a[0]);
+        const V m4 = vsplat(-4.0f, st_a[0]);
+        // tan_approx numerator / denominator, src/lib.rs:63-70.  In the SAFE operand window
+        // (4*a)*b == 4*(a*b) exactly (scaling by 4 commutes with rounding, nothing under- or
+        // overflows), so 5 - (4*a)*b == fma(-4, a*b, 5): one rounding of the same real number.
+        FOR_L {
+            const V x = e_freq[k];
+            const V omx = 1.0f - x;
+            const V xph = x + 0.5f;
+            const V hmx = 0.5f - x;
+            const V ox = omx * x;                       // (1-x)*x, shared by both polynomials
+            const V ph = xph * hmx;
+            num[k] = ox * vfma(m4, ph, five);           // ((1-x)*x) * (5 - (4*(x+.5))*(.5-x))
+            den[k] = (xph * vfma(m4, ox, five)) * hmx;  // ((x+.5) * (5 - (4*(1-x))*x)) * (.5-x)
+        }
         // g = num/den and kq = bw/freq by div_exact<true>, a1 = 1/d3 by rcp_exact<true>,
         // spelled out step by step across k
-        const V one = vsplat(1.0f, num[0]);
-        V y2[NV], e2[NV], q2[NV], r2[NV];
-        FOR_K { y[k] = vrcp(den[k]); y2[k] = vrcp(e_freq[k]); }
-        FOR_K { e[k] = vfma(-den[k], y[k], one); e2[k] = vfma(-e_freq[k], y2[k], one); }
-        FOR_K { y[k] = vfma(e[k], y[k], y[k]); y2[k] = vfma(e2[k], y2[k], y2[k]); }
-        FOR_K { q[k] = num[k] * y[k]; q2[k] = e_bw[k] * y2[k]; }
-        FOR_K { r[k] = vfma(-den[k], q[k], num[k]); r2[k] = vfma(-e_freq[k], q2[k], e_bw[k]); }
-        FOR_K { g[k] = vfma(r[k], y[k], q[k]); kq[k] = vfma(r2[k], y2[k], q2[k]); }   // :555, :558
-        FOR_K d3[k] = 1.0f + g[k] * (g[k] + kq[k]);                                   // :560
-        FOR_K y[k] = vrcp(d3[k]);
-        FOR_K e[k] = vfma(-d3[k], y[k], one);
-        FOR_K a1[k] = vfma(e[k], y[k], y[k]);
-    } else {
-        FOR_K g[k] = num[k] / den[k];                                                 // :555
-        FOR_K kq[k] = e_bw[k] / e_freq[k];                                            // :558
-        FOR_K d3[k] = 1.0f + g[k] * (g[k] + kq[k]);
-        FOR_K a1[k] = vsplat(1.0f, d3[k]) / d3[k];                                    // :560
+        FOR_L { y[k] = vrcp(den[k]); y2[k] = vrcp(e_freq[k]); }
+        FOR_L { e[k] = vfma(-den[k], y[k], one); e2[k] = vfma(-e_freq[k], y2[k], one); }
+        FOR_L { y[k] = vfma(e[k], y[k], y[k]); y2[k] = vfma(e2[k], y2[k], y2[k]); }
+        FOR_L { q[k] = num[k] * y[k]; q2[k] = e_bw[k] * y2[k]; }
+        FOR_L { r[k] = vfma(-den[k], q[k], num[k]); r2[k] = vfma(-e_freq[k], q2[k], e_bw[k]); }
+        FOR_L { g[k] = vfma(r[k], y[k], q[k]); kq[k] = vfma(r2[k], y2[k], q2[k]); }   // :555, :558
+        FOR_L d3[k] = 1.0f + g[k] * (g[k] + kq[k]);                                   // :560
+        FOR_L y[k] = vrcp(d3[k]);
+        FOR_L e[k] = vfma(-d3[k], y[k], one);
+        FOR_L a1[k] = vfma(e[k], y[k], y[k]);
+        V nw[NV], lp[NV];
+        FOR_K nw[k] = saw * (1.0f - e_breath[k]) + noise * e_breath[k];                   // :531
+        FOR_K lp[k] = exp_approx(e_smooth[k]);                                            // :535
+        FOR_K st_a[k] = st_a[k] + (1.0f - lp[k]) * (nw[k] - st_a[k]);                     // :538
+        V tw[NLIVE], v0[NLIVE], a2[NLIVE], a3[NLIVE], v3[NLIVE], w1[NLIVE], w2[NLIVE];
+        // :544-545  1.0*(1-turb) + noise*turb; the multiply by 1.0 is exact and dropped
+        FOR_L tw[k] = st_a[k] * ((1.0f - e_turb[k]) + noise * e_turb[k]);
+        FOR_L v0[k] = tw[k] * e_amp[k];                                                   // :550
+        FOR_L a2[k] = g[k] * a1[k];                                                       // :561
+        FOR_L a3[k] = g[k] * a2[k];                                                       // :562
+        FOR_L v3[k] = v0[k] - st_c[k];                                                    // :565
+        FOR_L w1[k] = a1[k] * st_b[k] + a2[k] * v3[k];                                    // :566
+        FOR_L w2[k] = (st_c[k] + a2[k] * st_b[k]) + a3[k] * v3[k];                        // :567
+        FOR_L st_b[k] = 2.0f * w1[k] - st_b[k];                                           // :570
+        FOR_L st_c[k] = 2.0f * w2[k] - st_c[k];                                           // :571
+        FOR_L v1[k] = w1[k];
+#pragma unroll
+        for (int k = NLIVE; k < NV; ++k) v1[k] = vsplat(0.0f, st_a[0]);                   // exactly +0
     }
-    V nw[NV], lp[NV], tw[NV], v0[NV], a2[NV], a3[NV], v3[NV], w1[NV], w2[NV];
-    FOR_K nw[k] = saw * (1.0f - e_breath[k]) + noise * e_breath[k];                   // :531
-    FOR_K lp[k] = exp_approx(e_smooth[k]);                                            // :535
-    FOR_K st_a[k] = st_a[k] + (1.0f - lp[k]) * (nw[k] - st_a[k]);                     // :538
-    // :544-545  1.0*(1-turb) + noise*turb; the multiply by 1.0 is exact and dropped
-    FOR_K tw[k] = st_a[k] * ((1.0f - e_turb[k]) + noise * e_turb[k]);
-    FOR_K v0[k] = tw[k] * e_amp[k];                                                   // :550
-    FOR_K a2[k] = g[k] * a1[k];                                                       // :561
-    FOR_K a3[k] = g[k] * a2[k];                                                       // :562
-    FOR_K v3[k] = v0[k] - st_c[k];                                                    // :565
-    FOR_K w1[k] = a1[k] * st_b[k] + a2[k] * v3[k];                                    // :566
-    FOR_K w2[k] = (st_c[k] + a2[k] * st_b[k]) + a3[k] * v3[k];                        // :567
-    FOR_K st_b[k] = 2.0f * w1[k] - st_b[k];                                           // :570
-    FOR_K st_c[k] = 2.0f * w2[k] - st_c[k];                                           // :571
-    FOR_K v1[k] = w1[k];
 }
+#undef FOR_L
 #undef FOR_K
 
 // Can every division of the coming segment pair take the SAFE path?  Bounds every
@@ -341,6 +355,39 @@ __device__ __forceinline__ bool pair_is_safe(const Part<NV, V> &X, const Part<NV
             ok = ok && (xf * 0.999f - jm >= X_LO) && (yf * 0.999f - jm >= X_LO) &&
                  (xf * 1.001f + jm <= X_HI) && (yf * 1.001f + jm <= X_HI) &&
                  (xb >= W_LO) && (yb >= W_LO) && (xb <= W_HI) && (yb <= W_HI);
+        }
+    }
+    return ok;
+}
+
+// Is the upper half of this lane's formant vectors silent for the coming segment pair?  Then the
+// quiet step may skip their band-pass filters (formant_filters<.., NLIVE = NV/2>) and still be
+// bit-identical.  Needs, for every such formant: amplitude exactly +0 in both blended elems and
+// 0 <= 0.5*jitter_delta_amplitude <= 1/4 (so the jittered amplitude 0*(1-delta) is +0, delta <=
+// 1/2), band-pass state b, c exactly +0, and breath / turbulence / smoothness in [0,1] with a
+// finite low-pass state (so tw = a*(..) is finite and v0 = tw*(+0) is +-0, never NaN).  Finite,
+// positive a1, a2, a3 and a finite saw come from pair_is_safe.
+template <int NV, int W, typename V>
+__device__ __forceinline__ bool upper_half_is_silent(const Part<NV, V> &X, const Part<NV, V> &Y,
+                                                     const V (&st_a)[NV], const V (&st_b)[NV],
+                                                     const V (&st_c)[NV], float amp_scale)
+{
+    bool ok = (amp_scale >= 0.0f) && (amp_scale <= 0.25f);
+#pragma unroll
+    for (int k = NV / 2; k < NV; ++k) {
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            const float xb = vget(X.breath[k], c), yb = vget(Y.breath[k], c);
+            const float xt = vget(X.turb[k], c), yt = vget(Y.turb[k], c);
+            const float xs = vget(X.smooth[k], c), ys = vget(Y.smooth[k], c);
+            ok = ok && (__float_as_uint(vget(X.amp[k], c)) == 0u) &&
+                 (__float_as_uint(vget(Y.amp[k], c)) == 0u) &&
+                 (__float_as_uint(vget(st_b[k], c)) == 0u) &&
+                 (__float_as_uint(vget(st_c[k], c)) == 0u) &&
+                 (xb >= 0.0f) && (xb <= 1.0f) && (yb >= 0.0f) && (yb <= 1.0f) &&
+                 (xt >= 0.0f) && (xt <= 1.0f) && (yt >= 0.0f) && (yt <= 1.0f) &&
+                 (xs >= 0.0f) && (xs <= 1.0f) && (ys >= 0.0f) && (ys <= 1.0f) &&
+                 (__builtin_fabsf(vget(st_a[k], c)) <= 1.152921504606847e18f);   // 2^60
         }
     }
     return ok;
@@ -494,6 +541,12 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     bool quiet_ok = false;
 
     bool finished = false;   // the chain has returned None (persistent); `done` also covers pauses
+    bool upper_silent = false;   // this pair: the lane's upper NV/2 formant vectors are silent
+    auto update_silent = [&]() __attribute__((always_inline)) {
+        if constexpr (NV >= 2)
+            upper_silent = A.skip_silent && pair_safe &&
+                           upper_half_is_silent<NV, W>(X, Y, st_a, st_b, st_c, amp_scale);
+    };
 
     // (cur, nxt) -> X, Y, blend constants: the match of Sequencer::next resolved once per pair
     auto setup_pair = [&]() __attribute__((always_inline)) {
@@ -552,6 +605,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         done = finished;
         if (cur.some) setup_pair();
         quiet_ok = pair_safe && blend_pow2;
+        update_silent();
     }
 
     // ---- the general sample step: any lane may be finished, advance a segment, wrap its
@@ -581,6 +635,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             if (!done && cur.some) {
                 setup_pair();
                 pair_safe = pair_is_safe<NV, W>(X, Y, clk, blend_length, jinc, d_ffreq, d_freq);
+                update_silent();
             }
         }
         if (!cur.some) { done = true; finished = true; }      // :930
@@ -668,7 +723,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 
         // events are rare: this step always takes the IEEE-division body (same bits)
         V v1[NV];
-        formant_filters<false, NV, V>(saw, noise, e_freq, e_bw, e_smooth, e_breath, e_turb, e_amp,
+        formant_filters<false, NV, NV, V>(saw, noise, e_freq, e_bw, e_smooth, e_breath, e_turb, e_amp,
                                       st_a, st_b, st_c, v1);
         if (!pair_safe) ++slow_steps;
 
@@ -691,8 +746,9 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     // ---- the quiet sample step: taken when a single ballot shows that NO lane of the wave
     // has any of those events at this sample.  Same arithmetic, straight-line: the polyBLEP
     // quotient is evaluated unconditionally with div_exact<true> and selected afterwards.
-    auto quiet_step = [&](const int t, const float clk_next, const float jphase_next)
+    auto quiet_step = [&](auto nlive_tag, const int t, const float clk_next, const float jphase_next)
                           __attribute__((always_inline)) {
+        constexpr int NLIVE = decltype(nlive_tag)::value;   // vectors whose band-pass runs
         if (done) return;                                                  // finished lanes sit out
         clk = clk_next;                                                    // :861
         float alpha = __builtin_fminf(clk * inv_blend_length, 1.0f);       // :899/:908/:917
@@ -702,19 +758,23 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         V e_freq[NV], e_bw[NV], e_smooth[NV], e_breath[NV], e_turb[NV], e_amp[NV];
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            e_freq[k] = X.freq[k] * oma + Y.freq[k] * alpha;
             e_smooth[k] = X.smooth[k] * oma + Y.smooth[k] * alpha;
-            e_bw[k] = X.bw[k] * oma + Y.bw[k] * alpha;
-            e_turb[k] = X.turb[k] * oma + Y.turb[k] * alpha;
             e_breath[k] = X.breath[k] * oma + Y.breath[k] * alpha;
-            e_amp[k] = X.amp[k] * oma + Y.amp[k] * alpha;
+            if (k < NLIVE) {
+                e_freq[k] = X.freq[k] * oma + Y.freq[k] * alpha;
+                e_bw[k] = X.bw[k] * oma + Y.bw[k] * alpha;
+                e_turb[k] = X.turb[k] * oma + Y.turb[k] * alpha;
+                e_amp[k] = X.amp[k] * oma + Y.amp[k] * alpha;
+            } else {   // silent vectors: only the low-pass inputs are needed
+                e_freq[k] = e_smooth[k]; e_bw[k] = e_smooth[k]; e_turb[k] = e_smooth[k]; e_amp[k] = e_smooth[k];
+            }
         }
         jphase = jphase_next;                                              // :242 / :291, no wrap
         const float jomp = 1.0f - jphase;
         const float n_freq = fn_cur * jomp + fn_next * jphase;             // :254
         frequency = frequency + n_freq * d_freq;                           // :763
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
+        for (int k = 0; k < NLIVE; ++k) {
             const V n_ff = ff_cur[k] * jomp + ff_next[k] * jphase;         // :305
             const V n_fa = fa_cur[k] * jomp + fa_next[k] * jphase;
             e_freq[k] = e_freq[k] + n_ff * d_ffreq;                        // :764
@@ -733,8 +793,8 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         phase = (phase >= 1.0f) ? phase - 1.0f : phase;                    // :523-525
         const float noise = lcg_f32(noise_seed);                           // :528
         V v1[NV];
-        formant_filters<true, NV, V>(saw, noise, e_freq, e_bw, e_smooth, e_breath, e_turb, e_amp,
-                                     st_a, st_b, st_c, v1);
+        formant_filters<true, NV, NLIVE, V>(saw, noise, e_freq, e_bw, e_smooth, e_breath, e_turb,
+                                            e_amp, st_a, st_b, st_c, v1);
         float acc = 0.0f;
 #pragma unroll
         for (int step = 0; step < L; ++step) {
@@ -753,15 +813,26 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         int t = 0;
         while (t < T) {
             // a run of quiet steps: a tight inner loop, so the loop-carried state keeps its
-            // registers from one sample to the next
-            for (; t < T; ++t) {
-                const float clk_next = clk - dt;
-                const float jphase_next = jphase + jinc;
-                // bitwise on purpose: no short-circuit, so no exec-mask regions
-                const bool eventful = !done & (!quiet_ok | (clk_next < 0.0f) |
-                                               (jphase_next > 1.0f) | (n_out >= cap32));
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(eventful) != 0, 0)) break;
-                quiet_step(t, clk_next, jphase_next);
+            // registers from one sample to the next.  Two flavours of the same loop: every
+            // formant vector live, or (all lanes agree) the upper half silent for this pair.
+            auto quiet_run = [&](auto nlive_tag) __attribute__((always_inline)) {
+                for (; t < T; ++t) {
+                    const float clk_next = clk - dt;
+                    const float jphase_next = jphase + jinc;
+                    // bitwise on purpose: no short-circuit, so no exec-mask regions
+                    const bool eventful = !done & (!quiet_ok | (clk_next < 0.0f) |
+                                                   (jphase_next > 1.0f) | (n_out >= cap32));
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(eventful) != 0, 0)) break;
+                    quiet_step(nlive_tag, t, clk_next, jphase_next);
+                }
+            };
+            if constexpr (NV >= 2) {
+                if (__builtin_amdgcn_ballot_w64(!done & !upper_silent) == 0)
+                    quiet_run(std::integral_constant<int, NV / 2>());
+                else
+                    quiet_run(std::integral_constant<int, NV>());
+            } else {
+                quiet_run(std::integral_constant<int, NV>());
             }
             if (t < T) {
                 general_step(t);

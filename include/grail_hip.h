@@ -166,8 +166,15 @@ int grail_device_count(int *count);
  * src/lib.rs:1013, 941, 786) to HBM.  Utterances refer to it by voice id. */
 int grail_set_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices);
 int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t *n_voices);
-/* Tuning knobs. name = "lanes_per_utterance": 0 = auto, or 1/2/4/8 — how many
- * wavefront lanes share one utterance's 8 formants.  Never changes results. */
+/* Tuning knobs; none of them ever changes a result bit.
+ *   "lanes_per_utterance": 0 = auto, or 1/2/4/8 — how many wavefront lanes share one
+ *       utterance's 8 formants.
+ *   "skip_silent_formants": 1 (default) / 0 — formants whose amplitude is exactly 0 in both
+ *       elems of a segment pair and whose band-pass state is exactly 0 contribute exactly +0.0;
+ *       their band-pass filters are skipped (voices::generic() has four such formants,
+ *       src/voices/generic.rs:19,31).  0 forces the literal evaluation of all eight.
+ *   "kernel_variant": experiments only.
+ * Read-only statistic: "slow_division_wave_steps". */
 int grail_set_option(grail_ctx *ctx, const char *name, int64_t value);
 int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value);
 

@@ -299,3 +299,70 @@ def test_config3_full_size_on_device_digest(gpu_ctx):
     for k, u in enumerate(pick):
         want = int(ref[k, :ref_len[k]].view(np.uint32).astype(np.uint64).sum())
         assert int(digests[0][u]) == want, u
+
+
+def _elem(rng, amp_mask):
+    e = np.zeros(49, dtype=np.float32)
+    e[0] = rng.uniform(0.002, 0.006)
+    e[1:9] = rng.uniform(0.01, 0.2, 8)
+    e[9:17] = rng.uniform(0.001, 0.01, 8)
+    e[17:25] = rng.uniform(0.01, 0.1, 8)
+    e[25:33] = rng.uniform(0, 1, 8)
+    e[33:41] = rng.uniform(0, 1, 8)
+    amp = rng.uniform(0.1, 1, 8) * np.asarray(amp_mask, dtype=np.float64)
+    e[41:49] = amp / amp.sum()
+    return e
+
+
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_silent_formant_skip_is_bit_exact_when_formants_wake_up(gpu_ctx, lanes):
+    """"skip_silent_formants" may only skip what is provably +0: utterances whose upper formants
+    are silent, become live, fall silent again (ringing state != 0), against the oracle, with the
+    option on and off."""
+    rng = np.random.default_rng(11)
+    lo, all8 = [1, 1, 1, 1, 0, 0, 0, 0], [1] * 8
+    plans = [[lo, lo, lo], [lo, all8, lo], [all8, lo, lo], [lo, lo, all8, lo, lo], [all8, all8],
+             [lo, None, lo, all8], [None, lo, lo]]
+    gsegs, osegs, offs = [], [], [0]
+    for plan in plans * 3:
+        for mask in plan:
+            has = mask is not None
+            e = _elem(rng, mask if has else all8)
+            ln = float(rng.uniform(0.004, 0.012))
+            gsegs.append(G.SequenceElem(int(has), G.SynthesisElem.from_np(e), ln, 0.0078125))
+            osegs.append(O.SequenceElem(int(has), O.SynthesisElem.from_buffer_copy(e.tobytes()), ln, 0.0078125))
+        offs.append(len(gsegs))
+    n = len(offs) - 1
+    seeds = np.arange(n, dtype=np.uint32) * 31 + 5
+    v = G.voice_generic(48000.0)
+    gpu_ctx.set_voices([v])
+    gpu_ctx.set_option("lanes_per_utterance", lanes)
+    ov = O.Voice.from_buffer_copy(bytes(v))
+    try:
+        outs = {}
+        for skip in (1, 0):
+            gpu_ctx.set_option("skip_silent_formants", skip)
+            outs[skip] = gpu_ctx.synthesize_elems(gsegs, offs, None, seeds, out_stride=4096)
+        assert np.array_equal(outs[0][1], outs[1][1])
+        assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+        for u in range(n):
+            ref = O.synthesize_sequence(ov, osegs[offs[u]:offs[u + 1]], int(seeds[u]))
+            assert outs[1][1][u] == len(ref)
+            assert np.array_equal(outs[1][0][u, :len(ref)].view(np.uint32), ref.view(np.uint32)), u
+    finally:
+        gpu_ctx.set_option("skip_silent_formants", 1)
+        gpu_ctx.set_option("lanes_per_utterance", 0)
+
+
+def test_silent_formant_skip_respects_the_amplitude_jitter_bound(gpu_ctx):
+    """0.5*jitter_delta_amplitude > 1/4 could make 0*(1-delta) a -0: such voices never skip."""
+    v = G.voice_generic(48000.0)
+    v.jitter_delta_amplitude = 1.7
+    segs, offs, vids, seeds = W.make_batch(70, length=0.02, blend_length=0.02)
+    stride = W.max_samples(length=0.02)
+    gpu_ctx.set_option("lanes_per_utterance", 1)
+    try:
+        out, out_len, ref, ref_len = run_both(gpu_ctx, [v], segs, offs, vids, seeds, stride, 1)
+        assert_bit_identical(out, out_len, ref, ref_len, "wide amplitude jitter")
+    finally:
+        gpu_ctx.set_option("lanes_per_utterance", 0)
