@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--voices", type=int, default=1, help="1 = single Voice, 8 = config-4 presets")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per utterance (0 = auto)")
     ap.add_argument("--variant", type=int, default=0, help="kernel instantiation (experiments)")
+    ap.add_argument("--literal", action="store_true",
+                    help="after the timed region, also time the batch with skip_silent_formants=0")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank code path even with one rank (testing)")
     ap.add_argument("--cpu-utts", type=int, default=1536,
@@ -184,7 +186,7 @@ def main():
     # Outside the timed region, for the record: the same batch with every formant evaluated
     # literally ("skip_silent_formants" = 0).  Same output bits; see DESIGN.md section 4.
     literal_ms = None
-    if rank == 0 and ctx.get_option("skip_silent_formants"):
+    if args.literal and rank == 0 and ctx.get_option("skip_silent_formants"):
         ctx.set_option("skip_silent_formants", 0)
         literal_ms = float(np.mean([step() for _ in range(2)]))
         ctx.set_option("skip_silent_formants", 1)
