@@ -1,0 +1,56 @@
+"""Randomised parity: random utterances (phonemes incl. Silence/Stop/Glide, lengths, blend
+lengths — power-of-two and not — pitches, voices, seeds, ragged segment counts) through the HIP
+path vs the oracle, bit for bit, for every lane mapping; the streaming path on the same inputs."""
+import numpy as np
+import pytest
+
+import grail_hip as G
+import oracle_lib as O
+from grail_hip import workload as W
+
+pytestmark = pytest.mark.gpu
+
+
+def random_batch(rng, n_utt, n_voices, rate):
+    segs, offs, vids, seeds = [], [0], [], []
+    pow2 = [2.0 ** -k for k in range(5, 9)]
+    for _ in range(n_utt):
+        for _ in range(int(rng.integers(0, 7))):
+            ph = int(rng.choice([G.PH_SILENCE, G.PH_STOP, G.PH_GLIDE, G.PH_A, G.PH_E], p=[.15, .05, .05, .4, .35]))
+            length = float(rng.choice([rng.uniform(0.0005, 0.03), rng.choice(pow2), 0.0]))
+            blend = float(rng.choice([rng.uniform(0.0005, 0.04), rng.choice(pow2), rng.choice(pow2)]))
+            hz = float(rng.uniform(60, 400))
+            segs.append((ph, length, blend, np.float32(hz) / np.float32(rate)))
+        offs.append(len(segs))
+        vids.append(int(rng.integers(0, n_voices)))
+        seeds.append(int(rng.integers(0, 2 ** 32)))
+    return (G.segments(segs), np.array(offs, dtype=np.uint32), np.array(vids, dtype=np.uint32),
+            np.array(seeds, dtype=np.uint32))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_batches_every_lane_mapping(gpu_ctx, seed):
+    rng = np.random.default_rng(seed)
+    voices = W.preset_voices(8) if seed != 2 else [G.voice_generic(48000.0), G.voice_generic(44100.0)]
+    gpu_ctx.set_voices(voices)
+    segs, offs, vids, seeds = random_batch(rng, 130, len(voices), 48000.0)
+    ov = [O.Voice.from_buffer_copy(bytes(v)) for v in voices]
+    stride = 10048
+    ref, ref_len = O.synthesize_batch(ov, segs, offs, vids, seeds, stride)
+    assert ref_len.max() < stride and ref_len.max() > 3000
+    try:
+        for lanes in (1, 2, 4, 8):
+            gpu_ctx.set_option("lanes_per_utterance", lanes)
+            out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+            assert np.array_equal(out_len, ref_len), lanes
+            for u in range(len(ref_len)):
+                assert np.array_equal(out[u, :ref_len[u]].view(np.uint32),
+                                      ref[u, :ref_len[u]].view(np.uint32)), (lanes, u)
+        # the batch pre-pass agrees with what was rendered
+        b = gpu_ctx.upload(segs, offs, vids, seeds)
+        try:
+            assert np.array_equal(b.lengths(), ref_len)
+        finally:
+            b.free()
+    finally:
+        gpu_ctx.set_option("lanes_per_utterance", 0)
