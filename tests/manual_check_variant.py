@@ -1,4 +1,4 @@
-"""Quick parity + timing check of a kernel variant on the GPU box: tools/check_variant.py <variant>"""
+"""Quick parity + timing check of a kernel variant on the GPU box: tests/manual_check_variant.py <variant>"""
 import sys
 sys.path.insert(0, 'grail-rs_amd'); sys.path.insert(0, 'tests')
 import numpy as np
