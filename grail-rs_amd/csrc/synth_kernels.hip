@@ -238,8 +238,11 @@ __device__ __forceinline__ void fetch_seg(Seg &s, const DevSeg *__restrict__ seg
 // their one-pole low-pass state (:538) still has to advance; v1 = +0 is returned for the fold.
 #define FOR_K _Pragma("unroll") for (int k = 0; k < NV; ++k)
 #define FOR_L _Pragma("unroll") for (int k = 0; k < NLIVE; ++k)
-template <bool SAFE, int NV, int NLIVE, typename V>
-__device__ __forceinline__ void formant_filters(const float saw, const float noise,
+// SU = true (quiet step only): the blended smoothness is the same number for all of the lane's
+// formants (bit-equal table entries), so 1 - exp_approx(smooth) was evaluated once, as a scalar,
+// by the caller (`oml_s`): the same operations on the same operands give the same bits.
+template <bool SAFE, int NV, int NLIVE, bool SU, typename V>
+__device__ __forceinline__ void formant_filters(const float saw, const float noise, const float oml_s,
                                                 const V (&e_freq)[NV], const V (&e_bw)[NV],
                                                 const V (&e_smooth)[NV], const V (&e_breath)[NV],
                                                 const V (&e_turb)[NV], const V (&e_amp)[NV],
@@ -299,10 +302,15 @@ __device__ __forceinline__ void formant_filters(const float saw, const float noi
         FOR_L y[k] = vrcp(d3[k]);
         FOR_L e[k] = vfma(-d3[k], y[k], one);
         FOR_L a1[k] = vfma(e[k], y[k], y[k]);
-        V nw[NV], lp[NV];
+        V nw[NV];
         FOR_K nw[k] = saw * (1.0f - e_breath[k]) + noise * e_breath[k];                   // :531
-        FOR_K lp[k] = exp_approx(e_smooth[k]);                                            // :535
-        FOR_K st_a[k] = st_a[k] + (1.0f - lp[k]) * (nw[k] - st_a[k]);                     // :538
+        if constexpr (SU) {
+            FOR_K st_a[k] = st_a[k] + oml_s * (nw[k] - st_a[k]);                          // :535-538
+        } else {
+            V lp[NV];
+            FOR_K lp[k] = exp_approx(e_smooth[k]);                                        // :535
+            FOR_K st_a[k] = st_a[k] + (1.0f - lp[k]) * (nw[k] - st_a[k]);                 // :538
+        }
         V tw[NLIVE], v0[NLIVE], a2[NLIVE], a3[NLIVE], v3[NLIVE], w1[NLIVE], w2[NLIVE];
         // :544-545  1.0*(1-turb) + noise*turb; the multiply by 1.0 is exact and dropped
         FOR_L tw[k] = st_a[k] * ((1.0f - e_turb[k]) + noise * e_turb[k]);
@@ -541,11 +549,22 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     bool quiet_ok = false;
 
     bool finished = false;   // the chain has returned None (persistent); `done` also covers pauses
+    bool smooth_uniform = false; // this pair: X.smooth and Y.smooth are each one number for all formants
     bool upper_silent = false;   // this pair: the lane's upper NV/2 formant vectors are silent
     auto update_silent = [&]() __attribute__((always_inline)) {
         if constexpr (NV >= 2)
             upper_silent = A.skip_silent && pair_safe &&
                            upper_half_is_silent<NV, W>(X, Y, st_a, st_b, st_c, amp_scale);
+        bool su = true;
+        const uint32_t xs0 = __float_as_uint(vget(X.smooth[0], 0));
+        const uint32_t ys0 = __float_as_uint(vget(Y.smooth[0], 0));
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int c = 0; c < W; ++c)
+                su = su && (__float_as_uint(vget(X.smooth[k], c)) == xs0) &&
+                     (__float_as_uint(vget(Y.smooth[k], c)) == ys0);
+        smooth_uniform = su;
     };
 
     // (cur, nxt) -> X, Y, blend constants: the match of Sequencer::next resolved once per pair
@@ -723,7 +742,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 
         // events are rare: this step always takes the IEEE-division body (same bits)
         V v1[NV];
-        formant_filters<false, NV, NV, V>(saw, noise, e_freq, e_bw, e_smooth, e_breath, e_turb, e_amp,
+        formant_filters<false, NV, NV, false, V>(saw, noise, 0.0f, e_freq, e_bw, e_smooth, e_breath, e_turb, e_amp,
                                       st_a, st_b, st_c, v1);
         if (!pair_safe) ++slow_steps;
 
@@ -746,9 +765,10 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     // ---- the quiet sample step: taken when a single ballot shows that NO lane of the wave
     // has any of those events at this sample.  Same arithmetic, straight-line: the polyBLEP
     // quotient is evaluated unconditionally with div_exact<true> and selected afterwards.
-    auto quiet_step = [&](auto nlive_tag, const int t, const float clk_next, const float jphase_next)
-                          __attribute__((always_inline)) {
+    auto quiet_step = [&](auto nlive_tag, auto su_tag, const int t, const float clk_next,
+                          const float jphase_next) __attribute__((always_inline)) {
         constexpr int NLIVE = decltype(nlive_tag)::value;   // vectors whose band-pass runs
+        constexpr bool SU = decltype(su_tag)::value;        // one smoothness for every formant
         if (done) return;                                                  // finished lanes sit out
         clk = clk_next;                                                    // :861
         float alpha = __builtin_fminf(clk * inv_blend_length, 1.0f);       // :899/:908/:917
@@ -758,7 +778,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         V e_freq[NV], e_bw[NV], e_smooth[NV], e_breath[NV], e_turb[NV], e_amp[NV];
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            e_smooth[k] = X.smooth[k] * oma + Y.smooth[k] * alpha;
+            if (!SU) e_smooth[k] = X.smooth[k] * oma + Y.smooth[k] * alpha;
             e_breath[k] = X.breath[k] * oma + Y.breath[k] * alpha;
             if (k < NLIVE) {
                 e_freq[k] = X.freq[k] * oma + Y.freq[k] * alpha;
@@ -766,8 +786,14 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 e_turb[k] = X.turb[k] * oma + Y.turb[k] * alpha;
                 e_amp[k] = X.amp[k] * oma + Y.amp[k] * alpha;
             } else {   // silent vectors: only the low-pass inputs are needed
-                e_freq[k] = e_smooth[k]; e_bw[k] = e_smooth[k]; e_turb[k] = e_smooth[k]; e_amp[k] = e_smooth[k];
+                e_freq[k] = e_breath[k]; e_bw[k] = e_breath[k]; e_turb[k] = e_breath[k]; e_amp[k] = e_breath[k];
             }
+            if (SU) e_smooth[k] = e_breath[k];   // unused
+        }
+        float oml_s = 0.0f;
+        if constexpr (SU) {   // :404-414, :535 once for all formants (same operands, same bits)
+            const float es = vget(X.smooth[0], 0) * oma + vget(Y.smooth[0], 0) * alpha;
+            oml_s = 1.0f - exp_approx(es);
         }
         jphase = jphase_next;                                              // :242 / :291, no wrap
         const float jomp = 1.0f - jphase;
@@ -793,7 +819,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         phase = (phase >= 1.0f) ? phase - 1.0f : phase;                    // :523-525
         const float noise = lcg_f32(noise_seed);                           // :528
         V v1[NV];
-        formant_filters<true, NV, NLIVE, V>(saw, noise, e_freq, e_bw, e_smooth, e_breath, e_turb,
+        formant_filters<true, NV, NLIVE, SU, V>(saw, noise, oml_s, e_freq, e_bw, e_smooth, e_breath, e_turb,
                                             e_amp, st_a, st_b, st_c, v1);
         float acc = 0.0f;
 #pragma unroll
@@ -815,7 +841,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             // a run of quiet steps: a tight inner loop, so the loop-carried state keeps its
             // registers from one sample to the next.  Two flavours of the same loop: every
             // formant vector live, or (all lanes agree) the upper half silent for this pair.
-            auto quiet_run = [&](auto nlive_tag) __attribute__((always_inline)) {
+            auto quiet_run = [&](auto nlive_tag, auto su_tag) __attribute__((always_inline)) {
                 for (; t < T; ++t) {
                     const float clk_next = clk - dt;
                     const float jphase_next = jphase + jinc;
@@ -823,17 +849,18 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     const bool eventful = !done & (!quiet_ok | (clk_next < 0.0f) |
                                                    (jphase_next > 1.0f) | (n_out >= cap32));
                     if (__builtin_expect(__builtin_amdgcn_ballot_w64(eventful) != 0, 0)) break;
-                    quiet_step(nlive_tag, t, clk_next, jphase_next);
+                    quiet_step(nlive_tag, su_tag, t, clk_next, jphase_next);
                 }
             };
-            if constexpr (NV >= 2) {
-                if (__builtin_amdgcn_ballot_w64(!done & !upper_silent) == 0)
-                    quiet_run(std::integral_constant<int, NV / 2>());
-                else
-                    quiet_run(std::integral_constant<int, NV>());
-            } else {
-                quiet_run(std::integral_constant<int, NV>());
-            }
+            const bool all_su = __builtin_amdgcn_ballot_w64(!done & !smooth_uniform) == 0;
+            bool half = false;
+            if constexpr (NV >= 2) half = __builtin_amdgcn_ballot_w64(!done & !upper_silent) == 0;
+            typedef std::integral_constant<int, NV> FullTag;
+            typedef std::integral_constant<int, (NV >= 2 ? NV / 2 : NV)> HalfTag;
+            if (half && all_su) quiet_run(HalfTag(), std::true_type());
+            else if (half) quiet_run(HalfTag(), std::false_type());
+            else if (all_su) quiet_run(FullTag(), std::true_type());
+            else quiet_run(FullTag(), std::false_type());
             if (t < T) {
                 general_step(t);
                 quiet_ok = pair_safe && blend_pow2;

@@ -366,3 +366,19 @@ def test_silent_formant_skip_respects_the_amplitude_jitter_bound(gpu_ctx):
         assert_bit_identical(out, out_len, ref, ref_len, "wide amplitude jitter")
     finally:
         gpu_ctx.set_option("lanes_per_utterance", 0)
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 8])
+def test_non_uniform_smoothness_takes_the_vector_path(gpu_ctx, lanes):
+    """The quiet loop evaluates 1-exp_approx(smooth) once when every formant shares one
+    smoothness (voices::generic()); voices with per-formant smoothness must take the vector form."""
+    v = G.voice_generic(48000.0)
+    for p in range(2):
+        for i in range(8):
+            v.phonemes[p].formant_smooth[i] = float(np.float32(v.phonemes[p].formant_smooth[i]) *
+                                                    np.float32(1.0 + 0.07 * i + 0.01 * p))
+    segs, offs, vids, seeds = W.make_batch(70, length=0.02, blend_length=0.02)
+    stride = W.max_samples(length=0.02)
+    out, out_len, ref, ref_len = run_both(gpu_ctx, [v], segs, offs, vids, seeds, stride, lanes)
+    gpu_ctx.set_option("lanes_per_utterance", 0)
+    assert_bit_identical(out, out_len, ref, ref_len, f"per-formant smoothness L={lanes}")
