@@ -109,6 +109,7 @@ struct grail_ctx {
     std::vector<grail_voice> voices;  // host copy of the table
     DevVoice *d_voices = nullptr;
     float *d_voice_elems = nullptr;   // [n_voices * NUM_VOICED][49]
+    bool voices_upper_silent = false; // every voice: formants 5-8 have amplitude +0 in every phoneme
     uint32_t *d_truncated = nullptr;  // [0] truncation flag, [1] slow-path wave-steps
     uint64_t slow_steps = 0;          // of the kernels synced so far
     int lanes_option = 0;             // 0 = auto
@@ -223,6 +224,15 @@ int install_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices)
     HIP_TRY(hipMemcpy(ctx->d_voice_elems, elems.data(), elems.size() * sizeof(float),
                       hipMemcpyHostToDevice));
     ctx->voices.assign(voices, voices + n_voices);
+    bool silent = true;
+    for (uint32_t v = 0; v < n_voices; ++v)
+        for (int p = 0; p < NUM_VOICED; ++p)
+            for (int i = NF / 2; i < NF; ++i) {
+                uint32_t bits;
+                std::memcpy(&bits, &voices[v].phonemes[p].formant_amp[i], sizeof bits);
+                silent = silent && bits == 0u;
+            }
+    ctx->voices_upper_silent = silent;
     return GRAIL_OK;
 }
 
@@ -501,6 +511,7 @@ int grail_batch_synthesize_async(grail_ctx *ctx, const grail_batch *batch, float
     a.n_voices = (uint32_t)ctx->voices.size();
     a.phoneme_mode = batch->phoneme_mode ? 1u : 0u;
     a.skip_silent = ctx->skip_silent_option ? 1u : 0u;
+    a.half_capable = (a.skip_silent && batch->phoneme_mode && ctx->voices_upper_silent) ? 1u : 0u;
     const int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(batch->n_utt);
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
     hipError_t e = launch_synth(a, L, ctx->variant_option, ctx->stream);
@@ -560,6 +571,7 @@ int grail_stream_next_async(grail_ctx *ctx, grail_stream *stream, uint32_t max_s
     a.n_voices = (uint32_t)ctx->voices.size();
     a.phoneme_mode = batch->phoneme_mode ? 1u : 0u;
     a.skip_silent = ctx->skip_silent_option ? 1u : 0u;
+    a.half_capable = (a.skip_silent && batch->phoneme_mode && ctx->voices_upper_silent) ? 1u : 0u;
     a.state = stream->d_state;
     a.state_stride = stream->lanes;
     a.resume = stream->started ? 1u : 0u;

@@ -241,7 +241,10 @@ __device__ __forceinline__ void fetch_seg(Seg &s, const DevSeg *__restrict__ seg
 // SU = true (quiet step only): the blended smoothness is the same number for all of the lane's
 // formants (bit-equal table entries), so 1 - exp_approx(smooth) was evaluated once, as a scalar,
 // by the caller (`oml_s`): the same operations on the same operands give the same bits.
-template <bool SAFE, int NV, int NLIVE, bool SU, typename V>
+// KEEP_LP = false (one-shot kernels, NLIVE < NV): the silent formants can never become audible in
+// this launch (their amplitude is 0 in every phoneme of the voice table), so even their low-pass
+// state is dead and is not advanced.  Resumable streams keep it (KEEP_LP = true).
+template <bool SAFE, int NV, int NLIVE, bool SU, bool KEEP_LP, typename V>
 __device__ __forceinline__ void formant_filters(const float saw, const float noise, const float oml_s,
                                                 const V (&e_freq)[NV], const V (&e_bw)[NV],
                                                 const V (&e_smooth)[NV], const V (&e_breath)[NV],
@@ -302,15 +305,18 @@ __device__ __forceinline__ void formant_filters(const float saw, const float noi
         FOR_L y[k] = vrcp(d3[k]);
         FOR_L e[k] = vfma(-d3[k], y[k], one);
         FOR_L a1[k] = vfma(e[k], y[k], y[k]);
+        constexpr int NLP = (NLIVE < NV && !KEEP_LP) ? NLIVE : NV;   // low-pass states to advance
+#define FOR_P _Pragma("unroll") for (int k = 0; k < NLP; ++k)
         V nw[NV];
-        FOR_K nw[k] = saw * (1.0f - e_breath[k]) + noise * e_breath[k];                   // :531
+        FOR_P nw[k] = saw * (1.0f - e_breath[k]) + noise * e_breath[k];                   // :531
         if constexpr (SU) {
-            FOR_K st_a[k] = st_a[k] + oml_s * (nw[k] - st_a[k]);                          // :535-538
+            FOR_P st_a[k] = st_a[k] + oml_s * (nw[k] - st_a[k]);                          // :535-538
         } else {
             V lp[NV];
-            FOR_K lp[k] = exp_approx(e_smooth[k]);                                        // :535
-            FOR_K st_a[k] = st_a[k] + (1.0f - lp[k]) * (nw[k] - st_a[k]);                 // :538
+            FOR_P lp[k] = exp_approx(e_smooth[k]);                                        // :535
+            FOR_P st_a[k] = st_a[k] + (1.0f - lp[k]) * (nw[k] - st_a[k]);                 // :538
         }
+#undef FOR_P
         V tw[NLIVE], v0[NLIVE], a2[NLIVE], a3[NLIVE], v3[NLIVE], w1[NLIVE], w2[NLIVE];
         // :544-545  1.0*(1-turb) + noise*turb; the multiply by 1.0 is exact and dropped
         FOR_L tw[k] = st_a[k] * ((1.0f - e_turb[k]) + noise * e_turb[k]);
@@ -433,7 +439,10 @@ struct StateIO {
     }
 };
 
-template <int L, int T, int WAVES, int MIN_WAVES_PER_SIMD, bool STREAM>
+// HALF: instantiate the quiet loops that skip a silent upper half of the lane's formants.  The
+// host only asks for it when the voice table can make use of it (or for resumable streams), so
+// batches whose formants are all audible run a kernel that does not carry those loops.
+template <int L, int T, int WAVES, int MIN_WAVES_PER_SIMD, bool STREAM, bool HALF>
 __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(const SynthArgs A)
 {
     constexpr int FPL = NF / L;          // formants per lane
@@ -549,11 +558,23 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     bool quiet_ok = false;
 
     bool finished = false;   // the chain has returned None (persistent); `done` also covers pauses
+    // one-shot phoneme batches: the lane's upper formants have amplitude +0 in every phoneme of
+    // the voice table, so nothing in this launch can ever make them audible
+    bool upper_never_live = false;
+    if constexpr (HALF && NV >= 2 && !STREAM) {
+        upper_never_live = phoneme_mode;
+#pragma unroll
+        for (int p = 0; p < NUM_VOICED; ++p)
+#pragma unroll
+            for (int i = (NV / 2) * W; i < NV * W; ++i)
+                upper_never_live = upper_never_live &&
+                    (__float_as_uint(elems[(size_t)(VO.elem_base + p) * ELEM_FLOATS + F_AMP + f0 + i]) == 0u);
+    }
     bool smooth_uniform = false; // this pair: X.smooth and Y.smooth are each one number for all formants
     bool upper_silent = false;   // this pair: the lane's upper NV/2 formant vectors are silent
     auto update_silent = [&]() __attribute__((always_inline)) {
-        if constexpr (NV >= 2)
-            upper_silent = A.skip_silent && pair_safe &&
+        if constexpr (HALF && NV >= 2)
+            upper_silent = A.skip_silent && pair_safe && (STREAM || upper_never_live) &&
                            upper_half_is_silent<NV, W>(X, Y, st_a, st_b, st_c, amp_scale);
         bool su = true;
         const uint32_t xs0 = __float_as_uint(vget(X.smooth[0], 0));
@@ -742,7 +763,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 
         // events are rare: this step always takes the IEEE-division body (same bits)
         V v1[NV];
-        formant_filters<false, NV, NV, false, V>(saw, noise, 0.0f, e_freq, e_bw, e_smooth, e_breath, e_turb, e_amp,
+        formant_filters<false, NV, NV, false, true, V>(saw, noise, 0.0f, e_freq, e_bw, e_smooth, e_breath, e_turb, e_amp,
                                       st_a, st_b, st_c, v1);
         if (!pair_safe) ++slow_steps;
 
@@ -769,6 +790,8 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                           const float jphase_next) __attribute__((always_inline)) {
         constexpr int NLIVE = decltype(nlive_tag)::value;   // vectors whose band-pass runs
         constexpr bool SU = decltype(su_tag)::value;        // one smoothness for every formant
+        constexpr bool KEEP_LP = STREAM;                    // silent formants keep their low-pass
+        constexpr int NLP = (NLIVE < NV && !KEEP_LP) ? NLIVE : NV;
         if (done) return;                                                  // finished lanes sit out
         clk = clk_next;                                                    // :861
         float alpha = __builtin_fminf(clk * inv_blend_length, 1.0f);       // :899/:908/:917
@@ -778,17 +801,21 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         V e_freq[NV], e_bw[NV], e_smooth[NV], e_breath[NV], e_turb[NV], e_amp[NV];
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            if (!SU) e_smooth[k] = X.smooth[k] * oma + Y.smooth[k] * alpha;
-            e_breath[k] = X.breath[k] * oma + Y.breath[k] * alpha;
+            if (k < NLP) {
+                e_breath[k] = X.breath[k] * oma + Y.breath[k] * alpha;
+                e_smooth[k] = SU ? e_breath[k] : X.smooth[k] * oma + Y.smooth[k] * alpha;
+            } else {
+                e_breath[k] = vsplat(0.0f, e_breath[k]);   // unused
+                e_smooth[k] = e_breath[k];
+            }
             if (k < NLIVE) {
                 e_freq[k] = X.freq[k] * oma + Y.freq[k] * alpha;
                 e_bw[k] = X.bw[k] * oma + Y.bw[k] * alpha;
                 e_turb[k] = X.turb[k] * oma + Y.turb[k] * alpha;
                 e_amp[k] = X.amp[k] * oma + Y.amp[k] * alpha;
-            } else {   // silent vectors: only the low-pass inputs are needed
+            } else {   // silent vectors: no band-pass
                 e_freq[k] = e_breath[k]; e_bw[k] = e_breath[k]; e_turb[k] = e_breath[k]; e_amp[k] = e_breath[k];
             }
-            if (SU) e_smooth[k] = e_breath[k];   // unused
         }
         float oml_s = 0.0f;
         if constexpr (SU) {   // :404-414, :535 once for all formants (same operands, same bits)
@@ -819,16 +846,18 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         phase = (phase >= 1.0f) ? phase - 1.0f : phase;                    // :523-525
         const float noise = lcg_f32(noise_seed);                           // :528
         V v1[NV];
-        formant_filters<true, NV, NLIVE, SU, V>(saw, noise, oml_s, e_freq, e_bw, e_smooth, e_breath, e_turb,
+        formant_filters<true, NV, NLIVE, SU, KEEP_LP, V>(saw, noise, oml_s, e_freq, e_bw, e_smooth, e_breath, e_turb,
                                             e_amp, st_a, st_b, st_c, v1);
         float acc = 0.0f;
 #pragma unroll
         for (int step = 0; step < L; ++step) {
             float run = (step == 0) ? 0.0f : dpp_from_lane_below(acc);
 #pragma unroll
-            for (int k = 0; k < NV; ++k)
+            for (int k = 0; k < NLIVE; ++k)
 #pragma unroll
                 for (int c = 0; c < W; ++c) run = run + vget(v1[k], c);
+            // the silent formants' terms are literal +0.0: ((x + 0) + 0) + ... == x + 0
+            if (NLIVE < NV) run = run + 0.0f;
             acc = (j == step) ? run : acc;
         }
         if (j == L - 1) stage[t * SP + slot] = acc * 0.5f;
@@ -853,14 +882,18 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 }
             };
             const bool all_su = __builtin_amdgcn_ballot_w64(!done & !smooth_uniform) == 0;
-            bool half = false;
-            if constexpr (NV >= 2) half = __builtin_amdgcn_ballot_w64(!done & !upper_silent) == 0;
             typedef std::integral_constant<int, NV> FullTag;
-            typedef std::integral_constant<int, (NV >= 2 ? NV / 2 : NV)> HalfTag;
-            if (half && all_su) quiet_run(HalfTag(), std::true_type());
-            else if (half) quiet_run(HalfTag(), std::false_type());
-            else if (all_su) quiet_run(FullTag(), std::true_type());
-            else quiet_run(FullTag(), std::false_type());
+            bool half = false;
+            if constexpr (HALF && NV >= 2) {
+                typedef std::integral_constant<int, NV / 2> HalfTag;
+                half = __builtin_amdgcn_ballot_w64(!done & !upper_silent) == 0;
+                if (half && all_su) quiet_run(HalfTag(), std::true_type());
+                else if (half) quiet_run(HalfTag(), std::false_type());
+            }
+            if (!half) {
+                if (all_su) quiet_run(FullTag(), std::true_type());
+                else quiet_run(FullTag(), std::false_type());
+            }
             if (t < T) {
                 general_step(t);
                 quiet_ok = pair_safe && blend_pow2;
@@ -993,9 +1026,11 @@ static void launch_one(const SynthArgs &args, hipStream_t stream)
     const uint32_t per_block = (64u / L) * WAVES;
     const dim3 grid((args.n_utt + per_block - 1) / per_block), block(64 * WAVES);
     if (args.state)
-        hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, true>), grid, block, 0, stream, args);
+        hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, true, true>), grid, block, 0, stream, args);
+    else if (L == 1 && args.half_capable)
+        hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, false, true>), grid, block, 0, stream, args);
     else
-        hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, false>), grid, block, 0, stream, args);
+        hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, false, false>), grid, block, 0, stream, args);
 }
 
 hipError_t launch_synth(const SynthArgs &args, int L, int variant, hipStream_t stream)

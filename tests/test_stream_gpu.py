@@ -77,3 +77,40 @@ def test_stream_edge_cases_and_ragged_ends(gpu_ctx, lanes):
     for u in range(n_utt):
         assert len(got[u]) == full_len[u], (u, len(got[u]), full_len[u])
         assert np.array_equal(got[u].view(np.uint32), full[u, :full_len[u]].view(np.uint32)), u
+
+
+def test_stream_silent_formants_wake_up(gpu_ctx):
+    """The resumable kernel keeps the silent formants' low-pass state and may skip only their
+    band-pass: utterances whose upper formants fall silent and wake up again, streamed in
+    chunks, against the one-shot rendering and the oracle."""
+    import oracle_lib as O
+    from test_parity_gpu import _elem
+    rng = np.random.default_rng(21)
+    lo, all8 = [1, 1, 1, 1, 0, 0, 0, 0], [1] * 8
+    plans = [[lo, lo, lo], [lo, all8, lo], [all8, lo, lo], [lo, lo, all8, lo], [lo, None, lo, all8]]
+    gsegs, osegs, offs = [], [], [0]
+    for plan in plans * 4:
+        for mask in plan:
+            has = mask is not None
+            e = _elem(rng, mask if has else all8)
+            ln = float(rng.uniform(0.004, 0.012))
+            gsegs.append(G.SequenceElem(int(has), G.SynthesisElem.from_np(e), ln, 0.0078125))
+            osegs.append(O.SequenceElem(int(has), O.SynthesisElem.from_buffer_copy(e.tobytes()), ln, 0.0078125))
+        offs.append(len(gsegs))
+    n = len(offs) - 1
+    seeds = np.arange(n, dtype=np.uint32) * 17 + 3
+    v = G.voice_generic(48000.0)
+    gpu_ctx.set_voices([v])
+    ov = O.Voice.from_buffer_copy(bytes(v))
+    for lanes in (1, 2):
+        gpu_ctx.set_option("lanes_per_utterance", lanes)
+        b = gpu_ctx.upload_elems(gsegs, offs, None, seeds)
+        try:
+            got = stream_all(gpu_ctx, b, n, [257, 64, 1000], stride=1024)
+        finally:
+            b.free()
+            gpu_ctx.set_option("lanes_per_utterance", 0)
+        for u in range(n):
+            ref = O.synthesize_sequence(ov, osegs[offs[u]:offs[u + 1]], int(seeds[u]))
+            assert len(got[u]) == len(ref), (lanes, u)
+            assert np.array_equal(got[u].view(np.uint32), ref.view(np.uint32)), (lanes, u)
