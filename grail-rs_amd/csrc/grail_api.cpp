@@ -512,7 +512,11 @@ int grail_batch_synthesize_async(grail_ctx *ctx, const grail_batch *batch, float
     a.phoneme_mode = batch->phoneme_mode ? 1u : 0u;
     a.skip_silent = ctx->skip_silent_option ? 1u : 0u;
     a.half_capable = (a.skip_silent && batch->phoneme_mode && ctx->voices_upper_silent) ? 1u : 0u;
-    const int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(batch->n_utt);
+    int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(batch->n_utt);
+    // voices whose upper formants are never audible: one lane per utterance runs the half-live loop
+    // (54 ms per 2 s alone on a SIMD) and beats two lanes per utterance (57 ms), whose second lane
+    // would only hold silent formants
+    if (!ctx->lanes_option && L == 2 && a.half_capable) L = 1;
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
     hipError_t e = launch_synth(a, L, ctx->variant_option, ctx->stream);
     if (e != hipSuccess) return hip_fail(e, "synth kernel launch");
