@@ -52,6 +52,16 @@ def cpu_baseline(n_cpu, voices, W):
     }
 
 
+def committed_literal_ms():
+    """Kernel ms of the same batch with skip_silent_formants=0, from the committed run of
+    `bench.py --literal` (profiles/r01_bench_n1_literal.json); `--literal` measures it live."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_bench_n1_literal.json")) as f:
+            return json.load(f)["config"]["kernel_ms_all_formants_literal"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def committed_traffic(workload_key):
     """HBM bytes per launch measured with rocprofv3 --pmc (separate WRITE_SIZE / FETCH_SIZE
     passes, gfx950 corrections applied) for the same command; see profiles/README.md."""
@@ -224,9 +234,11 @@ def main():
                                        "state contribute exactly +0.0 and their filters are skipped "
                                        "(voices::generic() has 4 of 8 such formants; config 4's "
                                        "presets have none); output bits unchanged",
-                "kernel_ms_all_formants_literal": literal_ms,
+                "kernel_ms_all_formants_literal": literal_ms if literal_ms else committed_literal_ms(),
                 "samples_per_s_all_formants_literal":
                     (samples_per_step / (literal_ms * 1e-3)) if literal_ms else None,
+                "literal_source": "measured in this run" if literal_ms else
+                                  "profiles/r01_bench_n1_literal.json (run bench.py --literal to re-measure)",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
