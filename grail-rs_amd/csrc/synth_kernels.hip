@@ -455,7 +455,11 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 
     // every wave of the block works alone on its own S utterances and its own
     // slice of LDS: there is no inter-wave communication and no block barrier
-    __shared__ float stage_all[WAVES][T * SP];
+    // L >= 4: the lanes park all eight band-pass outputs of a sample and the left fold runs at
+    // flush time, spread over time steps, instead of a serial chain of L DPP hops per sample
+    constexpr bool FOLD_IN_FLUSH = L >= 4;
+    constexpr int STAGE_FLOATS = FOLD_IN_FLUSH ? T * S * NF : T * SP;
+    __shared__ float stage_all[WAVES][STAGE_FLOATS];
     __shared__ uint32_t cnt_all[WAVES][S];
     const int wave = threadIdx.x / 64;
     float *stage = stage_all[wave];
@@ -769,17 +773,25 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 
         // v1.sum() * 0.5: a left fold from 0.0 over formants 0..7  :574, :123-125,
         // carried down the utterance's L lanes.
-        float acc = 0.0f;
-#pragma unroll
-        for (int step = 0; step < L; ++step) {
-            float run = (step == 0) ? 0.0f : dpp_from_lane_below(acc);
+        if constexpr (FOLD_IN_FLUSH) {
 #pragma unroll
             for (int k = 0; k < NV; ++k)
 #pragma unroll
-                for (int c = 0; c < W; ++c) run = run + vget(v1[k], c);
-            acc = (j == step) ? run : acc;
+                for (int c = 0; c < W; ++c)
+                    stage[(t * S + slot) * NF + f0 + k * W + c] = vget(v1[k], c);
+        } else {
+            float acc = 0.0f;
+#pragma unroll
+            for (int step = 0; step < L; ++step) {
+                float run = (step == 0) ? 0.0f : dpp_from_lane_below(acc);
+#pragma unroll
+                for (int k = 0; k < NV; ++k)
+#pragma unroll
+                    for (int c = 0; c < W; ++c) run = run + vget(v1[k], c);
+                acc = (j == step) ? run : acc;
+            }
+            if (j == L - 1) stage[t * SP + slot] = acc * 0.5f;
         }
-        if (j == L - 1) stage[t * SP + slot] = acc * 0.5f;
         ++n_out;
     };
 
@@ -848,19 +860,27 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         V v1[NV];
         formant_filters<true, NV, NLIVE, SU, KEEP_LP, V>(saw, noise, oml_s, e_freq, e_bw, e_smooth, e_breath, e_turb,
                                             e_amp, st_a, st_b, st_c, v1);
-        float acc = 0.0f;
+        if constexpr (FOLD_IN_FLUSH) {
 #pragma unroll
-        for (int step = 0; step < L; ++step) {
-            float run = (step == 0) ? 0.0f : dpp_from_lane_below(acc);
+            for (int k = 0; k < NV; ++k)
 #pragma unroll
-            for (int k = 0; k < NLIVE; ++k)
+                for (int c = 0; c < W; ++c)
+                    stage[(t * S + slot) * NF + f0 + k * W + c] = vget(v1[k], c);   // silent: +0
+        } else {
+            float acc = 0.0f;
 #pragma unroll
-                for (int c = 0; c < W; ++c) run = run + vget(v1[k], c);
-            // the silent formants' terms are literal +0.0: ((x + 0) + 0) + ... == x + 0
-            if (NLIVE < NV) run = run + 0.0f;
-            acc = (j == step) ? run : acc;
+            for (int step = 0; step < L; ++step) {
+                float run = (step == 0) ? 0.0f : dpp_from_lane_below(acc);
+#pragma unroll
+                for (int k = 0; k < NLIVE; ++k)
+#pragma unroll
+                    for (int c = 0; c < W; ++c) run = run + vget(v1[k], c);
+                // the silent formants' terms are literal +0.0: ((x + 0) + 0) + ... == x + 0
+                if (NLIVE < NV) run = run + 0.0f;
+                acc = (j == step) ? run : acc;
+            }
+            if (j == L - 1) stage[t * SP + slot] = acc * 0.5f;
         }
-        if (j == L - 1) stage[t * SP + slot] = acc * 0.5f;
         ++n_out;
     };
 
@@ -916,10 +936,22 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             const int t0 = rl * 4;
             if ((uint32_t)t0 < c) {
                 float *dst = A.out + (uint64_t)(u0 + r) * A.out_stride + base + t0;
-                const float s0 = stage[(t0 + 0) * SP + r];
-                const float s1 = stage[(t0 + 1) * SP + r];
-                const float s2 = stage[(t0 + 2) * SP + r];
-                const float s3 = stage[(t0 + 3) * SP + r];
+                auto sample_at = [&](const int tt) __attribute__((always_inline)) -> float {
+                    if constexpr (FOLD_IN_FLUSH) {
+                        // v1.sum() * 0.5: the left fold from 0.0 over formants 0..7  :574, :123-125
+                        const float *p = stage + (tt * S + r) * NF;
+                        float run = 0.0f;
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) run = run + p[f];
+                        return run * 0.5f;
+                    } else {
+                        return stage[tt * SP + r];
+                    }
+                };
+                const float s0 = sample_at(t0 + 0);
+                const float s1 = sample_at(t0 + 1);
+                const float s2 = sample_at(t0 + 2);
+                const float s3 = sample_at(t0 + 3);
                 if (vec_ok && (uint32_t)(t0 + 4) <= c) {
                     *reinterpret_cast<float4 *>(dst) = make_float4(s0, s1, s2, s3);
                 } else {
@@ -1051,8 +1083,8 @@ hipError_t launch_synth(const SynthArgs &args, int L, int variant, hipStream_t s
     switch (L) {
     case 1: launch_one<1, 32, 1, 1>(args, stream); break;
     case 2: launch_one<2, 64, 1, 2>(args, stream); break;
-    case 4: launch_one<4, 64, 4, 3>(args, stream); break;
-    case 8: launch_one<8, 64, 4, 4>(args, stream); break;
+    case 4: launch_one<4, 32, 4, 2>(args, stream); break;
+    case 8: launch_one<8, 64, 4, 2>(args, stream); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
