@@ -52,6 +52,31 @@ def cpu_baseline(n_cpu, voices, W):
     }
 
 
+def cpu_all_cores(voices, W):
+    """Same oracle, utterances fanned out over every host core this process may use (pthreads,
+    one utterance per work item).  Reported beside cpu_baseline for scale only: the reference
+    has no threads, so the 1-thread figure is "the reference CPU path" (SURVEY.md §8d)."""
+    import oracle_lib as O
+    threads = len(os.sched_getaffinity(0))
+    n_cpu = min(8192, threads * 24)
+    ov = [O.Voice.from_buffer_copy(bytes(v)) for v in voices]
+    segs, offs, vids, seeds = W.make_batch(n_cpu, n_voices=len(voices))
+    stride = W.max_samples()
+    t0 = time.perf_counter()
+    _, out_len, started = O.synthesize_batch_threads(ov, segs, offs, vids, seeds, stride, threads)
+    dt = time.perf_counter() - t0
+    n = int(out_len.astype(np.uint64).sum())
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota = f.read().strip()          # "max 100000" or "<quota> <period>"
+    except OSError:
+        quota = "unknown"
+    return {"value": n / dt, "unit": "samples/s", "cores": started, "kind": "port",
+            "sample": f"first {n_cpu} utterances ({n} samples) in {dt:.2f} s wall on {started} "
+                      f"pthreads (logical cores, SMT included; cgroup cpu.max = '{quota}', so the "
+                      f"container may be granted fewer cores than it sees)"}
+
+
 def committed_literal_ms():
     """Kernel ms of the same batch with skip_silent_formants=0, from the committed run of
     `bench.py --literal` (profiles/r01_bench_n1_literal.json); `--literal` measures it live."""
@@ -98,6 +123,9 @@ def main():
     ap.add_argument("--voices", type=int, default=1, help="1 = single Voice, 8 = config-4 presets")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per utterance (0 = auto)")
     ap.add_argument("--variant", type=int, default=0, help="kernel instantiation (experiments)")
+    ap.add_argument("--pcm16", action="store_true",
+                    help="i16 PCM rows (the WAV sink's conversion fused into the store), not the "
+                         "headline: 2.01 algorithmic bytes per sample")
     ap.add_argument("--literal", action="store_true",
                     help="after the timed region, also time the batch with skip_silent_formants=0")
     ap.add_argument("--force-dist", action="store_true",
@@ -166,11 +194,14 @@ def main():
     batch = ctx.upload(segs, offs, vids, seeds)
     ctx.set_option("lanes_per_utterance", args.lanes)
     ctx.set_option("kernel_variant", args.variant)
-    d_out = ctx.device_alloc(n_utt * stride * 4)
+    d_out = ctx.device_alloc(n_utt * stride * (2 if args.pcm16 else 4))
     d_len = ctx.device_alloc(n_utt * 4)
 
     def step():
-        batch.synthesize_async(d_out, stride, d_len)
+        if args.pcm16:
+            batch.synthesize_pcm16_async(d_out, stride, d_len)
+        else:
+            batch.synthesize_async(d_out, stride, d_len)
         ctx.sync()
         return ctx.last_kernel_ms()   # hipEvents on the kernel's own stream
 
@@ -212,10 +243,10 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         value = total_samples_per_step * args.steps / elapsed
         k_ms = float(np.mean(kernel_ms))
-        alg_bytes = samples_per_step * ALG_BYTES_PER_SAMPLE
+        alg_bytes = samples_per_step * (ALG_BYTES_PER_SAMPLE - (2.0 if args.pcm16 else 0.0))
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         cfg = "3" if len(voices) == 1 else "4"
-        wl_key = f"config{cfg}_utts{n_utt}"
+        wl_key = f"config{cfg}_utts{n_utt}" + ("_pcm16" if args.pcm16 else "")
         line = {
             "metric": "audio samples/sec (whole node) at 48 kHz, batch=65536 utterances",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
@@ -223,7 +254,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"batch={n_utt} utterances x 2 s (4 segments x 0.5 s) per GPU, "
-                            f"{len(voices)} Voice preset(s), 48 kHz, f32 PCM left in HBM "
+                            f"{len(voices)} Voice preset(s), 48 kHz, {'i16' if args.pcm16 else 'f32'} PCM left in HBM "
                             f"(BASELINE config {cfg}{'; config 5 sharding' if world > 1 else ''})",
                 "utterances_per_gpu": n_utt, "samples_per_utterance": int(out_len[0]),
                 "samples_per_step_per_gpu": samples_per_step, "out_stride": stride,
@@ -253,6 +284,7 @@ def main():
         if world == 1 and args.cpu_utts > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_utts, voices, W)
             line["speedup_vs_cpu_1thread"] = value / line["cpu_baseline"]["value"]
+            line["cpu_all_cores"] = cpu_all_cores(voices, W)
         print(json.dumps(line), flush=True)
 
     ctx.device_free(d_out)

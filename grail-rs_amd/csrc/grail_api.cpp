@@ -487,15 +487,16 @@ int grail_batch_lengths(grail_ctx *ctx, const grail_batch *batch, uint32_t max_l
     return GRAIL_OK;
 }
 
-int grail_batch_synthesize_async(grail_ctx *ctx, const grail_batch *batch, float *out_dev,
-                                 uint64_t out_stride, uint32_t *out_len_dev)
+static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_dev,
+                           int16_t *out_pcm16_dev, uint64_t out_stride, uint32_t *out_len_dev)
 {
     int rc = bind(ctx);
     if (rc) return rc;
     if ((rc = check_ready(ctx, batch))) return rc;
     if (batch->n_utt == 0) return GRAIL_OK;
-    if (!out_dev && out_stride) return fail(GRAIL_ERR_INVALID_ARG, "out_dev is NULL");
+    if (!out_dev && !out_pcm16_dev && out_stride) return fail(GRAIL_ERR_INVALID_ARG, "out_dev is NULL");
     SynthArgs a{};
+    a.out_pcm16 = out_pcm16_dev;
     a.segs = batch->d_segs;
     a.seg_offsets = batch->d_offsets;
     a.voice_ids = batch->d_voice_ids;
@@ -523,6 +524,18 @@ int grail_batch_synthesize_async(grail_ctx *ctx, const grail_batch *batch, float
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->have_timing = true;
     return GRAIL_OK;
+}
+
+int grail_batch_synthesize_async(grail_ctx *ctx, const grail_batch *batch, float *out_dev,
+                                 uint64_t out_stride, uint32_t *out_len_dev)
+{
+    return synthesize_rows(ctx, batch, out_dev, nullptr, out_stride, out_len_dev);
+}
+
+int grail_batch_synthesize_pcm16_async(grail_ctx *ctx, const grail_batch *batch, int16_t *out_dev,
+                                       uint64_t out_stride, uint32_t *out_len_dev)
+{
+    return synthesize_rows(ctx, batch, nullptr, out_dev, out_stride, out_len_dev);
 }
 
 int grail_stream_open(grail_ctx *ctx, const grail_batch *batch, grail_stream **out)
@@ -742,15 +755,13 @@ int grail_synthesize_batch_pcm16(grail_ctx *ctx, const grail_phoneme_elem *segs,
     grail_batch *b = nullptr;
     int rc = grail_batch_upload(ctx, segs, seg_offsets, voice_ids, jitter_seeds, n_utt, &b);
     if (rc) return rc;
-    float *d_f32 = nullptr;
     int16_t *d_i16 = nullptr;
     uint32_t *d_len = nullptr;
     const bool dev_out = (flags & GRAIL_OUT_DEVICE) != 0;
     const size_t n_elems = (size_t)n_utt * out_stride;
     int sync_rc = GRAIL_OK;
     hipError_t e = hipSuccess;
-    if (n_elems) e = hipMalloc((void **)&d_f32, n_elems * sizeof(float));
-    if (e == hipSuccess && n_utt) e = hipMalloc((void **)&d_len, (size_t)n_utt * sizeof(uint32_t));
+    if (n_utt) e = hipMalloc((void **)&d_len, (size_t)n_utt * sizeof(uint32_t));
     if (e == hipSuccess) {
         if (dev_out) d_i16 = out;
         else if (n_elems) {
@@ -759,11 +770,8 @@ int grail_synthesize_batch_pcm16(grail_ctx *ctx, const grail_phoneme_elem *segs,
         }
     }
     if (e != hipSuccess) rc = hip_fail(e, "pcm16 output allocation");
-    if (!rc) rc = grail_batch_synthesize_async(ctx, b, d_f32, out_stride, d_len);
-    // the conversion runs behind the synthesis on the same stream; 6 B per sample of HBM traffic
-    if (!rc && n_utt)
-        rc = grail_pcm16_async(ctx, d_f32, out_stride, d_len, n_utt, (uint32_t)(out_stride > 0xFFFFFFFFull ? 0xFFFFFFFFu : out_stride),
-                               d_i16, out_stride);
+    // the conversion is part of the synthesis kernel's tile flush: 2 B per sample of HBM traffic
+    if (!rc) rc = grail_batch_synthesize_pcm16_async(ctx, b, d_i16, out_stride, d_len);
     if (!rc) {
         sync_rc = grail_sync(ctx);
         if (sync_rc != GRAIL_OK && sync_rc != GRAIL_ERR_BUFFER_TOO_SMALL) rc = sync_rc;
@@ -777,7 +785,6 @@ int grail_synthesize_batch_pcm16(grail_ctx *ctx, const grail_phoneme_elem *segs,
         if (e != hipSuccess) rc = hip_fail(e, "pcm16 output copy");
     }
     const std::string keep = g_last_error;
-    if (d_f32) (void)hipFree(d_f32);
     if (d_len) (void)hipFree(d_len);
     if (!dev_out && d_i16) (void)hipFree(d_i16);
     grail_batch_free(ctx, b);

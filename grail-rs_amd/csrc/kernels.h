@@ -48,10 +48,12 @@ struct SynthArgs {
     const float *elems;           // phoneme mode: voice elem table; elem mode: batch elem table
     const DevVoice *voices;
     float *out;
+    int16_t *out_pcm16;           // not nullptr: rows of i16 PCM instead (examples/cli.rs:49 fused
+                                  // into the tile flush); `out` is then unused
     uint32_t *out_len;            // may be nullptr
     uint32_t *truncated;          // [0]: set to 1 when an utterance is cut at out_stride;
                                   // [1]: += wave-steps that ran the IEEE-division body
-    uint64_t out_stride;          // floats between rows
+    uint64_t out_stride;          // samples between rows
     uint64_t cap;                 // samples a row may receive in this launch (<= out_stride)
     uint32_t n_utt;
     uint32_t n_voices;

@@ -3,18 +3,11 @@
 // NaN -> 0).  Elementwise and HBM-bound: 6 B per sample (4 read + 2 written); each lane moves
 // 8 samples (two 16-B loads, one 16-B store) so every wave instruction is a full 1-KiB/512-B run.
 #include "kernels.h"
+#include "pcm16.h"
 
 namespace grail {
 
 namespace {
-
-__device__ __forceinline__ int pcm16(float x)
-{
-    // v_cvt_i32_f32 truncates toward zero, saturates and maps NaN to 0 — Rust's `as` for
-    // f32 -> integer — and the i16 range is then a clamp of that i32.
-    const int v = __float2int_rz(x * 32767.0f);
-    return v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
-}
 
 __global__ __launch_bounds__(256) void pcm16_kernel(const float *__restrict__ in, uint64_t in_stride,
                                                     const uint32_t *__restrict__ len,
@@ -34,13 +27,13 @@ __global__ __launch_bounds__(256) void pcm16_kernel(const float *__restrict__ in
         const float4 a = *reinterpret_cast<const float4 *>(src);
         const float4 b = *reinterpret_cast<const float4 *>(src + 4);
         uint4 o;
-        o.x = (uint32_t)(pcm16(a.x) & 0xFFFF) | ((uint32_t)pcm16(a.y) << 16);
-        o.y = (uint32_t)(pcm16(a.z) & 0xFFFF) | ((uint32_t)pcm16(a.w) << 16);
-        o.z = (uint32_t)(pcm16(b.x) & 0xFFFF) | ((uint32_t)pcm16(b.y) << 16);
-        o.w = (uint32_t)(pcm16(b.z) & 0xFFFF) | ((uint32_t)pcm16(b.w) << 16);
+        o.x = (uint32_t)(pcm16_from_f32(a.x) & 0xFFFF) | ((uint32_t)pcm16_from_f32(a.y) << 16);
+        o.y = (uint32_t)(pcm16_from_f32(a.z) & 0xFFFF) | ((uint32_t)pcm16_from_f32(a.w) << 16);
+        o.z = (uint32_t)(pcm16_from_f32(b.x) & 0xFFFF) | ((uint32_t)pcm16_from_f32(b.y) << 16);
+        o.w = (uint32_t)(pcm16_from_f32(b.z) & 0xFFFF) | ((uint32_t)pcm16_from_f32(b.w) << 16);
         *reinterpret_cast<uint4 *>(dst) = o;
     } else {
-        for (uint32_t i = 0; i < 8u && t0 + i < n; ++i) dst[i] = (int16_t)pcm16(src[i]);
+        for (uint32_t i = 0; i < 8u && t0 + i < n; ++i) dst[i] = (int16_t)pcm16_from_f32(src[i]);
     }
 }
 

@@ -33,6 +33,7 @@
 #include <type_traits>
 
 #include "kernels.h"
+#include "pcm16.h"
 
 namespace grail {
 
@@ -556,6 +557,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     uint32_t slow_steps = 0;                 // wave-steps that took the IEEE-division body
     bool truncated = false;
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(A.out) & 15u) == 0) && ((A.out_stride & 3u) == 0);
+    const bool vec16_ok = ((reinterpret_cast<uintptr_t>(A.out_pcm16) & 7u) == 0) && ((A.out_stride & 3u) == 0);
 
     // false while the lane's segment pair needs the IEEE-division body or has a blend
     // length that is not a power of two: such lanes always take the general step
@@ -935,7 +937,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             const uint32_t c = cnt[r];
             const int t0 = rl * 4;
             if ((uint32_t)t0 < c) {
-                float *dst = A.out + (uint64_t)(u0 + r) * A.out_stride + base + t0;
+                const uint64_t at = (uint64_t)(u0 + r) * A.out_stride + base + t0;
                 auto sample_at = [&](const int tt) __attribute__((always_inline)) -> float {
                     if constexpr (FOLD_IN_FLUSH) {
                         // v1.sum() * 0.5: the left fold from 0.0 over formants 0..7  :574, :123-125
@@ -952,6 +954,24 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 const float s1 = sample_at(t0 + 1);
                 const float s2 = sample_at(t0 + 2);
                 const float s3 = sample_at(t0 + 3);
+                if (A.out_pcm16) {
+                    // the WAV sink's `(x * i16::MAX as f32) as i16` (examples/cli.rs:49) on the way out
+                    int16_t *dst = A.out_pcm16 + at;
+                    const int p0 = pcm16_from_f32(s0), p1 = pcm16_from_f32(s1);
+                    const int p2 = pcm16_from_f32(s2), p3 = pcm16_from_f32(s3);
+                    if (vec16_ok && (uint32_t)(t0 + 4) <= c) {
+                        *reinterpret_cast<uint2 *>(dst) =
+                            make_uint2((uint32_t)(p0 & 0xFFFF) | ((uint32_t)p1 << 16),
+                                       (uint32_t)(p2 & 0xFFFF) | ((uint32_t)p3 << 16));
+                    } else {
+                        dst[0] = (int16_t)p0;
+                        if ((uint32_t)(t0 + 1) < c) dst[1] = (int16_t)p1;
+                        if ((uint32_t)(t0 + 2) < c) dst[2] = (int16_t)p2;
+                        if ((uint32_t)(t0 + 3) < c) dst[3] = (int16_t)p3;
+                    }
+                    continue;
+                }
+                float *dst = A.out + at;
                 if (vec_ok && (uint32_t)(t0 + 4) <= c) {
                     *reinterpret_cast<float4 *>(dst) = make_float4(s0, s1, s2, s3);
                 } else {

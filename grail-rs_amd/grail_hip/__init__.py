@@ -52,7 +52,7 @@ EXPORTS = [
     "grail_last_kernel_ms", "grail_synthesize_batch", "grail_synthesize_batch_elems",
     "grail_stream_open", "grail_stream_next_async", "grail_stream_close",
     "grail_language_generic", "grail_transcribe", "grail_intonate", "grail_text_to_phoneme_elems",
-    "grail_synthesize_batch_pcm16", "grail_say_batch", "grail_pcm16_async", "grail_batch_digest", "grail_wav_write_i16",
+    "grail_synthesize_batch_pcm16", "grail_batch_synthesize_pcm16_async", "grail_say_batch", "grail_pcm16_async", "grail_batch_digest", "grail_wav_write_i16",
     "grail_device_alloc", "grail_device_free", "grail_memcpy_d2h", "grail_memcpy_h2d",
     "grail_memset_d", "grail_shard_range", "grail_comm_unique_id", "grail_comm_init",
     "grail_broadcast_voices", "grail_comm_destroy",
@@ -202,6 +202,7 @@ def load():
     L.grail_pcm16_async.argtypes = [vp, vp, u64, vp, C.c_uint32, C.c_uint32, vp, u64]
     L.grail_synthesize_batch_pcm16.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, u64, vp,
                                                C.c_uint32]
+    L.grail_batch_synthesize_pcm16_async.argtypes = [vp, vp, vp, u64, vp]
     L.grail_batch_digest.argtypes = [vp, vp, u64, vp, C.c_uint32, vp, vp, vp]
     L.grail_wav_write_i16.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
     L.grail_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
@@ -367,6 +368,11 @@ class Batch:
     def synthesize_async(self, out_dev, out_stride, out_len_dev=None):
         _check(load().grail_batch_synthesize_async(self.ctx.handle, self.handle, out_dev,
                                                    out_stride, out_len_dev))
+
+    def synthesize_pcm16_async(self, out_dev, out_stride, out_len_dev=None):
+        """Rows of i16 PCM: the WAV sink's conversion fused into the kernel's store."""
+        _check(load().grail_batch_synthesize_pcm16_async(self.ctx.handle, self.handle, out_dev,
+                                                         out_stride, out_len_dev))
 
     def free(self):
         if self.handle:

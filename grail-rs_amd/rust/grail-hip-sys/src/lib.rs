@@ -146,6 +146,8 @@ extern "C" {
         out_len: *mut u32, flags: u32) -> c_int;
     pub fn grail_pcm16_async(ctx: *mut grail_ctx, in_dev: *const f32, in_stride: u64,
         len_dev: *const u32, n_utt: u32, max_len: u32, out_dev: *mut i16, out_stride: u64) -> c_int;
+    pub fn grail_batch_synthesize_pcm16_async(ctx: *mut grail_ctx, b: *const grail_batch,
+        out_dev: *mut i16, out_stride: u64, out_len_dev: *mut u32) -> c_int;
     pub fn grail_synthesize_batch_pcm16(ctx: *mut grail_ctx, segs: *const grail_phoneme_elem,
         seg_offsets: *const u32, voice_ids: *const u32, jitter_seeds: *const u32, n_utt: u32,
         out: *mut i16, out_stride: u64, out_len: *mut u32, flags: u32) -> c_int;

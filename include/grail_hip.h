@@ -271,8 +271,14 @@ int grail_say_batch(grail_ctx *ctx, const char *const *texts_utf8, uint32_t n_te
 int grail_pcm16_async(grail_ctx *ctx, const float *in_dev, uint64_t in_stride,
                       const uint32_t *len_dev, uint32_t n_utt, uint32_t max_len,
                       int16_t *out_dev, uint64_t out_stride);
-/* grail_synthesize_batch() followed by the examples/cli.rs:49 conversion on the device: rows of
- * i16 PCM (half the PCIe bytes of the f32 form).  Same flags and row semantics. */
+/* grail_batch_synthesize_async() with the examples/cli.rs:49 conversion fused into the kernel's
+ * store: rows of i16 PCM in device memory, out_stride in samples; 2 B instead of 4 B of HBM
+ * written per sample and no f32 copy anywhere.  out_dev 8-byte aligned and out_stride % 4 == 0
+ * give vector stores. */
+int grail_batch_synthesize_pcm16_async(grail_ctx *ctx, const grail_batch *batch, int16_t *out_dev,
+                                       uint64_t out_stride, uint32_t *out_len_dev);
+/* grail_synthesize_batch() with the conversion fused the same way: rows of i16 PCM (half the
+ * PCIe bytes of the f32 form).  Same flags and row semantics. */
 int grail_synthesize_batch_pcm16(grail_ctx *ctx, const grail_phoneme_elem *segs,
                                  const uint32_t *seg_offsets, const uint32_t *voice_ids,
                                  const uint32_t *jitter_seeds, uint32_t n_utt, int16_t *out,

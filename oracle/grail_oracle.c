@@ -10,6 +10,7 @@
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fexcess-precision=standard
  * (rustc never contracts a*b+c to an FMA and never reassociates).
  */
+#include <pthread.h>
 #include "grail_oracle.h"
 
 #include <math.h>
@@ -602,6 +603,48 @@ void orc_synthesize_batch(const orc_voice *voices, uint32_t n_voices,
                                              out ? out_stride : 0);
         if (out_len) out_len[u] = (uint32_t)n;
     }
+}
+
+/* The reference has no threads anywhere in src/; this only exists so the bench can also report
+ * "every host core, one utterance per work item" next to the single-thread baseline. */
+typedef struct {
+    const orc_voice *voices; uint32_t n_voices;
+    const orc_phoneme_elem *segs; const uint32_t *seg_offsets, *voice_ids, *jitter_seeds;
+    uint32_t n_utt; float *out; uint64_t out_stride; uint32_t *out_len;
+    uint32_t next;                       /* work counter, __atomic */
+} batch_job;
+
+static void *batch_worker(void *p)
+{
+    batch_job *j = (batch_job *)p;
+    for (;;) {
+        uint32_t u = __atomic_fetch_add(&j->next, 1u, __ATOMIC_RELAXED);
+        if (u >= j->n_utt) return NULL;
+        orc_synthesize_batch(j->voices, j->n_voices, j->segs, j->seg_offsets + u,
+                             j->voice_ids ? j->voice_ids + u : NULL,
+                             j->jitter_seeds ? j->jitter_seeds + u : NULL, 1,
+                             j->out ? j->out + (uint64_t)u * j->out_stride : NULL, j->out_stride,
+                             j->out_len ? j->out_len + u : NULL);
+    }
+}
+
+int orc_synthesize_batch_threads(const orc_voice *voices, uint32_t n_voices,
+                                 const orc_phoneme_elem *segs, const uint32_t *seg_offsets,
+                                 const uint32_t *voice_ids, const uint32_t *jitter_seeds,
+                                 uint32_t n_utt, float *out, uint64_t out_stride,
+                                 uint32_t *out_len, uint32_t n_threads)
+{
+    batch_job j = { voices, n_voices, segs, seg_offsets, voice_ids, jitter_seeds,
+                    n_utt, out, out_stride, out_len, 0 };
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 1024) n_threads = 1024;
+    pthread_t tid[1024];
+    uint32_t started = 0;
+    for (; started < n_threads; ++started)
+        if (pthread_create(&tid[started], NULL, batch_worker, &j) != 0) break;
+    if (started == 0) batch_worker(&j);
+    for (uint32_t i = 0; i < started; ++i) pthread_join(tid[i], NULL);
+    return (int)started;
 }
 
 /* ------------------------------------------------------------------------ */

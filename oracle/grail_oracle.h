@@ -146,6 +146,12 @@ void orc_synthesize_batch(const orc_voice *voices, uint32_t n_voices,
                           const uint32_t *voice_ids, const uint32_t *jitter_seeds,
                           uint32_t n_utt, float *out, uint64_t out_stride,
                           uint32_t *out_len);
+/* Same, utterances handed out to n_threads pthreads (bench baseline only; returns threads started). */
+int orc_synthesize_batch_threads(const orc_voice *voices, uint32_t n_voices,
+                                 const orc_phoneme_elem *segs, const uint32_t *seg_offsets,
+                                 const uint32_t *voice_ids, const uint32_t *jitter_seeds,
+                                 uint32_t n_utt, float *out, uint64_t out_stride,
+                                 uint32_t *out_len, uint32_t n_threads);
 
 /* ---- text front half --------------------------------- */
 /* Transcriber::next loop, src/lib.rs:1116-1191.  leading_silence != 0 seeds

@@ -214,6 +214,30 @@ def synthesize_batch(voices, segs, seg_offsets, voice_ids, jitter_seeds, out_str
     return out, out_len
 
 
+def synthesize_batch_threads(voices, segs, seg_offsets, voice_ids, jitter_seeds, out_stride,
+                             n_threads, keep_output=True):
+    """synthesize_batch over n_threads pthreads (bench baseline).  keep_output=False only counts
+    (no PCM buffer), keep_output=True returns (out, out_len)."""
+    L = lib()
+    varr = voices_array(voices)
+    segs = np.ascontiguousarray(segs, dtype=PHONEME_DTYPE)
+    seg_offsets = np.ascontiguousarray(seg_offsets, dtype=np.uint32)
+    n_utt = len(seg_offsets) - 1
+    voice_ids = np.ascontiguousarray(_zeros_if_none(voice_ids, n_utt), dtype=np.uint32)
+    jitter_seeds = np.ascontiguousarray(_zeros_if_none(jitter_seeds, n_utt), dtype=np.uint32)
+    out = np.zeros((n_utt, out_stride), dtype=np.float32) if keep_output else None
+    out_len = np.zeros(n_utt, dtype=np.uint32)
+    L.orc_synthesize_batch_threads.restype = C.c_int
+    L.orc_synthesize_batch_threads.argtypes = [
+        C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+        C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]
+    started = L.orc_synthesize_batch_threads(
+        C.cast(varr, C.c_void_p), len(voices), segs.ctypes.data, seg_offsets.ctypes.data,
+        voice_ids.ctypes.data, jitter_seeds.ctypes.data, n_utt,
+        out.ctypes.data if keep_output else None, out_stride, out_len.ctypes.data, n_threads)
+    return out, out_len, started
+
+
 def count_batch(voices, segs, seg_offsets, voice_ids, jitter_seeds):
     L = lib()
     varr = voices_array(voices)

@@ -157,3 +157,50 @@ def test_one_call_pcm16_rows(gpu_ctx):
         want = np.array([L.orc_pcm16(float(v)) for v in f32[u, :n[u]]], dtype=np.int16)
         assert np.array_equal(i16[u, :n[u]], want), u
         assert np.all(i16[u, n[u]:] == 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8])
+def test_fused_pcm16_store_every_lane_mapping(gpu_ctx, lanes):
+    """grail_batch_synthesize_pcm16_async: the i16 rows written by the synthesis kernel's own flush
+    are the examples/cli.rs:49 conversion of the oracle's f32 samples; ragged lengths, a row
+    stride that forces the scalar tail, and a truncating stride."""
+    import grail_hip as G
+    from grail_hip import workload as W
+    voices = W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    n_utt = 70
+    segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=8, length=0.013, blend_length=0.008)
+    ov = [O.Voice.from_buffer_copy(bytes(v)) for v in voices]
+    full = W.max_samples(length=0.013)
+    ref, ref_len = O.synthesize_batch(ov, segs, offs, vids, seeds, full)
+    L = O.lib()
+    batch = gpu_ctx.upload(segs, offs, vids, seeds)
+    gpu_ctx.set_option("lanes_per_utterance", lanes)
+    try:
+        for stride in (full, full + 2, 1001):          # aligned / unaligned rows / truncating
+            d_out = gpu_ctx.device_alloc(n_utt * stride * 2 + 16)
+            d_len = gpu_ctx.device_alloc(n_utt * 4)
+            try:
+                gpu_ctx.memset(d_out, 0x5A, n_utt * stride * 2)
+                batch.synthesize_pcm16_async(d_out, stride, d_len)
+                try:
+                    gpu_ctx.sync()
+                except G.GrailError as e:
+                    assert stride == 1001 and e.status == G.ERR_BUFFER_TOO_SMALL
+                got = np.zeros((n_utt, stride), dtype=np.int16)
+                lens = np.zeros(n_utt, dtype=np.uint32)
+                gpu_ctx.d2h(got, d_out, got.nbytes)
+                gpu_ctx.d2h(lens, d_len, lens.nbytes)
+            finally:
+                gpu_ctx.device_free(d_out)
+                gpu_ctx.device_free(d_len)
+            for u in range(n_utt):
+                n = min(int(ref_len[u]), stride)
+                assert lens[u] == n, (stride, u)
+                want = np.array([L.orc_pcm16(float(v)) for v in ref[u, :n]], dtype=np.int16)
+                assert np.array_equal(got[u, :n], want), (stride, u)
+                assert np.all(got[u, n:] == 0x5A5A), (stride, u)   # nothing past the row's end
+    finally:
+        gpu_ctx.set_option("lanes_per_utterance", 0)
+        batch.free()

@@ -293,3 +293,17 @@ def test_pcm16_saturates_like_rust_as():
     assert L.orc_pcm16(1.0) == 32767 and L.orc_pcm16(2.0) == 32767
     assert L.orc_pcm16(-1.0) == -32767 and L.orc_pcm16(-2.0) == -32768
     assert L.orc_pcm16(float("nan")) == 0 and L.orc_pcm16(0.5) == 16383
+
+
+def test_threaded_batch_equals_serial_batch():
+    """The pthread fan-out used for the all-cores bench baseline changes nothing per utterance."""
+    from grail_hip import workload as W
+    v = [O.voice_generic(48000.0)]
+    segs, offs, vids, seeds = W.make_batch(6, n_voices=1, length=0.02, blend_length=0.02)
+    stride = 4096
+    a, la = O.synthesize_batch(v, segs, offs, vids, seeds, stride)
+    b, lb, started = O.synthesize_batch_threads(v, segs, offs, vids, seeds, stride, 3)
+    assert started == 3
+    assert np.array_equal(la, lb) and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    _, lc, _ = O.synthesize_batch_threads(v, segs, offs, vids, seeds, stride, 2, keep_output=False)
+    assert np.array_equal(la, lc)
