@@ -30,6 +30,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 ALG_BYTES_PER_SAMPLE = 4.01  # 4 B f32 written + <= 0.01 B of segment/voice input
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
+RCCL_TIMEOUT_S = float(os.environ.get("GRAIL_BENCH_RCCL_TIMEOUT", "240"))
 
 
 def cpu_baseline(n_cpu, voices, W):
@@ -85,6 +86,27 @@ def committed_literal_ms():
             return json.load(f)["config"]["kernel_ms_all_formants_literal"]
     except (OSError, KeyError, ValueError):
         return None
+
+
+def committed_valu(workload_key, kernel_ms):
+    """Secondary roofline, the binding one: VALU instructions the kernel issued per launch
+    (rocprofv3 --pmc SQ_INSTS_VALU, committed in profiles/traffic.json) over this run's kernel
+    time, against one instruction per 4 cycles per SIMD — the rate of the packed f32 ops that
+    make up two thirds of the loop (v_pk_{mul,add,fma}_f32; profiles/r01_valu_microbench.txt)."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            insts = json.load(f).get("valu_insts", {}).get(workload_key)
+    except OSError:
+        insts = None
+    if not insts:
+        return None
+    peak = 1024 * 2.4e9 / 4.0                     # 256 CUs x 4 SIMDs, 2.4 GHz, 4 cycles per issue
+    rate = insts / (kernel_ms * 1e-3)
+    return {"bound": "valu-issue", "achieved": rate / 1e9, "peak": peak / 1e9,
+            "unit": "G wave-instructions/s", "frac": rate / peak,
+            "valu_instructions_per_launch": insts,
+            "note": "SQ_INSTS_VALU from profiles/r01_pmc_sq_final_L1.txt; a lone wave per SIMD issues "
+                    "at most one instruction per ~5.3 cycles (measured), i.e. frac <= 0.75"}
 
 
 def committed_traffic(workload_key):
@@ -173,21 +195,58 @@ def main():
     if rank == 0:
         voices = W.single_voice() if n_voices == 1 else W.preset_voices(n_voices)
         ctx.set_voices(voices)
+    abandoned_ctx = None
     if distributed:
-        try:
-            with stdout_to_stderr():
-                uid = group.broadcast_bytes(G.Context.comm_unique_id() if rank == 0 else None)
+        # The collective runs on a worker thread so that a communicator that never forms (a hung
+        # ncclCommInitRank takes every rank with it) costs RCCL_TIMEOUT_S, not the whole job.
+        import threading
+        outcome = {}
+
+        def native_broadcast():
+            try:
+                if os.environ.get("GRAIL_BENCH_FAKE_RCCL_HANG"):      # test hook
+                    time.sleep(1e6)
+                uid = None
+                if rank == 0:        # rank 0 always publishes something: the others never wait in vain
+                    try:
+                        uid = G.Context.comm_unique_id()
+                    except G.GrailError as e:
+                        outcome["err"] = e
+                        uid = b""
+                uid = group.broadcast_bytes(uid)
+                if not uid:
+                    raise outcome.get("err") or RuntimeError("rank 0 could not create an RCCL id")
                 ctx.comm_init(uid, rank, world)
                 ctx.broadcast_voices(n_voices, root=0)   # ncclBroadcast over xGMI inside the C ABI
+                ctx.sync()
+                outcome["ok"] = True
+            except Exception as e:                       # noqa: BLE001 — reported below
+                outcome["err"] = e
+
+        worker = threading.Thread(target=native_broadcast, daemon=True)
+        with stdout_to_stderr():
+            worker.start()
+            worker.join(RCCL_TIMEOUT_S)
+        hung = worker.is_alive()
+        ok_everywhere = all(f[0] == 1.0 for f in
+                            group.gather_doubles((1.0 if outcome.get("ok") else 0.0,)))
+        if ok_everywhere:
             voices = ctx.get_voices()
             voice_path = "rccl ncclBroadcast (grail_broadcast_voices)"
-        except G.GrailError as e:      # keep the job alive: hand the same bytes over through /tmp
-            print(f"[rank {rank}] native RCCL broadcast failed ({e}); using the file rendezvous",
+        else:        # keep the job alive: hand the same bytes over through /tmp, on every rank
+            why = "timed out" if hung else outcome.get("err", "failed on another rank")
+            print(f"[rank {rank}] native RCCL broadcast: {why}; using the file rendezvous",
                   file=sys.stderr)
+            if hung:                 # its stream may be stuck behind the collective: start afresh
+                abandoned_ctx = ctx
+                ctx = G.Context(local_rank)
+                if rank == 0:
+                    ctx.set_voices(voices)
             blob = group.broadcast_bytes(G.voices_blob(voices) if rank == 0 else None)
             voices = G.voices_from_blob(blob)
             ctx.set_voices(voices)
-            voice_path = "file rendezvous (native RCCL failed)"
+            voice_path = "file rendezvous (native RCCL broadcast unavailable: %s)" % (
+                "timeout" if hung else "error")
 
     # ---- this rank's shard of the corpus, resident in HBM ---------------------------------
     first, last, segs, offs, vids, seeds = D.shard_inputs(n_utt, rank, world, len(voices))
@@ -280,6 +339,7 @@ def main():
                         "limit is f32 VALU issue (~660 unfusable flops + 25 IEEE divisions per "
                         "sample, SURVEY.md §8d) — see DESIGN.md §Roofline",
             },
+            "roofline_valu": committed_valu(wl_key, k_ms),
         }
         if world == 1 and args.cpu_utts > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_utts, voices, W)
@@ -293,6 +353,10 @@ def main():
     ctx.close()
     if distributed:
         group.close()
+    if abandoned_ctx is not None:     # a thread is still inside RCCL: do not wait for it
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
