@@ -63,6 +63,21 @@ __device__ __forceinline__ float vget(f2 v, int c) { return c == 0 ? v.x : v.y; 
 __device__ __forceinline__ void vset(float &v, int, float x) { v = x; }
 __device__ __forceinline__ void vset(f2 &v, int c, float x) { if (c == 0) v.x = x; else v.y = x; }
 
+// s -> s*16807 + 1 applied n times is s*mul[n] + add[n] (mod 2^32), n = 0..64
+struct LcgSkip {
+    uint32_t mul[65], add[65];
+    constexpr LcgSkip() : mul(), add()
+    {
+        mul[0] = 1u;
+        add[0] = 0u;
+        for (int n = 1; n <= 64; ++n) {
+            mul[n] = mul[n - 1] * 16807u;
+            add[n] = add[n - 1] * 16807u + 1u;
+        }
+    }
+};
+__device__ const LcgSkip LCG_SKIP{};
+
 // random_f32, src/lib.rs:36-55
 __device__ __forceinline__ float lcg_f32(uint32_t &s)
 {
@@ -800,13 +815,19 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     // ---- the quiet sample step: taken when a single ballot shows that NO lane of the wave
     // has any of those events at this sample.  Same arithmetic, straight-line: the polyBLEP
     // quotient is evaluated unconditionally with div_exact<true> and selected afterwards.
-    auto quiet_step = [&](auto nlive_tag, auto su_tag, const int t, const float clk_next,
-                          const float jphase_next) __attribute__((always_inline)) {
+    // CALM (calm_tag): the step belongs to a calm tile — every lane of the wave is active and none
+    // can have an event within the tile — so finished-lane masking is not needed, and the carrier
+    // noise (the same LCG state in every lane) arrives precomputed in `noise_in`.
+    auto quiet_step = [&](auto nlive_tag, auto su_tag, auto calm_tag, const int t, const float clk_next,
+                          const float jphase_next, const float noise_in) __attribute__((always_inline)) {
         constexpr int NLIVE = decltype(nlive_tag)::value;   // vectors whose band-pass runs
         constexpr bool SU = decltype(su_tag)::value;        // one smoothness for every formant
+        constexpr bool CALM = decltype(calm_tag)::value;
         constexpr bool KEEP_LP = STREAM;                    // silent formants keep their low-pass
         constexpr int NLP = (NLIVE < NV && !KEEP_LP) ? NLIVE : NV;
-        if (done) return;                                                  // finished lanes sit out
+        if constexpr (!CALM) {
+            if (done) return;                                              // finished lanes sit out
+        }
         clk = clk_next;                                                    // :861
         float alpha = __builtin_fminf(clk * inv_blend_length, 1.0f);       // :899/:908/:917
         alpha = silent_pair ? 1.0f : alpha;
@@ -858,7 +879,9 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         const float saw = (2.0f * phase - 1.0f) - polyblep;                // :517
         phase += frequency;                                                // :520
         phase = (phase >= 1.0f) ? phase - 1.0f : phase;                    // :523-525
-        const float noise = lcg_f32(noise_seed);                           // :528
+        float noise;                                                       // :528
+        if constexpr (CALM) noise = noise_in;
+        else noise = lcg_f32(noise_seed);
         V v1[NV];
         formant_filters<true, NV, NLIVE, SU, KEEP_LP, V>(saw, noise, oml_s, e_freq, e_bw, e_smooth, e_breath, e_turb,
                                             e_amp, st_a, st_b, st_c, v1);
@@ -892,7 +915,36 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             // a run of quiet steps: a tight inner loop, so the loop-carried state keeps its
             // registers from one sample to the next.  Two flavours of the same loop: every
             // formant vector live, or (all lanes agree) the upper half silent for this pair.
+            // A calm tile: all 64 lanes active, and for each of them the clock stays >= 0, the
+            // jitter phase <= 1 and the row has room for the T steps of the tile.  clk >= m*dt
+            // implies RN(clk - dt) >= (m - 1.01)*dt (RN is monotone), so clk > (T+8)*dt leaves
+            // > 7*dt after T <= 64 steps; the phase grows by at most jinc*(1 + 2^-23) per step.
+            bool calm_tile = false;
+            if (t == 0) {
+                static_assert(T <= 64, "calm-tile margins are written for T <= 64");
+                const bool calm = !done & quiet_ok & (dt > 0.0f) & (clk > (float)(T + 8) * dt) &
+                                  (jphase + (float)(T + 1) * jinc < 0.999f) &
+                                  (cap32 - n_out >= (uint32_t)T) &
+                                  (noise_seed == (uint32_t)__builtin_amdgcn_readfirstlane((int)noise_seed));
+                calm_tile = __builtin_amdgcn_ballot_w64(!calm) == 0;
+            }
             auto quiet_run = [&](auto nlive_tag, auto su_tag) __attribute__((always_inline)) {
+                if (calm_tile) {
+                    // no lane can have an event before the tile ends: no per-step ballot.  The
+                    // carrier noise of the T steps is drawn here, lane l taking step l (closed-form
+                    // skip-ahead of the LCG :36-55; wrapping u32 arithmetic is exact).
+                    const uint32_t ahead = (uint32_t)(lane < T ? lane : T - 1) + 1u;
+                    uint32_t sk = noise_seed * LCG_SKIP.mul[ahead] + LCG_SKIP.add[ahead];
+                    const float noise_of_lane = (__uint_as_float((sk >> 9) | 0x3F800000u) - 1.5f) * 2.0f;
+#pragma unroll 1
+                    for (; t < T; ++t) {
+                        const float nz = __builtin_bit_cast(
+                            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), t));
+                        quiet_step(nlive_tag, su_tag, std::true_type(), t, clk - dt, jphase + jinc, nz);
+                    }
+                    noise_seed = (uint32_t)__builtin_amdgcn_readlane((int)sk, T - 1);
+                    return;
+                }
                 for (; t < T; ++t) {
                     const float clk_next = clk - dt;
                     const float jphase_next = jphase + jinc;
@@ -900,7 +952,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     const bool eventful = !done & (!quiet_ok | (clk_next < 0.0f) |
                                                    (jphase_next > 1.0f) | (n_out >= cap32));
                     if (__builtin_expect(__builtin_amdgcn_ballot_w64(eventful) != 0, 0)) break;
-                    quiet_step(nlive_tag, su_tag, t, clk_next, jphase_next);
+                    quiet_step(nlive_tag, su_tag, std::false_type(), t, clk_next, jphase_next, 0.0f);
                 }
             };
             const bool all_su = __builtin_amdgcn_ballot_w64(!done & !smooth_uniform) == 0;
