@@ -873,9 +873,13 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         const bool head = phase < frequency;                               // :503
         const bool tail = phase > (1.0f - frequency);                      // :507
         const float tt = div_exact<true>(head ? phase : (phase - 1.0f), frequency);
-        const float pb_head = (2.0f * tt - (tt * tt)) - 1.0f;              // :506
-        const float pb_tail = ((tt * tt) + 2.0f * tt) + 1.0f;              // :510
-        const float polyblep = head ? pb_head : (tail ? pb_tail : 0.0f);
+        // :506 (2t - t*t) - 1  and  :510 (t*t + 2t) + 1  are both (2t + s*(t*t)) + s with s = -1
+        // (head) or +1 (tail): a - b is a + (-b), IEEE addition commutes, s*(t*t) is a sign flip,
+        // and 2t is exact (|t| <= 1 here), so fma(2, t, .) rounds the same sum once
+        const float tt2 = tt * tt;
+        const float s_tt2 = __uint_as_float(__float_as_uint(tt2) ^ (head ? 0x80000000u : 0u));
+        const float pb = vfma(2.0f, tt, s_tt2) + (head ? -1.0f : 1.0f);
+        const float polyblep = (head | tail) ? pb : 0.0f;
         const float saw = (2.0f * phase - 1.0f) - polyblep;                // :517
         phase += frequency;                                                // :520
         phase = (phase >= 1.0f) ? phase - 1.0f : phase;                    // :523-525
@@ -906,7 +910,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             }
             if (j == L - 1) stage[t * SP + slot] = acc * 0.5f;
         }
-        ++n_out;
+        if constexpr (!CALM) ++n_out;      // a calm tile adds its T samples at once
     };
 
     for (uint32_t base = 0;; base += T) {
@@ -936,12 +940,21 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     const uint32_t ahead = (uint32_t)(lane < T ? lane : T - 1) + 1u;
                     uint32_t sk = noise_seed * LCG_SKIP.mul[ahead] + LCG_SKIP.add[ahead];
                     const float noise_of_lane = (__uint_as_float((sk >> 9) | 0x3F800000u) - 1.5f) * 2.0f;
+                    // two steps per trip halve the loop overhead; with all four formant vectors
+                    // live the doubled body no longer fits the register file (measured: slower)
+                    constexpr int STEPS_PER_TRIP = decltype(nlive_tag)::value <= 2 ? 2 : 1;
+                    static_assert(T % STEPS_PER_TRIP == 0, "whole trips");
 #pragma unroll 1
-                    for (; t < T; ++t) {
-                        const float nz = __builtin_bit_cast(
-                            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), t));
-                        quiet_step(nlive_tag, su_tag, std::true_type(), t, clk - dt, jphase + jinc, nz);
+                    for (int tc = 0; tc < T; tc += STEPS_PER_TRIP) {
+#pragma unroll
+                        for (int h = 0; h < STEPS_PER_TRIP; ++h) {
+                            const float nz = __builtin_bit_cast(
+                                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc + h));
+                            quiet_step(nlive_tag, su_tag, std::true_type(), tc + h, clk - dt, jphase + jinc, nz);
+                        }
                     }
+                    t = T;
+                    n_out += (uint32_t)T;
                     noise_seed = (uint32_t)__builtin_amdgcn_readlane((int)sk, T - 1);
                     return;
                 }
