@@ -880,7 +880,8 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         const float s_tt2 = __uint_as_float(__float_as_uint(tt2) ^ (head ? 0x80000000u : 0u));
         const float pb = vfma(2.0f, tt, s_tt2) + (head ? -1.0f : 1.0f);
         const float polyblep = (head | tail) ? pb : 0.0f;
-        const float saw = (2.0f * phase - 1.0f) - polyblep;                // :517
+        // :517  2*phase is exact (0 <= phase < 1), so the fma rounds the same difference once
+        const float saw = vfma(2.0f, phase, -1.0f) - polyblep;
         phase += frequency;                                                // :520
         phase = (phase >= 1.0f) ? phase - 1.0f : phase;                    // :523-525
         float noise;                                                       // :528
