@@ -815,7 +815,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     // ---- the quiet sample step: taken when a single ballot shows that NO lane of the wave
     // has any of those events at this sample.  Same arithmetic, straight-line: the polyBLEP
     // quotient is evaluated unconditionally with div_exact<true> and selected afterwards.
-    // CALM (calm_tag): the step belongs to a calm tile — every lane of the wave is active and none
+    // CALM (calm_tag): the step belongs to a calm tile — no lane that still renders
     // can have an event within the tile — so finished-lane masking is not needed, and the carrier
     // noise (the same LCG state in every lane) arrives precomputed in `noise_in`.
     auto quiet_step = [&](auto nlive_tag, auto su_tag, auto calm_tag, const int t, const float clk_next,
@@ -920,18 +920,26 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             // a run of quiet steps: a tight inner loop, so the loop-carried state keeps its
             // registers from one sample to the next.  Two flavours of the same loop: every
             // formant vector live, or (all lanes agree) the upper half silent for this pair.
-            // A calm tile: all 64 lanes active, and for each of them the clock stays >= 0, the
-            // jitter phase <= 1 and the row has room for the T steps of the tile.  clk >= m*dt
+            // A calm tile: for every lane that is still rendering, the clock stays >= 0, the
+            // jitter phase <= 1 and the row has room for the T steps of the tile.  Lanes that
+            // will not render again in this launch (chain exhausted, row full, no utterance) ride
+            // along: what they compute is never read and their sample count stands still, so
+            // nothing of theirs is flushed.  clk >= m*dt
             // implies RN(clk - dt) >= (m - 1.01)*dt (RN is monotone), so clk > (T+8)*dt leaves
             // > 7*dt after T <= 64 steps; the phase grows by at most jinc*(1 + 2^-23) per step.
             bool calm_tile = false;
+            const bool idle = STREAM ? finished : done;   // a paused stream lane resumes: not idle
+            uint32_t tile_seed = 0u;                       // the carrier-noise state the tile starts from
             if (t == 0) {
                 static_assert(T <= 64, "calm-tile margins are written for T <= 64");
-                const bool calm = !done & quiet_ok & (dt > 0.0f) & (clk > (float)(T + 8) * dt) &
-                                  (jphase + (float)(T + 1) * jinc < 0.999f) &
-                                  (cap32 - n_out >= (uint32_t)T) &
-                                  (noise_seed == (uint32_t)__builtin_amdgcn_readfirstlane((int)noise_seed));
-                calm_tile = __builtin_amdgcn_ballot_w64(!calm) == 0;
+                const uint64_t busy = __builtin_amdgcn_ballot_w64(!idle);
+                if (busy != 0) {
+                    tile_seed = (uint32_t)__builtin_amdgcn_readlane((int)noise_seed, __builtin_ctzll(busy));
+                    const bool calm = !done & quiet_ok & (dt > 0.0f) & (clk > (float)(T + 8) * dt) &
+                                      (jphase + (float)(T + 1) * jinc < 0.999f) &
+                                      (cap32 - n_out >= (uint32_t)T) & (noise_seed == tile_seed);
+                    calm_tile = __builtin_amdgcn_ballot_w64(!(calm | idle)) == 0;
+                }
             }
             auto quiet_run = [&](auto nlive_tag, auto su_tag) __attribute__((always_inline)) {
                 if (calm_tile) {
@@ -939,7 +947,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     // carrier noise of the T steps is drawn here, lane l taking step l (closed-form
                     // skip-ahead of the LCG :36-55; wrapping u32 arithmetic is exact).
                     const uint32_t ahead = (uint32_t)(lane < T ? lane : T - 1) + 1u;
-                    uint32_t sk = noise_seed * LCG_SKIP.mul[ahead] + LCG_SKIP.add[ahead];
+                    uint32_t sk = tile_seed * LCG_SKIP.mul[ahead] + LCG_SKIP.add[ahead];
                     const float noise_of_lane = (__uint_as_float((sk >> 9) | 0x3F800000u) - 1.5f) * 2.0f;
                     // two steps per trip halve the loop overhead; with all four formant vectors
                     // live the doubled body no longer fits the register file (measured: slower)
@@ -955,7 +963,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                         }
                     }
                     t = T;
-                    n_out += (uint32_t)T;
+                    n_out += idle ? 0u : (uint32_t)T;
                     noise_seed = (uint32_t)__builtin_amdgcn_readlane((int)sk, T - 1);
                     return;
                 }

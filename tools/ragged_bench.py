@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Kernel time on a RAGGED corpus: per-segment lengths drawn from [0.3, 0.7] s and (optionally)
+per-voice jitter rates that differ, so segment boundaries and jitter wraps of the 64 utterances of
+a wave do not coincide (the bench corpus has them all aligned).  usage: ragged_bench.py [n_utt]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "grail-rs_amd"))
+import numpy as np
+import grail_hip as G
+from grail_hip import workload as W
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+ctx = G.Context(0)
+rng = np.random.default_rng(1)
+for label, ragged_len, ragged_jit, n_voices in (("aligned 1 voice", False, False, 1),
+                                                 ("ragged lengths, 1 voice", True, False, 1),
+                                                 ("aligned 8 presets", False, False, 8),
+                                                 ("ragged lengths, 8 presets", True, False, 8),
+                                                 ("ragged lengths + jitter rates, 8 presets", True, True, 8)):
+    voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
+    if ragged_jit:
+        for i, v in enumerate(voices):
+            v.jitter_frequency = np.float32((12.0 + i) / 48000.0)
+    ctx.set_voices(voices)
+    segs, offs, vids, seeds = W.make_batch(n, n_voices=n_voices)
+    if ragged_len:
+        segs["length"] = rng.uniform(0.3, 0.7, len(segs)).astype(np.float32)
+    stride = (int(0.7 * 4 * 48000) + 64 + 63) // 64 * 64
+    batch = ctx.upload(segs, offs, vids, seeds)
+    d_out = ctx.device_alloc(n * stride * 4)
+    d_len = ctx.device_alloc(n * 4)
+    ms = []
+    for _ in range(3):
+        batch.synthesize_async(d_out, stride, d_len)
+        ctx.sync()
+        ms.append(ctx.last_kernel_ms())
+    lens = np.zeros(n, dtype=np.uint32)
+    ctx.d2h(lens, d_len, lens.nbytes)
+    total = int(lens.astype(np.uint64).sum())
+    print(f"{label:45s} kernel {min(ms):7.2f} ms  {total / (min(ms) * 1e-3):.3e} samples/s  "
+          f"(max row {int(lens.max())} samples)", flush=True)
+    ctx.device_free(d_out)
+    ctx.device_free(d_len)
+    batch.free()
