@@ -515,7 +515,7 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     a.half_capable = (a.skip_silent && batch->phoneme_mode && ctx->voices_upper_silent) ? 1u : 0u;
     int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(batch->n_utt);
     // voices whose upper formants are never audible: one lane per utterance runs the half-live loop
-    // (54 ms per 2 s alone on a SIMD) and beats two lanes per utterance (57 ms), whose second lane
+    // (46 ms per 2 s alone on a SIMD) and ties two lanes per utterance, whose second lane
     // would only hold silent formants
     if (!ctx->lanes_option && L == 2 && a.half_capable) L = 1;
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));

@@ -382,3 +382,44 @@ def test_non_uniform_smoothness_takes_the_vector_path(gpu_ctx, lanes):
     out, out_len, ref, ref_len = run_both(gpu_ctx, [v], segs, offs, vids, seeds, stride, lanes)
     gpu_ctx.set_option("lanes_per_utterance", 0)
     assert_bit_identical(out, out_len, ref, ref_len, f"per-formant smoothness L={lanes}")
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8])
+def test_calm_tile_boundaries(gpu_ctx, lanes):
+    """The kernel runs whole tiles (32 or 64 steps) without per-step event checks when no lane can
+    have an event inside the tile.  Segment ends placed on every offset around the tile edges,
+    jitter wraps every 37 / 64 / 65 steps, rows that fill up inside a tile, utterances of a wave
+    that end at different samples: all must still equal the oracle bit for bit."""
+    voices = []
+    for every in (37.0, 64.0, 65.0, 3000.0):
+        v = G.voice_generic(48000.0)
+        v.jitter_frequency = float(np.float32(1.0) / np.float32(every))
+        voices.append(v)
+    rate = np.float32(48000.0)
+    segs, offs, vids, seeds = [], [0], [], []
+    for k in range(20, 150):                       # segment ends sweep across two tile sizes
+        length = float((np.float32(k) + np.float32(0.5)) / rate)
+        n_seg = 2 + k % 3
+        for i in range(n_seg):
+            ph = (G.PH_A, G.PH_E, G.PH_SILENCE)[(k + i) % 3]
+            segs.append((ph, length, 2.0 ** -8 if k % 2 else 2.0 ** -10,
+                         float(np.float32(90 + k) / rate)))
+        offs.append(len(segs))
+        vids.append(k % len(voices))
+        seeds.append(k * 7919)
+    segs = G.segments(segs)
+    offs = np.array(offs, dtype=np.uint32)
+    vids = np.array(vids, dtype=np.uint32)
+    seeds = np.array(seeds, dtype=np.uint32)
+    try:
+        for stride in (1024, 333):                 # 333: rows fill up inside a tile
+            gpu_ctx.set_voices(voices)
+            gpu_ctx.set_option("lanes_per_utterance", lanes)
+            out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride,
+                                              allow_truncation=True)
+            ref, ref_len = O.synthesize_batch(ovoices(voices), segs, offs, vids, seeds, stride)
+            ref_len = np.minimum(ref_len, stride)
+            assert ref_len.max() == stride or stride == 1024
+            assert_bit_identical(out, out_len, ref, ref_len, f"tile edges L={lanes} stride={stride}")
+    finally:
+        gpu_ctx.set_option("lanes_per_utterance", 0)
