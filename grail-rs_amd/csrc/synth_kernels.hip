@@ -951,7 +951,10 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     const float noise_of_lane = (__uint_as_float((sk >> 9) | 0x3F800000u) - 1.5f) * 2.0f;
                     // two steps per trip halve the loop overhead; with all four formant vectors
                     // live the doubled body no longer fits the register file (measured: slower)
-                    constexpr int STEPS_PER_TRIP = decltype(nlive_tag)::value <= 2 ? 2 : 1;
+                    #ifndef GRAIL_TRIP_FULL
+#define GRAIL_TRIP_FULL 1
+#endif
+                    constexpr int STEPS_PER_TRIP = decltype(nlive_tag)::value <= 2 ? 2 : GRAIL_TRIP_FULL;
                     static_assert(T % STEPS_PER_TRIP == 0, "whole trips");
 #pragma unroll 1
                     for (int tc = 0; tc < T; tc += STEPS_PER_TRIP) {
