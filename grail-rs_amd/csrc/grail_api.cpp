@@ -138,6 +138,7 @@ struct grail_batch {
     uint32_t n_segs = 0;
     uint32_t max_voice_id = 0;
     bool phoneme_mode = true;
+    bool any_blend = false;    // some segment's blend length is not +-2^k (selects the kernel)
 };
 
 namespace {
@@ -166,6 +167,15 @@ void free_batch_buffers(grail_batch *b)
     if (b->d_voice_ids) (void)hipFree(b->d_voice_ids);
     if (b->d_seeds) (void)hipFree(b->d_seeds);
     if (b->d_elems) (void)hipFree(b->d_elems);
+}
+
+// clk / 2^k is clk * 2^-k exactly; any other blend length needs the division code of the kernel
+bool blend_is_pow2(float blend_length)
+{
+    uint32_t bits;
+    std::memcpy(&bits, &blend_length, sizeof bits);
+    const uint32_t e = (bits >> 23) & 0xFFu;
+    return (bits & 0x7FFFFFu) == 0u && e >= 1u && e <= 253u;
 }
 
 int check_offsets(const uint32_t *seg_offsets, uint32_t n_utt, uint32_t *n_segs)
@@ -383,12 +393,15 @@ int grail_batch_upload(grail_ctx *ctx, const grail_phoneme_elem *segs, const uin
     uint32_t n_segs = 0;
     if ((rc = check_offsets(seg_offsets, n_utt, &n_segs))) return rc;
     if (n_segs && !segs) return fail(GRAIL_ERR_INVALID_ARG, "segs is NULL");
+    bool any_blend = false;
+    for (uint32_t i = 0; i < n_segs && !any_blend; ++i) any_blend = !blend_is_pow2(segs[i].blend_length);
     for (uint32_t i = 0; i < n_segs; ++i)
         if (segs[i].phoneme < 0 || segs[i].phoneme >= GRAIL_PH_COUNT)
             return fail(GRAIL_ERR_INVALID_ARG, "phoneme discriminant out of range");
     grail_batch *b = new (std::nothrow) grail_batch();
     if (!b) return fail(GRAIL_ERR_OUT_OF_MEMORY, "host allocation failed");
     b->phoneme_mode = true;
+    b->any_blend = any_blend;
     b->n_segs = n_segs;
     if ((rc = upload(&b->d_segs, segs, n_segs, ctx->stream)) ||
         (rc = upload_common(ctx, b, seg_offsets, voice_ids, jitter_seeds, n_utt))) {
@@ -414,16 +427,19 @@ int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
     // Split the SequenceElems into the 16-B segment records and the elem table.
     std::vector<DevSeg> ds(n_segs);
     std::vector<float> elems((size_t)(n_segs ? n_segs : 1) * ELEM_FLOATS);
+    bool any_blend = false;
     for (uint32_t i = 0; i < n_segs; ++i) {
         ds[i].elem = segs[i].has_elem ? (int32_t)i : -1;
         ds[i].length = segs[i].length;
         ds[i].blend_length = segs[i].blend_length;
+        any_blend = any_blend || !blend_is_pow2(segs[i].blend_length);
         ds[i].frequency = segs[i].elem.frequency;
         std::memcpy(&elems[(size_t)i * ELEM_FLOATS], &segs[i].elem, sizeof(grail_synthesis_elem));
     }
     grail_batch *b = new (std::nothrow) grail_batch();
     if (!b) return fail(GRAIL_ERR_OUT_OF_MEMORY, "host allocation failed");
     b->phoneme_mode = false;
+    b->any_blend = any_blend;
     b->n_segs = n_segs;
     if ((rc = upload(&b->d_segs, ds.data(), n_segs, ctx->stream)) ||
         (rc = upload(&b->d_elems, elems.data(), elems.size(), ctx->stream)) ||
@@ -513,6 +529,7 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     a.phoneme_mode = batch->phoneme_mode ? 1u : 0u;
     a.skip_silent = ctx->skip_silent_option ? 1u : 0u;
     a.half_capable = (a.skip_silent && batch->phoneme_mode && ctx->voices_upper_silent) ? 1u : 0u;
+    a.any_blend = batch->any_blend ? 1u : 0u;
     int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(batch->n_utt);
     // voices whose upper formants are never audible: one lane per utterance runs the half-live loop
     // (46 ms per 2 s alone on a SIMD) and ties two lanes per utterance, whose second lane
@@ -589,6 +606,7 @@ int grail_stream_next_async(grail_ctx *ctx, grail_stream *stream, uint32_t max_s
     a.phoneme_mode = batch->phoneme_mode ? 1u : 0u;
     a.skip_silent = ctx->skip_silent_option ? 1u : 0u;
     a.half_capable = (a.skip_silent && batch->phoneme_mode && ctx->voices_upper_silent) ? 1u : 0u;
+    a.any_blend = batch->any_blend ? 1u : 0u;
     a.state = stream->d_state;
     a.state_stride = stream->lanes;
     a.resume = stream->started ? 1u : 0u;

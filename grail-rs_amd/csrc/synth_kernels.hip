@@ -458,7 +458,10 @@ struct StateIO {
 // HALF: instantiate the quiet loops that skip a silent upper half of the lane's formants.  The
 // host only asks for it when the voice table can make use of it (or for resumable streams), so
 // batches whose formants are all audible run a kernel that does not carry those loops.
-template <int L, int T, int WAVES, int MIN_WAVES_PER_SIMD, bool STREAM, bool HALF>
+// ANYBL: blend lengths that are not powers of two also take the quiet step (clk / blend_length by
+// the short exact division).  The host asks for it only when the batch holds such a segment, so the
+// usual case (the Intonator always emits 0.5, src/lib.rs:1071) runs a kernel without that code.
+template <int L, int T, int WAVES, int MIN_WAVES_PER_SIMD, bool STREAM, bool HALF, bool ANYBL>
 __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(const SynthArgs A)
 {
     constexpr int FPL = NF / L;          // formants per lane
@@ -510,6 +513,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     float blend_length = 1.0f;
     float inv_blend_length = 1.0f;           // exact when blend_length is +-2^k
     bool blend_pow2 = true;
+    bool blend_div_ok = false;               // ANYBL: clk / blend_length may use the short exact division
     bool silent_pair = true;
     bool pair_safe = false;                  // every division of this pair may use div_exact<true>
 
@@ -641,7 +645,13 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         const uint32_t blb = __float_as_uint(blend_length);
         const uint32_t ble = (blb >> 23) & 0xFFu;
         blend_pow2 = ((blb & 0x7FFFFFu) == 0u) && ble >= 1u && ble <= 253u;
-        inv_blend_length = 1.0f / blend_length;
+        inv_blend_length = 1.0f / blend_length;       // IEEE: RN(1/b), what div_exact<true> starts from
+        // any other blend length: q = clk*RN(1/b), r = fma(-b, q, clk), q' = fma(r, RN(1/b), q) is the
+        // correctly rounded clk/b while b and clk are in the proven window (tools/div_exhaustive.hip);
+        // clk <= length, and steps whose clk is below the window take the general step
+        if constexpr (ANYBL)
+            blend_div_ok = (blend_length >= 0x1p-59f) && (blend_length <= 0x1p59f) &&
+                           (cur.length <= 0x1p59f) && (dt >= 0x1p-59f);
     };
 
     constexpr bool streaming = STREAM;       // a separate instantiation: the one-shot kernel
@@ -665,7 +675,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         visit_state(io);
         done = finished;
         if (cur.some) setup_pair();
-        quiet_ok = pair_safe && blend_pow2;
+        quiet_ok = pair_safe && (blend_pow2 || blend_div_ok);
         update_silent();
     }
 
@@ -829,7 +839,13 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             if (done) return;                                              // finished lanes sit out
         }
         clk = clk_next;                                                    // :861
-        float alpha = __builtin_fminf(clk * inv_blend_length, 1.0f);       // :899/:908/:917
+        float ratio = clk * inv_blend_length;                              // exact quotient for 2^k
+        if constexpr (ANYBL) {
+            const float rem = vfma(-blend_length, ratio, clk);
+            const float quot = vfma(rem, inv_blend_length, ratio);         // RN(clk / blend_length)
+            ratio = blend_pow2 ? ratio : quot;
+        }
+        float alpha = __builtin_fminf(ratio, 1.0f);                        // :899/:908/:917
         alpha = silent_pair ? 1.0f : alpha;
         const float oma = 1.0f - alpha;
         float frequency = X.frequency * oma + Y.frequency * alpha;         // :404-414
@@ -974,7 +990,10 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     const float clk_next = clk - dt;
                     const float jphase_next = jphase + jinc;
                     // bitwise on purpose: no short-circuit, so no exec-mask regions
-                    const bool eventful = !done & (!quiet_ok | (clk_next < 0.0f) |
+                    // ANYBL: a blend length that is not 2^k also sends a clk below the division
+                    // window (2^-59, or zero) to the general step
+                    const float clk_floor = (ANYBL && !blend_pow2) ? 0x1p-59f : 0.0f;
+                    const bool eventful = !done & (!quiet_ok | (clk_next < clk_floor) |
                                                    (jphase_next > 1.0f) | (n_out >= cap32));
                     if (__builtin_expect(__builtin_amdgcn_ballot_w64(eventful) != 0, 0)) break;
                     quiet_step(nlive_tag, su_tag, std::false_type(), t, clk_next, jphase_next, 0.0f);
@@ -995,7 +1014,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             }
             if (t < T) {
                 general_step(t);
-                quiet_ok = pair_safe && blend_pow2;
+                quiet_ok = pair_safe && (blend_pow2 || blend_div_ok);
                 ++t;
             }
         }
@@ -1155,11 +1174,13 @@ static void launch_one(const SynthArgs &args, hipStream_t stream)
     const uint32_t per_block = (64u / L) * WAVES;
     const dim3 grid((args.n_utt + per_block - 1) / per_block), block(64 * WAVES);
     if (args.state)
-        hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, true, true>), grid, block, 0, stream, args);
+        hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, true, true, true>), grid, block, 0, stream, args);
+    else if (args.any_blend)
+        hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, false, true, true>), grid, block, 0, stream, args);
     else if (L == 1 && args.half_capable)
-        hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, false, true>), grid, block, 0, stream, args);
+        hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, false, true, false>), grid, block, 0, stream, args);
     else
-        hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, false, false>), grid, block, 0, stream, args);
+        hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, false, false, false>), grid, block, 0, stream, args);
 }
 
 hipError_t launch_synth(const SynthArgs &args, int L, int variant, hipStream_t stream)

@@ -402,8 +402,10 @@ def test_calm_tile_boundaries(gpu_ctx, lanes):
         n_seg = 2 + k % 3
         for i in range(n_seg):
             ph = (G.PH_A, G.PH_E, G.PH_SILENCE)[(k + i) % 3]
-            segs.append((ph, length, 2.0 ** -8 if k % 2 else 2.0 ** -10,
-                         float(np.float32(90 + k) / rate)))
+            # blend lengths: two powers of two and one that is not (the kernel with the short
+            # exact clk / blend_length division, its clk floor included: length < blend length)
+            blend = (2.0 ** -8, 2.0 ** -10, 0.0031)[(k + i) % 3] if k % 5 else (2.0 ** -8, 2.0 ** -10)[i % 2]
+            segs.append((ph, length, blend, float(np.float32(90 + k) / rate)))
         offs.append(len(segs))
         vids.append(k % len(voices))
         seeds.append(k * 7919)
