@@ -184,7 +184,11 @@ def main():
     from grail_hip import workload as W
     G.load()
 
-    ctx = G.Context(local_rank)
+    # test hook: GRAIL_BENCH_DEVICE pins every rank to one device (two ranks on a 1-GPU box exercise
+    # the multi-process control flow; RCCL refuses duplicate GPUs, so the voice table then takes the
+    # file fallback)
+    device = int(os.environ.get("GRAIL_BENCH_DEVICE", local_rank))
+    ctx = G.Context(device)
     n_utt = args.utts
     n_voices = max(args.voices, 1)
     stride = W.max_samples()
@@ -239,7 +243,7 @@ def main():
                   file=sys.stderr)
             if hung:                 # its stream may be stuck behind the collective: start afresh
                 abandoned_ctx = ctx
-                ctx = G.Context(local_rank)
+                ctx = G.Context(device)
                 if rank == 0:
                     ctx.set_voices(voices)
             blob = group.broadcast_bytes(G.voices_blob(voices) if rank == 0 else None)
