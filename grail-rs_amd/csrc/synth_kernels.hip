@@ -13,23 +13,35 @@
 // per lane).  Time is serial (phase, clocks, RNG and filter states all carry
 // sample to sample, exactly as in the reference); the per-utterance scalar
 // state is recomputed identically in each of its L lanes so lanes never wait on
-// each other.  The 8-term `Array::sum` is a left fold and must stay one: it is
-// run as a chain down the L lanes with DPP row_shr:1 hand-offs.  Samples are
-// staged through LDS for T steps and flushed as 16-B-per-lane row stores, so
-// every utterance row is written in contiguous 4*T-byte runs.
+// each other.  The 8-term `Array::sum` is a left fold and must stay one: for
+// L = 2 it runs as a chain down the lanes with DPP row_shr:1 hand-offs, for
+// L >= 4 the lanes park their band-pass outputs in LDS and the fold runs at
+// flush time.  Samples are staged through LDS for T steps and flushed as
+// 16-B-per-lane row stores, so every utterance row is written in contiguous
+// 4*T-byte runs (8-B stores for i16 PCM rows).
 //
-// Exactness.  Built with -ffp-contract=off: every a*b+c is a multiply then an add
-// (never a fused multiply-add), divisions are correctly rounded (hipcc's IEEE
-// sequence, or the proven-equal short sequence div_exact<true>), f32 denormals are
-// kept (the kernel descriptor's default).  The result is bit-identical to the
-// reference arithmetic, whatever L is.
+// Steps.  general_step: the literal control flow of the reference with IEEE
+// divisions, taken whenever some lane has an event (segment boundary, jitter
+// wrap, full row) or its segment pair is outside the proven operand window.
+// quiet_step: the same arithmetic straight-line, short exact divisions, behind
+// one ballot per step.  Calm tiles: T quiet steps without that ballot, when no
+// lane can have an event before the tile ends (see the tile loop).
 //
-// Packed math.  On gfx950 only v_{add,mul,fma}_f32 issue at 2 cycles per wave64;
-// one wave issues at most one VALU instruction every ~5 cycles, so with the two
-// waves per SIMD this register budget allows the scarce resource is issue slots.
-// The per-formant arithmetic is therefore written on float2 values, which hipcc
-// lowers to v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two formants per issue
-// slot, each component still an individually rounded IEEE operation.
+// Exactness.  Built with -ffp-contract=off: the compiler never fuses a*b+c, so every
+// multiply and add of the reference is an individually rounded IEEE operation.  The
+// few explicit fma calls are places where a fused form is PROVEN to round the same
+// real number once (the division sequences, 5 - 4*p with an exact 4*p, 2*x - 1 with an
+// exact 2*x); divisions are correctly rounded (hipcc's IEEE sequence, or the
+// proven-equal short sequence div_exact<true>); f32 denormals are kept (the kernel
+// descriptor's default).  The result is bit-identical to the reference arithmetic,
+// whatever L is.
+//
+// Packed math.  A lone wave issues at most one instruction every ~5 cycles, whatever the
+// instruction (measured, tools/valu_microbench.hip), and the headline batch is exactly one
+// wave per SIMD, so the scarce resource is issue slots.  The per-formant arithmetic is
+// therefore written on float2 values, which hipcc lowers to v_pk_mul_f32 / v_pk_add_f32 /
+// v_pk_fma_f32: two formants per issue slot, each component still an individually
+// rounded IEEE operation.
 #include <type_traits>
 
 #include "kernels.h"
