@@ -6,6 +6,8 @@
 //       .select(v).sequence(v).jitter(seed, v)
 //       .synthesize().collect::<Vec<f32>>()           -> gpu.synthesize({Utterance{...}})
 //   voices::generic()                                 -> grail::voices::generic()
+//   pulling the iterator a buffer at a time             -> grail::Stream(gpu, utterances, chunk).next(...)
+//       (examples/interactive.rs:31-48)
 //
 // No arithmetic lives here; everything forwards to libgrail_hip.so.
 #pragma once
@@ -145,6 +147,74 @@ public:
 private:
     grail_ctx *ctx_ = nullptr;
     std::vector<Voice> voices_;
+};
+
+// The lazy use of the chain: the crate's iterator is pulled a buffer at a time
+// (examples/interactive.rs:31-48).  Here every utterance of the batch yields its next `chunk`
+// samples per call; the iterator state stays in HBM between calls (grail_stream_*), and the
+// chunks concatenate to exactly what Gpu::synthesize returns.
+class Stream {
+public:
+    Stream(const Gpu &gpu, const std::vector<Utterance> &utts, uint32_t chunk)
+        : ctx_(gpu.ctx()), n_((uint32_t)utts.size()), chunk_(chunk), stride_(((uint64_t)chunk + 63) / 64 * 64)
+    {
+        std::vector<PhonemeElem> segs;
+        std::vector<uint32_t> offs(1, 0u), vids, seeds;
+        for (const Utterance &u : utts) {
+            segs.insert(segs.end(), u.phonemes.begin(), u.phonemes.end());
+            offs.push_back((uint32_t)segs.size());
+            vids.push_back(u.voice);
+            seeds.push_back(u.jitter_seed);
+        }
+        check(grail_batch_upload(ctx_, segs.data(), offs.data(), vids.data(), seeds.data(), n_, &batch_));
+        int rc = grail_stream_open(ctx_, batch_, &stream_);
+        if (!rc) rc = grail_device_alloc(ctx_, (size_t)(n_ ? n_ : 1) * stride_ * sizeof(float), &d_out_);
+        if (!rc) rc = grail_device_alloc(ctx_, (size_t)(n_ ? n_ : 1) * sizeof(uint32_t), &d_len_);
+        if (rc) {
+            release();
+            check(rc);
+        }
+        host_.resize((size_t)n_ * stride_);
+        lens_.resize(n_);
+    }
+    ~Stream() { release(); }
+    Stream(const Stream &) = delete;
+    Stream &operator=(const Stream &) = delete;
+
+    // Iterator::next, `chunk` samples at a time: false once every chain has returned None
+    bool next(std::vector<std::vector<float>> &chunks)
+    {
+        chunks.assign(n_, {});
+        if (n_ == 0 || chunk_ == 0) return false;
+        check(grail_stream_next_async(ctx_, stream_, chunk_, (float *)d_out_, stride_, (uint32_t *)d_len_));
+        check(grail_sync(ctx_));
+        check(grail_memcpy_d2h(ctx_, lens_.data(), d_len_, (size_t)n_ * sizeof(uint32_t)));
+        check(grail_memcpy_d2h(ctx_, host_.data(), d_out_, host_.size() * sizeof(float)));
+        bool any = false;
+        for (uint32_t u = 0; u < n_; ++u) {
+            chunks[u].assign(host_.begin() + (size_t)u * stride_, host_.begin() + (size_t)u * stride_ + lens_[u]);
+            any = any || lens_[u] != 0;
+        }
+        return any;
+    }
+
+private:
+    void release()
+    {
+        if (stream_) grail_stream_close(ctx_, stream_);
+        if (batch_) grail_batch_free(ctx_, batch_);
+        if (d_out_) grail_device_free(ctx_, d_out_);
+        if (d_len_) grail_device_free(ctx_, d_len_);
+        stream_ = nullptr; batch_ = nullptr; d_out_ = nullptr; d_len_ = nullptr;
+    }
+    grail_ctx *ctx_;
+    uint32_t n_, chunk_;
+    uint64_t stride_;
+    grail_batch *batch_ = nullptr;
+    grail_stream *stream_ = nullptr;
+    void *d_out_ = nullptr, *d_len_ = nullptr;
+    std::vector<float> host_;
+    std::vector<uint32_t> lens_;
 };
 
 }  // namespace grail
