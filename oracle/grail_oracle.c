@@ -7,7 +7,7 @@
  * struct fields, same evaluation order.  PARITY UNPINNED by the reference's
  * own tests (they are empty for this path) — see the header.
  *
- * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fexcess-precision=standard
+ * Build: gcc -O3 -ffp-contract=off -fno-fast-math -fexcess-precision=standard
  * (rustc never contracts a*b+c to an FMA and never reassociates).
  */
 #include <pthread.h>
