@@ -942,6 +942,104 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         if constexpr (!CALM) ++n_out;      // a calm tile adds its T samples at once
     };
 
+    // ---- L = 8 (one formant per lane): the packed slot that holds a second formant for smaller L
+    // takes the SAME formant at the NEXT sample instead.  In a calm tile nothing but the carrier
+    // phase and the filter state links sample tc to tc+1, so everything else — blend, jitter,
+    // tan_approx, the divisions, polyBLEP — is evaluated for both samples at once (.x = tc,
+    // .y = tc+1): the same operations on the same operands as two quiet steps, two per issue slot.
+    auto time_packed_steps = [&](const int tc, const float nz0, const float nz1) __attribute__((always_inline)) {
+        if constexpr (W == 1 && NV == 1 && FOLD_IN_FLUSH) {
+            const f2 one2 = vsplat(1.0f, f2());
+            const float clk0 = clk - dt, clk1 = clk0 - dt;                     // :861
+            const float jp0 = jphase + jinc, jp1 = jp0 + jinc;                 // :242 / :291
+            clk = clk1;
+            jphase = jp1;
+            f2 CLK, JP, NZ;
+            CLK.x = clk0; CLK.y = clk1; JP.x = jp0; JP.y = jp1; NZ.x = nz0; NZ.y = nz1;
+            f2 ratio = CLK * inv_blend_length;
+            if constexpr (ANYBL) {
+                const f2 rem = vfma(-blend_length * one2, ratio, CLK);
+                const f2 quot = vfma(rem, inv_blend_length * one2, ratio);     // RN(clk / blend_length)
+                ratio = blend_pow2 ? ratio : quot;
+            }
+            f2 alpha;                                                          // :899/:908/:917
+            alpha.x = silent_pair ? 1.0f : __builtin_fminf(ratio.x, 1.0f);
+            alpha.y = silent_pair ? 1.0f : __builtin_fminf(ratio.y, 1.0f);
+            const f2 oma = 1.0f - alpha;
+            const f2 jomp = 1.0f - JP;
+            // SynthesisElem::blend :404-414, Jitter::next :753-777
+            f2 frequency = X.frequency * oma + Y.frequency * alpha;
+            const f2 n_freq = fn_cur * jomp + fn_next * JP;                    // :254
+            frequency = frequency + n_freq * d_freq;                           // :763
+            f2 e_freq = X.freq[0] * oma + Y.freq[0] * alpha;
+            const f2 e_bw = X.bw[0] * oma + Y.bw[0] * alpha;
+            const f2 e_smooth = X.smooth[0] * oma + Y.smooth[0] * alpha;
+            const f2 e_breath = X.breath[0] * oma + Y.breath[0] * alpha;
+            const f2 e_turb = X.turb[0] * oma + Y.turb[0] * alpha;
+            f2 e_amp = X.amp[0] * oma + Y.amp[0] * alpha;
+            const f2 n_ff = ff_cur[0] * jomp + ff_next[0] * JP;                // :305
+            const f2 n_fa = fa_cur[0] * jomp + fa_next[0] * JP;
+            e_freq = e_freq + n_ff * d_ffreq;                                  // :764
+            const f2 delta = (n_fa + 1.0f) * amp_scale;                        // :768-769
+            e_amp = e_amp * (1.0f - delta);                                    // :772-773
+            // Synthesize::next coefficients :535, :555-562 (as formant_filters<true>)
+            const f2 oml = 1.0f - exp_approx(e_smooth);
+            const f2 omx = 1.0f - e_freq, xph = e_freq + 0.5f, hmx = 0.5f - e_freq;
+            const f2 ox = omx * e_freq, ph = xph * hmx;
+            const f2 five = vsplat(5.0f, f2()), m4 = vsplat(-4.0f, f2());
+            const f2 num = ox * vfma(m4, ph, five);
+            const f2 den = (xph * vfma(m4, ox, five)) * hmx;
+            const f2 g = div_exact<true>(num, den);                            // :555
+            const f2 kq = div_exact<true>(e_bw, e_freq);                       // :558
+            const f2 a1 = rcp_exact<true>(1.0f + g * (g + kq));                // :560
+            const f2 a2 = g * a1;                                              // :561
+            const f2 a3 = g * a2;                                              // :562
+            const f2 tmix = (1.0f - e_turb) + NZ * e_turb;                     // :544-545
+            // carrier :503-525: the phase is the one carried quantity, two short serial steps
+            const f2 omf = 1.0f - frequency;
+            const float ph0 = phase;
+            const bool head0 = ph0 < frequency.x, tail0 = ph0 > omf.x;
+            float ph1 = ph0 + frequency.x;
+            ph1 = (ph1 >= 1.0f) ? ph1 - 1.0f : ph1;
+            const bool head1 = ph1 < frequency.y, tail1 = ph1 > omf.y;
+            float ph2 = ph1 + frequency.y;
+            phase = (ph2 >= 1.0f) ? ph2 - 1.0f : ph2;
+            f2 PH;
+            PH.x = ph0; PH.y = ph1;
+            const f2 phm1 = PH - 1.0f;
+            f2 dividend;
+            dividend.x = head0 ? ph0 : phm1.x;
+            dividend.y = head1 ? ph1 : phm1.y;
+            const f2 tt = div_exact<true>(dividend, frequency);
+            const f2 tt2 = tt * tt;
+            f2 s_tt2, sgn, polyblep;                                           // see quiet_step
+            s_tt2.x = __uint_as_float(__float_as_uint(tt2.x) ^ (head0 ? 0x80000000u : 0u));
+            s_tt2.y = __uint_as_float(__float_as_uint(tt2.y) ^ (head1 ? 0x80000000u : 0u));
+            sgn.x = head0 ? -1.0f : 1.0f;
+            sgn.y = head1 ? -1.0f : 1.0f;
+            const f2 pb = vfma(vsplat(2.0f, f2()), tt, s_tt2) + sgn;
+            polyblep.x = (head0 | tail0) ? pb.x : 0.0f;
+            polyblep.y = (head1 | tail1) ? pb.y : 0.0f;
+            const f2 saw = vfma(vsplat(2.0f, f2()), PH, -one2) - polyblep;     // :517
+            const f2 nw = saw * (1.0f - e_breath) + NZ * e_breath;             // :531
+            // the filter recurrences :538-571, sample tc then tc+1
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float sa = st_a[0], sb = st_b[0], sc = st_c[0];
+                sa = sa + vget(oml, h) * (vget(nw, h) - sa);                   // :538
+                const float tw = sa * vget(tmix, h);
+                const float v0 = tw * vget(e_amp, h);                          // :550
+                const float v3 = v0 - sc;                                      // :565
+                const float w1 = vget(a1, h) * sb + vget(a2, h) * v3;          // :566
+                const float w2 = (sc + vget(a2, h) * sb) + vget(a3, h) * v3;   // :567
+                st_a[0] = sa;
+                st_b[0] = 2.0f * w1 - sb;                                      // :570
+                st_c[0] = 2.0f * w2 - sc;                                      // :571
+                stage[((tc + h) * S + slot) * NF + f0] = w1;
+            }
+        }
+    };
+
     for (uint32_t base = 0;; base += T) {
         int t = 0;
         while (t < T) {
@@ -979,18 +1077,23 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     const float noise_of_lane = (__uint_as_float((sk >> 9) | 0x3F800000u) - 1.5f) * 2.0f;
                     // two steps per trip halve the loop overhead; with all four formant vectors
                     // live the doubled body no longer fits the register file (measured: slower)
-                    #ifndef GRAIL_TRIP_FULL
-#define GRAIL_TRIP_FULL 1
-#endif
-                    constexpr int STEPS_PER_TRIP = decltype(nlive_tag)::value <= 2 ? 2 : GRAIL_TRIP_FULL;
+                    constexpr int STEPS_PER_TRIP = decltype(nlive_tag)::value <= 2 ? 2 : 1;
                     static_assert(T % STEPS_PER_TRIP == 0, "whole trips");
+                    auto noise_at = [&](const int step) __attribute__((always_inline)) {
+                        return __builtin_bit_cast(
+                            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), step));
+                    };
+                    if constexpr (W == 1 && NV == 1 && FOLD_IN_FLUSH) {
 #pragma unroll 1
-                    for (int tc = 0; tc < T; tc += STEPS_PER_TRIP) {
+                        for (int tc = 0; tc < T; tc += 2)
+                            time_packed_steps(tc, noise_at(tc), noise_at(tc + 1));
+                    } else {
+#pragma unroll 1
+                        for (int tc = 0; tc < T; tc += STEPS_PER_TRIP) {
 #pragma unroll
-                        for (int h = 0; h < STEPS_PER_TRIP; ++h) {
-                            const float nz = __builtin_bit_cast(
-                                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc + h));
-                            quiet_step(nlive_tag, su_tag, std::true_type(), tc + h, clk - dt, jphase + jinc, nz);
+                            for (int h = 0; h < STEPS_PER_TRIP; ++h)
+                                quiet_step(nlive_tag, su_tag, std::true_type(), tc + h, clk - dt,
+                                           jphase + jinc, noise_at(tc + h));
                         }
                     }
                     t = T;
