@@ -1079,21 +1079,24 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     // live the doubled body no longer fits the register file (measured: slower)
                     constexpr int STEPS_PER_TRIP = decltype(nlive_tag)::value <= 2 ? 2 : 1;
                     static_assert(T % STEPS_PER_TRIP == 0, "whole trips");
-                    auto noise_at = [&](const int step) __attribute__((always_inline)) {
-                        return __builtin_bit_cast(
-                            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), step));
-                    };
                     if constexpr (W == 1 && NV == 1 && FOLD_IN_FLUSH) {
 #pragma unroll 1
-                        for (int tc = 0; tc < T; tc += 2)
-                            time_packed_steps(tc, noise_at(tc), noise_at(tc + 1));
+                        for (int tc = 0; tc < T; tc += 2) {
+                            const float nz0 = __builtin_bit_cast(
+                                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc));
+                            const float nz1 = __builtin_bit_cast(
+                                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc + 1));
+                            time_packed_steps(tc, nz0, nz1);
+                        }
                     } else {
 #pragma unroll 1
                         for (int tc = 0; tc < T; tc += STEPS_PER_TRIP) {
 #pragma unroll
-                            for (int h = 0; h < STEPS_PER_TRIP; ++h)
-                                quiet_step(nlive_tag, su_tag, std::true_type(), tc + h, clk - dt,
-                                           jphase + jinc, noise_at(tc + h));
+                            for (int h = 0; h < STEPS_PER_TRIP; ++h) {
+                                const float nz = __builtin_bit_cast(
+                                    float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc + h));
+                                quiet_step(nlive_tag, su_tag, std::true_type(), tc + h, clk - dt, jphase + jinc, nz);
+                            }
                         }
                     }
                     t = T;
