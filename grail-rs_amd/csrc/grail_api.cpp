@@ -578,8 +578,8 @@ int grail_stream_open(grail_ctx *ctx, const grail_batch *batch, grail_stream **o
     return GRAIL_OK;
 }
 
-int grail_stream_next_async(grail_ctx *ctx, grail_stream *stream, uint32_t max_samples,
-                            float *out_dev, uint64_t out_stride, uint32_t *out_len_dev)
+static int stream_next(grail_ctx *ctx, grail_stream *stream, uint32_t max_samples, float *out_dev,
+                       int16_t *out_pcm16_dev, uint64_t out_stride, uint32_t *out_len_dev)
 {
     int rc = bind(ctx);
     if (rc) return rc;
@@ -588,7 +588,7 @@ int grail_stream_next_async(grail_ctx *ctx, grail_stream *stream, uint32_t max_s
     if ((rc = check_ready(ctx, batch))) return rc;
     if (max_samples > out_stride) return fail(GRAIL_ERR_INVALID_ARG, "max_samples exceeds out_stride");
     if (batch->n_utt == 0) return GRAIL_OK;
-    if (!out_dev && max_samples) return fail(GRAIL_ERR_INVALID_ARG, "out_dev is NULL");
+    if (!out_dev && !out_pcm16_dev && max_samples) return fail(GRAIL_ERR_INVALID_ARG, "out_dev is NULL");
     SynthArgs a{};
     a.segs = batch->d_segs;
     a.seg_offsets = batch->d_offsets;
@@ -597,6 +597,7 @@ int grail_stream_next_async(grail_ctx *ctx, grail_stream *stream, uint32_t max_s
     a.elems = batch->phoneme_mode ? ctx->d_voice_elems : batch->d_elems;
     a.voices = ctx->d_voices;
     a.out = out_dev;
+    a.out_pcm16 = out_pcm16_dev;
     a.out_len = out_len_dev;
     a.truncated = ctx->d_truncated;
     a.out_stride = out_stride;
@@ -617,6 +618,18 @@ int grail_stream_next_async(grail_ctx *ctx, grail_stream *stream, uint32_t max_s
     ctx->have_timing = true;
     stream->started = true;
     return GRAIL_OK;
+}
+
+int grail_stream_next_async(grail_ctx *ctx, grail_stream *stream, uint32_t max_samples,
+                            float *out_dev, uint64_t out_stride, uint32_t *out_len_dev)
+{
+    return stream_next(ctx, stream, max_samples, out_dev, nullptr, out_stride, out_len_dev);
+}
+
+int grail_stream_next_pcm16_async(grail_ctx *ctx, grail_stream *stream, uint32_t max_samples,
+                                  int16_t *out_dev, uint64_t out_stride, uint32_t *out_len_dev)
+{
+    return stream_next(ctx, stream, max_samples, nullptr, out_dev, out_stride, out_len_dev);
 }
 
 int grail_stream_close(grail_ctx *ctx, grail_stream *stream)

@@ -52,7 +52,7 @@ EXPORTS = [
     "grail_last_kernel_ms", "grail_synthesize_batch", "grail_synthesize_batch_elems",
     "grail_stream_open", "grail_stream_next_async", "grail_stream_close",
     "grail_language_generic", "grail_transcribe", "grail_intonate", "grail_text_to_phoneme_elems",
-    "grail_synthesize_batch_pcm16", "grail_batch_synthesize_pcm16_async", "grail_say_batch", "grail_pcm16_async", "grail_batch_digest", "grail_wav_write_i16",
+    "grail_synthesize_batch_pcm16", "grail_batch_synthesize_pcm16_async", "grail_stream_next_pcm16_async", "grail_say_batch", "grail_pcm16_async", "grail_batch_digest", "grail_wav_write_i16",
     "grail_device_alloc", "grail_device_free", "grail_memcpy_d2h", "grail_memcpy_h2d",
     "grail_memset_d", "grail_shard_range", "grail_comm_unique_id", "grail_comm_init",
     "grail_broadcast_voices", "grail_comm_destroy",
@@ -190,6 +190,7 @@ def load():
                                                C.c_uint32]
     L.grail_stream_open.argtypes = [vp, vp, C.POINTER(vp)]
     L.grail_stream_next_async.argtypes = [vp, vp, C.c_uint32, vp, u64, vp]
+    L.grail_stream_next_pcm16_async.argtypes = [vp, vp, C.c_uint32, vp, u64, vp]
     L.grail_stream_close.argtypes = [vp, vp]
     L.grail_language_generic.restype = C.c_uint32
     L.grail_language_generic.argtypes = [C.POINTER(C.POINTER(Rule)), C.POINTER(C.c_int)]
@@ -392,6 +393,10 @@ class Stream:
     def next_async(self, max_samples, out_dev, out_stride, out_len_dev=None):
         _check(load().grail_stream_next_async(self.ctx.handle, self.handle, max_samples, out_dev,
                                               out_stride, out_len_dev))
+
+    def next_pcm16_async(self, max_samples, out_dev, out_stride, out_len_dev=None):
+        _check(load().grail_stream_next_pcm16_async(self.ctx.handle, self.handle, max_samples,
+                                                    out_dev, out_stride, out_len_dev))
 
     def close(self):
         if self.handle:

@@ -124,6 +124,8 @@ extern "C" {
         out: *mut *mut grail_stream) -> c_int;
     pub fn grail_stream_next_async(ctx: *mut grail_ctx, stream: *mut grail_stream, max_samples: u32,
         out_dev: *mut f32, out_stride: u64, out_len_dev: *mut u32) -> c_int;
+    pub fn grail_stream_next_pcm16_async(ctx: *mut grail_ctx, stream: *mut grail_stream,
+        max_samples: u32, out_dev: *mut i16, out_stride: u64, out_len_dev: *mut u32) -> c_int;
     pub fn grail_stream_close(ctx: *mut grail_ctx, stream: *mut grail_stream) -> c_int;
     pub fn grail_sync(ctx: *mut grail_ctx) -> c_int;
     pub fn grail_last_kernel_ms(ctx: *mut grail_ctx, ms: *mut f32) -> c_int;

@@ -223,6 +223,10 @@ int grail_last_kernel_ms(grail_ctx *ctx, float *ms);
 int grail_stream_open(grail_ctx *ctx, const grail_batch *batch, grail_stream **out);
 int grail_stream_next_async(grail_ctx *ctx, grail_stream *stream, uint32_t max_samples,
                             float *out_dev, uint64_t out_stride, uint32_t *out_len_dev);
+/* The same chunk as i16 PCM (the WAV sink's conversion, examples/cli.rs:49, fused into the store):
+ * what a sound-card callback wants.  f32 and i16 calls may be mixed on one stream. */
+int grail_stream_next_pcm16_async(grail_ctx *ctx, grail_stream *stream, uint32_t max_samples,
+                                  int16_t *out_dev, uint64_t out_stride, uint32_t *out_len_dev);
 int grail_stream_close(grail_ctx *ctx, grail_stream *stream);
 
 /* One-call forms: upload, synthesize, copy back (GRAIL_OUT_HOST) or leave in

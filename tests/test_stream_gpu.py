@@ -114,3 +114,53 @@ def test_stream_silent_formants_wake_up(gpu_ctx):
             ref = O.synthesize_sequence(ov, osegs[offs[u]:offs[u + 1]], int(seeds[u]))
             assert len(got[u]) == len(ref), (lanes, u)
             assert np.array_equal(got[u].view(np.uint32), ref.view(np.uint32)), (lanes, u)
+
+
+@pytest.mark.parametrize("lanes", [0, 1, 8])
+def test_stream_pcm16_chunks_mixed_with_f32(gpu_ctx, lanes):
+    """grail_stream_next_pcm16_async: chunks come out as i16 PCM (examples/cli.rs:49 fused into the
+    store); f32 and i16 calls alternate on one stream and together give the one-shot rendering."""
+    import oracle_lib as O
+    voices = W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    gpu_ctx.set_option("lanes_per_utterance", lanes)
+    n_utt = 66
+    segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=8, length=0.02, blend_length=0.02)
+    full, full_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=W.max_samples(length=0.02))
+    L = O.lib()
+    b = gpu_ctx.upload(segs, offs, vids, seeds)
+    st = G.Stream(b)
+    stride, q = 512, 500
+    d_f = gpu_ctx.device_alloc(n_utt * stride * 4)
+    d_i = gpu_ctx.device_alloc(n_utt * stride * 2)
+    d_len = gpu_ctx.device_alloc(n_utt * 4)
+    pos = np.zeros(n_utt, dtype=np.int64)
+    try:
+        for k in range(40):
+            as_i16 = k % 2 == 1
+            if as_i16:
+                st.next_pcm16_async(q, d_i, stride, d_len)
+            else:
+                st.next_async(q, d_f, stride, d_len)
+            gpu_ctx.sync()
+            lens = np.zeros(n_utt, dtype=np.uint32)
+            gpu_ctx.d2h(lens, d_len, lens.nbytes)
+            if lens.max() == 0:
+                break
+            buf = np.zeros((n_utt, stride), dtype=np.int16 if as_i16 else np.float32)
+            gpu_ctx.d2h(buf, d_i if as_i16 else d_f, buf.nbytes)
+            for u in range(n_utt):
+                want = full[u, pos[u]:pos[u] + lens[u]]
+                if as_i16:
+                    want = np.array([L.orc_pcm16(float(v)) for v in want], dtype=np.int16)
+                    assert np.array_equal(buf[u, :lens[u]], want), (k, u)
+                else:
+                    assert np.array_equal(buf[u, :lens[u]].view(np.uint32), want.view(np.uint32)), (k, u)
+                pos[u] += lens[u]
+        assert np.array_equal(pos, full_len.astype(np.int64))
+    finally:
+        st.close()
+        b.free()
+        for d in (d_f, d_i, d_len):
+            gpu_ctx.device_free(d)
+        gpu_ctx.set_option("lanes_per_utterance", 0)
