@@ -54,3 +54,29 @@ def test_random_batches_every_lane_mapping(gpu_ctx, seed):
             b.free()
     finally:
         gpu_ctx.set_option("lanes_per_utterance", 0)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_voice_tables_every_lane_mapping(gpu_ctx, seed):
+    """Random phoneme tables (per-formant smoothness, random breath / turbulence, some amplitudes
+    exactly zero) and random jitter settings: the vector-smoothness loops, partly silent formants
+    and fast jitter wraps, against the oracle bit for bit."""
+    from test_oracle_crosscheck import random_voice
+    rng = np.random.default_rng(seed)
+    ovoices = [random_voice(rng, 48000.0) for _ in range(6)]
+    voices = [G.Voice.from_buffer_copy(bytes(v)) for v in ovoices]
+    gpu_ctx.set_voices(voices)
+    segs, offs, vids, seeds = random_batch(rng, 100, len(voices), 48000.0)
+    stride = 10048
+    ref, ref_len = O.synthesize_batch(ovoices, segs, offs, vids, seeds, stride)
+    assert ref_len.max() < stride
+    try:
+        for lanes in (1, 2, 4, 8):
+            gpu_ctx.set_option("lanes_per_utterance", lanes)
+            out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+            assert np.array_equal(out_len, ref_len), lanes
+            for u in range(len(ref_len)):
+                assert np.array_equal(out[u, :ref_len[u]].view(np.uint32),
+                                      ref[u, :ref_len[u]].view(np.uint32)), (lanes, u)
+    finally:
+        gpu_ctx.set_option("lanes_per_utterance", 0)

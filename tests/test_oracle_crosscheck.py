@@ -65,3 +65,53 @@ def test_per_sample_elems_agree():
         ref = M.trace(v, segs, 5, stage)
         assert got.shape == ref.shape
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def random_voice(rng, rate):
+    """A voice with random phoneme tables (through the crate's own constructor arithmetic,
+    SynthesisElem::new_phoneme :381-401, resample :418-440) and random jitter settings."""
+    import ctypes as C
+    L = O.lib()
+    L.orc_elem_new_phoneme.restype = None
+    L.orc_elem_new_phoneme.argtypes = [C.POINTER(O.SynthesisElem)] + [C.POINTER(C.c_float)] * 6
+    v = O.voice_generic(rate)
+    for p in range(2):
+        amp = rng.uniform(0, 1, 8) * (rng.uniform(0, 1, 8) > 0.3)
+        amp[0] = max(amp[0], 0.1)
+        arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (
+            rng.uniform(200, 5000, 8), rng.uniform(30, 400, 8), rng.uniform(500, 6000, 8),
+            rng.uniform(0, 1, 8), rng.uniform(0, 1, 8), amp)]      # freq, bw, smooth, turb, breath, amp
+        e = O.SynthesisElem()
+        L.orc_elem_new_phoneme(C.byref(e), *[a.ctypes.data_as(C.POINTER(C.c_float)) for a in arrs])
+        if float(v.sample_rate) != 44100.0:
+            L.orc_elem_resample(C.byref(e), 44100.0, float(v.sample_rate))
+        v.phonemes[p] = e
+    sr = np.float32(v.sample_rate)
+    v.jitter_frequency = float(np.float32(rng.uniform(4, 400)) / sr)
+    v.jitter_delta_frequency = float(np.float32(rng.uniform(0, 20)) / sr)
+    v.jitter_delta_formant_frequency = float(np.float32(rng.uniform(0, 60)) / sr)
+    v.jitter_delta_amplitude = float(np.float32(rng.uniform(0, 0.9)))
+    return v
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_voices_and_segments_agree(seed):
+    """Randomised: random phoneme tables, jitter settings, segment lists (every phoneme kind,
+    lengths and blend lengths, pitches) — the C oracle and the numpy model read the reference
+    independently and must still agree on every bit."""
+    rng = np.random.default_rng(1000 + seed)
+    rate = float(rng.choice([44100.0, 48000.0, 22050.0]))
+    v = random_voice(rng, rate)
+    segs = []
+    for _ in range(int(rng.integers(1, 6))):
+        ph = int(rng.choice([A, E, S, ST, GL], p=[.4, .35, .15, .05, .05]))
+        blend = float(rng.choice([rng.uniform(0.0005, 0.02), 2.0 ** -7]))
+        segs.append((ph, float(rng.uniform(0.0005, 0.012)), blend,
+                     float(np.float32(rng.uniform(60, 500)) / np.float32(rate))))
+    with np.errstate(all="ignore"):
+        out, ref = both(v, segs, int(rng.integers(0, 2 ** 32)))
+    assert len(out) == len(ref) and len(out) > 0
+    a, b = out.view(np.uint32), ref.view(np.uint32)
+    if not np.array_equal(a, b):
+        i = int(np.argmax(a != b))
+        raise AssertionError(f"seed {seed}: first difference at sample {i}: {out[i]!r} vs {ref[i]!r}")
