@@ -55,9 +55,15 @@ float orc_exp_approx(float x)
 /* src/lib.rs:123-125: self.0.iter().sum::<f32>() — a sequential left fold.
  * The fold's identity is +0.0 up to Rust 1.82 and -0.0 from 1.83; the two
  * differ only when every term is -0.0, and then only in the sign of zero. */
+static float g_sum_identity = 0.0f;
+
+/* Tests only: fold from -0.0 (Rust >= 1.83) instead of +0.0, to show the rendering does not depend
+ * on which toolchain built the crate. */
+void orc_set_sum_identity(int negative_zero) { g_sum_identity = negative_zero ? -0.0f : 0.0f; }
+
 float orc_array_sum(const orc_array *a)
 {
-    float s = 0.0f;
+    float s = g_sum_identity;
     for (int i = 0; i < NF; ++i) s = s + a->v[i];
     return s;
 }

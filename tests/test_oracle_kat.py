@@ -307,3 +307,34 @@ def test_threaded_batch_equals_serial_batch():
     assert np.array_equal(la, lb) and np.array_equal(a.view(np.uint32), b.view(np.uint32))
     _, lc, _ = O.synthesize_batch_threads(v, segs, offs, vids, seeds, stride, 2, keep_output=False)
     assert np.array_equal(la, lc)
+
+
+def test_sum_identity_of_newer_rust_gives_the_same_bits():
+    """Array::sum is `iter().sum::<f32>()` (src/lib.rs:123-125): the fold starts from +0.0 up to
+    Rust 1.82 and from -0.0 since 1.83.  The two can differ only when all eight band-pass outputs
+    are -0.0.  With positive filter coefficients (formant frequencies inside (0, 1/2), every voice
+    the crate can build) a band-pass output a1*b + a2*v3 is -0.0 only if its state b is -0.0, which
+    b' = 2*w1 - b never produces from a +0.0 start ((-0) - (+0) needs w1 = -0, which needs b = -0).
+    So the rendering is the same for either toolchain; checked here on voiced, silent, fading and
+    NaN-producing inputs."""
+    from grail_hip import workload as W
+    L = O.lib()
+    L.orc_set_sum_identity.argtypes = [C.c_int]
+    L.orc_set_sum_identity.restype = None
+    cases = []
+    v48 = [O.voice_generic(48000.0)]
+    cases.append((v48,) + W.make_batch(12, length=0.02, blend_length=0.02))
+    cases.append((v48, O.segments([(O.PH_SILENCE, .01, .01, 0.1), (O.PH_STOP, .01, .01, 0.1)]),
+                  np.array([0, 2], dtype=np.uint32), None, None))
+    cases.append((v48, O.segments([(O.PH_A, .01, .01, 0.0), (O.PH_E, .01, .01, 0.7)]),
+                  np.array([0, 2], dtype=np.uint32), None, None))
+    try:
+        for voices, segs, offs, vids, seeds in cases:
+            L.orc_set_sum_identity(0)
+            a, la = O.synthesize_batch(voices, segs, offs, vids, seeds, 4096)
+            L.orc_set_sum_identity(1)
+            b, lb = O.synthesize_batch(voices, segs, offs, vids, seeds, 4096)
+            assert np.array_equal(la, lb) and la.max() > 0
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    finally:
+        L.orc_set_sum_identity(0)
