@@ -224,6 +224,7 @@ int install_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices)
                     sizeof(grail_synthesis_elem) * NUM_VOICED);
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // kernels may still read the old table
+    ctx->voices.clear();                          // a failure below leaves "no voice table set"
     if (ctx->d_voices) (void)hipFree(ctx->d_voices);
     if (ctx->d_voice_elems) (void)hipFree(ctx->d_voice_elems);
     ctx->d_voices = nullptr;
@@ -468,7 +469,8 @@ uint32_t grail_batch_size(const grail_batch *batch) { return batch ? batch->n_ut
 static int check_ready(grail_ctx *ctx, const grail_batch *batch)
 {
     if (!batch) return fail(GRAIL_ERR_INVALID_ARG, "batch is NULL");
-    if (ctx->voices.empty()) return fail(GRAIL_ERR_NO_VOICES, "call grail_set_voices first");
+    if (ctx->voices.empty() || !ctx->d_voices || !ctx->d_voice_elems)   // also after a failed upload
+        return fail(GRAIL_ERR_NO_VOICES, "call grail_set_voices first");
     if (batch->max_voice_id >= ctx->voices.size())
         return fail(GRAIL_ERR_INVALID_ARG, "a voice id exceeds the voice table");
     return GRAIL_OK;
