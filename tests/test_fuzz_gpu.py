@@ -1,6 +1,8 @@
 """Randomised parity: random utterances (phonemes incl. Silence/Stop/Glide, lengths, blend
 lengths — power-of-two and not — pitches, voices, seeds, ragged segment counts) through the HIP
 path vs the oracle, bit for bit, for every lane mapping; the streaming path on the same inputs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -28,7 +30,11 @@ def random_batch(rng, n_utt, n_voices, rate):
             np.array(seeds, dtype=np.uint32))
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+# GRAIL_FUZZ_EXTRA=n adds n more seeds (soak runs; the default suite stays short)
+EXTRA_SEEDS = list(range(100, 100 + int(os.environ.get("GRAIL_FUZZ_EXTRA", "0"))))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3] + EXTRA_SEEDS)
 def test_random_batches_every_lane_mapping(gpu_ctx, seed):
     rng = np.random.default_rng(seed)
     voices = W.preset_voices(8) if seed != 2 else [G.voice_generic(48000.0), G.voice_generic(44100.0)]
@@ -56,7 +62,7 @@ def test_random_batches_every_lane_mapping(gpu_ctx, seed):
         gpu_ctx.set_option("lanes_per_utterance", 0)
 
 
-@pytest.mark.parametrize("seed", [11, 12])
+@pytest.mark.parametrize("seed", [11, 12] + EXTRA_SEEDS)
 def test_random_voice_tables_every_lane_mapping(gpu_ctx, seed):
     """Random phoneme tables (per-formant smoothness, random breath / turbulence, some amplitudes
     exactly zero) and random jitter settings: the vector-smoothness loops, partly silent formants
