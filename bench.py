@@ -72,10 +72,16 @@ def cpu_all_cores(voices, W):
             quota = f.read().strip()          # "max 100000" or "<quota> <period>"
     except OSError:
         quota = "unknown"
-    return {"value": n / dt, "unit": "samples/s", "cores": started, "kind": "port",
+    granted = started
+    try:                                  # "<quota> <period>": the container's CPU-time allowance
+        q, per = quota.split()
+        granted = min(started, max(1, -(-int(q) // int(per))))
+    except ValueError:
+        pass
+    return {"value": n / dt, "unit": "samples/s", "cores": granted, "kind": "port",
             "sample": f"first {n_cpu} utterances ({n} samples) in {dt:.2f} s wall on {started} "
-                      f"pthreads (logical cores, SMT included; cgroup cpu.max = '{quota}', so the "
-                      f"container may be granted fewer cores than it sees)"}
+                      f"pthreads over {threads} visible logical cores; cgroup cpu.max = '{quota}' "
+                      f"grants {granted} cores' worth of CPU time, which is what `cores` reports"}
 
 
 def committed_literal_ms():
