@@ -3,6 +3,7 @@
 The reference's own tests for this path are empty bodies (src/lib.rs:603-608,
 804-805), so these replace them; the property tests carry the stub names."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -338,3 +339,29 @@ def test_sum_identity_of_newer_rust_gives_the_same_bits():
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     finally:
         L.orc_set_sum_identity(0)
+
+
+def test_reference_golden_reader_round_trip(tmp_path):
+    """tests/test_reference_golden.py reads the files grail-rs_amd/rust/reference-golden writes; here
+    the same layout is written from the oracle and read back through that module, so the reader
+    (manifest, raw little-endian f32, grail_voice field order) is known to work before real
+    reference output exists."""
+    import importlib
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    lines = []
+    for name, rate, segs, seed in make_golden.cases():
+        pcm, n = O.synthesize_phonemes(O.voice_generic(rate), O.segments(segs), seed)
+        pcm.astype("<f4").tofile(str(tmp_path / f"{name}.f32"))
+        lines.append(f"{name} {n}")
+    (tmp_path / "manifest.txt").write_text("\n".join(lines) + "\n")
+    for tag, rate in (("44k", None), ("48k", 48000.0)):
+        np.frombuffer(bytes(O.voice_generic(rate)), dtype="<f4").tofile(str(tmp_path / f"voice_{tag}.f32"))
+    env = dict(os.environ, GRAIL_REFERENCE_GOLDEN_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x",
+                        os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_reference_golden.py")],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:]
+    assert "8 passed" in r.stdout, r.stdout[-500:]
