@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--utts", type=int, default=65536, help="utterances per GPU")
     ap.add_argument("--voices", type=int, default=1, help="1 = single Voice, 8 = config-4 presets")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4],
+                    help="BASELINE.json config: 2 = 4096 utterances, 3 = the headline (default), "
+                         "4 = 8 voice presets; shorthand for --utts / --voices")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per utterance (0 = auto)")
     ap.add_argument("--variant", type=int, default=0, help="kernel instantiation (experiments)")
     ap.add_argument("--pcm16", action="store_true",
@@ -161,6 +164,12 @@ def main():
     ap.add_argument("--cpu-utts", type=int, default=1536,
                     help="utterances for the CPU baseline (0 = skip); 1536 is ~12-25 s of CPU")
     args = ap.parse_args()
+    if args.config == 2:
+        args.utts, args.voices = 4096, 1
+    elif args.config == 3:
+        args.utts, args.voices = 65536, 1
+    elif args.config == 4:
+        args.utts, args.voices = 65536, 8
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -314,7 +323,7 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         alg_bytes = samples_per_step * (ALG_BYTES_PER_SAMPLE - (2.0 if args.pcm16 else 0.0))
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        cfg = "3" if len(voices) == 1 else "4"
+        cfg = "4" if len(voices) > 1 else ("2" if n_utt == 4096 else "3")
         wl_key = f"config{cfg}_utts{n_utt}" + ("_pcm16" if args.pcm16 else "")
         line = {
             "metric": "audio samples/sec (whole node) at 48 kHz, batch=65536 utterances",
