@@ -259,15 +259,16 @@ def test_rccl_voice_broadcast_single_rank(gpu_ctx):
     G._check(G.load().grail_comm_destroy(gpu_ctx.handle))
 
 
-def test_config3_full_size_on_device_digest(gpu_ctx):
-    """BASELINE config 3 at FULL size (65536 utterances x 2 s, 25 GB of PCM left in HBM): lengths,
-    finiteness and the normalisation bound over all 6.3e9 samples via the on-device digest; a
-    checksum of checksums between two lane mappings (batch invariance at scale); bit parity of a
-    sample of utterances against the oracle through their digests."""
+@pytest.mark.parametrize("n_voices", [1, 8])
+def test_config3_and_4_full_size_on_device_digest(gpu_ctx, n_voices):
+    """BASELINE configs 3 and 4 at FULL size (65536 utterances x 2 s, 25 GB of PCM left in HBM):
+    lengths, finiteness and the normalisation bound over all 6.3e9 samples via the on-device digest;
+    a checksum of checksums between two lane mappings (batch invariance at scale); bit parity of
+    138 utterances spread over the batch against the oracle through their digests."""
     n_utt = 65536
-    voices = W.single_voice()
+    voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
     gpu_ctx.set_voices(voices)
-    segs, offs, vids, seeds = W.make_batch(n_utt)
+    segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=n_voices)
     stride = W.max_samples()
     b = gpu_ctx.upload(segs, offs, vids, seeds)
     d_out = gpu_ctx.device_alloc(n_utt * stride * 4)
@@ -292,7 +293,8 @@ def test_config3_full_size_on_device_digest(gpu_ctx):
         gpu_ctx.device_free(d_len)
         b.free()
     assert np.array_equal(digests[0], digests[2])       # 65536 checksums agree across lane mappings
-    pick = [0, 1, 63, 64, 1023, 1024, 32767, 32768, 65534, 65535]
+    pick = sorted(set([0, 1, 63, 64, 1023, 1024, 32767, 32768, 65534, 65535] +
+                      [int(u) for u in np.random.default_rng(7).integers(0, n_utt, 128)]))
     sub = np.concatenate([segs[offs[u]:offs[u + 1]] for u in pick])
     sub_offs = np.arange(len(pick) + 1, dtype=np.uint32) * 4
     ref, ref_len = O.synthesize_batch(ovoices(voices), sub, sub_offs, vids[pick], seeds[pick], stride)
