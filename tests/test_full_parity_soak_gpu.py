@@ -1,0 +1,58 @@
+"""Soak (opt-in: GRAIL_SOAK=1): EVERY utterance of the full-size batch — 65536 x 96006 = 6.29e9
+samples — against the oracle, through per-utterance checksums (sum of the samples' bit patterns
+mod 2^64, computed on the device for the HIP rows and on the host for the oracle's).  The oracle
+renders the batch in chunks on all host cores; a few minutes of CPU, so it is not part of the
+default suite.  Last run: profiles/r01_full_parity.txt."""
+import os
+
+import numpy as np
+import pytest
+
+import grail_hip as G
+import oracle_lib as O
+from grail_hip import workload as W
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("GRAIL_SOAK") != "1", reason="opt-in soak: GRAIL_SOAK=1")]
+
+
+@pytest.mark.parametrize("n_voices", [1, 8])
+def test_every_utterance_of_the_full_batch(gpu_ctx, n_voices):
+    n_utt = int(os.environ.get("GRAIL_SOAK_UTTS", "65536"))
+    voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
+    ov = [O.Voice.from_buffer_copy(bytes(v)) for v in voices]
+    gpu_ctx.set_voices(voices)
+    segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=n_voices)
+    stride = W.max_samples()
+    b = gpu_ctx.upload(segs, offs, vids, seeds)
+    d_out = gpu_ctx.device_alloc(n_utt * stride * 4)
+    d_len = gpu_ctx.device_alloc(n_utt * 4)
+    try:
+        b.synthesize_async(d_out, stride, d_len)
+        gpu_ctx.sync()
+        out_len = np.zeros(n_utt, dtype=np.uint32)
+        gpu_ctx.d2h(out_len, d_len, n_utt * 4)
+        sums, _, bad = gpu_ctx.digest(d_out, stride, d_len, n_utt)
+    finally:
+        gpu_ctx.device_free(d_out)
+        gpu_ctx.device_free(d_len)
+        b.free()
+    assert bad.sum() == 0
+    threads = len(os.sched_getaffinity(0))
+    chunk = 1024
+    checked = 0
+    for first in range(0, n_utt, chunk):
+        last = min(first + chunk, n_utt)
+        sub = segs[offs[first]:offs[last]]
+        sub_offs = (offs[first:last + 1] - offs[first]).astype(np.uint32)
+        ref, ref_len, _ = O.synthesize_batch_threads(ov, sub, sub_offs, vids[first:last], seeds[first:last],
+                                                     stride, threads)
+        assert np.array_equal(ref_len, out_len[first:last]), first
+        bits = ref.view(np.uint32)
+        mask = np.arange(stride, dtype=np.uint32)[None, :] < ref_len[:, None]
+        want = np.where(mask, bits, 0).astype(np.uint64).sum(axis=1)
+        bad_rows = np.nonzero(want != sums[first:last])[0]
+        assert len(bad_rows) == 0, (first, bad_rows[:8])
+        checked += int(ref_len.astype(np.uint64).sum())
+    print(f"\nfull parity: {n_utt} utterances, {checked} samples, {n_voices} voice(s): "
+          f"every per-utterance checksum equals the oracle's")
