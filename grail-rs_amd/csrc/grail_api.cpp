@@ -110,6 +110,9 @@ struct grail_ctx {
     DevVoice *d_voices = nullptr;
     float *d_voice_elems = nullptr;   // [n_voices * NUM_VOICED][49]
     bool voices_upper_silent = false; // every voice: formants 5-8 have amplitude +0 in every phoneme
+    bool voices_live4_ok = false;     // ... and parameters that keep their output at exactly +0 (live4_ok)
+    float max_dt = 0.0f;              // largest 1/sample_rate of the table
+    int last_formants = 8, last_lanes = 0;   // what the last synthesis launch used (statistics)
     uint32_t *d_truncated = nullptr;  // [0] truncation flag, [1] slow-path wave-steps
     uint64_t slow_steps = 0;          // of the kernels synced so far
     int lanes_option = 0;             // 0 = auto
@@ -139,6 +142,8 @@ struct grail_batch {
     uint32_t max_voice_id = 0;
     bool phoneme_mode = true;
     bool any_blend = false;    // some segment's blend length is not +-2^k (selects the kernel)
+    bool plain = false;        // every length / blend length / pitch finite, blend lengths > 0
+    float min_length = 0.0f;   // shortest segment (plain batches)
 };
 
 namespace {
@@ -207,6 +212,39 @@ int upload_common(grail_ctx *ctx, grail_batch *b, const uint32_t *seg_offsets,
     return GRAIL_OK;
 }
 
+// Can formants 5-8 of this voice be left out of a one-shot render altogether?  They must contribute
+// exactly +0.0 to every sample of the reference's own arithmetic, whatever the segments are (given
+// alpha in [0,1], i.e. no segment shorter than two samples — checked per batch):
+//   amplitude exactly +0 in every phoneme, 0 <= jitter_delta_amplitude/2 <= 1/4  => v0 = tw * (+0) = +-0
+//   breath, turbulence, smoothness in [0,1]                                      => the low-pass state and tw stay finite
+//   frequency and bandwidth inside pair_is_safe's window with the jitter margin  => finite g, k and 0 < a1, a2, a3 < inf
+// and then w1 = a1*(+0) + a2*(+-0) = +0 and the band-pass state never leaves +0 ("Silent
+// formants").  SynthesisElem::silent() (0.25 / 0.25 / 0.25 / 0 / 0 / 0) satisfies all of it.
+bool live4_ok(const grail_voice &v)
+{
+    constexpr float X_LO = 9.5367431640625e-07f, X_HI = 0.5f - 9.5367431640625e-07f;
+    constexpr float W_LO = 1.8189894035458565e-12f, W_HI = 512.0f;
+    const float amp_scale = 0.5f * v.jitter_delta_amplitude;
+    const float jm = 1.002f * std::fabs(v.jitter_delta_formant_frequency);
+    bool ok = (amp_scale >= 0.0f) && (amp_scale <= 0.25f) && (jm <= 1.0f) &&
+              (v.jitter_frequency >= 0.0f) && (v.jitter_frequency <= 1.0f) &&
+              (v.sample_rate > 0.0f) && std::isfinite(v.sample_rate) &&
+              std::isfinite(v.jitter_delta_frequency);
+    for (int p = 0; p < NUM_VOICED && ok; ++p) {
+        const grail_synthesis_elem &e = v.phonemes[p];
+        for (int i = NF / 2; i < NF && ok; ++i) {
+            uint32_t bits;
+            std::memcpy(&bits, &e.formant_amp[i], sizeof bits);
+            const float f = e.formant_freq[i], w = e.formant_bw[i];
+            ok = bits == 0u && e.formant_breath[i] >= 0.0f && e.formant_breath[i] <= 1.0f &&
+                 e.formant_turb[i] >= 0.0f && e.formant_turb[i] <= 1.0f &&
+                 e.formant_smooth[i] >= 0.0f && e.formant_smooth[i] <= 1.0f &&
+                 (f * 0.999f - jm >= X_LO) && (f * 1.001f + jm <= X_HI) && (w >= W_LO) && (w <= W_HI);
+        }
+    }
+    return ok;
+}
+
 int install_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices)
 {
     if (!voices || n_voices == 0) return fail(GRAIL_ERR_INVALID_ARG, "no voices given");
@@ -244,6 +282,13 @@ int install_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices)
                 silent = silent && bits == 0u;
             }
     ctx->voices_upper_silent = silent;
+    ctx->voices_live4_ok = true;
+    ctx->max_dt = 0.0f;
+    for (uint32_t v = 0; v < n_voices; ++v) {
+        ctx->voices_live4_ok = ctx->voices_live4_ok && live4_ok(voices[v]);
+        const float dt = 1.0f / voices[v].sample_rate;
+        if (!(dt <= ctx->max_dt)) ctx->max_dt = dt;       // NaN-proof max
+    }
     return GRAIL_OK;
 }
 
@@ -380,6 +425,14 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
         *value = (int64_t)ctx->slow_steps;
         return GRAIL_OK;
     }
+    if (std::strcmp(name, "last_launch_formants") == 0) {      // read-only: 4 or 8 laid out over the lanes
+        *value = ctx->last_formants;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "last_launch_lanes") == 0) {         // read-only: lanes per utterance chosen
+        *value = ctx->last_lanes;
+        return GRAIL_OK;
+    }
     return fail(GRAIL_ERR_INVALID_ARG, std::string("unknown option ") + name);
 }
 
@@ -396,6 +449,13 @@ int grail_batch_upload(grail_ctx *ctx, const grail_phoneme_elem *segs, const uin
     if (n_segs && !segs) return fail(GRAIL_ERR_INVALID_ARG, "segs is NULL");
     bool any_blend = false;
     for (uint32_t i = 0; i < n_segs && !any_blend; ++i) any_blend = !blend_is_pow2(segs[i].blend_length);
+    bool plain = true;
+    float min_length = INFINITY;
+    for (uint32_t i = 0; i < n_segs; ++i) {
+        plain = plain && std::isfinite(segs[i].length) && std::isfinite(segs[i].blend_length) &&
+                std::isfinite(segs[i].frequency) && segs[i].blend_length > 0.0f;
+        if (segs[i].length < min_length) min_length = segs[i].length;
+    }
     for (uint32_t i = 0; i < n_segs; ++i)
         if (segs[i].phoneme < 0 || segs[i].phoneme >= GRAIL_PH_COUNT)
             return fail(GRAIL_ERR_INVALID_ARG, "phoneme discriminant out of range");
@@ -403,6 +463,8 @@ int grail_batch_upload(grail_ctx *ctx, const grail_phoneme_elem *segs, const uin
     if (!b) return fail(GRAIL_ERR_OUT_OF_MEMORY, "host allocation failed");
     b->phoneme_mode = true;
     b->any_blend = any_blend;
+    b->plain = plain;
+    b->min_length = min_length;
     b->n_segs = n_segs;
     if ((rc = upload(&b->d_segs, segs, n_segs, ctx->stream)) ||
         (rc = upload_common(ctx, b, seg_offsets, voice_ids, jitter_seeds, n_utt))) {
@@ -532,11 +594,24 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     a.skip_silent = ctx->skip_silent_option ? 1u : 0u;
     a.half_capable = (a.skip_silent && batch->phoneme_mode && ctx->voices_upper_silent) ? 1u : 0u;
     a.any_blend = batch->any_blend ? 1u : 0u;
+    // formants 5-8 left out altogether: the table qualifies (live4_ok) and every segment is at least
+    // two samples long, so the Sequencer clock never goes negative and alpha stays in [0,1]
+    a.live4 = (a.half_capable && ctx->voices_live4_ok && batch->plain && !batch->any_blend &&
+               batch->min_length >= 2.0f * ctx->max_dt) ? 1u : 0u;
     int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(batch->n_utt);
-    // voices whose upper formants are never audible: one lane per utterance runs the half-live loop
-    // (46 ms per 2 s alone on a SIMD) and ties two lanes per utterance, whose second lane
-    // would only hold silent formants
-    if (!ctx->lanes_option && L == 2 && a.half_capable) L = 1;
+    // eight lanes per utterance need eight formants to lay out; for batches that small the
+    // 8-lane kernel is also the fastest (18.2 against 18.8 ms: half the rows to flush per wave)
+    if (a.live4 && L == 8) a.live4 = 0u;
+    if (a.live4 && !ctx->lanes_option) {
+        // same rule as auto_lanes_per_utt — the widest mapping with one wave per SIMD — over 4 formants
+        L = ((uint64_t)batch->n_utt * 4 + 63) / 64 <= 1024 ? 4 : ((uint64_t)batch->n_utt * 2 + 63) / 64 <= 1024 ? 2 : 1;
+    }
+    // voices whose upper formants are never audible but that do not qualify for the 4-formant
+    // kernels: one lane per utterance runs the half-live loop and ties two lanes per utterance,
+    // whose second lane would only hold silent formants
+    if (!ctx->lanes_option && !a.live4 && L == 2 && a.half_capable) L = 1;
+    ctx->last_formants = a.live4 ? 4 : 8;
+    ctx->last_lanes = L;
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
     hipError_t e = launch_synth(a, L, ctx->variant_option, ctx->stream);
     if (e != hipSuccess) return hip_fail(e, "synth kernel launch");

@@ -61,6 +61,8 @@ struct SynthArgs {
     uint32_t skip_silent;         // 1: skip the band-pass of formant vectors proven silent (same bits)
     uint32_t half_capable;        // host hint: every voice has amplitude 0 in formants 5-8 of every
                                   // phoneme (phoneme batches), so the half-live loops can be used
+    uint32_t live4;               // host-verified: formants 5-8 contribute exactly +0.0 for the whole
+                                  // batch (see grail_api.cpp live4_ok); selects the NFA = 4 kernels
     uint32_t any_blend;           // host hint: some segment has a blend length that is not +-2^k
     uint32_t *state;              // resumable synthesis: state[word][lane] or nullptr (one-shot)
     uint64_t state_stride;        // lanes of the launch (= state_lanes())

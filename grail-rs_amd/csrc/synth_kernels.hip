@@ -477,10 +477,16 @@ struct StateIO {
 // ANYBL: blend lengths that are not powers of two also take the quiet step (clk / blend_length by
 // the short exact division).  The host asks for it only when the batch holds such a segment, so the
 // usual case (the Intonator always emits 0.5, src/lib.rs:1071) runs a kernel without that code.
-template <int L, int T, int WAVES, int MIN_WAVES_PER_SIMD, bool STREAM, bool HALF, bool ANYBL>
+// NFA: formants laid out over the lanes, 8 or 4.  NFA = 4 (one-shot phoneme batches only) renders
+// formants 1-4 and nothing else: the host has verified (grail_api.cpp, live4_ok) that formants 5-8
+// of every phoneme of every voice have amplitude +0 and parameters for which the reference's own
+// arithmetic keeps their band-pass state and output at exactly +0 for the whole batch, so the fold
+// only gains literal +0.0 terms.
+template <int L, int T, int WAVES, int MIN_WAVES_PER_SIMD, bool STREAM, bool HALF, bool ANYBL, int NFA = NF>
 __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(const SynthArgs A)
 {
-    constexpr int FPL = NF / L;          // formants per lane
+    static_assert(NFA == NF || (NFA == 4 && !STREAM && !HALF), "NFA");
+    constexpr int FPL = NFA / L;         // formants per lane
     constexpr int W = FPL >= 2 ? 2 : 1;  // formants per packed value
     constexpr int NV = FPL / W;          // packed values per lane and field
     typedef typename VecOf<W>::type V;
@@ -493,7 +499,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     // L >= 4: the lanes park all eight band-pass outputs of a sample and the left fold runs at
     // flush time, spread over time steps, instead of a serial chain of L DPP hops per sample
     constexpr bool FOLD_IN_FLUSH = L >= 4;
-    constexpr int STAGE_FLOATS = FOLD_IN_FLUSH ? T * S * NF : T * SP;
+    constexpr int STAGE_FLOATS = FOLD_IN_FLUSH ? T * S * NFA : T * SP;
     __shared__ float stage_all[WAVES][STAGE_FLOATS];
     __shared__ uint32_t cnt_all[WAVES][S];
     const int wave = threadIdx.x / 64;
@@ -821,7 +827,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             for (int k = 0; k < NV; ++k)
 #pragma unroll
                 for (int c = 0; c < W; ++c)
-                    stage[(t * S + slot) * NF + f0 + k * W + c] = vget(v1[k], c);
+                    stage[(t * S + slot) * NFA + f0 + k * W + c] = vget(v1[k], c);
         } else {
             float acc = 0.0f;
 #pragma unroll
@@ -831,6 +837,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 for (int k = 0; k < NV; ++k)
 #pragma unroll
                     for (int c = 0; c < W; ++c) run = run + vget(v1[k], c);
+                if (NFA < NF && step == L - 1) run = run + 0.0f;   // formants 5-8: literal +0.0 terms
                 acc = (j == step) ? run : acc;
             }
             if (j == L - 1) stage[t * SP + slot] = acc * 0.5f;
@@ -927,7 +934,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             for (int k = 0; k < NV; ++k)
 #pragma unroll
                 for (int c = 0; c < W; ++c)
-                    stage[(t * S + slot) * NF + f0 + k * W + c] = vget(v1[k], c);   // silent: +0
+                    stage[(t * S + slot) * NFA + f0 + k * W + c] = vget(v1[k], c);   // silent: +0
         } else {
             float acc = 0.0f;
 #pragma unroll
@@ -938,7 +945,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 #pragma unroll
                     for (int c = 0; c < W; ++c) run = run + vget(v1[k], c);
                 // the silent formants' terms are literal +0.0: ((x + 0) + 0) + ... == x + 0
-                if (NLIVE < NV) run = run + 0.0f;
+                if (NLIVE < NV || (NFA < NF && step == L - 1)) run = run + 0.0f;
                 acc = (j == step) ? run : acc;
             }
             if (j == L - 1) stage[t * SP + slot] = acc * 0.5f;
@@ -1039,7 +1046,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 st_a[0] = sa;
                 st_b[0] = 2.0f * w1 - sb;                                      // :570
                 st_c[0] = 2.0f * w2 - sc;                                      // :571
-                stage[((tc + h) * S + slot) * NF + f0] = w1;
+                stage[((tc + h) * S + slot) * NFA + f0] = w1;
             }
         }
     };
@@ -1148,7 +1155,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 for (int k = 0; k < NV; ++k)
 #pragma unroll
                     for (int c = 0; c < W; ++c)
-                        stage[(t * S + slot) * NF + f0 + k * W + c] = vget(v1[k], c);   // silent: +0
+                        stage[(t * S + slot) * NFA + f0 + k * W + c] = vget(v1[k], c);   // silent: +0
             } else {
                 float acc = 0.0f;
 #pragma unroll
@@ -1158,7 +1165,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     for (int k = 0; k < NLIVE; ++k)
 #pragma unroll
                         for (int c = 0; c < W; ++c) run = run + vget(v1[k], c);
-                    if (NLIVE < NV) run = run + 0.0f;
+                    if (NLIVE < NV || (NFA < NF && step == L - 1)) run = run + 0.0f;
                     acc = (j == step) ? run : acc;
                 }
                 if (j == L - 1) stage[t * SP + slot] = acc * 0.5f;
@@ -1290,10 +1297,11 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 auto sample_at = [&](const int tt) __attribute__((always_inline)) -> float {
                     if constexpr (FOLD_IN_FLUSH) {
                         // v1.sum() * 0.5: the left fold from 0.0 over formants 0..7  :574, :123-125
-                        const float *p = stage + (tt * S + r) * NF;
+                        const float *p = stage + (tt * S + r) * NFA;
                         float run = 0.0f;
 #pragma unroll
-                        for (int f = 0; f < NF; ++f) run = run + p[f];
+                        for (int f = 0; f < NFA; ++f) run = run + p[f];
+                        if (NFA < NF) run = run + 0.0f;   // formants 5-8: literal +0.0 terms
                         return run * 0.5f;
                     } else {
                         return stage[tt * SP + r];
@@ -1426,6 +1434,14 @@ static void launch_one(const SynthArgs &args, hipStream_t stream)
 {
     const uint32_t per_block = (64u / L) * WAVES;
     const dim3 grid((args.n_utt + per_block - 1) / per_block), block(64 * WAVES);
+    if constexpr (L <= 4) {
+        if (!args.state && !args.any_blend && args.live4) {
+            // L = 4 parks 4 floats per sample instead of 8: room for the 64-step tiles of L = 8
+            constexpr int T4 = L == 4 ? 64 : T;
+            hipLaunchKernelGGL((synth_kernel<L, T4, WAVES, MINW, false, false, false, 4>), grid, block, 0, stream, args);
+            return;
+        }
+    }
     if (args.state)
         hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, true, true, true>), grid, block, 0, stream, args);
     else if (args.any_blend)

@@ -172,9 +172,14 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *   "skip_silent_formants": 1 (default) / 0 — formants whose amplitude is exactly 0 in both
  *       elems of a segment pair and whose band-pass state is exactly 0 contribute exactly +0.0;
  *       their band-pass filters are skipped (voices::generic() has four such formants,
- *       src/voices/generic.rs:19,31).  0 forces the literal evaluation of all eight.
+ *       src/voices/generic.rs:19,31).  When in addition the whole voice table and the batch
+ *       guarantee it for every sample (formants 5-8 of every phoneme: amplitude +0, parameters
+ *       inside the safe window; no segment shorter than two samples; one-shot phoneme batches),
+ *       formants 5-8 are not laid out over the lanes at all.  0 forces the literal evaluation
+ *       of all eight.
  *   "kernel_variant": experiments only.
- * Read-only statistic: "slow_division_wave_steps". */
+ * Read-only statistics: "slow_division_wave_steps", "last_launch_formants" (4 or 8),
+ * "last_launch_lanes". */
 int grail_set_option(grail_ctx *ctx, const char *name, int64_t value);
 int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value);
 

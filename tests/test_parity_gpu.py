@@ -427,3 +427,44 @@ def test_calm_tile_boundaries(gpu_ctx, lanes):
             assert_bit_identical(out, out_len, ref, ref_len, f"tile edges L={lanes} stride={stride}")
     finally:
         gpu_ctx.set_option("lanes_per_utterance", 0)
+
+
+def _upper_silent_voice(mutate=None):
+    v = G.voice_generic(48000.0)
+    if mutate:
+        mutate(v)
+    return v
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4])
+def test_four_formant_kernels_and_their_gate(gpu_ctx, lanes):
+    """voices::generic() qualifies for the kernels that lay out formants 1-4 only.  The gate must
+    refuse tables or batches for which formants 5-8 could matter (a dead formant with frequency 0
+    makes the reference itself emit NaN; a segment shorter than two samples lets the clock go
+    negative) and the result must equal the oracle either way, NaN patterns included."""
+    def freq0(v):
+        v.phonemes[1].formant_freq[6] = 0.0
+
+    def breathy(v):
+        v.phonemes[0].formant_breath[5] = 1.5
+
+    def wild_amp_jitter(v):
+        v.jitter_delta_amplitude = 0.9
+
+    n_utt = 70
+    cases = [("generic", None, 0.02, 4), ("dead formant at frequency 0", freq0, 0.02, 8),
+             ("dead formant breath 1.5", breathy, 0.02, 8), ("amplitude jitter 0.9", wild_amp_jitter, 0.02, 8),
+             ("a one-sample segment", None, None, 8)]
+    try:
+        for what, mutate, length, want_formants in cases:
+            voices = [_upper_silent_voice(mutate)]
+            segs, offs, vids, seeds = W.make_batch(n_utt, length=0.02, blend_length=2.0 ** -6)
+            if length is None:
+                segs["length"][5] = np.float32(1.0 / 48000.0)
+            stride = W.max_samples(length=0.02)
+            with np.errstate(all="ignore"):
+                out, out_len, ref, ref_len = run_both(gpu_ctx, voices, segs, offs, vids, seeds, stride, lanes)
+            assert gpu_ctx.get_option("last_launch_formants") == want_formants, what
+            assert_bit_identical(out, out_len, ref, ref_len, f"{what} L={lanes}")
+    finally:
+        gpu_ctx.set_option("lanes_per_utterance", 0)
