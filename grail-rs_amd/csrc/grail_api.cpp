@@ -112,6 +112,7 @@ struct grail_ctx {
     bool voices_upper_silent = false; // every voice: formants 5-8 have amplitude +0 in every phoneme
     bool voices_live4_ok = false;     // ... and parameters that keep their output at exactly +0 (live4_ok)
     float max_dt = 0.0f;              // largest 1/sample_rate of the table
+    float max_pitch_jitter = 0.0f;    // largest |jitter_delta_frequency| of the table
     int last_formants = 8, last_lanes = 0;   // what the last synthesis launch used (statistics)
     uint32_t *d_truncated = nullptr;  // [0] truncation flag, [1] slow-path wave-steps
     uint64_t slow_steps = 0;          // of the kernels synced so far
@@ -144,6 +145,7 @@ struct grail_batch {
     bool any_blend = false;    // some segment's blend length is not +-2^k (selects the kernel)
     bool plain = false;        // every length / blend length / pitch finite, blend lengths > 0
     float min_length = 0.0f;   // shortest segment (plain batches)
+    float min_pitch = 0.0f;    // lowest frequency.min(0.5) of any segment (plain batches)
 };
 
 namespace {
@@ -284,10 +286,13 @@ int install_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices)
     ctx->voices_upper_silent = silent;
     ctx->voices_live4_ok = true;
     ctx->max_dt = 0.0f;
+    ctx->max_pitch_jitter = 0.0f;
     for (uint32_t v = 0; v < n_voices; ++v) {
         ctx->voices_live4_ok = ctx->voices_live4_ok && live4_ok(voices[v]);
         const float dt = 1.0f / voices[v].sample_rate;
         if (!(dt <= ctx->max_dt)) ctx->max_dt = dt;       // NaN-proof max
+        const float pj = std::fabs(voices[v].jitter_delta_frequency);
+        if (!(pj <= ctx->max_pitch_jitter)) ctx->max_pitch_jitter = pj;
     }
     return GRAIL_OK;
 }
@@ -450,11 +455,13 @@ int grail_batch_upload(grail_ctx *ctx, const grail_phoneme_elem *segs, const uin
     bool any_blend = false;
     for (uint32_t i = 0; i < n_segs && !any_blend; ++i) any_blend = !blend_is_pow2(segs[i].blend_length);
     bool plain = true;
-    float min_length = INFINITY;
+    float min_length = INFINITY, min_pitch = INFINITY;
     for (uint32_t i = 0; i < n_segs; ++i) {
         plain = plain && std::isfinite(segs[i].length) && std::isfinite(segs[i].blend_length) &&
                 std::isfinite(segs[i].frequency) && segs[i].blend_length > 0.0f;
         if (segs[i].length < min_length) min_length = segs[i].length;
+        const float pitch = std::fmin(segs[i].frequency, 0.5f);   // copy_with_frequency :445-450
+        if (pitch < min_pitch) min_pitch = pitch;
     }
     for (uint32_t i = 0; i < n_segs; ++i)
         if (segs[i].phoneme < 0 || segs[i].phoneme >= GRAIL_PH_COUNT)
@@ -465,6 +472,7 @@ int grail_batch_upload(grail_ctx *ctx, const grail_phoneme_elem *segs, const uin
     b->any_blend = any_blend;
     b->plain = plain;
     b->min_length = min_length;
+    b->min_pitch = min_pitch;
     b->n_segs = n_segs;
     if ((rc = upload(&b->d_segs, segs, n_segs, ctx->stream)) ||
         (rc = upload_common(ctx, b, seg_offsets, voice_ids, jitter_seeds, n_utt))) {
@@ -594,10 +602,13 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     a.skip_silent = ctx->skip_silent_option ? 1u : 0u;
     a.half_capable = (a.skip_silent && batch->phoneme_mode && ctx->voices_upper_silent) ? 1u : 0u;
     a.any_blend = batch->any_blend ? 1u : 0u;
-    // formants 5-8 left out altogether: the table qualifies (live4_ok) and every segment is at least
-    // two samples long, so the Sequencer clock never goes negative and alpha stays in [0,1]
+    // formants 5-8 left out altogether: the table qualifies (live4_ok); every segment is at least
+    // two samples long, so the Sequencer clock never goes negative and alpha stays in [0,1]; and
+    // every pitch stays >= 2^-20 under the pitch jitter, so the polyBLEP quotient and with it the
+    // saw every formant is fed from stay finite (a dead formant fed +-inf would emit NaN)
     a.live4 = (a.half_capable && ctx->voices_live4_ok && batch->plain && !batch->any_blend &&
-               batch->min_length >= 2.0f * ctx->max_dt) ? 1u : 0u;
+               batch->min_length >= 2.0f * ctx->max_dt &&
+               batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f) ? 1u : 0u;
     int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(batch->n_utt);
     // eight lanes per utterance need eight formants to lay out; for batches that small the
     // 8-lane kernel is also the fastest (18.2 against 18.8 ms: half the rows to flush per wave)

@@ -454,13 +454,15 @@ def test_four_formant_kernels_and_their_gate(gpu_ctx, lanes):
     n_utt = 70
     cases = [("generic", None, 0.02, 4), ("dead formant at frequency 0", freq0, 0.02, 8),
              ("dead formant breath 1.5", breathy, 0.02, 8), ("amplitude jitter 0.9", wild_amp_jitter, 0.02, 8),
-             ("a one-sample segment", None, None, 8)]
+             ("a one-sample segment", None, None, 8), ("a pitch of 1e-30", None, -1.0, 8)]
     try:
         for what, mutate, length, want_formants in cases:
             voices = [_upper_silent_voice(mutate)]
             segs, offs, vids, seeds = W.make_batch(n_utt, length=0.02, blend_length=2.0 ** -6)
             if length is None:
                 segs["length"][5] = np.float32(1.0 / 48000.0)
+            elif length < 0:      # the polyBLEP quotient overflows: +-inf reaches every formant
+                segs["frequency"][9] = np.float32(1e-30)
             stride = W.max_samples(length=0.02)
             with np.errstate(all="ignore"):
                 out, out_len, ref, ref_len = run_both(gpu_ctx, voices, segs, offs, vids, seeds, stride, lanes)
