@@ -343,6 +343,8 @@ def main():
                                        "state contribute exactly +0.0 and their filters are skipped "
                                        "(voices::generic() has 4 of 8 such formants; config 4's "
                                        "presets have none); output bits unchanged",
+                "formants_laid_out": ctx.get_option("last_launch_formants"),
+                "lanes_per_utterance_used": ctx.get_option("last_launch_lanes"),
                 "kernel_ms_all_formants_literal": literal_ms if literal_ms else committed_literal_ms(),
                 "samples_per_s_all_formants_literal":
                     (samples_per_step / (literal_ms * 1e-3)) if literal_ms else None,
