@@ -86,3 +86,55 @@ def test_random_voice_tables_every_lane_mapping(gpu_ctx, seed):
                                       ref[u, :ref_len[u]].view(np.uint32)), (lanes, u)
     finally:
         gpu_ctx.set_option("lanes_per_utterance", 0)
+
+
+def four_formant_voice(rng, rate):
+    """A random voice that qualifies for the four-formant kernels: formants 5-8 silent in every
+    phoneme with ordinary parameters, random formants 1-4 and jitter settings."""
+    from test_oracle_crosscheck import random_voice
+    v = random_voice(rng, rate)
+    g = O.voice_generic(rate)
+    for p in range(2):
+        for i in range(4, 8):
+            v.phonemes[p].formant_amp.v[i] = 0.0          # oracle_lib's Array wraps `v`
+            for field in ("formant_freq", "formant_bw", "formant_smooth", "formant_breath", "formant_turb"):
+                getattr(v.phonemes[p], field).v[i] = getattr(g.phonemes[p], field).v[i]
+    v.jitter_delta_amplitude = float(np.float32(rng.uniform(0, 0.5)))
+    v.jitter_delta_formant_frequency = float(np.float32(rng.uniform(0, 20)) / np.float32(rate))
+    return v
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23] + EXTRA_SEEDS)
+def test_random_batches_four_formant_path(gpu_ctx, seed):
+    """Random batches that pass the four-formant gate (power-of-two blend lengths, segments of at
+    least two samples, ordinary pitches): the kernels that lay out formants 1-4 only, for 1, 2 and 4
+    lanes per utterance, against the oracle (which evaluates all eight) bit for bit."""
+    rng = np.random.default_rng(seed)
+    ovoices = [four_formant_voice(rng, 48000.0) for _ in range(3)]
+    voices = [G.Voice.from_buffer_copy(bytes(v)) for v in ovoices]
+    gpu_ctx.set_voices(voices)
+    segs, offs, vids, seeds = [], [0], [], []
+    for _ in range(90):
+        for _ in range(int(rng.integers(0, 6))):
+            ph = int(rng.choice([G.PH_SILENCE, G.PH_STOP, G.PH_GLIDE, G.PH_A, G.PH_E], p=[.15, .05, .05, .4, .35]))
+            length = float(rng.choice([rng.uniform(0.0005, 0.03), 2.0 ** -int(rng.integers(5, 9)), 2.0 / 48000.0]))
+            segs.append((ph, length, 2.0 ** -int(rng.integers(4, 11)), np.float32(rng.uniform(60, 400)) / np.float32(48000.0)))
+        offs.append(len(segs))
+        vids.append(int(rng.integers(0, len(voices))))
+        seeds.append(int(rng.integers(0, 2 ** 32)))
+    segs = G.segments(segs)
+    offs, vids, seeds = (np.array(a, dtype=np.uint32) for a in (offs, vids, seeds))
+    stride = 10048
+    ref, ref_len = O.synthesize_batch(ovoices, segs, offs, vids, seeds, stride)
+    assert ref_len.max() < stride
+    try:
+        for lanes in (1, 2, 4):
+            gpu_ctx.set_option("lanes_per_utterance", lanes)
+            out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+            assert gpu_ctx.get_option("last_launch_formants") == 4, lanes
+            assert np.array_equal(out_len, ref_len), lanes
+            for u in range(len(ref_len)):
+                assert np.array_equal(out[u, :ref_len[u]].view(np.uint32),
+                                      ref[u, :ref_len[u]].view(np.uint32)), (lanes, u)
+    finally:
+        gpu_ctx.set_option("lanes_per_utterance", 0)
