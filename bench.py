@@ -153,6 +153,8 @@ def main():
                     help="BASELINE.json config: 2 = 4096 utterances, 3 = the headline (default), "
                          "4 = 8 voice presets; shorthand for --utts / --voices")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per utterance (0 = auto)")
+    ap.add_argument("--pipeline", type=int, default=1, choices=[0, 1],
+                    help="0 disables the small-batch producer/consumer kernels (A/B)")
     ap.add_argument("--variant", type=int, default=0, help="kernel instantiation (experiments)")
     ap.add_argument("--pcm16", action="store_true",
                     help="i16 PCM rows (the WAV sink's conversion fused into the store), not the "
@@ -272,6 +274,7 @@ def main():
     batch = ctx.upload(segs, offs, vids, seeds)
     ctx.set_option("lanes_per_utterance", args.lanes)
     ctx.set_option("kernel_variant", args.variant)
+    ctx.set_option("small_batch_pipeline", args.pipeline)
     d_out = ctx.device_alloc(n_utt * stride * (2 if args.pcm16 else 4))
     d_len = ctx.device_alloc(n_utt * 4)
 
@@ -345,6 +348,7 @@ def main():
                                        "presets have none); output bits unchanged",
                 "formants_laid_out": ctx.get_option("last_launch_formants"),
                 "lanes_per_utterance_used": ctx.get_option("last_launch_lanes"),
+                "pipelined": ctx.get_option("last_launch_pipelined"),
                 "kernel_ms_all_formants_literal": literal_ms if literal_ms else committed_literal_ms(),
                 "samples_per_s_all_formants_literal":
                     (samples_per_step / (literal_ms * 1e-3)) if literal_ms else None,

@@ -113,12 +113,13 @@ struct grail_ctx {
     bool voices_live4_ok = false;     // ... and parameters that keep their output at exactly +0 (live4_ok)
     float max_dt = 0.0f;              // largest 1/sample_rate of the table
     float max_pitch_jitter = 0.0f;    // largest |jitter_delta_frequency| of the table
-    int last_formants = 8, last_lanes = 0;   // what the last synthesis launch used (statistics)
+    int last_formants = 8, last_lanes = 0, last_pipe = 0;   // what the last synthesis launch used (statistics)
     uint32_t *d_truncated = nullptr;  // [0] truncation flag, [1] slow-path wave-steps
     uint64_t slow_steps = 0;          // of the kernels synced so far
     int lanes_option = 0;             // 0 = auto
     int variant_option = 0;           // experiments: explicit kernel instantiation
     int skip_silent_option = 1;       // skip band-pass filters of provably silent formants
+    int pipeline_option = 1;          // small qualifying batches: producer/consumer workgroups
     ncclComm_t comm = nullptr;
     uint32_t comm_rank = 0, comm_world = 1;
 };
@@ -403,6 +404,10 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         ctx->skip_silent_option = value ? 1 : 0;
         return GRAIL_OK;
     }
+    if (std::strcmp(name, "small_batch_pipeline") == 0) {
+        ctx->pipeline_option = value ? 1 : 0;
+        return GRAIL_OK;
+    }
     if (std::strcmp(name, "kernel_variant") == 0) {
         if (value < 0 || value > 1) return fail(GRAIL_ERR_INVALID_ARG, "kernel_variant out of range");
         ctx->variant_option = (int)value;
@@ -436,6 +441,14 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
     }
     if (std::strcmp(name, "last_launch_lanes") == 0) {         // read-only: lanes per utterance chosen
         *value = ctx->last_lanes;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "small_batch_pipeline") == 0) {
+        *value = ctx->pipeline_option;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "last_launch_pipelined") == 0) {     // read-only
+        *value = ctx->last_pipe;
         return GRAIL_OK;
     }
     return fail(GRAIL_ERR_INVALID_ARG, std::string("unknown option ") + name);
@@ -610,10 +623,17 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
                batch->min_length >= 2.0f * ctx->max_dt &&
                batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f) ? 1u : 0u;
     int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(batch->n_utt);
+    // small batches leave SIMDs idle: four-wave workgroups (one wave renders 16 utterances, one carries
+    // the per-utterance chain, two prepare the filter coefficients) while there is a CU for each
+    if (a.live4 && !ctx->lanes_option && ctx->pipeline_option &&
+        ((uint64_t)batch->n_utt + 15) / 16 <= 256) {      // one workgroup per CU
+        a.pipe = 1u;
+        L = 4;
+    }
     // eight lanes per utterance need eight formants to lay out; for batches that small the
     // 8-lane kernel is also the fastest (18.2 against 18.8 ms: half the rows to flush per wave)
-    if (a.live4 && L == 8) a.live4 = 0u;
-    if (a.live4 && !ctx->lanes_option) {
+    if (a.live4 && !a.pipe && L == 8) a.live4 = 0u;
+    if (a.live4 && !a.pipe && !ctx->lanes_option) {
         // same rule as auto_lanes_per_utt — the widest mapping with one wave per SIMD — over 4 formants
         L = ((uint64_t)batch->n_utt * 4 + 63) / 64 <= 1024 ? 4 : ((uint64_t)batch->n_utt * 2 + 63) / 64 <= 1024 ? 2 : 1;
     }
@@ -623,6 +643,7 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     if (!ctx->lanes_option && !a.live4 && L == 2 && a.half_capable) L = 1;
     ctx->last_formants = a.live4 ? 4 : 8;
     ctx->last_lanes = L;
+    ctx->last_pipe = a.pipe ? 1 : 0;
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
     hipError_t e = launch_synth(a, L, ctx->variant_option, ctx->stream);
     if (e != hipSuccess) return hip_fail(e, "synth kernel launch");

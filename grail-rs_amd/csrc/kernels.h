@@ -63,6 +63,8 @@ struct SynthArgs {
                                   // phoneme (phoneme batches), so the half-live loops can be used
     uint32_t live4;               // host-verified: formants 5-8 contribute exactly +0.0 for the whole
                                   // batch (see grail_api.cpp live4_ok); selects the NFA = 4 kernels
+    uint32_t pipe;                // live4 batches small enough to leave SIMDs idle: the four-wave
+                                  // pipelined workgroups (synth_kernel<..., PIPE>)
     uint32_t any_blend;           // host hint: some segment has a blend length that is not +-2^k
     uint32_t *state;              // resumable synthesis: state[word][lane] or nullptr (one-shot)
     uint64_t state_stride;        // lanes of the launch (= state_lanes())

@@ -50,6 +50,9 @@
 #ifndef GRAIL_SCALAR_PACK
 #define GRAIL_SCALAR_PACK 1
 #endif
+#ifndef PIPE_PAIRS_PER_PHASE
+#define PIPE_PAIRS_PER_PHASE 2     // PIPE kernels: sample pairs per coefficient wave between barriers
+#endif
 
 namespace grail {
 
@@ -482,10 +485,18 @@ struct StateIO {
 // of every phoneme of every voice have amplitude +0 and parameters for which the reference's own
 // arithmetic keeps their band-pass state and output at exactly +0 for the whole batch, so the fold
 // only gains literal +0.0 terms.
-template <int L, int T, int WAVES, int MIN_WAVES_PER_SIMD, bool STREAM, bool HALF, bool ANYBL, int NFA = NF>
+// PIPE: the four waves of a workgroup share ONE set of 16 utterances (small batches, idle SIMDs).
+// In calm tiles wave 0 runs the filter recurrences, wave 1 the per-utterance chain, waves 2 and 3 the
+// filter coefficients of alternate sample pairs, each stage handing its results on through LDS one
+// round behind the previous one (pipe_chain / pipe_coeffs / pipe_render below).  Outside calm tiles
+// every wave runs the whole step redundantly (only wave 0 stores), so all four carry the same
+// per-utterance state, take the same decisions and meet at the same barriers.
+template <int L, int T, int WAVES, int MIN_WAVES_PER_SIMD, bool STREAM, bool HALF, bool ANYBL, int NFA = NF,
+          bool PIPE = false>
 __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(const SynthArgs A)
 {
     static_assert(NFA == NF || (NFA == 4 && !STREAM && !HALF), "NFA");
+    static_assert(!PIPE || (WAVES == 4 && NFA / L == 1 && L >= 4 && !STREAM && !HALF && !ANYBL && T % 4 == 0), "PIPE");
     constexpr int FPL = NFA / L;         // formants per lane
     constexpr int W = FPL >= 2 ? 2 : 1;  // formants per packed value
     constexpr int NV = FPL / W;          // packed values per lane and field
@@ -500,17 +511,21 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     // flush time, spread over time steps, instead of a serial chain of L DPP hops per sample
     constexpr bool FOLD_IN_FLUSH = L >= 4;
     constexpr int STAGE_FLOATS = FOLD_IN_FLUSH ? T * S * NFA : T * SP;
-    __shared__ float stage_all[WAVES][STAGE_FLOATS];
-    __shared__ uint32_t cnt_all[WAVES][S];
+    __shared__ float stage_all[PIPE ? 1 : WAVES][STAGE_FLOATS];
+    __shared__ uint32_t cnt_all[PIPE ? 1 : WAVES][S];
     const int wave = threadIdx.x / 64;
-    float *stage = stage_all[wave];
-    uint32_t *cnt = cnt_all[wave];
+    float *stage = stage_all[PIPE ? 0 : wave];
+    uint32_t *cnt = cnt_all[PIPE ? 0 : wave];
+    // PIPE: role 0 renders (owns stage, counts, output), role 1 carries the per-utterance chain,
+    // roles 2 and 3 prepare coefficients; `emit` is constant true otherwise
+    const int role = PIPE ? wave : 0;
+    const bool emit = !PIPE || role == 0;
 
     const int lane = threadIdx.x % 64;
     const int slot = lane / L;
     const int j = lane % L;
     const int f0 = j * FPL;
-    const uint32_t u0 = (blockIdx.x * WAVES + wave) * S;
+    const uint32_t u0 = PIPE ? blockIdx.x * S : (blockIdx.x * WAVES + wave) * S;
     const uint32_t u = u0 + slot;
     bool done = u >= A.n_utt;
     const uint32_t uc = done ? 0u : u;
@@ -827,7 +842,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             for (int k = 0; k < NV; ++k)
 #pragma unroll
                 for (int c = 0; c < W; ++c)
-                    stage[(t * S + slot) * NFA + f0 + k * W + c] = vget(v1[k], c);
+                    if (emit) stage[(t * S + slot) * NFA + f0 + k * W + c] = vget(v1[k], c);
         } else {
             float acc = 0.0f;
 #pragma unroll
@@ -934,7 +949,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             for (int k = 0; k < NV; ++k)
 #pragma unroll
                 for (int c = 0; c < W; ++c)
-                    stage[(t * S + slot) * NFA + f0 + k * W + c] = vget(v1[k], c);   // silent: +0
+                    if (emit) stage[(t * S + slot) * NFA + f0 + k * W + c] = vget(v1[k], c);   // silent: +0
         } else {
             float acc = 0.0f;
 #pragma unroll
@@ -1043,6 +1058,125 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 const float v3 = v0 - sc;                                      // :565
                 const float w1 = vget(a1, h) * sb + vget(a2, h) * v3;          // :566
                 const float w2 = (sc + vget(a2, h) * sb) + vget(a3, h) * v3;   // :567
+                st_a[0] = sa;
+                st_b[0] = 2.0f * w1 - sb;                                      // :570
+                st_c[0] = 2.0f * w2 - sc;                                      // :571
+                stage[((tc + h) * S + slot) * NFA + f0] = w1;
+            }
+        }
+    };
+
+    // ---- PIPE: time_packed_steps cut in three, one piece per role, handed on through LDS.
+    //   pipe_chain  (wave 1): clock, alpha, jitter phase, pitch blend and jitter, carrier phase, polyBLEP
+    //                         and saw of samples tc, tc+1 — the per-utterance chain, once for all formants
+    //   pipe_coeffs (waves 2, 3, alternate pairs): blend, jitter, 1-exp(smooth), the low-pass input, the
+    //                         turbulence mix, the jittered amplitude and a1, a2, a3 from that chain
+    //   pipe_render (wave 0): the two filter recurrence steps and the band-pass outputs
+    // Same operations on the same operands in the same order as time_packed_steps.
+    constexpr int QP = PIPE_PAIRS_PER_PHASE;     // sample pairs each coefficient wave handles per phase
+    __shared__ float4 chain_all[PIPE ? 2 : 1][PIPE ? 2 * QP : 1][PIPE ? 3 : 1][PIPE ? 64 : 1];   // [round&1][pair][q][lane]
+    __shared__ float4 ring_all[PIPE ? 2 : 1][PIPE ? 2 * QP : 1][PIPE ? 4 : 1][PIPE ? 64 : 1];
+    __shared__ float hand_all[PIPE ? 3 : 1][PIPE ? 64 : 1];
+    auto pipe_chain = [&](float4 (*dst)[64], const float nz0, const float nz1) __attribute__((always_inline)) {
+        if constexpr (PIPE) {
+            const f2 one2 = vsplat(1.0f, f2());
+            const float clk0 = clk - dt, clk1 = clk0 - dt;                     // :861
+            const float jp0 = jphase + jinc, jp1 = jp0 + jinc;                 // :242 / :291
+            clk = clk1;
+            jphase = jp1;
+            f2 CLK, JP;
+            CLK.x = clk0; CLK.y = clk1; JP.x = jp0; JP.y = jp1;
+            const f2 ratio = CLK * inv_blend_length;
+            f2 alpha;                                                          // :899/:908/:917
+            alpha.x = silent_pair ? 1.0f : __builtin_fminf(ratio.x, 1.0f);
+            alpha.y = silent_pair ? 1.0f : __builtin_fminf(ratio.y, 1.0f);
+            const f2 oma = 1.0f - alpha;
+            const f2 jomp = 1.0f - JP;
+            f2 frequency = X.frequency * oma + Y.frequency * alpha;            // :404-414
+            const f2 n_freq = fn_cur * jomp + fn_next * JP;                    // :254
+            frequency = frequency + n_freq * d_freq;                           // :763
+            // carrier :503-525
+            const f2 omf = 1.0f - frequency;
+            const float ph0 = phase;
+            const bool head0 = ph0 < frequency.x, tail0 = ph0 > omf.x;
+            float ph1 = ph0 + frequency.x;
+            ph1 = (ph1 >= 1.0f) ? ph1 - 1.0f : ph1;
+            const bool head1 = ph1 < frequency.y, tail1 = ph1 > omf.y;
+            const float ph2 = ph1 + frequency.y;
+            phase = (ph2 >= 1.0f) ? ph2 - 1.0f : ph2;
+            f2 PH;
+            PH.x = ph0; PH.y = ph1;
+            const f2 phm1 = PH - 1.0f;
+            f2 dividend;
+            dividend.x = head0 ? ph0 : phm1.x;
+            dividend.y = head1 ? ph1 : phm1.y;
+            const f2 tt = div_exact<true>(dividend, frequency);
+            const f2 tt2 = tt * tt;
+            f2 s_tt2, sgn, polyblep;                                           // see quiet_step
+            s_tt2.x = __uint_as_float(__float_as_uint(tt2.x) ^ (head0 ? 0x80000000u : 0u));
+            s_tt2.y = __uint_as_float(__float_as_uint(tt2.y) ^ (head1 ? 0x80000000u : 0u));
+            sgn.x = head0 ? -1.0f : 1.0f;
+            sgn.y = head1 ? -1.0f : 1.0f;
+            const f2 pb = vfma(vsplat(2.0f, f2()), tt, s_tt2) + sgn;
+            polyblep.x = (head0 | tail0) ? pb.x : 0.0f;
+            polyblep.y = (head1 | tail1) ? pb.y : 0.0f;
+            const f2 saw = vfma(vsplat(2.0f, f2()), PH, -one2) - polyblep;     // :517
+            dst[0][lane] = make_float4(alpha.x, alpha.y, oma.x, oma.y);
+            dst[1][lane] = make_float4(JP.x, JP.y, jomp.x, jomp.y);
+            dst[2][lane] = make_float4(saw.x, saw.y, nz0, nz1);
+        }
+    };
+    auto pipe_coeffs = [&](const float4 (*src)[64], float4 (*dst)[64]) __attribute__((always_inline)) {
+        if constexpr (PIPE) {
+            const float4 c0 = src[0][lane], c1 = src[1][lane], c2 = src[2][lane];
+            f2 alpha, oma, JP, jomp, saw, NZ;
+            alpha.x = c0.x; alpha.y = c0.y; oma.x = c0.z; oma.y = c0.w;
+            JP.x = c1.x; JP.y = c1.y; jomp.x = c1.z; jomp.y = c1.w;
+            saw.x = c2.x; saw.y = c2.y; NZ.x = c2.z; NZ.y = c2.w;
+            f2 e_freq = X.freq[0] * oma + Y.freq[0] * alpha;                   // :404-414
+            const f2 e_bw = X.bw[0] * oma + Y.bw[0] * alpha;
+            const f2 e_smooth = X.smooth[0] * oma + Y.smooth[0] * alpha;
+            const f2 e_breath = X.breath[0] * oma + Y.breath[0] * alpha;
+            const f2 e_turb = X.turb[0] * oma + Y.turb[0] * alpha;
+            f2 e_amp = X.amp[0] * oma + Y.amp[0] * alpha;
+            const f2 n_ff = ff_cur[0] * jomp + ff_next[0] * JP;                // :305
+            const f2 n_fa = fa_cur[0] * jomp + fa_next[0] * JP;
+            e_freq = e_freq + n_ff * d_ffreq;                                  // :764
+            const f2 delta = (n_fa + 1.0f) * amp_scale;                        // :768-769
+            e_amp = e_amp * (1.0f - delta);                                    // :772-773
+            const f2 oml = 1.0f - exp_approx(e_smooth);                        // :535
+            const f2 omx = 1.0f - e_freq, xph = e_freq + 0.5f, hmx = 0.5f - e_freq;
+            const f2 ox = omx * e_freq, ph = xph * hmx;
+            const f2 five = vsplat(5.0f, f2()), m4 = vsplat(-4.0f, f2());
+            const f2 num = ox * vfma(m4, ph, five);
+            const f2 den = (xph * vfma(m4, ox, five)) * hmx;
+            const f2 g = div_exact<true>(num, den);                            // :555
+            const f2 kq = div_exact<true>(e_bw, e_freq);                       // :558
+            const f2 a1 = rcp_exact<true>(1.0f + g * (g + kq));                // :560
+            const f2 a2 = g * a1;                                              // :561
+            const f2 a3 = g * a2;                                              // :562
+            const f2 tmix = (1.0f - e_turb) + NZ * e_turb;                     // :544-545
+            const f2 nw = saw * (1.0f - e_breath) + NZ * e_breath;             // :531
+            dst[0][lane] = make_float4(oml.x, oml.y, nw.x, nw.y);
+            dst[1][lane] = make_float4(tmix.x, tmix.y, e_amp.x, e_amp.y);
+            dst[2][lane] = make_float4(a1.x, a1.y, a2.x, a2.y);
+            dst[3][lane] = make_float4(a3.x, a3.y, 0.0f, 0.0f);
+        }
+    };
+    auto pipe_render = [&](const float4 (*src)[64], const int tc) __attribute__((always_inline)) {
+        if constexpr (PIPE) {
+            const float4 q0 = src[0][lane], q1 = src[1][lane], q2 = src[2][lane], q3 = src[3][lane];
+            const float oml[2] = {q0.x, q0.y}, nw[2] = {q0.z, q0.w}, tmix[2] = {q1.x, q1.y};
+            const float amp[2] = {q1.z, q1.w}, a1[2] = {q2.x, q2.y}, a2[2] = {q2.z, q2.w}, a3[2] = {q3.x, q3.y};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                                      // :538-571
+                float sa = st_a[0], sb = st_b[0], sc = st_c[0];
+                sa = sa + oml[h] * (nw[h] - sa);                               // :538
+                const float tw = sa * tmix[h];
+                const float v0 = tw * amp[h];                                  // :550
+                const float v3 = v0 - sc;                                      // :565
+                const float w1 = a1[h] * sb + a2[h] * v3;                      // :566
+                const float w2 = (sc + a2[h] * sb) + a3[h] * v3;               // :567
                 st_a[0] = sa;
                 st_b[0] = 2.0f * w1 - sb;                                      // :570
                 st_c[0] = 2.0f * w2 - sc;                                      // :571
@@ -1212,7 +1346,55 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     // live the doubled body no longer fits the register file (measured: slower)
                     constexpr int STEPS_PER_TRIP = decltype(nlive_tag)::value <= 2 ? 2 : 1;
                     static_assert(T % STEPS_PER_TRIP == 0, "whole trips");
-                    if constexpr (W == 1 && NV == 1 && FOLD_IN_FLUSH) {
+                    if constexpr (PIPE) {
+                        // Rounds of two sample pairs, three stages one round apart: in phase p wave 1
+                        // writes the chain of round p+2, waves 2 and 3 turn the chain of round p+1 into
+                        // coefficients (one pair each), wave 0 renders round p; one barrier per phase.
+                        constexpr int SPR = 4 * QP;              // samples per round
+                        constexpr int ROUNDS = T / SPR;
+                        static_assert(T % SPR == 0, "whole rounds");
+                        auto noise_at = [&](const int step) __attribute__((always_inline)) {
+                            return __builtin_bit_cast(
+                                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), step));
+                        };
+#pragma unroll 1
+                        for (int ph_ = -2; ph_ < ROUNDS; ++ph_) {
+                            if (role == 1) {
+                                const int m = ph_ + 2;
+                                if (m < ROUNDS) {
+#pragma unroll
+                                    for (int q = 0; q < 2 * QP; ++q)
+                                        pipe_chain(chain_all[m & 1][q], noise_at(SPR * m + 2 * q),
+                                                   noise_at(SPR * m + 2 * q + 1));
+                                }
+                            } else if (role >= 2) {
+                                const int m = ph_ + 1;
+                                if (m >= 0 && m < ROUNDS) {
+#pragma unroll
+                                    for (int q = 0; q < QP; ++q) {
+                                        const int pair = 2 * q + (role - 2);
+                                        pipe_coeffs(chain_all[m & 1][pair], ring_all[m & 1][pair]);
+                                    }
+                                }
+                            } else if (ph_ >= 0) {
+#pragma unroll
+                                for (int q = 0; q < 2 * QP; ++q) pipe_render(ring_all[ph_ & 1][q], SPR * ph_ + 2 * q);
+                            }
+                            __syncthreads();
+                        }
+                        // every wave takes over the clocks the chain wave arrived at
+                        if (role == 1) {
+                            hand_all[0][lane] = clk;
+                            hand_all[1][lane] = jphase;
+                            hand_all[2][lane] = phase;
+                        }
+                        __syncthreads();
+                        if (role != 1) {
+                            clk = hand_all[0][lane];
+                            jphase = hand_all[1][lane];
+                            phase = hand_all[2][lane];
+                        }
+                    } else if constexpr (W == 1 && NV == 1 && FOLD_IN_FLUSH) {
 #pragma unroll 1
                         for (int tc = 0; tc < T; tc += 2) {
                             const float nz0 = __builtin_bit_cast(
@@ -1280,6 +1462,10 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         }
 
         // ---- flush the staged tile: row `slot` holds samples [base, base+T)
+        if (!emit) {      // PIPE: only the rendering wave has something to flush
+            if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+            continue;
+        }
         if (j == L - 1) cnt[slot] = n_out > base ? n_out - base : 0u;
         wave_lds_sync();
         constexpr int ROW_LANES = T / 4;
@@ -1343,7 +1529,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
     }
 
-    if (j == L - 1 && u < A.n_utt) {
+    if (emit && j == L - 1 && u < A.n_utt) {
         if (A.out_len) A.out_len[u] = n_out;
         if (truncated) atomicOr(A.truncated, 1u);
     }
@@ -1351,7 +1537,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         StateIO<false> io{A.state, A.state_stride, state_lane};
         visit_state(io);
     }
-    if (lane == 0 && slow_steps) atomicAdd(A.truncated + 1, slow_steps);
+    if (emit && lane == 0 && slow_steps) atomicAdd(A.truncated + 1, slow_steps);
 }
 
 // Sequencer clock only (src/lib.rs:861-888, :930): how many elems the
@@ -1455,6 +1641,12 @@ static void launch_one(const SynthArgs &args, hipStream_t stream)
 hipError_t launch_synth(const SynthArgs &args, int L, int variant, hipStream_t stream)
 {
     if (args.n_utt == 0) return hipSuccess;
+    if (args.pipe && args.live4 && !args.state && !args.any_blend) {
+        // 16 utterances (4 lanes each) per workgroup of four waves: render, chain, 2 x coefficients
+        const dim3 grid((args.n_utt + 15) / 16), block(256);
+        hipLaunchKernelGGL((synth_kernel<4, 64, 4, 1, false, false, false, 4, true>), grid, block, 0, stream, args);
+        return hipGetLastError();
+    }
     // 64-thread workgroups are admitted 8 per CU (2 waves per SIMD, measured); L = 4 / 8 use
     // 256-thread workgroups so that more waves can be resident.  variant 1 (experiments only):
     // 256-thread workgroups for L = 1 / 2 as well.

@@ -177,9 +177,12 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       inside the safe window; no segment shorter than two samples; one-shot phoneme batches),
  *       formants 5-8 are not laid out over the lanes at all.  0 forces the literal evaluation
  *       of all eight.
+ *   "small_batch_pipeline": 1 (default) / 0 — batches of at most 4096 utterances that qualify
+ *       for the four-formant layout run four-wave workgroups (render / per-utterance chain /
+ *       2 x filter coefficients, handed on through LDS) instead of one wave per 8 utterances.
  *   "kernel_variant": experiments only.
  * Read-only statistics: "slow_division_wave_steps", "last_launch_formants" (4 or 8),
- * "last_launch_lanes". */
+ * "last_launch_lanes", "last_launch_pipelined". */
 int grail_set_option(grail_ctx *ctx, const char *name, int64_t value);
 int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value);
 

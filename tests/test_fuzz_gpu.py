@@ -128,10 +128,11 @@ def test_random_batches_four_formant_path(gpu_ctx, seed):
     ref, ref_len = O.synthesize_batch(ovoices, segs, offs, vids, seeds, stride)
     assert ref_len.max() < stride
     try:
-        for lanes in (1, 2, 4):
+        for lanes in (0, 1, 2, 4):          # 0 = auto: the small-batch pipeline (four-wave workgroups)
             gpu_ctx.set_option("lanes_per_utterance", lanes)
             out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
             assert gpu_ctx.get_option("last_launch_formants") == 4, lanes
+            assert gpu_ctx.get_option("last_launch_pipelined") == (1 if lanes == 0 else 0), lanes
             assert np.array_equal(out_len, ref_len), lanes
             for u in range(len(ref_len)):
                 assert np.array_equal(out[u, :ref_len[u]].view(np.uint32),

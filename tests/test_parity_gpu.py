@@ -470,3 +470,24 @@ def test_four_formant_kernels_and_their_gate(gpu_ctx, lanes):
             assert_bit_identical(out, out_len, ref, ref_len, f"{what} L={lanes}")
     finally:
         gpu_ctx.set_option("lanes_per_utterance", 0)
+
+
+@pytest.mark.parametrize("n_utt", [1, 17, 300])
+def test_small_batch_pipeline_is_bit_exact(gpu_ctx, n_utt):
+    """Small qualifying batches run four-wave workgroups: one wave renders 16 utterances, one carries
+    the per-utterance chain, two prepare the filter coefficients, LDS rings and barriers in between.
+    Whole 2-second utterances (hundreds of calm tiles, segment boundaries, jitter wraps), a partly
+    filled last workgroup, and the same batch with the pipeline switched off: all equal the oracle."""
+    voices = W.single_voice()
+    segs, offs, vids, seeds = W.make_batch(n_utt)              # config-3 utterances: 4 x 0.5 s
+    stride = W.max_samples()
+    ref, ref_len = O.synthesize_batch(ovoices(voices), segs, offs, vids, seeds, stride)
+    try:
+        for pipeline in (1, 0):
+            gpu_ctx.set_option("small_batch_pipeline", pipeline)
+            gpu_ctx.set_voices(voices)
+            out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+            assert gpu_ctx.get_option("last_launch_pipelined") == pipeline
+            assert_bit_identical(out, out_len, ref, ref_len, f"pipeline={pipeline} n={n_utt}")
+    finally:
+        gpu_ctx.set_option("small_batch_pipeline", 1)
