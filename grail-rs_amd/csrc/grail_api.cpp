@@ -60,6 +60,8 @@ struct Rccl {
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t,
                               hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -68,11 +70,10 @@ Rccl &rccl()
 {
     static Rccl r = [] {
         Rccl x;
-        // Single-node defaults (never override the user's): the ranks of one xGMI node meet over
-        // loopback; probing InfiniBand / every network interface only costs start-up time
-        // (measured: up to 2 minutes on a box without a network).
-        setenv("NCCL_IB_DISABLE", "1", 0);
-        setenv("NCCL_SOCKET_IFNAME", "lo", 0);
+        // The process environment is the host application's: nothing is set here.  A single-node
+        // launcher that wants RCCL to skip the InfiniBand / interface probing (up to 2 minutes on a
+        // box without a network) exports NCCL_IB_DISABLE=1 NCCL_SOCKET_IFNAME=lo itself, as bench.py
+        // and the tests do.
         // The ROCm installation's RCCL by absolute path first: a bare "librccl.so" would be
         // satisfied by any copy the host process already holds (PyTorch wheels bundle one that
         // is bound to their own private HIP runtime, not to the one this library links).
@@ -86,6 +87,8 @@ Rccl &rccl()
         x.CommInitRank = (decltype(x.CommInitRank))dlsym(x.handle, "ncclCommInitRank");
         x.Broadcast = (decltype(x.Broadcast))dlsym(x.handle, "ncclBroadcast");
         x.CommDestroy = (decltype(x.CommDestroy))dlsym(x.handle, "ncclCommDestroy");
+        x.CommCount = (decltype(x.CommCount))dlsym(x.handle, "ncclCommCount");
+        x.CommUserRank = (decltype(x.CommUserRank))dlsym(x.handle, "ncclCommUserRank");
         x.GetErrorString = (decltype(x.GetErrorString))dlsym(x.handle, "ncclGetErrorString");
         x.ok = x.GetUniqueId && x.CommInitRank && x.Broadcast && x.CommDestroy;
         return x;
@@ -120,6 +123,8 @@ struct grail_ctx {
     int variant_option = 0;           // experiments: explicit kernel instantiation
     int skip_silent_option = 1;       // skip band-pass filters of provably silent formants
     int pipeline_option = 1;          // small qualifying batches: producer/consumer workgroups
+    int fast_option = 0;              // "arithmetic": 0 exact (bit-identical), 1 fast (stated tolerance)
+    std::string last_kernel = "none"; // instantiation of the last synthesis launch
     ncclComm_t comm = nullptr;
     uint32_t comm_rank = 0, comm_world = 1;
 };
@@ -272,9 +277,12 @@ int install_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices)
     ctx->d_voice_elems = nullptr;
     HIP_TRY(hipMalloc((void **)&ctx->d_voices, dv.size() * sizeof(DevVoice)));
     HIP_TRY(hipMalloc((void **)&ctx->d_voice_elems, elems.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(ctx->d_voices, dv.data(), dv.size() * sizeof(DevVoice), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ctx->d_voice_elems, elems.data(), elems.size() * sizeof(float),
-                      hipMemcpyHostToDevice));
+    // on the context's own (non-blocking) stream: ordered with the kernels that read the table
+    HIP_TRY(hipMemcpyAsync(ctx->d_voices, dv.data(), dv.size() * sizeof(DevVoice), hipMemcpyHostToDevice,
+                           ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->d_voice_elems, elems.data(), elems.size() * sizeof(float),
+                           hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // dv / elems are locals
     ctx->voices.assign(voices, voices + n_voices);
     bool silent = true;
     for (uint32_t v = 0; v < n_voices; ++v)
@@ -351,7 +359,8 @@ int grail_create(int device, grail_ctx **out)
         (err = hipEventCreate(&ctx->ev_start)) != hipSuccess ||
         (err = hipEventCreate(&ctx->ev_stop)) != hipSuccess ||
         (err = hipMalloc((void **)&ctx->d_truncated, 2 * sizeof(uint32_t))) != hipSuccess ||
-        (err = hipMemset(ctx->d_truncated, 0, 2 * sizeof(uint32_t))) != hipSuccess) {
+        (err = hipMemsetAsync(ctx->d_truncated, 0, 2 * sizeof(uint32_t), ctx->stream)) != hipSuccess ||
+        (err = hipStreamSynchronize(ctx->stream)) != hipSuccess) {
         grail_destroy(ctx);
         return hip_fail(err, "grail_create");
     }
@@ -408,6 +417,11 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         ctx->pipeline_option = value ? 1 : 0;
         return GRAIL_OK;
     }
+    if (std::strcmp(name, "arithmetic") == 0) {
+        if (value != 0 && value != 1) return fail(GRAIL_ERR_INVALID_ARG, "arithmetic must be 0 (exact) or 1 (fast)");
+        ctx->fast_option = (int)value;
+        return GRAIL_OK;
+    }
     if (std::strcmp(name, "kernel_variant") == 0) {
         if (value < 0 || value > 1) return fail(GRAIL_ERR_INVALID_ARG, "kernel_variant out of range");
         ctx->variant_option = (int)value;
@@ -429,6 +443,10 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
     }
     if (std::strcmp(name, "skip_silent_formants") == 0) {
         *value = ctx->skip_silent_option;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "arithmetic") == 0) {
+        *value = ctx->fast_option;
         return GRAIL_OK;
     }
     if (std::strcmp(name, "slow_division_wave_steps") == 0) {  // read-only statistic
@@ -622,10 +640,11 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     a.live4 = (a.half_capable && ctx->voices_live4_ok && batch->plain && !batch->any_blend &&
                batch->min_length >= 2.0f * ctx->max_dt &&
                batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f) ? 1u : 0u;
+    a.fast = ctx->fast_option ? 1u : 0u;
     int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(batch->n_utt);
     // small batches leave SIMDs idle: four-wave workgroups (one wave renders 16 utterances, one carries
     // the per-utterance chain, two prepare the filter coefficients) while there is a CU for each
-    if (a.live4 && !ctx->lanes_option && ctx->pipeline_option &&
+    if (a.live4 && !a.fast && !ctx->lanes_option && ctx->pipeline_option &&
         ((uint64_t)batch->n_utt + 15) / 16 <= 256) {      // one workgroup per CU
         a.pipe = 1u;
         L = 4;
@@ -647,6 +666,7 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
     hipError_t e = launch_synth(a, L, ctx->variant_option, ctx->stream);
     if (e != hipSuccess) return hip_fail(e, "synth kernel launch");
+    ctx->last_kernel = last_kernel_name();
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->have_timing = true;
     return GRAIL_OK;
@@ -723,6 +743,7 @@ static int stream_next(grail_ctx *ctx, grail_stream *stream, uint32_t max_sample
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
     hipError_t e = launch_synth(a, stream->L, stream->variant, ctx->stream);
     if (e != hipSuccess) return hip_fail(e, "synth kernel launch");
+    ctx->last_kernel = last_kernel_name();
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->have_timing = true;
     stream->started = true;
@@ -756,11 +777,16 @@ int grail_sync(grail_ctx *ctx)
 {
     int rc = bind(ctx);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // flag read-back and reset travel on the stream the kernels run on (a non-blocking stream has
+    // no implicit ordering with the null stream)
     uint32_t flags[2] = {0, 0};
-    HIP_TRY(hipMemcpy(flags, ctx->d_truncated, sizeof flags, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(flags, ctx->d_truncated, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     const uint32_t flag = flags[0];
-    if (flags[0] || flags[1]) HIP_TRY(hipMemset(ctx->d_truncated, 0, sizeof flags));
+    if (flags[0] || flags[1]) {
+        HIP_TRY(hipMemsetAsync(ctx->d_truncated, 0, sizeof flags, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
     ctx->slow_steps += flags[1];
     if (flag) {
         return fail(GRAIL_ERR_BUFFER_TOO_SMALL,
@@ -768,6 +794,8 @@ int grail_sync(grail_ctx *ctx)
     }
     return GRAIL_OK;
 }
+
+const char *grail_last_kernel_name(grail_ctx *ctx) { return ctx ? ctx->last_kernel.c_str() : "none"; }
 
 int grail_last_kernel_ms(grail_ctx *ctx, float *ms)
 {
@@ -884,6 +912,34 @@ int grail_batch_digest(grail_ctx *ctx, const float *in_dev, uint64_t in_stride,
     if (d_m) (void)hipFree(d_m);
     if (d_b) (void)hipFree(d_b);
     if (e != hipSuccess) return hip_fail(e, "grail_batch_digest");
+    return GRAIL_OK;
+}
+
+int grail_batch_compare(grail_ctx *ctx, const float *a_dev, const float *b_dev, uint64_t stride,
+                        const uint32_t *len_a_dev, const uint32_t *len_b_dev, uint32_t n_utt, float *maxdiff,
+                        double *sumsq, uint32_t *mismatches)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (n_utt == 0) return GRAIL_OK;
+    if (!a_dev || !b_dev || !len_a_dev || !len_b_dev || !maxdiff || !sumsq || !mismatches)
+        return fail(GRAIL_ERR_INVALID_ARG, "NULL buffer");
+    float *d_m = nullptr;
+    double *d_q = nullptr;
+    uint32_t *d_b = nullptr;
+    hipError_t e = hipMalloc((void **)&d_m, (size_t)n_utt * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_q, (size_t)n_utt * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_b, (size_t)n_utt * 4);
+    if (e == hipSuccess)
+        e = launch_compare(a_dev, b_dev, stride, len_a_dev, len_b_dev, n_utt, d_m, d_q, d_b, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(maxdiff, d_m, (size_t)n_utt * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(sumsq, d_q, (size_t)n_utt * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(mismatches, d_b, (size_t)n_utt * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (d_m) (void)hipFree(d_m);
+    if (d_q) (void)hipFree(d_q);
+    if (d_b) (void)hipFree(d_b);
+    if (e != hipSuccess) return hip_fail(e, "grail_batch_compare");
     return GRAIL_OK;
 }
 
@@ -1067,6 +1123,24 @@ int grail_broadcast_voices(grail_ctx *ctx, uint32_t n_voices, uint32_t root)
     if (e != hipSuccess) return hip_fail(e, "voice blob download");
     if (ctx->comm_rank == root) return GRAIL_OK;  // already installed
     return install_voices(ctx, got.data(), n_voices);
+}
+
+int grail_comm_info(grail_ctx *ctx, uint32_t *ranks, uint32_t *rank)
+{
+    if (!ctx) return fail(GRAIL_ERR_INVALID_ARG, "ctx is NULL");
+    if (ranks) *ranks = 0;
+    if (rank) *rank = 0;
+    if (!ctx->comm) return GRAIL_OK;              // no communicator: 0 ranks
+    if (!rccl().ok || !rccl().CommCount || !rccl().CommUserRank)
+        return fail(GRAIL_ERR_RCCL, "librccl.so lacks ncclCommCount / ncclCommUserRank");
+    int n = 0, r = 0;
+    ncclResult_t e = rccl().CommCount(ctx->comm, &n);
+    if (e != ncclSuccess) return rccl_fail(e, "ncclCommCount");
+    e = rccl().CommUserRank(ctx->comm, &r);
+    if (e != ncclSuccess) return rccl_fail(e, "ncclCommUserRank");
+    if (ranks) *ranks = (uint32_t)n;
+    if (rank) *rank = (uint32_t)r;
+    return GRAIL_OK;
 }
 
 int grail_comm_destroy(grail_ctx *ctx)

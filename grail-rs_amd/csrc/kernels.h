@@ -65,6 +65,7 @@ struct SynthArgs {
                                   // batch (see grail_api.cpp live4_ok); selects the NFA = 4 kernels
     uint32_t pipe;                // live4 batches small enough to leave SIMDs idle: the four-wave
                                   // pipelined workgroups (synth_kernel<..., PIPE>)
+    uint32_t fast;                // tolerance-mode arithmetic in calm tiles (option "arithmetic" = 1)
     uint32_t any_blend;           // host hint: some segment has a blend length that is not +-2^k
     uint32_t *state;              // resumable synthesis: state[word][lane] or nullptr (one-shot)
     uint64_t state_stride;        // lanes of the launch (= state_lanes())
@@ -82,6 +83,8 @@ struct LenArgs {
     uint32_t max_len;
 };
 
+// the instantiation the calling thread's last launch_synth started, e.g. "synth_kernel<L=1,T=32,...>"
+const char *last_kernel_name();
 // lanes_per_utt in {1, 2, 4, 8}; returns hipSuccess or the launch error.
 hipError_t launch_synth(const SynthArgs &args, int lanes_per_utt, int variant, hipStream_t stream);
 hipError_t launch_lengths(const LenArgs &args, hipStream_t stream);
@@ -92,6 +95,10 @@ hipError_t launch_pcm16(const float *in, uint64_t in_stride, const uint32_t *len
 hipError_t launch_digest(const float *in, uint64_t in_stride, const uint32_t *len, uint32_t n_utt,
                          unsigned long long *sums, float *maxabs, uint32_t *nonfinite,
                          hipStream_t stream);
+// per-row distance of two renderings: max |a-b|, sum of squared differences, structural mismatches
+hipError_t launch_compare(const float *a, const float *b, uint64_t stride, const uint32_t *len_a,
+                          const uint32_t *len_b, uint32_t n_utt, float *maxdiff, double *sumsq, uint32_t *bad,
+                          hipStream_t stream);
 // resumable synthesis: words per lane and lanes per launch of the state buffer
 uint32_t state_words(int lanes_per_utt);
 uint64_t state_lanes(uint32_t n_utt, int lanes_per_utt, int variant);

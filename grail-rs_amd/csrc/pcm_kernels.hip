@@ -81,7 +81,65 @@ __global__ __launch_bounds__(256) void digest_kernel(const float *__restrict__ i
     }
 }
 
+// Per-row distance between two renderings of the same batch (tolerance mode against exact mode at
+// sizes no CPU oracle reaches): the largest |a - b|, the sum of squared differences, and the number of
+// samples at which exactly one of the two is non-finite or the lengths disagree.
+__global__ __launch_bounds__(256) void compare_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                      uint64_t stride, const uint32_t *__restrict__ len_a,
+                                                      const uint32_t *__restrict__ len_b,
+                                                      float *__restrict__ maxdiff, double *__restrict__ sumsq,
+                                                      uint32_t *__restrict__ bad)
+{
+    const uint32_t u = blockIdx.x;
+    const uint32_t n = len_a[u];
+    const float *ra = a + (uint64_t)u * stride;
+    const float *rb = b + (uint64_t)u * stride;
+    float m = 0.0f;
+    double q = 0.0;
+    uint32_t nb = (threadIdx.x == 0 && len_b[u] != n) ? 1u : 0u;
+    for (uint32_t t = threadIdx.x; t < n; t += 256u) {
+        const float d = __builtin_fabsf(ra[t] - rb[t]);
+        if (!(d <= 3.4028234663852886e38f)) {
+            // both NaN / both the same infinity count as equal; anything else is a mismatch
+            if (__float_as_uint(ra[t]) != __float_as_uint(rb[t]) && !(ra[t] != ra[t] && rb[t] != rb[t])) ++nb;
+        } else {
+            m = d > m ? d : m;
+            q += (double)d * (double)d;
+        }
+    }
+    __shared__ float sm[256];
+    __shared__ double sq[256];
+    __shared__ uint32_t sb[256];
+    sm[threadIdx.x] = m;
+    sq[threadIdx.x] = q;
+    sb[threadIdx.x] = nb;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) {
+            sm[threadIdx.x] = sm[threadIdx.x] > sm[threadIdx.x + k] ? sm[threadIdx.x] : sm[threadIdx.x + k];
+            sq[threadIdx.x] += sq[threadIdx.x + k];
+            sb[threadIdx.x] += sb[threadIdx.x + k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        maxdiff[u] = sm[0];
+        sumsq[u] = sq[0];
+        bad[u] = sb[0];
+    }
+}
+
 }  // namespace
+
+hipError_t launch_compare(const float *a, const float *b, uint64_t stride, const uint32_t *len_a,
+                          const uint32_t *len_b, uint32_t n_utt, float *maxdiff, double *sumsq, uint32_t *bad,
+                          hipStream_t stream)
+{
+    if (n_utt == 0) return hipSuccess;
+    hipLaunchKernelGGL(compare_kernel, dim3(n_utt), dim3(256), 0, stream, a, b, stride, len_a, len_b, maxdiff,
+                       sumsq, bad);
+    return hipGetLastError();
+}
 
 hipError_t launch_digest(const float *in, uint64_t in_stride, const uint32_t *len, uint32_t n_utt,
                          unsigned long long *sums, float *maxabs, uint32_t *nonfinite,

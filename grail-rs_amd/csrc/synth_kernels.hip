@@ -42,6 +42,7 @@
 // therefore written on float2 values, which hipcc lowers to v_pk_mul_f32 / v_pk_add_f32 /
 // v_pk_fma_f32: two formants per issue slot, each component still an individually
 // rounded IEEE operation.
+#include <cstdio>
 #include <type_traits>
 
 #include "kernels.h"
@@ -491,10 +492,16 @@ struct StateIO {
 // round behind the previous one (pipe_chain / pipe_coeffs / pipe_render below).  Outside calm tiles
 // every wave runs the whole step redundantly (only wave 0 stores), so all four carry the same
 // per-utterance state, take the same decisions and meet at the same barriers.
+// FAST: calm tiles run the tolerance-mode arithmetic (fast_tile below): the discontinuous per-utterance
+// state (Sequencer clock, jitter phase, carrier phase, the LCGs) is advanced exactly as in the exact
+// kernels, so no segment boundary, noise wrap or saw edge ever moves; the continuous per-formant
+// arithmetic uses fused multiply-adds, one uncorrected reciprocal per formant, and filter
+// coefficients interpolated linearly across the tile.  Tiles with an event run the exact steps.
 template <int L, int T, int WAVES, int MIN_WAVES_PER_SIMD, bool STREAM, bool HALF, bool ANYBL, int NFA = NF,
-          bool PIPE = false>
+          bool PIPE = false, bool FAST = false>
 __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(const SynthArgs A)
 {
+    static_assert(!FAST || !PIPE, "FAST");
     static_assert(NFA == NF || (NFA == 4 && !STREAM && !HALF), "NFA");
     static_assert(!PIPE || (WAVES == 4 && NFA / L == 1 && L >= 4 && !STREAM && !HALF && !ANYBL && T % 4 == 0), "PIPE");
     constexpr int FPL = NFA / L;         // formants per lane
@@ -1307,6 +1314,295 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         }
     };
 
+
+    // ---- FAST: one calm tile of T samples in tolerance-mode arithmetic.
+    // Exact, as everywhere: clk (:861), alpha, the pitch blend and its jitter (:404, :254, :763), the
+    // jitter phase (:242) and the carrier phase with its wrap (:520-525) — two samples per packed
+    // slot, the same operations on the same operands as the exact kernels.  Within tolerance:
+    //   * the polyBLEP quotient (:505/:509) is dividend * v_rcp(frequency);
+    //   * the band-pass (:560-571) is used in the algebraically equal form a2 = g a1, a3 = g a2 =>
+    //     v1 = a1 (b + g v3),  v2 = c + g v1,  so only a1 and g = tan_approx(x) are needed per sample;
+    //   * per formant, everything that is a smooth function of (alpha, jitter phase) — a1, g, the
+    //     jittered amplitude G, amplitude x turbulence H, breath, 1 - exp_approx(smooth) — is evaluated
+    //     at the ends of sub-tiles of TS <= 32 samples and interpolated linearly in between (alpha and the
+    //     jitter phase are linear in time inside a calm tile; a tile that holds the kink of
+    //     alpha = min(., 1) is not calm).  The end of a sub-tile is the start of the next one.
+    //   * the interpolation error is bounded per wave when a run of calm tiles starts (after every
+    //     event): a relative change r of a1, g or 1 - exp_approx over 32 samples gives an error below
+    //     r^2/16 <= 2^-23 for r <= 2^-9.5 (g is close to linear in x: far below that); G and H are
+    //     products of linear functions, error <= |dA dM| / 4 and |dT dG| / 4 <= 2^-22 absolute.
+    //     Faster parameter motion halves TS (error / 4) until it fits; below TS = 2 the tile takes the
+    //     exact steps.  The reference's own front end always emits 0.5 s blends (Intonator :1070-1071),
+    //     for which TS = 32.
+    //   * :531 as saw + breath (noise - saw), :538 as fma, :544-550 as a (G + H (noise - 1)), the
+    //     eight-term sum (:574) in tree order.
+    struct FastEnds {
+        V a1[NV], tg[NV], g[NV], h[NV], b[NV], om[NV];   // tg = tan_approx(x), g = amplitude
+        float oml;
+    };
+    struct FastAux {
+        V ap[NV], mu[NV], tb[NV];
+    };
+    FastEnds FS;             // the interpolated quantities at the first sample of the NEXT tile, kept while calm
+                             // tiles follow each other
+    int fast_have = -1;      // which flavour (NLIVE * 2 + SU) stored FS; -1: nothing kept
+    int fast_shift = 0;      // sub-tile length 32 >> fast_shift, chosen when a run of calm tiles starts
+    auto fast_tile = [&](auto nlive_tag, auto su_tag, const float noise_of_lane,
+                         const bool idle_lane) __attribute__((always_inline)) -> bool {
+        constexpr int NLIVE = decltype(nlive_tag)::value;
+        constexpr bool SU = decltype(su_tag)::value;
+        constexpr bool KEEP_LP = STREAM;
+        constexpr int NLP = (NLIVE < NV && !KEEP_LP) ? NLIVE : NV;
+        constexpr int TS0 = 32;
+        static_assert(T % TS0 == 0, "whole sub-tiles");
+        constexpr int FLAVOUR = NLIVE * 2 + (SU ? 1 : 0);
+        const V one = vsplat(1.0f, V());
+        const V five = vsplat(5.0f, V()), m4 = vsplat(-4.0f, V());
+        // the smooth quantities `after` samples from now (the clock and the jitter phase extrapolated:
+        // they only feed continuous functions here).  SLOPE: e receives (value - FS) * scale instead.
+        auto endpoint = [&](auto slope_tag, const float after, const float scale, FastEnds &e,
+                            FastAux &x) __attribute__((always_inline)) {
+            constexpr bool SLOPE = decltype(slope_tag)::value;
+            const float c = clk - after * dt;
+            const float jp = jphase + after * jinc;
+            float alpha = __builtin_fminf(c * inv_blend_length, 1.0f);
+            alpha = silent_pair ? 1.0f : alpha;
+            const float oma = 1.0f - alpha, jomp = 1.0f - jp;
+            auto put = [&](V &dst, const V &start, const V value) __attribute__((always_inline)) {
+                if constexpr (SLOPE) dst = (value - start) * scale;
+                else dst = value;
+            };
+#pragma unroll
+            for (int k = 0; k < NLIVE; ++k) {
+                V ef = vfma(Y.freq[k], vsplat(alpha, V()), X.freq[k] * oma);
+                const V eb = vfma(Y.bw[k], vsplat(alpha, V()), X.bw[k] * oma);
+                const V et = vfma(Y.turb[k], vsplat(alpha, V()), X.turb[k] * oma);
+                const V ea = vfma(Y.amp[k], vsplat(alpha, V()), X.amp[k] * oma);
+                const V nff = vfma(ff_next[k], vsplat(jp, V()), ff_cur[k] * jomp);
+                const V nfa = vfma(fa_next[k], vsplat(jp, V()), fa_cur[k] * jomp);
+                ef = vfma(nff, vsplat(d_ffreq, V()), ef);
+                const V mul = vfma(nfa + 1.0f, vsplat(-amp_scale, V()), one);
+                const V omx = 1.0f - ef, xph = ef + 0.5f, hmx = 0.5f - ef;
+                const V ox = omx * ef, ph = xph * hmx;
+                const V num = ox * vfma(m4, ph, five);
+                const V den = (xph * vfma(m4, ox, five)) * hmx;
+                // g = num / den (:555), k = bw / x (:558), a1 = 1 / (1 + g (g + k)) (:560): v_rcp + one
+                // Newton step each (correctly rounded reciprocals; the quotients are within an ulp)
+                V rd = vrcp(den), rx = vrcp(ef);
+                rd = vfma(vfma(-den, rd, one), rd, rd);
+                rx = vfma(vfma(-ef, rx, one), rx, rx);
+                const V tg = num * rd;
+                const V kq = eb * rx;
+                const V d3 = vfma(tg, tg + kq, one);
+                V r3 = vrcp(d3);
+                r3 = vfma(vfma(-d3, r3, one), r3, r3);
+                const V gg = ea * mul;
+                put(e.a1[k], FS.a1[k], r3);
+                put(e.tg[k], FS.tg[k], tg);
+                put(e.g[k], FS.g[k], gg);
+                put(e.h[k], FS.h[k], et * gg);
+                x.ap[k] = ea;
+                x.mu[k] = mul;
+                x.tb[k] = et;
+            }
+#pragma unroll
+            for (int k = 0; k < NLP; ++k) {
+                put(e.b[k], FS.b[k], vfma(Y.breath[k], vsplat(alpha, V()), X.breath[k] * oma));
+                if constexpr (!SU) {
+                    const V es = vfma(Y.smooth[k], vsplat(alpha, V()), X.smooth[k] * oma);
+                    put(e.om[k], FS.om[k], 1.0f - exp_approx(es));
+                } else {
+                    e.om[k] = one;
+                }
+            }
+            e.oml = 1.0f;
+            if constexpr (SU) {
+                const float es = __builtin_fmaf(vget(Y.smooth[0], 0), alpha, vget(X.smooth[0], 0) * oma);
+                const float v = 1.0f - exp_approx(es);
+                e.oml = SLOPE ? (v - FS.oml) * scale : v;
+            }
+        };
+        FastEnds D;              // per-sample slopes of the sub-tile
+        FastAux xe;
+        bool have_slopes = false;
+        if (fast_have != FLAVOUR) {
+            // a run of calm tiles starts: the values now, the slopes over 32 samples, and the error guard
+            FastAux xs;
+            endpoint(std::false_type(), 1.0f, 1.0f, FS, xs);
+            endpoint(std::true_type(), (float)(TS0 + 1), 1.0f / (float)TS0, D, xe);
+            float ra = 0.0f, rg = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NLIVE; ++k)
+#pragma unroll
+                for (int c = 0; c < W; ++c) {
+                    // relative change of a1 and g over 32 samples; 32^2 x the products of slopes behind G and H
+                    ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(D.a1[k], c)) * (float)TS0 *
+                                                 __builtin_amdgcn_rcpf(vget(FS.a1[k], c)));
+                    ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(D.tg[k], c)) * (float)TS0 *
+                                                 __builtin_amdgcn_rcpf(vget(FS.tg[k], c)));
+                    rg = __builtin_fmaxf(rg, __builtin_fabsf((vget(xe.ap[k], c) - vget(xs.ap[k], c)) *
+                                                             (vget(xe.mu[k], c) - vget(xs.mu[k], c))));
+                    rg = __builtin_fmaxf(rg, __builtin_fabsf((vget(xe.tb[k], c) - vget(xs.tb[k], c)) *
+                                                             vget(D.g[k], c) * (float)TS0));
+                }
+            if constexpr (SU) {
+                ra = __builtin_fmaxf(ra, __builtin_fabsf(D.oml) * (float)TS0 * __builtin_amdgcn_rcpf(FS.oml));
+            } else {
+#pragma unroll
+                for (int k = 0; k < NLP; ++k)
+#pragma unroll
+                    for (int c = 0; c < W; ++c)
+                        ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(D.om[k], c)) * (float)TS0 *
+                                                     __builtin_amdgcn_rcpf(vget(FS.om[k], c)));
+            }
+            // halvings needed: r / 2^s <= 2^-9.5 (error ~ r^2 / 16), |.| / 4 / 4^s <= 2^-22
+            const int la = __builtin_amdgcn_frexp_expf(ra * 724.0773439350247f);      // 2^9.5
+            const int lg = (__builtin_amdgcn_frexp_expf(rg * 1048576.0f) + 1) >> 1;    // 2^22 / 4
+            int level = la > lg ? la : lg;
+            level = level < 0 ? 0 : level;
+            if (!(ra == ra) || !(rg == rg)) level = 99;                                // NaN: not here
+            level = idle_lane ? 0 : level;
+            int lvl = 0;
+            for (; lvl <= 4; ++lvl)
+                if (__builtin_amdgcn_ballot_w64(level > lvl) == 0) break;
+            if (lvl > 4) return false;               // faster than TS = 2 can follow: the exact steps
+            fast_shift = lvl;
+            have_slopes = lvl == 0;
+            fast_have = FLAVOUR;
+        }
+        const int TS = TS0 >> fast_shift;
+        const float inv_ts = __builtin_bit_cast(float, (uint32_t)(127 - 5 + fast_shift) << 23);   // 1 / TS
+        const float nm1_of_lane = noise_of_lane - 1.0f;
+        const f2 one2 = vsplat(1.0f, f2());
+#pragma unroll 1
+        for (int ts = 0; ts < T; ts += TS) {
+            if (!(have_slopes && ts == 0)) endpoint(std::true_type(), (float)(TS + 1), inv_ts, D, xe);
+            f2 TI;
+            TI.x = 0.0f; TI.y = 1.0f;
+#pragma unroll 1
+            for (int tc = ts; tc < ts + TS; tc += 2) {
+                const float nz[2] = {
+                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc)),
+                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc + 1))};
+                const float nm[2] = {
+                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nm1_of_lane), tc)),
+                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nm1_of_lane), tc + 1))};
+                // ---- the per-utterance chain of samples tc, tc+1: exact (see scalar_packed_steps)
+                const float clk0 = clk - dt, clk1 = clk0 - dt;                     // :861
+                const float jp0 = jphase + jinc, jp1 = jp0 + jinc;                 // :242 / :291
+                clk = clk1;
+                jphase = jp1;
+                f2 CLK, JP;
+                CLK.x = clk0; CLK.y = clk1; JP.x = jp0; JP.y = jp1;
+                f2 ratio = CLK * inv_blend_length;
+                if constexpr (ANYBL) {
+                    const f2 rem = vfma(-blend_length * one2, ratio, CLK);
+                    const f2 quot = vfma(rem, inv_blend_length * one2, ratio);     // RN(clk / blend_length)
+                    ratio = blend_pow2 ? ratio : quot;
+                }
+                f2 alpha;                                                          // :899/:908/:917
+                alpha.x = silent_pair ? 1.0f : __builtin_fminf(ratio.x, 1.0f);
+                alpha.y = silent_pair ? 1.0f : __builtin_fminf(ratio.y, 1.0f);
+                const f2 oma = 1.0f - alpha;
+                const f2 jomp = 1.0f - JP;
+                f2 frequency = X.frequency * oma + Y.frequency * alpha;            // :404-414
+                const f2 n_freq = fn_cur * jomp + fn_next * JP;                    // :254
+                frequency = frequency + n_freq * d_freq;                           // :763
+                const f2 omf = 1.0f - frequency;                                   // carrier :503-525
+                const float ph0 = phase;
+                const bool head0 = ph0 < frequency.x, tail0 = ph0 > omf.x;
+                float ph1 = ph0 + frequency.x;
+                ph1 = (ph1 >= 1.0f) ? ph1 - 1.0f : ph1;
+                const bool head1 = ph1 < frequency.y, tail1 = ph1 > omf.y;
+                const float ph2 = ph1 + frequency.y;
+                phase = (ph2 >= 1.0f) ? ph2 - 1.0f : ph2;
+                f2 PH;
+                PH.x = ph0; PH.y = ph1;
+                const f2 phm1 = PH - 1.0f;
+                f2 dividend;
+                dividend.x = head0 ? ph0 : phm1.x;
+                dividend.y = head1 ? ph1 : phm1.y;
+                const f2 tt = dividend * vrcp(frequency);                          // tolerance: 1 ulp quotient
+                f2 s_tt2, sgn, polyblep;
+                const f2 tt2 = tt * tt;
+                s_tt2.x = __uint_as_float(__float_as_uint(tt2.x) ^ (head0 ? 0x80000000u : 0u));
+                s_tt2.y = __uint_as_float(__float_as_uint(tt2.y) ^ (head1 ? 0x80000000u : 0u));
+                sgn.x = head0 ? -1.0f : 1.0f;
+                sgn.y = head1 ? -1.0f : 1.0f;
+                const f2 pb = vfma(vsplat(2.0f, f2()), tt, s_tt2) + sgn;
+                polyblep.x = (head0 | tail0) ? pb.x : 0.0f;
+                polyblep.y = (head1 | tail1) ? pb.y : 0.0f;
+                const f2 saw2 = vfma(vsplat(2.0f, f2()), PH, -one2) - polyblep;    // :517
+                // ---- the formants, sample by sample, coefficients by interpolation
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float ti = vget(TI, h), saw = vget(saw2, h);
+                    const V tiv = vsplat(ti, V());
+                    const V nms = vsplat(nz[h] - saw, V());
+                    const V nm1 = vsplat(nm[h], V());
+                    const V sawv = vsplat(saw, V());
+                    V oml_v = one;
+                    if constexpr (SU) oml_v = vsplat(__builtin_fmaf(D.oml, ti, FS.oml), V());
+                    V acc = vsplat(0.0f, V());
+#pragma unroll
+                    for (int k = 0; k < NLP; ++k) {
+                        const V b = vfma(D.b[k], tiv, FS.b[k]);
+                        const V nw = vfma(b, nms, sawv);                            // :531
+                        if constexpr (!SU) oml_v = vfma(D.om[k], tiv, FS.om[k]);
+                        st_a[k] = vfma(oml_v, nw - st_a[k], st_a[k]);               // :538
+                    }
+#pragma unroll
+                    for (int k = 0; k < NLIVE; ++k) {
+                        const V a1 = vfma(D.a1[k], tiv, FS.a1[k]);
+                        const V tg = vfma(D.tg[k], tiv, FS.tg[k]);
+                        const V g_ = vfma(D.g[k], tiv, FS.g[k]);
+                        const V h_ = vfma(D.h[k], tiv, FS.h[k]);
+                        const V v0 = st_a[k] * vfma(h_, nm1, g_);                   // :544-550
+                        const V v3 = v0 - st_c[k];                                  // :565
+                        const V w1 = a1 * vfma(tg, v3, st_b[k]);                    // :566  a1 b + a2 v3
+                        const V w2 = vfma(tg, w1, st_c[k]);                         // :567  c + a2 b + a3 v3
+                        st_b[k] = vfma(vsplat(2.0f, V()), w1, -st_b[k]);            // :570
+                        st_c[k] = vfma(vsplat(2.0f, V()), w2, -st_c[k]);            // :571
+                        acc = acc + w1;
+                    }
+                    float part = vget(acc, 0);
+                    if constexpr (W == 2) part = part + vget(acc, 1);
+                    const int t_ = tc + h;
+                    if constexpr (FOLD_IN_FLUSH) {
+                        // the flush folds NFA parked values per sample: this lane's partial sum, then zeros
+                        if (emit) stage[(t_ * S + slot) * NFA + f0] = part;
+#pragma unroll
+                        for (int i = 1; i < FPL; ++i)
+                            if (emit) stage[(t_ * S + slot) * NFA + f0 + i] = 0.0f;
+                    } else {
+                        float tot = part;
+#pragma unroll
+                        for (int step = 1; step < L; ++step) tot = dpp_from_lane_below(tot) + part;
+                        if (j == L - 1) stage[t_ * SP + slot] = tot * 0.5f;
+                    }
+                }
+                TI = TI + 2.0f;
+            }
+            // the sub-tile's end is the next one's start: start + TS * slope (the end value the slopes were
+            // made from, to within an ulp; every sub-tile's end is evaluated afresh, so nothing accumulates)
+            const float fts = (float)TS;
+#pragma unroll
+            for (int k = 0; k < NLIVE; ++k) {
+                FS.a1[k] = vfma(D.a1[k], vsplat(fts, V()), FS.a1[k]);
+                FS.tg[k] = vfma(D.tg[k], vsplat(fts, V()), FS.tg[k]);
+                FS.g[k] = vfma(D.g[k], vsplat(fts, V()), FS.g[k]);
+                FS.h[k] = vfma(D.h[k], vsplat(fts, V()), FS.h[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < NLP; ++k) {
+                FS.b[k] = vfma(D.b[k], vsplat(fts, V()), FS.b[k]);
+                if constexpr (!SU) FS.om[k] = vfma(D.om[k], vsplat(fts, V()), FS.om[k]);
+            }
+            if constexpr (SU) FS.oml = __builtin_fmaf(D.oml, fts, FS.oml);
+        }
+        return true;
+    };
+
     for (uint32_t base = 0;; base += T) {
         int t = 0;
         while (t < T) {
@@ -1328,9 +1624,16 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 const uint64_t busy = __builtin_amdgcn_ballot_w64(!idle);
                 if (busy != 0) {
                     tile_seed = (uint32_t)__builtin_amdgcn_readlane((int)noise_seed, __builtin_ctzll(busy));
-                    const bool calm = !done & quiet_ok & (dt > 0.0f) & (clk > (float)(T + 8) * dt) &
-                                      (jphase + (float)(T + 1) * jinc < 0.999f) &
-                                      (cap32 - n_out >= (uint32_t)T) & (noise_seed == tile_seed);
+                    bool calm = !done & quiet_ok & (dt > 0.0f) & (clk > (float)(T + 8) * dt) &
+                                (jphase + (float)(T + 1) * jinc < 0.999f) &
+                                (cap32 - n_out >= (uint32_t)T) & (noise_seed == tile_seed);
+                    if constexpr (FAST) {
+                        // the interpolated coefficients need alpha linear in time across the tile:
+                        // a tile that holds the kink of min(clk / blend_length, 1) takes the exact steps
+                        const float r_first = (clk - dt) * inv_blend_length;
+                        const float r_next = (clk - (float)(T + 1) * dt) * inv_blend_length;
+                        calm = calm & !((r_first > 1.0f) & (r_next < 1.0f));
+                    }
                     calm_tile = __builtin_amdgcn_ballot_w64(!(calm | idle)) == 0;
                 }
             }
@@ -1346,7 +1649,10 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     // live the doubled body no longer fits the register file (measured: slower)
                     constexpr int STEPS_PER_TRIP = decltype(nlive_tag)::value <= 2 ? 2 : 1;
                     static_assert(T % STEPS_PER_TRIP == 0, "whole trips");
-                    if constexpr (PIPE) {
+                    bool rendered = true;
+                    if constexpr (FAST) {
+                        rendered = fast_tile(nlive_tag, su_tag, noise_of_lane, idle);
+                    } else if constexpr (PIPE) {
                         // Rounds of two sample pairs, three stages one round apart: in phase p wave 1
                         // writes the chain of round p+2, waves 2 and 3 turn the chain of round p+1 into
                         // coefficients (one pair each), wave 0 renders round p; one barrier per phase.
@@ -1423,11 +1729,17 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                             }
                         }
                     }
-                    t = T;
-                    n_out += idle ? 0u : (uint32_t)T;
-                    noise_seed = (uint32_t)__builtin_amdgcn_readlane((int)sk, T - 1);
-                    return;
+                    if (rendered) {
+                        t = T;
+                        n_out += idle ? 0u : (uint32_t)T;
+                        noise_seed = (uint32_t)__builtin_amdgcn_readlane((int)sk, T - 1);
+                        return;
+                    }
                 }
+                fast_have = -1;          // exact steps follow: the kept interpolation ends go stale
+                // FAST kernels take the general step for every sample of a tile that is not calm (about
+                // one tile in a hundred): without the quiet-step loops the kernel needs far fewer registers
+                if constexpr (FAST) return;
                 for (; t < T; ++t) {
                     const float clk_next = clk - dt;
                     const float jphase_next = jphase + jinc;
@@ -1466,12 +1778,38 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
             continue;
         }
-        if (j == L - 1) cnt[slot] = n_out > base ? n_out - base : 0u;
-        wave_lds_sync();
+        const uint32_t mine = n_out > base ? n_out - base : 0u;
         constexpr int ROW_LANES = T / 4;
         constexpr int ROWS_PER_IT = 64 / ROW_LANES;
         const int rl = lane % ROW_LANES;
         const int rr = lane / ROW_LANES;
+        if constexpr (!FOLD_IN_FLUSH && ROWS_PER_IT <= S) {
+            // the usual tile: every row of the wave received all T samples and the rows take 16-B stores.
+            // No per-row conditions, so the LDS reads of all rows are in flight together (a lone wave has
+            // nothing else to hide their latency behind) and the stores follow back to back.
+            const bool all_full = __builtin_amdgcn_ballot_w64((j == L - 1) & (mine != (uint32_t)T)) == 0;
+            if (all_full && !A.out_pcm16 && vec_ok) {
+                wave_lds_sync();
+                float4 v[S / ROWS_PER_IT];
+#pragma unroll
+                for (int i = 0; i < S / ROWS_PER_IT; ++i) {
+                    const int r = i * ROWS_PER_IT + rr;
+                    const int t0 = rl * 4;
+                    v[i] = make_float4(stage[(t0 + 0) * SP + r], stage[(t0 + 1) * SP + r], stage[(t0 + 2) * SP + r],
+                                       stage[(t0 + 3) * SP + r]);
+                }
+#pragma unroll
+                for (int i = 0; i < S / ROWS_PER_IT; ++i) {
+                    const int r = i * ROWS_PER_IT + rr;
+                    *reinterpret_cast<float4 *>(A.out + (uint64_t)(u0 + r) * A.out_stride + base + rl * 4) = v[i];
+                }
+                wave_lds_sync();
+                if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+                continue;
+            }
+        }
+        if (j == L - 1) cnt[slot] = mine;
+        wave_lds_sync();
 #pragma unroll 1
         for (int r0 = 0; r0 < S; r0 += ROWS_PER_IT) {
             const int r = r0 + rr;
@@ -1615,6 +1953,21 @@ int auto_lanes_per_utt(uint32_t n_utt)
     return 1;
 }
 
+// what the last launch_synth call started, for the bench line and the profile bookkeeping
+static thread_local char g_kernel_name[96] = "none";
+const char *last_kernel_name() { return g_kernel_name; }
+
+template <int L, int T, int WAVES, int MINW, bool STREAM, bool HALF, bool ANYBL, int NFA = NF, bool PIPE = false,
+          bool FAST = false>
+static void start(const SynthArgs &args, dim3 grid, dim3 block, hipStream_t stream)
+{
+    std::snprintf(g_kernel_name, sizeof g_kernel_name, "synth_kernel<L=%d,T=%d,W=%d,%d,%s%s%sNFA=%d%s%s>", L, T, WAVES,
+                  MINW, STREAM ? "STREAM," : "", HALF ? "HALF," : "", ANYBL ? "ANYBL," : "", NFA,
+                  PIPE ? ",PIPE" : "", FAST ? ",FAST" : "");
+    hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, STREAM, HALF, ANYBL, NFA, PIPE, FAST>), grid, block, 0, stream,
+                       args);
+}
+
 template <int L, int T, int WAVES, int MINW>
 static void launch_one(const SynthArgs &args, hipStream_t stream)
 {
@@ -1624,27 +1977,35 @@ static void launch_one(const SynthArgs &args, hipStream_t stream)
         if (!args.state && !args.any_blend && args.live4) {
             // L = 4 parks 4 floats per sample instead of 8: room for the 64-step tiles of L = 8
             constexpr int T4 = L == 4 ? 64 : T;
-            hipLaunchKernelGGL((synth_kernel<L, T4, WAVES, MINW, false, false, false, 4>), grid, block, 0, stream, args);
+            if (args.fast) start<L, T4, WAVES, MINW, false, false, false, 4, false, true>(args, grid, block, stream);
+            else start<L, T4, WAVES, MINW, false, false, false, 4>(args, grid, block, stream);
             return;
         }
     }
+    if (args.fast && !args.state) {
+        // tolerance mode: the same kernels with the fast calm tile; ANYBL folded in (one instantiation
+        // per layout keeps the library small), HALF only where the exact policy uses it
+        if (L == 1 && args.half_capable) start<L, T, WAVES, MINW, false, true, true, NF, false, true>(args, grid, block, stream);
+        else start<L, T, WAVES, MINW, false, false, true, NF, false, true>(args, grid, block, stream);
+        return;
+    }
     if (args.state)
-        hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, true, true, true>), grid, block, 0, stream, args);
+        start<L, T, WAVES, MINW, true, true, true>(args, grid, block, stream);
     else if (args.any_blend)
-        hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, false, true, true>), grid, block, 0, stream, args);
+        start<L, T, WAVES, MINW, false, true, true>(args, grid, block, stream);
     else if (L == 1 && args.half_capable)
-        hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, false, true, false>), grid, block, 0, stream, args);
+        start<L, T, WAVES, MINW, false, true, false>(args, grid, block, stream);
     else
-        hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, false, false, false>), grid, block, 0, stream, args);
+        start<L, T, WAVES, MINW, false, false, false>(args, grid, block, stream);
 }
 
 hipError_t launch_synth(const SynthArgs &args, int L, int variant, hipStream_t stream)
 {
     if (args.n_utt == 0) return hipSuccess;
-    if (args.pipe && args.live4 && !args.state && !args.any_blend) {
+    if (args.pipe && args.live4 && !args.state && !args.any_blend && !args.fast) {
         // 16 utterances (4 lanes each) per workgroup of four waves: render, chain, 2 x coefficients
         const dim3 grid((args.n_utt + 15) / 16), block(256);
-        hipLaunchKernelGGL((synth_kernel<4, 64, 4, 1, false, false, false, 4, true>), grid, block, 0, stream, args);
+        start<4, 64, 4, 1, false, false, false, 4, true>(args, grid, block, stream);
         return hipGetLastError();
     }
     // 64-thread workgroups are admitted 8 per CU (2 waves per SIMD, measured); L = 4 / 8 use

@@ -34,6 +34,12 @@ ERR_NO_VOICES = -7
 
 OUT_HOST = 0
 OUT_DEVICE = 1
+# "arithmetic" = 1 (fast mode): GRAIL_FAST_TOLERANCE of include/grail_hip.h
+FAST_TOLERANCE_ULPS = 256
+FAST_TOLERANCE = FAST_TOLERANCE_ULPS * 2.0 ** -23
+FAST_TOLERANCE_NOTE = (f"fast mode: max |fast - exact| <= {FAST_TOLERANCE_ULPS} * 2^-23 = {FAST_TOLERANCE:.3g} of "
+                       "full scale vs the oracle (tests/test_fast_gpu.py asserts it on configs 2, 3, 4 "
+                       "and a fuzz corpus); clock, phases, wraps and LCGs stay exact")
 UNIQUE_ID_BYTES = 128
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -49,13 +55,13 @@ EXPORTS = [
     "grail_get_voices", "grail_set_option", "grail_get_option",
     "grail_batch_upload", "grail_batch_upload_elems", "grail_batch_free", "grail_batch_size",
     "grail_batch_lengths", "grail_batch_synthesize_async", "grail_sync",
-    "grail_last_kernel_ms", "grail_synthesize_batch", "grail_synthesize_batch_elems",
+    "grail_last_kernel_ms", "grail_last_kernel_name", "grail_synthesize_batch", "grail_synthesize_batch_elems",
     "grail_stream_open", "grail_stream_next_async", "grail_stream_close",
     "grail_language_generic", "grail_transcribe", "grail_intonate", "grail_text_to_phoneme_elems",
-    "grail_synthesize_batch_pcm16", "grail_batch_synthesize_pcm16_async", "grail_stream_next_pcm16_async", "grail_say_batch", "grail_pcm16_async", "grail_batch_digest", "grail_wav_write_i16",
+    "grail_synthesize_batch_pcm16", "grail_batch_synthesize_pcm16_async", "grail_stream_next_pcm16_async", "grail_say_batch", "grail_pcm16_async", "grail_batch_digest", "grail_batch_compare", "grail_wav_write_i16",
     "grail_device_alloc", "grail_device_free", "grail_memcpy_d2h", "grail_memcpy_h2d",
     "grail_memset_d", "grail_shard_range", "grail_comm_unique_id", "grail_comm_init",
-    "grail_broadcast_voices", "grail_comm_destroy",
+    "grail_broadcast_voices", "grail_comm_info", "grail_comm_destroy",
 ]
 
 
@@ -185,6 +191,8 @@ def load():
     L.grail_batch_synthesize_async.argtypes = [vp, vp, vp, u64, vp]
     L.grail_sync.argtypes = [vp]
     L.grail_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.grail_last_kernel_name.restype = C.c_char_p
+    L.grail_last_kernel_name.argtypes = [vp]
     L.grail_synthesize_batch.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, u64, vp, C.c_uint32]
     L.grail_synthesize_batch_elems.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, u64, vp,
                                                C.c_uint32]
@@ -205,6 +213,7 @@ def load():
                                                C.c_uint32]
     L.grail_batch_synthesize_pcm16_async.argtypes = [vp, vp, vp, u64, vp]
     L.grail_batch_digest.argtypes = [vp, vp, u64, vp, C.c_uint32, vp, vp, vp]
+    L.grail_batch_compare.argtypes = [vp, vp, vp, u64, vp, vp, C.c_uint32, vp, vp, vp]
     L.grail_wav_write_i16.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
     L.grail_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.grail_device_free.argtypes = [vp, vp]
@@ -216,6 +225,7 @@ def load():
     L.grail_comm_unique_id.argtypes = [vp]
     L.grail_comm_init.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
     L.grail_broadcast_voices.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.grail_comm_info.argtypes = [vp, u32p, u32p]
     L.grail_comm_destroy.argtypes = [vp]
     _lib = L
     return L
@@ -552,6 +562,15 @@ class Context:
                                          sums.ctypes.data, maxabs.ctypes.data, bad.ctypes.data))
         return sums[:n_utt], maxabs[:n_utt], bad[:n_utt]
 
+    def compare(self, a_dev, b_dev, stride, len_a_dev, len_b_dev, n_utt):
+        """(max |a-b|, sum (a-b)^2, structural mismatches) per row of two device renderings."""
+        md = np.zeros(max(n_utt, 1), dtype=np.float32)
+        sq = np.zeros(max(n_utt, 1), dtype=np.float64)
+        bad = np.zeros(max(n_utt, 1), dtype=np.uint32)
+        _check(load().grail_batch_compare(self.handle, a_dev, b_dev, stride, len_a_dev, len_b_dev, n_utt,
+                                          md.ctypes.data, sq.ctypes.data, bad.ctypes.data))
+        return md[:n_utt], sq[:n_utt], bad[:n_utt]
+
     def h2d(self, dst_dev, src, nbytes):
         _check(load().grail_memcpy_h2d(self.handle, dst_dev, src.ctypes.data, nbytes))
 
@@ -562,6 +581,9 @@ class Context:
         ms = C.c_float()
         _check(load().grail_last_kernel_ms(self.handle, C.byref(ms)))
         return ms.value
+
+    def last_kernel_name(self):
+        return load().grail_last_kernel_name(self.handle).decode()
 
     def device_alloc(self, nbytes):
         p = C.c_void_p()
@@ -591,3 +613,9 @@ class Context:
 
     def broadcast_voices(self, n_voices, root=0):
         _check(load().grail_broadcast_voices(self.handle, n_voices, root))
+
+    def comm_info(self):
+        """(ncclCommCount, ncclCommUserRank) of this context's communicator; (0, 0) without one."""
+        n, r = C.c_uint32(), C.c_uint32()
+        _check(load().grail_comm_info(self.handle, C.byref(n), C.byref(r)))
+        return n.value, r.value

@@ -6,7 +6,7 @@ Used by bench.py and the parity tests so both sides see identical inputs.
 import numpy as np
 
 from . import (NUM_FORMANTS, PH_A, PH_E, PH_SILENCE, PHONEME_DTYPE, elem_new_phoneme,
-               elem_resample, voice_generic)
+               elem_resample, shard_range, voice_generic)
 
 SAMPLE_RATE = 48000.0
 SEGMENTS_PER_UTT = 4
@@ -47,6 +47,13 @@ def make_batch(n_utt, first_utt=0, n_voices=1, segments=SEGMENTS_PER_UTT, sample
     voice_ids = (u % np.uint32(max(n_voices, 1))).astype(np.uint32)
     jitter_seeds = u.copy()
     return segs.reshape(-1), seg_offsets, voice_ids, jitter_seeds
+
+
+def shard_inputs(utts_per_rank, rank, world, n_voices, **kw):
+    """This rank's slice of the global synthetic corpus of utts_per_rank*world utterances
+    (contiguous shards, no data-path collective)."""
+    first, last = shard_range(utts_per_rank * world, rank, world)
+    return (first, last) + make_batch(last - first, first_utt=first, n_voices=n_voices, **kw)
 
 
 # BASELINE.json config 4: 8 presets with divergent formant coefficients.  The

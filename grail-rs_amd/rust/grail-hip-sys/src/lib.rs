@@ -129,6 +129,7 @@ extern "C" {
     pub fn grail_stream_close(ctx: *mut grail_ctx, stream: *mut grail_stream) -> c_int;
     pub fn grail_sync(ctx: *mut grail_ctx) -> c_int;
     pub fn grail_last_kernel_ms(ctx: *mut grail_ctx, ms: *mut f32) -> c_int;
+    pub fn grail_last_kernel_name(ctx: *mut grail_ctx) -> *const c_char;
     pub fn grail_synthesize_batch(ctx: *mut grail_ctx, segs: *const grail_phoneme_elem,
         seg_offsets: *const u32, voice_ids: *const u32, jitter_seeds: *const u32, n_utt: u32,
         out: *mut f32, out_stride: u64, out_len: *mut u32, flags: u32) -> c_int;
@@ -155,6 +156,9 @@ extern "C" {
         out: *mut i16, out_stride: u64, out_len: *mut u32, flags: u32) -> c_int;
     pub fn grail_batch_digest(ctx: *mut grail_ctx, in_dev: *const f32, in_stride: u64,
         len_dev: *const u32, n_utt: u32, sums: *mut u64, maxabs: *mut f32, nonfinite: *mut u32) -> c_int;
+    pub fn grail_batch_compare(ctx: *mut grail_ctx, a_dev: *const f32, b_dev: *const f32, stride: u64,
+                               len_a_dev: *const u32, len_b_dev: *const u32, n_utt: u32,
+                               maxdiff: *mut f32, sumsq: *mut f64, mismatches: *mut u32) -> c_int;
     pub fn grail_wav_write_i16(path: *const c_char, pcm: *const i16, n: u32, sample_rate: u32) -> c_int;
 
     pub fn grail_device_alloc(ctx: *mut grail_ctx, bytes: usize, out: *mut *mut std::ffi::c_void) -> c_int;
@@ -167,5 +171,6 @@ extern "C" {
     pub fn grail_comm_unique_id(id: *mut u8) -> c_int;
     pub fn grail_comm_init(ctx: *mut grail_ctx, id: *const u8, rank: u32, world: u32) -> c_int;
     pub fn grail_broadcast_voices(ctx: *mut grail_ctx, n_voices: u32, root: u32) -> c_int;
+    pub fn grail_comm_info(ctx: *mut grail_ctx, ranks: *mut u32, rank: *mut u32) -> c_int;
     pub fn grail_comm_destroy(ctx: *mut grail_ctx) -> c_int;
 }

@@ -40,6 +40,9 @@ extern "C" {
 #endif
 
 #define GRAIL_ABI_VERSION 1
+/* fast mode ("arithmetic" = 1): bound on |fast - exact| per sample, full scale = 1.0; k * 2^-23 */
+#define GRAIL_FAST_TOLERANCE_ULPS 256
+#define GRAIL_FAST_TOLERANCE (GRAIL_FAST_TOLERANCE_ULPS * 1.1920928955078125e-07f)
 
 /* src/lib.rs:24  NUM_FORMANTS, src/lib.rs:21 DEFAULT_SAMPLE_RATE */
 #define GRAIL_NUM_FORMANTS 8
@@ -166,7 +169,7 @@ int grail_device_count(int *count);
  * src/lib.rs:1013, 941, 786) to HBM.  Utterances refer to it by voice id. */
 int grail_set_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices);
 int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t *n_voices);
-/* Tuning knobs; none of them ever changes a result bit.
+/* Tuning knobs; with "arithmetic" = 0 none of them ever changes a result bit.
  *   "lanes_per_utterance": 0 = auto, or 1/2/4/8 — how many wavefront lanes share one
  *       utterance's 8 formants.
  *   "skip_silent_formants": 1 (default) / 0 — formants whose amplitude is exactly 0 in both
@@ -180,6 +183,13 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *   "small_batch_pipeline": 1 (default) / 0 — batches of at most 4096 utterances that qualify
  *       for the four-formant layout run four-wave workgroups (render / per-utterance chain /
  *       2 x filter coefficients, handed on through LDS) instead of one wave per 8 utterances.
+ *   "arithmetic": 0 (default) = exact, every sample bit-identical to the reference's binary32
+ *       arithmetic; 1 = fast, the tolerance mode north_star allows: the discontinuous state
+ *       (Sequencer clock, jitter phase, carrier phase and its wrap, both LCGs) stays exact, the
+ *       per-formant arithmetic uses fused multiply-adds, one uncorrected reciprocal and filter
+ *       coefficients interpolated across 32-sample tiles.  |fast - exact| <= GRAIL_FAST_TOLERANCE
+ *       for parameters like voices::generic()'s (DESIGN.md "Fast mode"; tests/test_fast_gpu.py).
+ *       This is the ONE knob that changes result bits.
  *   "kernel_variant": experiments only.
  * Read-only statistics: "slow_division_wave_steps", "last_launch_formants" (4 or 8),
  * "last_launch_lanes", "last_launch_pipelined". */
@@ -221,6 +231,10 @@ int grail_sync(grail_ctx *ctx);
 /* HIP-event time (ms) of the most recent synthesis kernel on ctx's stream
  * (events recorded on the stream the kernel is launched on).  Syncs. */
 int grail_last_kernel_ms(grail_ctx *ctx, float *ms);
+/* Which kernel instantiation the most recent synthesis launch of ctx started, e.g.
+ * "synth_kernel<L=1,T=32,W=1,1,NFA=4>" (profiling bookkeeping: counters measured on one
+ * instantiation are never reported for another).  Owned by ctx; valid until its next launch. */
+const char *grail_last_kernel_name(grail_ctx *ctx);
 
 /* Resumable synthesis (the lazy-iterator use of the chain, examples/interactive.rs:31-48):
  * the per-utterance iterator state (Sequencer :839-854, Jitter :724-748, Synthesize :470-488)
@@ -302,6 +316,13 @@ int grail_synthesize_batch_pcm16(grail_ctx *ctx, const grail_phoneme_elem *segs,
 int grail_batch_digest(grail_ctx *ctx, const float *in_dev, uint64_t in_stride,
                        const uint32_t *len_dev, uint32_t n_utt, uint64_t *sums, float *maxabs,
                        uint32_t *nonfinite);
+/* Per-row distance between two renderings of one batch, computed on the device (fast mode against
+ * exact mode at full size): maxdiff[u] = max |a - b|, sumsq[u] = sum (a - b)^2 over the first
+ * len_a_dev[u] samples, mismatches[u] = samples where exactly one side is non-finite, plus 1 if
+ * the two lengths differ.  a/b/len_* are device memory, the three results host memory [n_utt]. */
+int grail_batch_compare(grail_ctx *ctx, const float *a_dev, const float *b_dev, uint64_t stride,
+                        const uint32_t *len_a_dev, const uint32_t *len_b_dev, uint32_t n_utt,
+                        float *maxdiff, double *sumsq, uint32_t *mismatches);
 /* save_wav  examples/cli.rs:28-67: 44-byte RIFF header (PCM, mono, 16 bit) + samples. */
 int grail_wav_write_i16(const char *path, const int16_t *pcm, uint32_t n, uint32_t sample_rate);
 
@@ -327,6 +348,9 @@ int grail_comm_unique_id(uint8_t id[GRAIL_UNIQUE_ID_BYTES]);
 int grail_comm_init(grail_ctx *ctx, const uint8_t id[GRAIL_UNIQUE_ID_BYTES], uint32_t rank,
                     uint32_t world);
 int grail_broadcast_voices(grail_ctx *ctx, uint32_t n_voices, uint32_t root);
+/* What RCCL itself reports for ctx's communicator: *ranks = ncclCommCount (0 when no communicator
+ * has been formed), *rank = ncclCommUserRank.  Lets a launcher prove that N ranks really met. */
+int grail_comm_info(grail_ctx *ctx, uint32_t *ranks, uint32_t *rank);
 int grail_comm_destroy(grail_ctx *ctx);
 
 #ifdef __cplusplus

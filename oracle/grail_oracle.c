@@ -441,7 +441,15 @@ typedef struct {
     float phase;
     orc_array filter_state_a, filter_state_b, filter_state_c;
     uint32_t seed;
+    double pa[NF], pb[NF], pc[NF]; /* filter states of the double-precision variant (orc_set_precise) */
 } synthesize;
+
+/* Tests only: evaluate the per-formant arithmetic of Synthesize::next (src/lib.rs:531-574) in
+ * double precision on the SAME f32 parameter track, saw and noise.  The distance between this and
+ * the binary32 rendering is the rounding noise of the reference itself — the yardstick the fast
+ * (tolerance) mode of the product is measured against.  Never the parity target. */
+static int g_precise = 0;
+void orc_set_precise(int on) { g_precise = on; }
 
 /* IntoSynthesize::synthesize src/lib.rs:587-596 */
 static void synthesize_init(synthesize *s)
@@ -451,6 +459,7 @@ static void synthesize_init(synthesize *s)
     array_splat(&s->filter_state_b, 0.0f);
     array_splat(&s->filter_state_c, 0.0f);
     s->seed = 0;
+    for (int i = 0; i < NF; ++i) s->pa[i] = s->pb[i] = s->pc[i] = 0.0;
 }
 
 /* the arithmetic of Synthesize::next src/lib.rs:501-577 on one elem */
@@ -477,6 +486,31 @@ static float synthesize_step(synthesize *s, const orc_synthesis_elem *elem)
 
     /* :528 */
     float noise = orc_random_f32(&s->seed);
+
+    if (g_precise) {
+        double sum = 0.0;
+        for (int i = 0; i < NF; ++i) {
+            double breath = elem->formant_breath.v[i], turb = elem->formant_turb.v[i];
+            double x = elem->formant_freq.v[i], w = elem->formant_bw.v[i];
+            double nw = (double)saw * (1.0 - breath) + (double)noise * breath;
+            double o = 1.0 - (double)elem->formant_smooth.v[i];
+            double lp = (o * o) * (o * o) * o;
+            s->pa[i] = s->pa[i] + (1.0 - lp) * (nw - s->pa[i]);
+            double v0 = s->pa[i] * ((1.0 - turb) + (double)noise * turb) * (double)elem->formant_amp.v[i];
+            double g = ((1.0 - x) * x * (5.0 - 4.0 * (x + 0.5) * (0.5 - x)))
+                     / ((x + 0.5) * (5.0 - 4.0 * (1.0 - x) * x) * (0.5 - x));
+            double k = w / x;
+            double a1 = 1.0 / (1.0 + g * (g + k)), a2 = g * a1, a3 = g * a2;
+            double b = s->pb[i], c = s->pc[i];
+            double v3 = v0 - c;
+            double v1i = a1 * b + a2 * v3;
+            double v2 = c + a2 * b + a3 * v3;
+            s->pb[i] = 2.0 * v1i - b;
+            s->pc[i] = 2.0 * v2 - c;
+            sum += v1i;
+        }
+        return (float)(sum * 0.5);
+    }
 
     orc_array v1;
     for (int i = 0; i < NF; ++i) {

@@ -97,6 +97,9 @@ float orc_random_f32(uint32_t *state);          /* src/lib.rs:36-55 */
 float orc_tan_approx(float x);                  /* src/lib.rs:63-70 */
 float orc_exp_approx(float x);                  /* src/lib.rs:75-82 */
 void orc_set_sum_identity(int negative_zero);   /* tests: Iterator::sum identity of Rust >= 1.83 */
+/* Tests only: per-formant arithmetic in double precision on the same f32 parameter track (the
+ * rounding-noise yardstick for the product's tolerance mode; never the parity target). */
+void orc_set_precise(int on);
 float orc_array_sum(const orc_array *a);        /* src/lib.rs:123-125 */
 
 /* ---- SynthesisElem algebra --------------------------------------------- */

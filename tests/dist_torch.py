@@ -1,21 +1,13 @@
-"""Multi-GPU plumbing shared by bench.py and the gloo tests.
+"""TEST plumbing (torch.distributed / gloo) for the world_size-2 CPU tests of the N>1 path.
 
-The hot path shards by utterance with NO data-path collective: rank r renders utterances
-[r*N/W, (r+1)*N/W) of the corpus.  The only exchange is the voice table, once, before any
-synthesis: natively one ncclBroadcast inside the C ABI (grail_broadcast_voices, RCCL over
-xGMI); `broadcast_voices_torch` is the same hand-off through torch.distributed, used where
-RCCL cannot run (the CPU/gloo tests) and as a fallback.
+The product never imports torch: natively the voice table travels by one ncclBroadcast inside the
+C ABI (grail_broadcast_voices, RCCL over xGMI) and bench.py's control plane is the file
+rendezvous.  `broadcast_voices_torch` is the same hand-off through torch.distributed where RCCL
+cannot run (CPU, gloo); `reduce_step_stats` mirrors bench.py's max-over-ranks timing contract.
 """
 import numpy as np
 
-from . import Voice, shard_range, voices_blob, voices_from_blob
-from . import workload as W
-
-
-def shard_inputs(utts_per_rank, rank, world, n_voices, **kw):
-    """This rank's slice of the global synthetic corpus of utts_per_rank*world utterances."""
-    first, last = shard_range(utts_per_rank * world, rank, world)
-    return (first, last) + W.make_batch(last - first, first_utt=first, n_voices=n_voices, **kw)
+from grail_hip import Voice, voices_blob, voices_from_blob
 
 
 def broadcast_voices_torch(voices, n_voices, dist, device="cpu", src=0):

@@ -284,3 +284,12 @@ def say(voice, text, jitter_seed=0):
     out = np.zeros(max(n, 1), dtype=np.float32)
     lib().orc_say(C.byref(voice), cps, len(text), jitter_seed, out.ctypes.data, n)
     return out[:n]
+
+
+def set_precise(on):
+    """Per-formant arithmetic of the oracle in double precision (same f32 parameter track): the
+    yardstick for the fast mode's tolerance — NOT the parity target."""
+    L = lib()
+    L.orc_set_precise.argtypes = [C.c_int]
+    L.orc_set_precise.restype = None
+    L.orc_set_precise(1 if on else 0)

@@ -28,7 +28,7 @@ def _worker(rank, world, port, q):
 
     import grail_hip as G
     import oracle_lib as O
-    from grail_hip import dist as D
+    import dist_torch as D
     from grail_hip import workload as W
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -38,7 +38,7 @@ def _worker(rank, world, port, q):
         want = W.preset_voices(n_voices)
         assert all(bytes(a) == bytes(b) for a, b in zip(got, want)), "voice table differs"
 
-        first, last, segs, offs, vids, seeds = D.shard_inputs(per_rank, rank, world, n_voices,
+        first, last, segs, offs, vids, seeds = W.shard_inputs(per_rank, rank, world, n_voices,
                                                               length=0.004, blend_length=0.004)
         assert (first, last) == (rank * per_rank, (rank + 1) * per_rank)
         # every rank's shard is the matching slice of the one global corpus

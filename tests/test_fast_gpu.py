@@ -1,0 +1,210 @@
+"""Fast mode ("arithmetic" = 1, the tolerance north_star allows) against the oracle.
+
+Contract (include/grail_hip.h): |fast - reference| <= GRAIL_FAST_TOLERANCE = 256 * 2^-23 of full
+scale, sample for sample; lengths identical; the discontinuous state (segment boundaries, jitter
+wraps, saw edges) never moves, so the error is rounding-level everywhere, never an O(1) glitch.
+The yardstick printed beside it is the reference's own rounding noise: the oracle's binary32
+rendering against the same formulas evaluated in double precision on the same parameter track.
+"""
+import numpy as np
+import pytest
+
+import grail_hip as G
+import oracle_lib as O
+from grail_hip import workload as W
+
+pytestmark = pytest.mark.gpu
+
+ULP = 2.0 ** -23
+TOL = G.FAST_TOLERANCE          # 256 * 2^-23
+
+
+def _ovoices(voices):
+    return [O.Voice.from_buffer_copy(bytes(v)) for v in voices]
+
+
+def _render(ctx, fast, segs, offs, vids, seeds, stride, lanes=0):
+    ctx.set_option("arithmetic", 1 if fast else 0)
+    ctx.set_option("lanes_per_utterance", lanes)
+    try:
+        return ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+    finally:
+        ctx.set_option("arithmetic", 0)
+        ctx.set_option("lanes_per_utterance", 0)
+
+
+def _worst(a, b, lens):
+    k = 0.0
+    for u in range(len(lens)):
+        n = int(lens[u])
+        if n:
+            k = max(k, float(np.max(np.abs(a[u, :n].astype(np.float64) - b[u, :n].astype(np.float64)))))
+    return k / ULP
+
+
+@pytest.mark.parametrize("n_voices", [1, 8])
+@pytest.mark.parametrize("lanes", [0, 1, 2, 4, 8])
+def test_fast_mode_within_tolerance_of_the_oracle(gpu_ctx, n_voices, lanes):
+    """Configs 3 / 4 in miniature (same corpus generator, 0.25 s segments), every lane mapping."""
+    voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    n_utt = 96
+    segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=n_voices, length=0.25, blend_length=0.25)
+    stride = W.max_samples(length=0.25)
+    out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride, lanes)
+    assert "FAST" in gpu_ctx.last_kernel_name()
+    ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, stride)
+    assert np.array_equal(out_len, ref_len)
+    k = _worst(out, ref, ref_len)
+    print(f"fast vs oracle: voices={n_voices} lanes={lanes}: max |d| = {k:.1f} * 2^-23")
+    assert k * ULP <= TOL
+    assert k > 0.0          # it IS a different arithmetic: an exact match would mean the option was ignored
+
+
+def test_fast_mode_error_is_of_the_order_of_the_references_own_rounding_noise(gpu_ctx):
+    """k(fast vs reference) next to k0(reference vs its own formulas in double precision)."""
+    voices = W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    n_utt = 64
+    segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=8)        # full 2 s utterances
+    stride = W.max_samples()
+    out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
+    ov = _ovoices(voices)
+    ref, ref_len = O.synthesize_batch(ov, segs, offs, vids, seeds, stride)
+    O.set_precise(True)
+    try:
+        ref64, len64 = O.synthesize_batch(ov, segs, offs, vids, seeds, stride)
+    finally:
+        O.set_precise(False)
+    assert np.array_equal(out_len, ref_len) and np.array_equal(len64, ref_len)
+    k = _worst(out, ref, ref_len)
+    k0 = _worst(ref, ref64, ref_len)
+    k64 = _worst(out, ref64, ref_len)
+    print(f"config-4 corpus, 64 x 2 s: fast vs reference {k:.1f}, reference vs double precision {k0:.1f}, "
+          f"fast vs double precision {k64:.1f}  (units of 2^-23)")
+    assert k * ULP <= TOL
+    assert k <= 16.0 * max(k0, 1.0)
+
+
+def test_fast_mode_keeps_every_edge_case_structurally_exact(gpu_ctx):
+    """Ragged lists, empty utterances, silent pairs, blend lengths that are not powers of two, a
+    blend shorter than the segment (the alpha kink), one-sample segments: lengths equal the
+    oracle's and every sample is within tolerance (event tiles run the exact steps)."""
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
+    A, E, S = G.PH_A, G.PH_E, G.PH_SILENCE
+    f = 120.0 / 48000.0
+    utts = [
+        [(S, 0.05, 0.05, f), (A, 0.05, 0.05, f)],
+        [(A, 0.08, 0.02, f), (E, 0.08, 0.02, 1.3 * f), (A, 0.03, 0.01, f)],      # kink: blend < length
+        [(E, 0.07, 0.03, f), (S, 0.04, 0.03, f), (S, 0.04, 0.03, f), (A, 0.05, 0.03, f)],  # non-2^k blends
+        [],
+        [(A, 1.0 / 48000.0, 0.5, f), (E, 0.05, 0.05, f)],                        # one-sample segment
+        [(A, 0.2, 0.2, 0.9 * f)],
+        [(G.PH_STOP, 0.03, 0.03, f), (G.PH_GLIDE, 0.03, 0.03, f), (E, 0.06, 0.06, 2 * f)],
+    ] * 5
+    segs = G.segments([s for u in utts for s in u])
+    offs = np.cumsum([0] + [len(u) for u in utts]).astype(np.uint32)
+    seeds = np.arange(len(utts), dtype=np.uint32) * 77
+    stride = 16384
+    ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, None, seeds, stride)
+    for lanes in (0, 1, 2, 4, 8):
+        out, out_len = _render(gpu_ctx, True, segs, offs, None, seeds, stride, lanes)
+        assert np.array_equal(out_len, ref_len), lanes
+        k = _worst(out, ref, ref_len)
+        print(f"edge cases, lanes={lanes}: {k:.1f} * 2^-23")
+        assert k * ULP <= TOL
+
+
+def test_fast_mode_fuzz_on_random_voice_tables(gpu_ctx):
+    """Random (sane) voice tables and segment lists: formants anywhere in (30 Hz, 0.45 fs),
+    bandwidths 20-600 Hz, every amplitude pattern; the tolerance holds and no structure moves."""
+    rng = np.random.default_rng(20261002)
+    worst = 0.0
+    for trial in range(6):
+        voices = []
+        for _ in range(3):
+            v = G.voice_generic(48000.0)
+            for p in range(2):
+                e = G.elem_new_phoneme(rng.uniform(30, 0.45 * 48000, 8), rng.uniform(20, 600, 8),
+                                       rng.uniform(200, 4000, 8), rng.uniform(0, 1, 8), rng.uniform(0, 1, 8),
+                                       rng.uniform(0.0, 1, 8) * (rng.uniform(0, 1, 8) > 0.3) + 1e-3)
+                v.phonemes[p] = G.elem_resample(e, 1.0, 48000.0)
+            voices.append(v)
+        gpu_ctx.set_voices(voices)
+        n_utt = 40
+        utts = []
+        for u in range(n_utt):
+            n = int(rng.integers(1, 6))
+            utts.append([(int(rng.choice([G.PH_A, G.PH_E, G.PH_SILENCE])), float(rng.uniform(0.01, 0.12)),
+                          float(rng.choice([0.0078125, 0.015625, 0.03125, 0.02, 0.05])),
+                          float(rng.uniform(80, 400) / 48000.0)) for _ in range(n)])
+        segs = G.segments([s for u in utts for s in u])
+        offs = np.cumsum([0] + [len(u) for u in utts]).astype(np.uint32)
+        vids = rng.integers(0, 3, n_utt).astype(np.uint32)
+        seeds = rng.integers(0, 2 ** 32, n_utt, dtype=np.uint64).astype(np.uint32)
+        stride = 32768
+        ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, stride)
+        scale = max(1.0, float(np.max(np.abs(ref))))
+        for lanes in (0, 1, 4):
+            out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride, lanes)
+            assert np.array_equal(out_len, ref_len)
+            k = _worst(out, ref, ref_len) / scale
+            worst = max(worst, k)
+            assert k * ULP <= TOL, (trial, lanes, k)
+    print(f"fuzz: worst {worst:.1f} * 2^-23 (relative to max(1, peak))")
+    gpu_ctx.set_voices(W.single_voice())
+
+
+@pytest.mark.parametrize("config", [2, 3, 4])
+def test_fast_mode_full_size_against_exact_mode_on_the_device(gpu_ctx, config):
+    """BASELINE configs 2, 3, 4 at full size: fast rows against exact rows (which are bit-identical
+    to the oracle) compared on the device; 64 utterances spread over the batch also against the oracle."""
+    n_utt = 4096 if config == 2 else 65536
+    n_voices = 8 if config == 4 else 1
+    voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
+    ctx = gpu_ctx
+    ctx.set_voices(voices)
+    segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=n_voices)
+    stride = W.max_samples()
+    batch = ctx.upload(segs, offs, vids, seeds)
+    d_a = ctx.device_alloc(n_utt * stride * 4)
+    d_b = ctx.device_alloc(n_utt * stride * 4)
+    d_la = ctx.device_alloc(n_utt * 4)
+    d_lb = ctx.device_alloc(n_utt * 4)
+    try:
+        ctx.set_option("arithmetic", 0)
+        batch.synthesize_async(d_a, stride, d_la)
+        ctx.sync()
+        ctx.set_option("arithmetic", 1)
+        batch.synthesize_async(d_b, stride, d_lb)
+        ctx.sync()
+        assert "FAST" in ctx.last_kernel_name()
+        md, sq, bad = ctx.compare(d_a, d_b, stride, d_la, d_lb, n_utt)
+        lens = np.zeros(n_utt, dtype=np.uint32)
+        ctx.d2h(lens, d_la, n_utt * 4)
+        assert int(bad.sum()) == 0
+        k = float(md.max()) / ULP
+        rms = float(np.sqrt(sq.sum() / float(lens.astype(np.uint64).sum()))) / ULP
+        print(f"config {config}: fast vs exact over {n_utt} utterances: max {k:.1f}, rms {rms:.2f} (2^-23)")
+        assert md.max() <= TOL
+        # and a spread sample of the fast rows against the oracle itself
+        pick = np.linspace(0, n_utt - 1, 64).astype(np.int64)
+        ps = segs.reshape(n_utt, -1)[pick].reshape(-1)
+        po = (np.arange(len(pick) + 1) * W.SEGMENTS_PER_UTT).astype(np.uint32)
+        ref, ref_len = O.synthesize_batch(_ovoices(voices), ps, po, vids[pick], seeds[pick], stride)
+        row = np.zeros(stride, dtype=np.float32)
+        worst = 0.0
+        for i, u in enumerate(pick):
+            ctx.d2h(row, d_b, stride * 4, offset=int(u) * stride * 4)
+            n = int(ref_len[i])
+            assert n == int(lens[u])
+            worst = max(worst, float(np.max(np.abs(row[:n].astype(np.float64) - ref[i, :n]))))
+        print(f"config {config}: 64 spread utterances, fast vs oracle: {worst / ULP:.1f} * 2^-23")
+        assert worst <= TOL
+    finally:
+        ctx.set_option("arithmetic", 0)
+        for p in (d_a, d_b, d_la, d_lb):
+            ctx.device_free(p)
+        batch.free()
+        ctx.set_voices(W.single_voice())
