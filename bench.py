@@ -238,9 +238,9 @@ def main():
                     help="after the timed region: per-utterance digests of every rank's rows must equal "
                          "the digests rank 0 gets when it renders the same global utterances itself "
                          "(GPU-count invariance), and a re-batched subset must match (batch invariance)")
-    ap.add_argument("--cpu-utts", type=int, default=256,
-                    help="utterances for the CPU baseline (0 = skip); 256 is ~2-4 s of CPU "
-                         "(BASELINE.md's N_cpu; samples/s does not depend on it)")
+    ap.add_argument("--cpu-utts", type=int, default=512,
+                    help="utterances for the CPU baseline (0 = skip); 512 is ~4-7 s of CPU on one "
+                         "thread (samples/s does not depend on it)")
     args = ap.parse_args()
     if args.config == 2:
         args.utts, args.voices = 4096, 1

@@ -6,8 +6,13 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -117,16 +122,19 @@ struct grail_ctx {
     float max_dt = 0.0f;              // largest 1/sample_rate of the table
     float max_pitch_jitter = 0.0f;    // largest |jitter_delta_frequency| of the table
     int last_formants = 8, last_lanes = 0, last_pipe = 0;   // what the last synthesis launch used (statistics)
-    uint32_t *d_truncated = nullptr;  // [0] truncation flag, [1] slow-path wave-steps
+    uint32_t *d_truncated = nullptr;  // [0] truncation flag, [1] slow-path wave-steps, [2] fast wave-tiles, [3] general wave-steps
     uint64_t slow_steps = 0;          // of the kernels synced so far
+    uint64_t fast_tiles = 0, general_steps = 0;
     int lanes_option = 0;             // 0 = auto
     int variant_option = 0;           // experiments: explicit kernel instantiation
     int skip_silent_option = 1;       // skip band-pass filters of provably silent formants
     int pipeline_option = 1;          // small qualifying batches: producer/consumer workgroups
+    uint64_t voices_epoch = 0;        // bumped by every install_voices
     int fast_option = 0;              // "arithmetic": 0 exact (bit-identical), 1 fast (stated tolerance)
     std::string last_kernel = "none"; // instantiation of the last synthesis launch
     ncclComm_t comm = nullptr;
     uint32_t comm_rank = 0, comm_world = 1;
+    void *host_pipe = nullptr;        // HostPipe: streams, events and buffers of the host-output path
 };
 
 struct grail_stream {
@@ -136,6 +144,9 @@ struct grail_stream {
     int L = 1;
     int variant = 0;
     bool started = false;
+    // the kernel flavour, fixed when the stream is opened (the state layout follows it)
+    bool live4 = false, half_capable = false, any_blend = false;
+    uint64_t voices_epoch = 0;
 };
 
 struct grail_batch {
@@ -284,6 +295,7 @@ int install_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices)
                            hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // dv / elems are locals
     ctx->voices.assign(voices, voices + n_voices);
+    ++ctx->voices_epoch;
     bool silent = true;
     for (uint32_t v = 0; v < n_voices; ++v)
         for (int p = 0; p < NUM_VOICED; ++p)
@@ -307,6 +319,8 @@ int install_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices)
 }
 
 }  // namespace
+
+static void pipe_destroy_opaque(void *p);
 
 extern "C" {
 
@@ -358,8 +372,8 @@ int grail_create(int device, grail_ctx **out)
     if ((err = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (err = hipEventCreate(&ctx->ev_start)) != hipSuccess ||
         (err = hipEventCreate(&ctx->ev_stop)) != hipSuccess ||
-        (err = hipMalloc((void **)&ctx->d_truncated, 2 * sizeof(uint32_t))) != hipSuccess ||
-        (err = hipMemsetAsync(ctx->d_truncated, 0, 2 * sizeof(uint32_t), ctx->stream)) != hipSuccess ||
+        (err = hipMalloc((void **)&ctx->d_truncated, 4 * sizeof(uint32_t))) != hipSuccess ||
+        (err = hipMemsetAsync(ctx->d_truncated, 0, 4 * sizeof(uint32_t), ctx->stream)) != hipSuccess ||
         (err = hipStreamSynchronize(ctx->stream)) != hipSuccess) {
         grail_destroy(ctx);
         return hip_fail(err, "grail_create");
@@ -374,6 +388,7 @@ int grail_destroy(grail_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm && rccl().ok) rccl().CommDestroy(ctx->comm);
+    pipe_destroy_opaque(ctx->host_pipe);
     if (ctx->d_voices) (void)hipFree(ctx->d_voices);
     if (ctx->d_voice_elems) (void)hipFree(ctx->d_voice_elems);
     if (ctx->d_truncated) (void)hipFree(ctx->d_truncated);
@@ -451,6 +466,14 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
     }
     if (std::strcmp(name, "slow_division_wave_steps") == 0) {  // read-only statistic
         *value = (int64_t)ctx->slow_steps;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "fast_wave_tiles") == 0) {           // read-only: wave-tiles rendered in fast arithmetic
+        *value = (int64_t)ctx->fast_tiles;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "general_wave_steps") == 0) {        // read-only: wave-steps through the general step
+        *value = (int64_t)ctx->general_steps;
         return GRAIL_OK;
     }
     if (std::strcmp(name, "last_launch_formants") == 0) {      // read-only: 4 or 8 laid out over the lanes
@@ -606,20 +629,41 @@ int grail_batch_lengths(grail_ctx *ctx, const grail_batch *batch, uint32_t max_l
     return GRAIL_OK;
 }
 
+static bool batch_half_capable(const grail_ctx *ctx, const grail_batch *batch)
+{
+    return ctx->skip_silent_option && batch->phoneme_mode && ctx->voices_upper_silent;
+}
+
+// formants 5-8 left out altogether: the table qualifies (live4_ok); every segment is at least
+// two samples long, so the Sequencer clock never goes negative and alpha stays in [0,1]; and
+// every pitch stays >= 2^-20 under the pitch jitter, so the polyBLEP quotient and with it the
+// saw every formant is fed from stay finite (a dead formant fed +-inf would emit NaN)
+static bool batch_live4(const grail_ctx *ctx, const grail_batch *batch)
+{
+    return batch_half_capable(ctx, batch) && ctx->voices_live4_ok && batch->plain && !batch->any_blend &&
+           batch->min_length >= 2.0f * ctx->max_dt &&
+           batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f;
+}
+
+// Rows [first, first + count) of the batch (count = 0: all of it).  out_dev / out_len_dev point at the
+// first row RENDERED, i.e. the caller has already applied the row offset to them.
 static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_dev,
-                           int16_t *out_pcm16_dev, uint64_t out_stride, uint32_t *out_len_dev)
+                           int16_t *out_pcm16_dev, uint64_t out_stride, uint32_t *out_len_dev,
+                           uint32_t first = 0, uint32_t count = 0)
 {
     int rc = bind(ctx);
     if (rc) return rc;
     if ((rc = check_ready(ctx, batch))) return rc;
     if (batch->n_utt == 0) return GRAIL_OK;
     if (!out_dev && !out_pcm16_dev && out_stride) return fail(GRAIL_ERR_INVALID_ARG, "out_dev is NULL");
+    if (count == 0) count = batch->n_utt - first;
+    if (first > batch->n_utt || count > batch->n_utt - first) return fail(GRAIL_ERR_INVALID_ARG, "row range");
     SynthArgs a{};
     a.out_pcm16 = out_pcm16_dev;
     a.segs = batch->d_segs;
-    a.seg_offsets = batch->d_offsets;
-    a.voice_ids = batch->d_voice_ids;
-    a.seeds = batch->d_seeds;
+    a.seg_offsets = batch->d_offsets + first;      // the offsets themselves are absolute into segs
+    a.voice_ids = batch->d_voice_ids ? batch->d_voice_ids + first : nullptr;
+    a.seeds = batch->d_seeds ? batch->d_seeds + first : nullptr;
     a.elems = batch->phoneme_mode ? ctx->d_voice_elems : batch->d_elems;
     a.voices = ctx->d_voices;
     a.out = out_dev;
@@ -627,25 +671,19 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     a.truncated = ctx->d_truncated;
     a.out_stride = out_stride;
     a.cap = out_stride;
-    a.n_utt = batch->n_utt;
+    a.n_utt = count;
     a.n_voices = (uint32_t)ctx->voices.size();
     a.phoneme_mode = batch->phoneme_mode ? 1u : 0u;
     a.skip_silent = ctx->skip_silent_option ? 1u : 0u;
-    a.half_capable = (a.skip_silent && batch->phoneme_mode && ctx->voices_upper_silent) ? 1u : 0u;
+    a.half_capable = batch_half_capable(ctx, batch) ? 1u : 0u;
     a.any_blend = batch->any_blend ? 1u : 0u;
-    // formants 5-8 left out altogether: the table qualifies (live4_ok); every segment is at least
-    // two samples long, so the Sequencer clock never goes negative and alpha stays in [0,1]; and
-    // every pitch stays >= 2^-20 under the pitch jitter, so the polyBLEP quotient and with it the
-    // saw every formant is fed from stay finite (a dead formant fed +-inf would emit NaN)
-    a.live4 = (a.half_capable && ctx->voices_live4_ok && batch->plain && !batch->any_blend &&
-               batch->min_length >= 2.0f * ctx->max_dt &&
-               batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f) ? 1u : 0u;
+    a.live4 = batch_live4(ctx, batch) ? 1u : 0u;
     a.fast = ctx->fast_option ? 1u : 0u;
-    int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(batch->n_utt);
+    int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(count);
     // small batches leave SIMDs idle: four-wave workgroups (one wave renders 16 utterances, one carries
     // the per-utterance chain, two prepare the filter coefficients) while there is a CU for each
     if (a.live4 && !a.fast && !ctx->lanes_option && ctx->pipeline_option &&
-        ((uint64_t)batch->n_utt + 15) / 16 <= 256) {      // one workgroup per CU
+        ((uint64_t)count + 15) / 16 <= 256) {             // one workgroup per CU
         a.pipe = 1u;
         L = 4;
     }
@@ -654,7 +692,7 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     if (a.live4 && !a.pipe && L == 8) a.live4 = 0u;
     if (a.live4 && !a.pipe && !ctx->lanes_option) {
         // same rule as auto_lanes_per_utt — the widest mapping with one wave per SIMD — over 4 formants
-        L = ((uint64_t)batch->n_utt * 4 + 63) / 64 <= 1024 ? 4 : ((uint64_t)batch->n_utt * 2 + 63) / 64 <= 1024 ? 2 : 1;
+        L = ((uint64_t)count * 4 + 63) / 64 <= 1024 ? 4 : ((uint64_t)count * 2 + 63) / 64 <= 1024 ? 2 : 1;
     }
     // voices whose upper formants are never audible but that do not qualify for the 4-formant
     // kernels: one lane per utterance runs the half-live loop and ties two lanes per utterance,
@@ -694,7 +732,16 @@ int grail_stream_open(grail_ctx *ctx, const grail_batch *batch, grail_stream **o
     grail_stream *s = new (std::nothrow) grail_stream();
     if (!s) return fail(GRAIL_ERR_OUT_OF_MEMORY, "host allocation failed");
     s->batch = batch;
+    s->half_capable = batch_half_capable(ctx, batch);
+    s->any_blend = batch->any_blend;
+    s->live4 = batch_live4(ctx, batch);
+    s->voices_epoch = ctx->voices_epoch;
     s->L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(batch->n_utt);
+    if (s->live4) {
+        if (s->L == 8) s->live4 = false;     // eight lanes per utterance need eight formants to lay out
+        else if (!ctx->lanes_option)         // same rule over four formants: the widest one-wave-per-SIMD mapping
+            s->L = ((uint64_t)batch->n_utt * 4 + 63) / 64 <= 1024 ? 4 : ((uint64_t)batch->n_utt * 2 + 63) / 64 <= 1024 ? 2 : 1;
+    }
     s->variant = ctx->variant_option;
     s->lanes = state_lanes(batch->n_utt, s->L, s->variant);
     const size_t bytes = (size_t)state_words(s->L) * s->lanes * sizeof(uint32_t);
@@ -735,8 +782,11 @@ static int stream_next(grail_ctx *ctx, grail_stream *stream, uint32_t max_sample
     a.n_voices = (uint32_t)ctx->voices.size();
     a.phoneme_mode = batch->phoneme_mode ? 1u : 0u;
     a.skip_silent = ctx->skip_silent_option ? 1u : 0u;
-    a.half_capable = (a.skip_silent && batch->phoneme_mode && ctx->voices_upper_silent) ? 1u : 0u;
-    a.any_blend = batch->any_blend ? 1u : 0u;
+    if (stream->voices_epoch != ctx->voices_epoch)
+        return fail(GRAIL_ERR_INVALID_ARG, "the voice table changed since the stream was opened");
+    a.half_capable = stream->half_capable ? 1u : 0u;
+    a.any_blend = stream->any_blend ? 1u : 0u;
+    a.live4 = stream->live4 ? 1u : 0u;
     a.state = stream->d_state;
     a.state_stride = stream->lanes;
     a.resume = stream->started ? 1u : 0u;
@@ -744,6 +794,9 @@ static int stream_next(grail_ctx *ctx, grail_stream *stream, uint32_t max_sample
     hipError_t e = launch_synth(a, stream->L, stream->variant, ctx->stream);
     if (e != hipSuccess) return hip_fail(e, "synth kernel launch");
     ctx->last_kernel = last_kernel_name();
+    ctx->last_formants = a.live4 ? 4 : 8;
+    ctx->last_lanes = stream->L;
+    ctx->last_pipe = 0;
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->have_timing = true;
     stream->started = true;
@@ -779,11 +832,13 @@ int grail_sync(grail_ctx *ctx)
     if (rc) return rc;
     // flag read-back and reset travel on the stream the kernels run on (a non-blocking stream has
     // no implicit ordering with the null stream)
-    uint32_t flags[2] = {0, 0};
+    uint32_t flags[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(flags, ctx->d_truncated, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const uint32_t flag = flags[0];
-    if (flags[0] || flags[1]) {
+    ctx->fast_tiles += flags[2];
+    ctx->general_steps += flags[3];
+    if (flags[0] || flags[1] || flags[2] || flags[3]) {
         HIP_TRY(hipMemsetAsync(ctx->d_truncated, 0, sizeof flags, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
@@ -808,39 +863,245 @@ int grail_last_kernel_ms(grail_ctx *ctx, float *ms)
     return GRAIL_OK;
 }
 
+// ---- the one-call forms with a host destination: render and copy back, overlapped -------------
+// Rows are rendered in blocks (kernel on ctx->stream into one of two device buffers) while the
+// previous block travels to the host on a second stream.  A destination that is pinned /
+// registered host memory (grail_host_alloc, hipHostMalloc, hipHostRegister) receives the
+// device-to-host copies directly; a pageable destination is fed through a ring of pinned staging
+// buffers that copier threads empty into it (one memcpy thread cannot keep up with PCIe Gen5).
+// Same bytes as the device-resident result; rows end in zeros.
+namespace {
+
+constexpr size_t PIECE_BYTES = 32u << 20;   // pinned staging granularity
+constexpr int N_PIECES = 12;                // ring size
+constexpr int N_COPIERS = 8;               // memcpy threads for a pageable destination
+
+struct HostPipe {
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t rendered[2] = {nullptr, nullptr};   // block in dev[i] is complete (on ctx->stream)
+    hipEvent_t drained[2] = {nullptr, nullptr};    // dev[i] has been copied out (on copy_stream)
+    hipEvent_t landed[N_PIECES] = {};              // pinned piece i holds its data
+    void *dev[2] = {nullptr, nullptr};
+    size_t dev_bytes = 0;
+    void *pin[N_PIECES] = {};
+    bool have_pins = false;
+};
+
+void pipe_destroy(HostPipe *p)
+{
+    if (!p) return;
+    for (int i = 0; i < 2; ++i) {
+        if (p->dev[i]) (void)hipFree(p->dev[i]);
+        if (p->rendered[i]) (void)hipEventDestroy(p->rendered[i]);
+        if (p->drained[i]) (void)hipEventDestroy(p->drained[i]);
+    }
+    for (int i = 0; i < N_PIECES; ++i) {
+        if (p->pin[i]) (void)hipHostFree(p->pin[i]);
+        if (p->landed[i]) (void)hipEventDestroy(p->landed[i]);
+    }
+    if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
+    delete p;
+}
+
+// created on first use and kept in the context: pinned allocations cost tens of milliseconds
+int pipe_get(grail_ctx *ctx, size_t block_bytes, bool need_pins, HostPipe **out)
+{
+    HostPipe *p = (HostPipe *)ctx->host_pipe;
+    if (!p) {
+        p = new (std::nothrow) HostPipe();
+        if (!p) return fail(GRAIL_ERR_OUT_OF_MEMORY, "host allocation failed");
+        ctx->host_pipe = p;
+        HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipEventCreateWithFlags(&p->rendered[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&p->drained[i], hipEventDisableTiming));
+        }
+        for (int i = 0; i < N_PIECES; ++i) HIP_TRY(hipEventCreateWithFlags(&p->landed[i], hipEventDisableTiming));
+    }
+    if (p->dev_bytes < block_bytes) {
+        HIP_TRY(hipStreamSynchronize(p->copy_stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < 2; ++i) {
+            if (p->dev[i]) (void)hipFree(p->dev[i]);
+            p->dev[i] = nullptr;
+        }
+        p->dev_bytes = 0;
+        for (int i = 0; i < 2; ++i) HIP_TRY(hipMalloc(&p->dev[i], block_bytes));
+        p->dev_bytes = block_bytes;
+    }
+    if (need_pins && !p->have_pins) {
+        for (int i = 0; i < N_PIECES; ++i) HIP_TRY(hipHostMalloc(&p->pin[i], PIECE_BYTES, hipHostMallocDefault));
+        p->have_pins = true;
+    }
+    *out = p;
+    return GRAIL_OK;
+}
+
+bool is_pinned_host(const void *ptr)
+{
+    hipPointerAttribute_t attr;
+    std::memset(&attr, 0, sizeof attr);
+    if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
+        (void)hipGetLastError();     // a plain malloc pointer is "invalid value": not an error here
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
+// the copier side of the pinned ring: each job is one piece that has been ENQUEUED for copy-out
+struct CopyJob {
+    int piece;
+    char *dst;
+    size_t bytes;
+};
+struct CopyRing {
+    std::mutex m;
+    std::condition_variable cv_job, cv_free;
+    std::deque<CopyJob> jobs;
+    bool piece_busy[N_PIECES] = {};
+    bool closing = false;
+    hipError_t error = hipSuccess;
+};
+
+void copier_main(int device, HostPipe *p, CopyRing *r)
+{
+    (void)hipSetDevice(device);
+    for (;;) {
+        CopyJob job;
+        {
+            std::unique_lock<std::mutex> lk(r->m);
+            r->cv_job.wait(lk, [&] { return !r->jobs.empty() || r->closing; });
+            if (r->jobs.empty()) return;
+            job = r->jobs.front();
+            r->jobs.pop_front();
+        }
+        const hipError_t e = hipEventSynchronize(p->landed[job.piece]);
+        if (e == hipSuccess) std::memcpy(job.dst, p->pin[job.piece], job.bytes);
+        {
+            std::lock_guard<std::mutex> lk(r->m);
+            if (e != hipSuccess && r->error == hipSuccess) r->error = e;
+            r->piece_busy[job.piece] = false;
+        }
+        r->cv_free.notify_all();
+    }
+}
+
+// ELEM = 4: f32 rows, 2: i16 PCM rows
+int render_to_host(grail_ctx *ctx, grail_batch *b, uint32_t n_utt, void *out, size_t elem, uint64_t out_stride,
+                   uint32_t *out_len)
+{
+    const size_t row_bytes = (size_t)out_stride * elem;
+    uint32_t *d_len = nullptr;
+    hipError_t e = hipSuccess;
+    if (n_utt) e = hipMalloc((void **)&d_len, (size_t)n_utt * sizeof(uint32_t));
+    if (e != hipSuccess) return hip_fail(e, "out_len allocation");
+    int rc = GRAIL_OK, sync_rc = GRAIL_OK;
+    if (n_utt && row_bytes) {
+        // block = up to 4096 rows and 2 GB: big enough for the kernel to outrun PCIe (a 4096-utterance
+        // launch renders > 100 GB/s of PCM), small enough for two of them to sit beside the batch
+        uint64_t rows = std::min<uint64_t>(4096, std::max<uint64_t>(1, (2ull << 30) / row_bytes));
+        rows = std::min<uint64_t>(rows, n_utt);
+        const bool direct = is_pinned_host(out);
+        HostPipe *p = nullptr;
+        rc = pipe_get(ctx, rows * row_bytes, !direct, &p);
+        CopyRing ring;
+        std::vector<std::thread> copiers;
+        if (!rc && !direct)
+            for (int i = 0; i < N_COPIERS; ++i) copiers.emplace_back(copier_main, ctx->device, p, &ring);
+        int piece_next = 0;
+        uint32_t blk = 0;
+        for (uint64_t first = 0; !rc && first < n_utt; first += rows, ++blk) {
+            const uint32_t count = (uint32_t)std::min<uint64_t>(rows, n_utt - first);
+            const int slot = blk & 1;
+            const size_t bytes = (size_t)count * row_bytes;
+            // the kernel may not overwrite dev[slot] before its previous contents have left
+            if (blk >= 2) e = hipStreamWaitEvent(ctx->stream, p->drained[slot], 0);
+            if (e == hipSuccess) e = hipMemsetAsync(p->dev[slot], 0, bytes, ctx->stream);
+            if (e != hipSuccess) { rc = hip_fail(e, "block set-up"); break; }
+            rc = synthesize_rows(ctx, b, elem == 4 ? (float *)p->dev[slot] : nullptr,
+                                 elem == 2 ? (int16_t *)p->dev[slot] : nullptr, out_stride, d_len + first,
+                                 (uint32_t)first, count);
+            if (rc) break;
+            e = hipEventRecord(p->rendered[slot], ctx->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(p->copy_stream, p->rendered[slot], 0);
+            char *dst = (char *)out + (size_t)first * row_bytes;
+            if (e == hipSuccess && direct) {
+                e = hipMemcpyAsync(dst, p->dev[slot], bytes, hipMemcpyDeviceToHost, p->copy_stream);
+            } else if (e == hipSuccess) {
+                for (size_t off = 0; off < bytes && e == hipSuccess; off += PIECE_BYTES) {
+                    const size_t n = std::min(PIECE_BYTES, bytes - off);
+                    const int piece = piece_next;
+                    piece_next = (piece_next + 1) % N_PIECES;
+                    {
+                        std::unique_lock<std::mutex> lk(ring.m);
+                        ring.cv_free.wait(lk, [&] { return !ring.piece_busy[piece]; });
+                        ring.piece_busy[piece] = true;
+                        if (ring.error != hipSuccess) e = ring.error;
+                    }
+                    if (e == hipSuccess)
+                        e = hipMemcpyAsync(p->pin[piece], (char *)p->dev[slot] + off, n, hipMemcpyDeviceToHost,
+                                           p->copy_stream);
+                    if (e == hipSuccess) e = hipEventRecord(p->landed[piece], p->copy_stream);
+                    {
+                        std::lock_guard<std::mutex> lk(ring.m);
+                        if (e == hipSuccess) ring.jobs.push_back(CopyJob{piece, dst + off, n});
+                        else ring.piece_busy[piece] = false;
+                    }
+                    ring.cv_job.notify_one();
+                }
+            }
+            if (e == hipSuccess) e = hipEventRecord(p->drained[slot], p->copy_stream);
+            if (e != hipSuccess) rc = hip_fail(e, "device-to-host pipeline");
+        }
+        {
+            std::lock_guard<std::mutex> lk(ring.m);
+            ring.closing = true;
+        }
+        ring.cv_job.notify_all();
+        for (auto &t : copiers) t.join();
+        if (p) {
+            e = hipStreamSynchronize(p->copy_stream);
+            if (!rc && e != hipSuccess) rc = hip_fail(e, "device-to-host pipeline");
+        }
+        if (!rc && ring.error != hipSuccess) rc = hip_fail(ring.error, "device-to-host pipeline");
+    }
+    if (!rc) {
+        sync_rc = grail_sync(ctx);
+        if (sync_rc != GRAIL_OK && sync_rc != GRAIL_ERR_BUFFER_TOO_SMALL) rc = sync_rc;
+    }
+    if (!rc && out_len && n_utt) {
+        e = hipMemcpyAsync(out_len, d_len, (size_t)n_utt * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = hip_fail(e, "out_len copy");
+    }
+    if (d_len) (void)hipFree(d_len);
+    return rc ? rc : sync_rc;
+}
+
+}  // namespace
+
+static void pipe_destroy_opaque(void *p) { pipe_destroy((HostPipe *)p); }
+
 static int run_one_call(grail_ctx *ctx, grail_batch *b, uint32_t n_utt, float *out,
                         uint64_t out_stride, uint32_t *out_len, uint32_t flags)
 {
+    if (!(flags & GRAIL_OUT_DEVICE)) return render_to_host(ctx, b, n_utt, out, sizeof(float), out_stride, out_len);
     int rc = GRAIL_OK;
-    float *d_out = nullptr;
     uint32_t *d_len = nullptr;
-    const bool dev_out = (flags & GRAIL_OUT_DEVICE) != 0;
-    const size_t out_bytes = (size_t)n_utt * out_stride * sizeof(float);
     hipError_t e = hipSuccess;
-    if (dev_out) {
-        d_out = out;
-    } else if (out_bytes) {
-        e = hipMalloc((void **)&d_out, out_bytes);
-        // the whole block is copied back: rows end in zeros, not stale HBM
-        if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, out_bytes, ctx->stream);
-    }
-    if (e == hipSuccess && n_utt) e = hipMalloc((void **)&d_len, (size_t)n_utt * sizeof(uint32_t));
+    if (n_utt) e = hipMalloc((void **)&d_len, (size_t)n_utt * sizeof(uint32_t));
     if (e != hipSuccess) rc = hip_fail(e, "output allocation");
-    if (!rc) rc = grail_batch_synthesize_async(ctx, b, d_out, out_stride, d_len);
+    if (!rc) rc = grail_batch_synthesize_async(ctx, b, out, out_stride, d_len);
     int sync_rc = GRAIL_OK;
     if (!rc) {
         sync_rc = grail_sync(ctx);
         if (sync_rc != GRAIL_OK && sync_rc != GRAIL_ERR_BUFFER_TOO_SMALL) rc = sync_rc;
     }
     if (!rc && out_len && n_utt) {
-        e = hipMemcpy(out_len, d_len, (size_t)n_utt * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        e = hipMemcpyAsync(out_len, d_len, (size_t)n_utt * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = hip_fail(e, "out_len copy");
     }
-    if (!rc && !dev_out && out_bytes) {
-        e = hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = hip_fail(e, "output copy");
-    }
-    if (!dev_out && d_out) (void)hipFree(d_out);
     if (d_len) (void)hipFree(d_len);
     return rc ? rc : sync_rc;
 }
@@ -951,38 +1212,28 @@ int grail_synthesize_batch_pcm16(grail_ctx *ctx, const grail_phoneme_elem *segs,
     grail_batch *b = nullptr;
     int rc = grail_batch_upload(ctx, segs, seg_offsets, voice_ids, jitter_seeds, n_utt, &b);
     if (rc) return rc;
-    int16_t *d_i16 = nullptr;
-    uint32_t *d_len = nullptr;
-    const bool dev_out = (flags & GRAIL_OUT_DEVICE) != 0;
-    const size_t n_elems = (size_t)n_utt * out_stride;
     int sync_rc = GRAIL_OK;
-    hipError_t e = hipSuccess;
-    if (n_utt) e = hipMalloc((void **)&d_len, (size_t)n_utt * sizeof(uint32_t));
-    if (e == hipSuccess) {
-        if (dev_out) d_i16 = out;
-        else if (n_elems) {
-            e = hipMalloc((void **)&d_i16, n_elems * sizeof(int16_t));
-            if (e == hipSuccess) e = hipMemsetAsync(d_i16, 0, n_elems * sizeof(int16_t), ctx->stream);
+    // the conversion is part of the synthesis kernel's tile flush: 2 B per sample of HBM and PCIe traffic
+    if (!(flags & GRAIL_OUT_DEVICE)) {
+        rc = render_to_host(ctx, b, n_utt, out, sizeof(int16_t), out_stride, out_len);
+    } else {
+        uint32_t *d_len = nullptr;
+        hipError_t e = hipSuccess;
+        if (n_utt) e = hipMalloc((void **)&d_len, (size_t)n_utt * sizeof(uint32_t));
+        if (e != hipSuccess) rc = hip_fail(e, "pcm16 output allocation");
+        if (!rc) rc = grail_batch_synthesize_pcm16_async(ctx, b, out, out_stride, d_len);
+        if (!rc) {
+            sync_rc = grail_sync(ctx);
+            if (sync_rc != GRAIL_OK && sync_rc != GRAIL_ERR_BUFFER_TOO_SMALL) rc = sync_rc;
         }
-    }
-    if (e != hipSuccess) rc = hip_fail(e, "pcm16 output allocation");
-    // the conversion is part of the synthesis kernel's tile flush: 2 B per sample of HBM traffic
-    if (!rc) rc = grail_batch_synthesize_pcm16_async(ctx, b, d_i16, out_stride, d_len);
-    if (!rc) {
-        sync_rc = grail_sync(ctx);
-        if (sync_rc != GRAIL_OK && sync_rc != GRAIL_ERR_BUFFER_TOO_SMALL) rc = sync_rc;
-    }
-    if (!rc && out_len && n_utt) {
-        e = hipMemcpy(out_len, d_len, (size_t)n_utt * sizeof(uint32_t), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = hip_fail(e, "out_len copy");
-    }
-    if (!rc && !dev_out && n_elems) {
-        e = hipMemcpy(out, d_i16, n_elems * sizeof(int16_t), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = hip_fail(e, "pcm16 output copy");
+        if (!rc && out_len && n_utt) {
+            e = hipMemcpyAsync(out_len, d_len, (size_t)n_utt * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) rc = hip_fail(e, "out_len copy");
+        }
+        if (d_len) (void)hipFree(d_len);
     }
     const std::string keep = g_last_error;
-    if (d_len) (void)hipFree(d_len);
-    if (!dev_out && d_i16) (void)hipFree(d_i16);
     grail_batch_free(ctx, b);
     g_last_error = keep;
     return rc ? rc : sync_rc;
@@ -1028,6 +1279,24 @@ int grail_device_free(grail_ctx *ctx, void *ptr)
     int rc = bind(ctx);
     if (rc) return rc;
     if (ptr) HIP_TRY(hipFree(ptr));
+    return GRAIL_OK;
+}
+
+int grail_host_alloc(grail_ctx *ctx, size_t bytes, void **out)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!out) return fail(GRAIL_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return GRAIL_OK;
+}
+
+int grail_host_free(grail_ctx *ctx, void *ptr)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (ptr) HIP_TRY(hipHostFree(ptr));
     return GRAIL_OK;
 }
 

@@ -53,6 +53,7 @@ struct SynthArgs {
     uint32_t *out_len;            // may be nullptr
     uint32_t *truncated;          // [0]: set to 1 when an utterance is cut at out_stride;
                                   // [1]: += wave-steps that ran the IEEE-division body
+                                  // [2]: += wave-tiles rendered in fast arithmetic, [3]: += general wave-steps
     uint64_t out_stride;          // samples between rows
     uint64_t cap;                 // samples a row may receive in this launch (<= out_stride)
     uint32_t n_utt;

@@ -481,7 +481,7 @@ struct StateIO {
 // ANYBL: blend lengths that are not powers of two also take the quiet step (clk / blend_length by
 // the short exact division).  The host asks for it only when the batch holds such a segment, so the
 // usual case (the Intonator always emits 0.5, src/lib.rs:1071) runs a kernel without that code.
-// NFA: formants laid out over the lanes, 8 or 4.  NFA = 4 (one-shot phoneme batches only) renders
+// NFA: formants laid out over the lanes, 8 or 4.  NFA = 4 (phoneme batches only) renders
 // formants 1-4 and nothing else: the host has verified (grail_api.cpp, live4_ok) that formants 5-8
 // of every phoneme of every voice have amplitude +0 and parameters for which the reference's own
 // arithmetic keeps their band-pass state and output at exactly +0 for the whole batch, so the fold
@@ -502,7 +502,7 @@ template <int L, int T, int WAVES, int MIN_WAVES_PER_SIMD, bool STREAM, bool HAL
 __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(const SynthArgs A)
 {
     static_assert(!FAST || !PIPE, "FAST");
-    static_assert(NFA == NF || (NFA == 4 && !STREAM && !HALF), "NFA");
+    static_assert(NFA == NF || (NFA == 4 && !HALF), "NFA");
     static_assert(!PIPE || (WAVES == 4 && NFA / L == 1 && L >= 4 && !STREAM && !HALF && !ANYBL && T % 4 == 0), "PIPE");
     constexpr int FPL = NFA / L;         // formants per lane
     constexpr int W = FPL >= 2 ? 2 : 1;  // formants per packed value
@@ -566,8 +566,13 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     // then keeps its own copy of the state.  The three noises share one phase
     // sequence (same start, same increment), kept once.
     uint32_t seed = A.seeds ? A.seeds[uc] : 0u;
-    float fn_cur = lcg_f32(seed);            // ValueNoise::new :228-229
-    float fn_next = lcg_f32(seed);
+    // a resumed stream call loads all of this from its state block: skip the 34 draws
+    const bool fresh_start = !(STREAM && A.state && A.resume);
+    float fn_cur = 0.0f, fn_next = 0.0f;
+    if (fresh_start) {
+        fn_cur = lcg_f32(seed);              // ValueNoise::new :228-229
+        fn_next = lcg_f32(seed);
+    }
     uint32_t fn_state = seed;
     V ff_cur[NV], ff_next[NV], fa_cur[NV], fa_next[NV];
 #pragma unroll
@@ -575,6 +580,8 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         ff_cur[k] = vsplat(0.0f, ff_cur[k]); ff_next[k] = ff_cur[k];
         fa_cur[k] = ff_cur[k]; fa_next[k] = ff_cur[k];
     }
+    uint32_t ff_state = seed;
+    if (fresh_start) {
 #pragma unroll
     for (int i = 0; i < NF; ++i) {           // ArrayValueNoise::new :275-278
         const float c0 = lcg_f32(seed);
@@ -585,7 +592,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             for (int c = 0; c < W; ++c)
                 if (i == f0 + k * W + c) { vset(ff_cur[k], c, c0); vset(ff_next[k], c, n0); }
     }
-    uint32_t ff_state = seed;
+    ff_state = seed;
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
         const float c0 = lcg_f32(seed);
@@ -595,6 +602,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 #pragma unroll
             for (int c = 0; c < W; ++c)
                 if (i == f0 + k * W + c) { vset(fa_cur[k], c, c0); vset(fa_next[k], c, n0); }
+    }
     }
     uint32_t fa_state = seed;
     float jphase = 0.0f;
@@ -618,6 +626,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     const uint32_t cap32 = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;   // n_out is 32-bit
     uint32_t n_out = 0;
     uint32_t slow_steps = 0;                 // wave-steps that took the IEEE-division body
+    uint32_t fast_tiles = 0, general_steps = 0;   // statistics: tiles rendered by fast_tile, general steps taken
     bool truncated = false;
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(A.out) & 15u) == 0) && ((A.out_stride & 3u) == 0);
     const bool vec16_ok = ((reinterpret_cast<uintptr_t>(A.out_pcm16) & 7u) == 0) && ((A.out_stride & 3u) == 0);
@@ -1730,6 +1739,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                         }
                     }
                     if (rendered) {
+                        if constexpr (FAST) ++fast_tiles;
                         t = T;
                         n_out += idle ? 0u : (uint32_t)T;
                         noise_seed = (uint32_t)__builtin_amdgcn_readlane((int)sk, T - 1);
@@ -1767,6 +1777,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 else quiet_run(FullTag(), std::false_type());
             }
             if (t < T) {
+                ++general_steps;
                 general_step(t);
                 quiet_ok = pair_safe && (blend_pow2 || blend_div_ok);
                 ++t;
@@ -1876,6 +1887,8 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         visit_state(io);
     }
     if (emit && lane == 0 && slow_steps) atomicAdd(A.truncated + 1, slow_steps);
+    if (emit && lane == 0 && fast_tiles) atomicAdd(A.truncated + 2, fast_tiles);
+    if (emit && lane == 0 && general_steps) atomicAdd(A.truncated + 3, general_steps);
 }
 
 // Sequencer clock only (src/lib.rs:861-888, :930): how many elems the
@@ -1974,6 +1987,10 @@ static void launch_one(const SynthArgs &args, hipStream_t stream)
     const uint32_t per_block = (64u / L) * WAVES;
     const dim3 grid((args.n_utt + per_block - 1) / per_block), block(64 * WAVES);
     if constexpr (L <= 4) {
+        if (args.state && !args.any_blend && args.live4) {
+            start<L, T, WAVES, MINW, true, false, false, 4>(args, grid, block, stream);
+            return;
+        }
         if (!args.state && !args.any_blend && args.live4) {
             // L = 4 parks 4 floats per sample instead of 8: room for the 64-step tiles of L = 8
             constexpr int T4 = L == 4 ? 64 : T;
@@ -1985,13 +2002,20 @@ static void launch_one(const SynthArgs &args, hipStream_t stream)
     if (args.fast && !args.state) {
         // tolerance mode: the same kernels with the fast calm tile; ANYBL folded in (one instantiation
         // per layout keeps the library small), HALF only where the exact policy uses it
+        // (64-sample tiles at L = 1 were measured: slower — a tile with an event takes the general step
+        // for all of its samples, and twice as many samples share a tile with each event)
         if (L == 1 && args.half_capable) start<L, T, WAVES, MINW, false, true, true, NF, false, true>(args, grid, block, stream);
         else start<L, T, WAVES, MINW, false, false, true, NF, false, true>(args, grid, block, stream);
         return;
     }
-    if (args.state)
-        start<L, T, WAVES, MINW, true, true, true>(args, grid, block, stream);
-    else if (args.any_blend)
+    if (args.state) {
+        // resumable streams: the lean instantiation when the batch allows it (chosen when the stream is
+        // opened: the state layout follows the formant layout), the general one otherwise
+        if (!args.any_blend && !args.half_capable)
+            start<L, T, WAVES, MINW, true, false, false>(args, grid, block, stream);
+        else
+            start<L, T, WAVES, MINW, true, true, true>(args, grid, block, stream);
+    } else if (args.any_blend)
         start<L, T, WAVES, MINW, false, true, true>(args, grid, block, stream);
     else if (L == 1 && args.half_capable)
         start<L, T, WAVES, MINW, false, true, false>(args, grid, block, stream);

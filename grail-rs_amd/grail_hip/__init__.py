@@ -59,7 +59,7 @@ EXPORTS = [
     "grail_stream_open", "grail_stream_next_async", "grail_stream_close",
     "grail_language_generic", "grail_transcribe", "grail_intonate", "grail_text_to_phoneme_elems",
     "grail_synthesize_batch_pcm16", "grail_batch_synthesize_pcm16_async", "grail_stream_next_pcm16_async", "grail_say_batch", "grail_pcm16_async", "grail_batch_digest", "grail_batch_compare", "grail_wav_write_i16",
-    "grail_device_alloc", "grail_device_free", "grail_memcpy_d2h", "grail_memcpy_h2d",
+    "grail_device_alloc", "grail_device_free", "grail_host_alloc", "grail_host_free", "grail_memcpy_d2h", "grail_memcpy_h2d",
     "grail_memset_d", "grail_shard_range", "grail_comm_unique_id", "grail_comm_init",
     "grail_broadcast_voices", "grail_comm_info", "grail_comm_destroy",
 ]
@@ -217,6 +217,8 @@ def load():
     L.grail_wav_write_i16.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
     L.grail_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.grail_device_free.argtypes = [vp, vp]
+    L.grail_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.grail_host_free.argtypes = [vp, vp]
     L.grail_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
     L.grail_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
     L.grail_memset_d.argtypes = [vp, vp, C.c_int, C.c_size_t]
@@ -592,6 +594,32 @@ class Context:
 
     def device_free(self, p):
         _check(load().grail_device_free(self.handle, p))
+
+    def host_alloc(self, shape, dtype):
+        """A numpy array in pinned host memory (grail_host_alloc); free it with host_free(array)."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        _check(load().grail_host_alloc(self.handle, n, C.byref(p)))
+        buf = (C.c_char * max(n, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr):
+        p = self._pinned.pop(arr.ctypes.data)
+        _check(load().grail_host_free(self.handle, p))
+
+    def synthesize_into(self, out, out_len, segs, seg_offsets, voice_ids=None, jitter_seeds=None):
+        """One-call form into a caller-owned host array out[n_utt, out_stride] (f32 or i16)."""
+        segs = np.ascontiguousarray(segs, dtype=PHONEME_DTYPE)
+        seg_offsets, n_utt, voice_ids, jitter_seeds = self._prep(None, segs, seg_offsets, voice_ids,
+                                                                 jitter_seeds)
+        assert out.shape[0] >= n_utt and out.flags.c_contiguous
+        fn = load().grail_synthesize_batch if out.dtype == np.float32 else load().grail_synthesize_batch_pcm16
+        _check(fn(self.handle, segs.ctypes.data, seg_offsets.ctypes.data, _ptr(voice_ids), _ptr(jitter_seeds),
+                  n_utt, out.ctypes.data, out.shape[1], out_len.ctypes.data, OUT_HOST))
 
     def d2h(self, dst, src_dev, nbytes, offset=0):
         src = C.c_void_p(src_dev.value + offset)

@@ -163,6 +163,8 @@ extern "C" {
 
     pub fn grail_device_alloc(ctx: *mut grail_ctx, bytes: usize, out: *mut *mut std::ffi::c_void) -> c_int;
     pub fn grail_device_free(ctx: *mut grail_ctx, ptr: *mut std::ffi::c_void) -> c_int;
+    pub fn grail_host_alloc(ctx: *mut grail_ctx, bytes: usize, out: *mut *mut std::ffi::c_void) -> c_int;
+    pub fn grail_host_free(ctx: *mut grail_ctx, ptr: *mut std::ffi::c_void) -> c_int;
     pub fn grail_memcpy_d2h(ctx: *mut grail_ctx, dst: *mut std::ffi::c_void, src: *const std::ffi::c_void, bytes: usize) -> c_int;
     pub fn grail_memcpy_h2d(ctx: *mut grail_ctx, dst: *mut std::ffi::c_void, src: *const std::ffi::c_void, bytes: usize) -> c_int;
     pub fn grail_memset_d(ctx: *mut grail_ctx, dst: *mut std::ffi::c_void, value: c_int, bytes: usize) -> c_int;

@@ -191,8 +191,9 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       for parameters like voices::generic()'s (DESIGN.md "Fast mode"; tests/test_fast_gpu.py).
  *       This is the ONE knob that changes result bits.
  *   "kernel_variant": experiments only.
- * Read-only statistics: "slow_division_wave_steps", "last_launch_formants" (4 or 8),
- * "last_launch_lanes", "last_launch_pipelined". */
+ * Read-only statistics: "slow_division_wave_steps", "fast_wave_tiles" (wave-tiles rendered in fast
+ * arithmetic), "general_wave_steps", "last_launch_formants" (4 or 8), "last_launch_lanes",
+ * "last_launch_pipelined". */
 int grail_set_option(grail_ctx *ctx, const char *name, int64_t value);
 int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value);
 
@@ -252,7 +253,9 @@ int grail_stream_next_pcm16_async(grail_ctx *ctx, grail_stream *stream, uint32_t
 int grail_stream_close(grail_ctx *ctx, grail_stream *stream);
 
 /* One-call forms: upload, synthesize, copy back (GRAIL_OUT_HOST) or leave in
- * place (GRAIL_OUT_DEVICE), wait.  out_len is host memory [n_utt] or NULL.
+ * place (GRAIL_OUT_DEVICE), wait.  With GRAIL_OUT_HOST the rows are rendered in blocks of up to
+ * 4096 utterances while the previous block travels over PCIe on a second stream, so the call
+ * costs about max(kernel, copy) instead of their sum and needs two blocks of HBM, not the batch.  out_len is host memory [n_utt] or NULL.
  * GRAIL_OUT_HOST overwrites all n_utt*out_stride floats: each row is its
  * samples followed by zeros.  GRAIL_OUT_DEVICE leaves the tail untouched. */
 int grail_synthesize_batch(grail_ctx *ctx, const grail_phoneme_elem *segs,
@@ -329,6 +332,11 @@ int grail_wav_write_i16(const char *path, const int16_t *pcm, uint32_t n, uint32
 /* ---- device memory plumbing ------------------------------------------- */
 int grail_device_alloc(grail_ctx *ctx, size_t bytes, void **out);
 int grail_device_free(grail_ctx *ctx, void *ptr);
+/* Pinned (page-locked) host memory.  A GRAIL_OUT_HOST destination that lives in it receives the
+ * device-to-host copies directly, at PCIe rate; a pageable destination is fed through pinned
+ * staging buffers and copier threads (still overlapped with the kernels, a little slower). */
+int grail_host_alloc(grail_ctx *ctx, size_t bytes, void **out);
+int grail_host_free(grail_ctx *ctx, void *ptr);
 int grail_memcpy_d2h(grail_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int grail_memcpy_h2d(grail_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int grail_memset_d(grail_ctx *ctx, void *dst_dev, int value, size_t bytes);

@@ -145,3 +145,18 @@ def test_cpp_facade_example_builds(built):
     if G.device_count() == 0:   # no CPU fallback: the example must fail loudly, not fake audio
         r = subprocess.run([exe, "a"], capture_output=True, text=True)
         assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+def test_bench_gpus_n_without_a_launcher_never_reports_one_gpu(built):
+    """`python bench.py --gpus 2` started directly must run two ranks or fail — never time one GPU and
+    print n_gpus: 1 (round-1 hole).  Without a device the ranks fail and the launcher must say so."""
+    if G.device_count() > 0:
+        pytest.skip("a device is present: covered by tests/test_bench_multirank_gpu.py")
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "0", "--utts", "64"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode != 0
+    assert "n_gpus" not in p.stdout

@@ -1,8 +1,9 @@
-"""bench.py's multi-rank control flow on a real GPU box: two ranks launched the way the driver
-launches them (python -m torch.distributed.run), both pinned to GPU 0 (GRAIL_BENCH_DEVICE test
-hook) because the test boxes have one GPU.  RCCL refuses a duplicate GPU, so this also shows the
-all-rank fallback for the voice table; the RCCL success path itself is covered single-rank in
-test_parity_gpu.py::test_rccl_voice_broadcast_single_rank."""
+"""bench.py's multi-rank control flow on a real GPU box.  The test boxes have one GPU, so both ranks
+are pinned to GPU 0 (GRAIL_BENCH_DEVICE test hook); RCCL refuses a duplicate GPU, which exercises
+(a) --require-rccl failing loudly and (b) with --no-require-rccl the all-rank file fallback for the
+voice table.  The RCCL success path itself is covered single-rank in
+test_parity_gpu.py::test_rccl_voice_broadcast_single_rank; N distinct GPUs only exist on the driver's
+8-GPU node."""
 import json
 import os
 import subprocess
@@ -13,22 +14,64 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ENV = dict(os.environ, GRAIL_BENCH_DEVICE="0", GRAIL_BENCH_RCCL_TIMEOUT="60",
+           HSA_ENABLE_IPC_MODE_LEGACY="0")
 
 
-def test_two_ranks_one_json_line(built):
-    env = dict(os.environ, GRAIL_BENCH_DEVICE="0", GRAIL_BENCH_RCCL_TIMEOUT="60",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "1", "--utts", "2048"]
-    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+def _one_line(p):
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, p.stdout[-2000:]          # rank 0 prints ONE JSON line, nothing else
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def _check_two_ranks(d):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
     per_rank = d["config"]["samples_per_step_per_gpu"]
     # whole-job value: both ranks' samples over the slowest rank's time
     assert abs(d["value"] - 2 * per_rank * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
-    assert "rendezvous" in d["config"]["voice_table"] or "rccl" in d["config"]["voice_table"]
+    assert d["rccl"]["broadcast"] in ("ncclBroadcast", "file-fallback")
+    assert d["rccl"]["ranks"] == (2 if d["rccl"]["broadcast"] == "ncclBroadcast" else 0)
     assert "cpu_baseline" not in d                      # N=1 only
+
+
+def test_two_ranks_under_torch_distributed_run(built):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--utts", "2048", "--no-require-rccl"]
+    d = _one_line(subprocess.run(cmd, cwd=ROOT, env=ENV, capture_output=True, text=True, timeout=600))
+    _check_two_ranks(d)
+
+
+def test_gpus_2_launches_its_own_ranks_and_verifies(built):
+    """`python bench.py --gpus 2` with no launcher: the parent starts two ranks, relays one line;
+    --verify proves every rank's rows equal rank 0's rendering of the same global utterances."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--utts", "2048", "--no-require-rccl", "--verify"]
+    env = {k: v for k, v in ENV.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    d = _one_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600))
+    _check_two_ranks(d)
+    assert d["verify"]["mismatches"] == 0 and d["verify"]["utterances_checked"] == 2 * 2048
+    assert d["verify"]["rebatched_subset_mismatches"] == 0
+
+
+def test_require_rccl_fails_loudly_when_the_ranks_cannot_meet(built):
+    """Default for N > 1: no silent file fallback.  Two ranks on one GPU cannot form a communicator."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--utts", "256"]
+    env = {k: v for k, v in ENV.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert "require-rccl" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{") and "n_gpus" in l]
+
+
+def test_single_gpu_verify_and_fast_leg(built):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--utts", "4096",
+           "--verify", "--cpu-utts", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    d = _one_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600))
+    assert d["n_gpus"] == 1 and d["verify"]["mismatches"] == 0
+    assert d["config"]["arithmetic"] == "exact"
+    assert d["fast_mode"]["value"] > 0 and "FAST" in d["fast_mode"]["kernel"]
+    assert d["rccl"]["ranks"] == 0
