@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X
 ALG_BYTES_PER_SAMPLE = 4.01  # 4 B f32 written + <= 0.01 B of segment/voice input
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
 RCCL_TIMEOUT_S = float(os.environ.get("GRAIL_BENCH_RCCL_TIMEOUT", "240"))
-KERNEL_SOURCES = ["synth_kernels.hip", "fast_tile.h", "kernels.h", "pcm16.h"]
+KERNEL_SOURCES = ["synth_kernels.hip", "scan_kernels.hip", "device_common.h", "kernels.h", "pcm16.h"]
 
 
 def kernel_source_sha():

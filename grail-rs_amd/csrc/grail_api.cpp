@@ -119,6 +119,10 @@ struct grail_ctx {
     float *d_voice_elems = nullptr;   // [n_voices * NUM_VOICED][49]
     bool voices_upper_silent = false; // every voice: formants 5-8 have amplitude +0 in every phoneme
     bool voices_live4_ok = false;     // ... and parameters that keep their output at exactly +0 (live4_ok)
+    bool voices_scan_ok = false;      // every formant of every voice inside the safe window (scan_voice_ok)
+    int scan_debug = 0;
+    int scan_option = 1;              // fast arithmetic: small batches go to the time-parallel scan kernel
+    int64_t scan_max_utts = 3072;     // ... up to this many utterances
     float max_dt = 0.0f;              // largest 1/sample_rate of the table
     float max_pitch_jitter = 0.0f;    // largest |jitter_delta_frequency| of the table
     int last_formants = 8, last_lanes = 0, last_pipe = 0;   // what the last synthesis launch used (statistics)
@@ -264,6 +268,30 @@ bool live4_ok(const grail_voice &v)
     return ok;
 }
 
+// Can this voice go through the time-parallel scan kernel (fast arithmetic, small batches)?  That path
+// has no IEEE-division fallback: every formant of every phoneme must sit inside pair_is_safe's window
+// with the jitter margin, and the jitter parameters must be sane.  SynthesisElem::silent() qualifies.
+bool scan_voice_ok(const grail_voice &v)
+{
+    constexpr float X_LO = 9.5367431640625e-07f, X_HI = 0.5f - 9.5367431640625e-07f;
+    constexpr float W_LO = 1.8189894035458565e-12f, W_HI = 512.0f;
+    const float amp_scale = 0.5f * v.jitter_delta_amplitude;
+    const float jm = 1.002f * std::fabs(v.jitter_delta_formant_frequency);
+    bool ok = std::isfinite(amp_scale) && (jm <= 1.0f) && (v.jitter_frequency >= 0.0f) &&
+              (v.jitter_frequency <= 0.25f) && (v.sample_rate > 0.0f) && std::isfinite(v.sample_rate) &&
+              std::isfinite(v.jitter_delta_frequency);
+    for (int p = 0; p < NUM_VOICED && ok; ++p) {
+        const grail_synthesis_elem &e = v.phonemes[p];
+        for (int i = 0; i < NF && ok; ++i) {
+            const float f = e.formant_freq[i], w = e.formant_bw[i];
+            ok = std::isfinite(e.formant_amp[i]) && std::isfinite(e.formant_breath[i]) &&
+                 std::isfinite(e.formant_turb[i]) && e.formant_smooth[i] >= 0.0f && e.formant_smooth[i] <= 1.0f &&
+                 (f * 0.999f - jm >= X_LO) && (f * 1.001f + jm <= X_HI) && (w >= W_LO) && (w <= W_HI);
+        }
+    }
+    return ok;
+}
+
 int install_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices)
 {
     if (!voices || n_voices == 0) return fail(GRAIL_ERR_INVALID_ARG, "no voices given");
@@ -306,6 +334,8 @@ int install_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices)
             }
     ctx->voices_upper_silent = silent;
     ctx->voices_live4_ok = true;
+    ctx->voices_scan_ok = true;
+    for (uint32_t v = 0; v < n_voices; ++v) ctx->voices_scan_ok = ctx->voices_scan_ok && scan_voice_ok(voices[v]);
     ctx->max_dt = 0.0f;
     ctx->max_pitch_jitter = 0.0f;
     for (uint32_t v = 0; v < n_voices; ++v) {
@@ -437,6 +467,19 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         ctx->fast_option = (int)value;
         return GRAIL_OK;
     }
+    if (std::strcmp(name, "time_parallel_scan") == 0) {
+        ctx->scan_option = value ? 1 : 0;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "scan_debug") == 0) {       // development aid: see scan_kernels.hip
+        ctx->scan_debug = (int)value;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "time_parallel_scan_max_utterances") == 0) {
+        if (value < 0) return fail(GRAIL_ERR_INVALID_ARG, "negative limit");
+        ctx->scan_max_utts = value;
+        return GRAIL_OK;
+    }
     if (std::strcmp(name, "kernel_variant") == 0) {
         if (value < 0 || value > 1) return fail(GRAIL_ERR_INVALID_ARG, "kernel_variant out of range");
         ctx->variant_option = (int)value;
@@ -462,6 +505,14 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
     }
     if (std::strcmp(name, "arithmetic") == 0) {
         *value = ctx->fast_option;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "time_parallel_scan") == 0) {
+        *value = ctx->scan_option;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "time_parallel_scan_max_utterances") == 0) {
+        *value = ctx->scan_max_utts;
         return GRAIL_OK;
     }
     if (std::strcmp(name, "slow_division_wave_steps") == 0) {  // read-only statistic
@@ -698,13 +749,32 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     // kernels: one lane per utterance runs the half-live loop and ties two lanes per utterance,
     // whose second lane would only hold silent formants
     if (!ctx->lanes_option && !a.live4 && L == 2 && a.half_capable) L = 1;
+    // fast arithmetic, few utterances: the machine is mostly idle under the lane-per-utterance mapping;
+    // one workgroup per utterance with the time axis across the lanes and the filter recurrences solved by
+    // parallel scans (scan_kernels.hip).  Needs every parameter inside the safe window (no IEEE fallback).
+    // (measured crossover against the lane-per-utterance fast kernels: ~3000 utterances with four live
+    // formants — two pair waves each — and half that with eight; profiles/r02_small_batch.txt)
+    const bool scan = a.fast && ctx->scan_option && !ctx->lanes_option &&
+                      (int64_t)count * (batch_live4(ctx, batch) ? 1 : 2) <= ctx->scan_max_utts &&
+                      batch->phoneme_mode && ctx->voices_scan_ok && batch->plain && !batch->any_blend &&
+                      batch->min_length >= 2.0f * ctx->max_dt &&
+                      batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f;
     ctx->last_formants = a.live4 ? 4 : 8;
-    ctx->last_lanes = L;
-    ctx->last_pipe = a.pipe ? 1 : 0;
+    ctx->last_lanes = scan ? 0 : L;
+    ctx->last_pipe = a.pipe && !scan ? 1 : 0;
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
-    hipError_t e = launch_synth(a, L, ctx->variant_option, ctx->stream);
+    hipError_t e;
+    if (scan) {
+        a.live4 = batch_live4(ctx, batch) ? 1u : 0u;     // (the L = 8 rule above may have cleared it)
+        ctx->last_formants = a.live4 ? 4 : 8;
+        a.resume = (uint32_t)ctx->scan_debug;
+        e = launch_scan(a, ctx->stream);
+        ctx->last_kernel = a.live4 ? "scan_kernel<pairs=2,FAST>" : "scan_kernel<pairs=4,FAST>";
+    } else {
+        e = launch_synth(a, L, ctx->variant_option, ctx->stream);
+        ctx->last_kernel = last_kernel_name();
+    }
     if (e != hipSuccess) return hip_fail(e, "synth kernel launch");
-    ctx->last_kernel = last_kernel_name();
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->have_timing = true;
     return GRAIL_OK;

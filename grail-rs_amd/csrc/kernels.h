@@ -89,6 +89,9 @@ const char *last_kernel_name();
 // lanes_per_utt in {1, 2, 4, 8}; returns hipSuccess or the launch error.
 hipError_t launch_synth(const SynthArgs &args, int lanes_per_utt, int variant, hipStream_t stream);
 hipError_t launch_lengths(const LenArgs &args, hipStream_t stream);
+// small batches, fast arithmetic: one workgroup per utterance, lanes = time, recurrences by parallel scan
+// (scan_kernels.hip).  args.live4 selects two formant-pair waves instead of four.
+hipError_t launch_scan(const SynthArgs &args, hipStream_t stream);
 // f32 rows -> i16 PCM rows (examples/cli.rs:49); only the first len[u] (<= max_len) samples of row u
 hipError_t launch_pcm16(const float *in, uint64_t in_stride, const uint32_t *len, uint32_t n_utt,
                         uint32_t max_len, int16_t *out, uint64_t out_stride, hipStream_t stream);

@@ -217,3 +217,79 @@ def test_fast_mode_full_size_against_exact_mode_on_the_device(gpu_ctx, config):
             ctx.device_free(p)
         batch.free()
         ctx.set_voices(W.single_voice())
+
+
+# ---- the time-parallel scan kernel (small batches, fast arithmetic) ------------------------------
+@pytest.mark.parametrize("n_voices", [1, 8])
+def test_scan_kernel_small_batch_within_tolerance(gpu_ctx, n_voices):
+    """Few utterances in fast mode go to scan_kernels.hip: lanes = time, recurrences by parallel scan.
+    Lengths equal the oracle's (the chain is exact), samples within the fast-mode tolerance."""
+    voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    n_utt = 48
+    segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=n_voices)          # full 2 s utterances
+    stride = W.max_samples()
+    out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
+    assert gpu_ctx.last_kernel_name().startswith("scan_kernel<pairs=%d" % (2 if n_voices == 1 else 4))
+    ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, stride)
+    assert np.array_equal(out_len, ref_len)
+    k = _worst(out, ref, ref_len)
+    print(f"scan kernel, voices={n_voices}: max |d| = {k:.1f} * 2^-23")
+    assert 0.0 < k * ULP <= TOL
+    # the option switches it off (A/B): the lane-per-utterance fast kernels take over
+    gpu_ctx.set_option("time_parallel_scan", 0)
+    try:
+        out2, len2 = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
+        assert "FAST" in gpu_ctx.last_kernel_name() and np.array_equal(len2, ref_len)
+    finally:
+        gpu_ctx.set_option("time_parallel_scan", 1)
+    gpu_ctx.set_voices(W.single_voice())
+
+
+def test_scan_kernel_edge_cases(gpu_ctx):
+    """Ragged lists, an empty utterance, silent pairs, specials, two-sample segments, rows cut at
+    out_stride: structure identical to the oracle, samples within tolerance."""
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
+    A, E, S = G.PH_A, G.PH_E, G.PH_SILENCE
+    f = 120.0 / 48000.0
+    utts = [
+        [(S, 0.05, 0.0625, f), (A, 0.05, 0.0625, f)],
+        [(A, 0.08, 0.03125, f), (E, 0.08, 0.03125, 1.3 * f), (A, 0.03, 0.015625, f)],
+        [(E, 0.07, 0.0625, f), (S, 0.04, 0.0625, f), (S, 0.04, 0.0625, f), (A, 0.05, 0.0625, f)],
+        [],
+        [(A, 2.5 / 48000.0, 0.5, f), (E, 0.05, 0.0625, f)],
+        [(A, 0.7, 0.25, 0.9 * f)],
+        [(G.PH_STOP, 0.03, 0.03125, f), (G.PH_GLIDE, 0.03, 0.03125, f), (E, 0.06, 0.0625, 2 * f)],
+    ] * 3
+    segs = G.segments([s for u in utts for s in u])
+    offs = np.cumsum([0] + [len(u) for u in utts]).astype(np.uint32)
+    seeds = np.arange(len(utts), dtype=np.uint32) * 1234567
+    for stride in (40000, 2048):                      # the second cuts the long rows
+        ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, None, seeds, stride)
+        ref_len = np.minimum(ref_len, stride)
+        gpu_ctx.set_option("arithmetic", 1)
+        try:
+            out, out_len = gpu_ctx.synthesize(segs, offs, None, seeds, out_stride=stride, allow_truncation=True)
+        finally:
+            gpu_ctx.set_option("arithmetic", 0)
+        assert gpu_ctx.last_kernel_name().startswith("scan_kernel")
+        assert np.array_equal(out_len, ref_len), stride
+        k = _worst(out, ref, ref_len)
+        print(f"scan kernel edge cases, stride {stride}: {k:.1f} * 2^-23")
+        assert k * ULP <= TOL
+
+
+def test_scan_kernel_gate_sends_unsafe_tables_elsewhere(gpu_ctx):
+    """A table outside the safe window (a formant at frequency 0: the reference emits NaN) and a batch
+    with a blend length that is not a power of two do not take the scan kernel."""
+    v = G.voice_generic(48000.0)
+    v.phonemes[0].formant_freq[7] = 0.0
+    gpu_ctx.set_voices([v])
+    segs, offs, vids, seeds = W.make_batch(8, length=0.05, blend_length=0.0625)
+    out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, 16384)
+    assert not gpu_ctx.last_kernel_name().startswith("scan_kernel")
+    gpu_ctx.set_voices(W.single_voice())
+    segs, offs, vids, seeds = W.make_batch(8, length=0.05, blend_length=0.03)
+    out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, 16384)
+    assert not gpu_ctx.last_kernel_name().startswith("scan_kernel")
