@@ -121,6 +121,7 @@ struct grail_ctx {
     bool voices_live4_ok = false;     // ... and parameters that keep their output at exactly +0 (live4_ok)
     bool voices_scan_ok = false;      // every formant of every voice inside the safe window (scan_voice_ok)
     int scan_debug = 0;
+    int64_t pipe8_max_groups = 512;   // eight-formant pipelined workgroups: up to two per CU
     int scan_option = 1;              // fast arithmetic: small batches go to the time-parallel scan kernel
     int64_t scan_max_utts = 3072;     // ... up to this many utterances
     float max_dt = 0.0f;              // largest 1/sample_rate of the table
@@ -471,6 +472,10 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         ctx->scan_option = value ? 1 : 0;
         return GRAIL_OK;
     }
+    if (std::strcmp(name, "pipeline8_max_groups") == 0) {   // tuning: 0 keeps eight-formant batches off the pipeline
+        ctx->pipe8_max_groups = value;
+        return GRAIL_OK;
+    }
     if (std::strcmp(name, "scan_debug") == 0) {       // development aid: see scan_kernels.hip
         ctx->scan_debug = (int)value;
         return GRAIL_OK;
@@ -737,6 +742,10 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
         ((uint64_t)count + 15) / 16 <= 256) {             // one workgroup per CU
         a.pipe = 1u;
         L = 4;
+    } else if (!a.live4 && !a.fast && !ctx->lanes_option && ctx->pipeline_option && !batch->any_blend &&
+               ((uint64_t)count + 7) / 8 <= (uint64_t)ctx->pipe8_max_groups) {
+        a.pipe = 1u;                                      // eight formants: 8 utterances per workgroup
+        L = 8;
     }
     // eight lanes per utterance need eight formants to lay out; for batches that small the
     // 8-lane kernel is also the fastest (18.2 against 18.8 ms: half the rows to flush per wave)

@@ -1884,10 +1884,16 @@ static void launch_one(const SynthArgs &args, hipStream_t stream)
 hipError_t launch_synth(const SynthArgs &args, int L, int variant, hipStream_t stream)
 {
     if (args.n_utt == 0) return hipSuccess;
-    if (args.pipe && args.live4 && !args.state && !args.any_blend && !args.fast) {
-        // 16 utterances (4 lanes each) per workgroup of four waves: render, chain, 2 x coefficients
-        const dim3 grid((args.n_utt + 15) / 16), block(256);
-        start<4, 64, 4, 1, false, false, false, 4, true>(args, grid, block, stream);
+    if (args.pipe && !args.state && !args.any_blend && !args.fast) {
+        // workgroups of four waves — render, chain, 2 x coefficients — share 16 utterances (four live
+        // formants, 4 lanes each) or 8 utterances (eight formants, 8 lanes each)
+        if (args.live4) {
+            const dim3 grid((args.n_utt + 15) / 16), block(256);
+            start<4, 64, 4, 1, false, false, false, 4, true>(args, grid, block, stream);
+        } else {
+            const dim3 grid((args.n_utt + 7) / 8), block(256);
+            start<8, 64, 4, 1, false, false, false, NF, true>(args, grid, block, stream);
+        }
         return hipGetLastError();
     }
     // 64-thread workgroups are admitted 8 per CU (2 waves per SIMD, measured); L = 4 / 8 use

@@ -491,3 +491,25 @@ def test_small_batch_pipeline_is_bit_exact(gpu_ctx, n_utt):
             assert_bit_identical(out, out_len, ref, ref_len, f"pipeline={pipeline} n={n_utt}")
     finally:
         gpu_ctx.set_option("small_batch_pipeline", 1)
+
+
+@pytest.mark.parametrize("n_utt", [13, 40])
+def test_small_batch_pipeline_with_eight_live_formants_is_bit_exact(gpu_ctx, n_utt):
+    """Tables whose eight formants are all audible (config 4's presets) take the same four-wave
+    pipeline with eight lanes per utterance (8 utterances per workgroup): bit-identical to the oracle,
+    pipeline on and off, partly filled last workgroup included."""
+    voices = W.preset_voices(8)
+    segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=8)
+    stride = W.max_samples()
+    ref, ref_len = O.synthesize_batch(ovoices(voices), segs, offs, vids, seeds, stride)
+    try:
+        for pipeline in (1, 0):
+            gpu_ctx.set_option("small_batch_pipeline", pipeline)
+            gpu_ctx.set_voices(voices)
+            out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+            assert gpu_ctx.get_option("last_launch_pipelined") == pipeline
+            assert gpu_ctx.get_option("last_launch_formants") == 8
+            assert_bit_identical(out, out_len, ref, ref_len, f"8 formants pipeline={pipeline} n={n_utt}")
+    finally:
+        gpu_ctx.set_option("small_batch_pipeline", 1)
+        gpu_ctx.set_voices(W.single_voice())
