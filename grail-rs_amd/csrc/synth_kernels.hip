@@ -705,8 +705,44 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 
         // events are rare: this step always takes the IEEE-division body (same bits)
         V v1[NV];
-        formant_filters<false, NV, NV, false, true, V>(saw, noise, 0.0f, e_freq, e_bw, e_smooth, e_breath, e_turb, e_amp,
-                                      st_a, st_b, st_c, v1);
+        bool fast_formants = false;
+        if constexpr (FAST) fast_formants = __builtin_amdgcn_ballot_w64(!pair_safe) == 0;
+        if (fast_formants) {
+            // FAST kernels, every lane's pair inside the safe window: the per-formant arithmetic of this
+            // sample in tolerance mode too (the control flow and the chain above stay the reference's) —
+            // reciprocals by v_rcp + one Newton step, fused multiply-adds, v1 = a1 (b + g v3), v2 = c + g v1
+            const V one = vsplat(1.0f, V()), five = vsplat(5.0f, V()), m4 = vsplat(-4.0f, V());
+            const V nms = vsplat(noise - saw, V()), nm1 = vsplat(noise - 1.0f, V()), sawv = vsplat(saw, V());
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const V x = e_freq[k];
+                const V omx = 1.0f - x, xph = x + 0.5f, hmx = 0.5f - x;
+                const V ox = omx * x, ph_ = xph * hmx;
+                const V num = ox * vfma(m4, ph_, five);
+                const V den = (xph * vfma(m4, ox, five)) * hmx;
+                V rd = vrcp(den), rx = vrcp(x);
+                rd = vfma(vfma(-den, rd, one), rd, rd);
+                rx = vfma(vfma(-x, rx, one), rx, rx);
+                const V tg = num * rd;                                              // :555
+                const V kq = e_bw[k] * rx;                                          // :558
+                const V d3 = vfma(tg, tg + kq, one);
+                V a1 = vrcp(d3);
+                a1 = vfma(vfma(-d3, a1, one), a1, a1);                              // :560
+                const V oml = 1.0f - exp_approx(e_smooth[k]);                       // :535
+                const V nw = vfma(e_breath[k], nms, sawv);                          // :531
+                st_a[k] = vfma(oml, nw - st_a[k], st_a[k]);                         // :538
+                const V v0 = st_a[k] * (e_amp[k] * vfma(e_turb[k], nm1, one));      // :544-550
+                const V v3 = v0 - st_c[k];                                          // :565
+                const V w1 = a1 * vfma(tg, v3, st_b[k]);                            // :566
+                const V w2 = vfma(tg, w1, st_c[k]);                                 // :567
+                st_b[k] = vfma(vsplat(2.0f, V()), w1, -st_b[k]);                    // :570
+                st_c[k] = vfma(vsplat(2.0f, V()), w2, -st_c[k]);                    // :571
+                v1[k] = w1;
+            }
+        } else {
+            formant_filters<false, NV, NV, false, true, V>(saw, noise, 0.0f, e_freq, e_bw, e_smooth, e_breath, e_turb, e_amp,
+                                          st_a, st_b, st_c, v1);
+        }
         if (!pair_safe) ++slow_steps;
 
         // v1.sum() * 0.5: a left fold from 0.0 over formants 0..7  :574, :123-125,
@@ -1341,6 +1377,45 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         const float inv_ts = __builtin_bit_cast(float, (uint32_t)(127 - 5 + fast_shift) << 23);   // 1 / TS
         const float nm1_of_lane = noise_of_lane - 1.0f;
         const f2 one2 = vsplat(1.0f, f2());
+        // ---- the per-utterance chain of samples tc, tc+1: exact (see scalar_packed_steps).  Advances
+        // clk, jphase and phase; returns the phases before the two samples and their pitch.
+        const float inv_bl = (!ANYBL && silent_pair) ? __builtin_inff() : inv_blend_length;
+        auto chain_pair = [&](f2 &PH, f2 &frequency) __attribute__((always_inline)) {
+            const float clk0 = clk - dt, clk1 = clk0 - dt;                     // :861
+            const float jp0 = jphase + jinc, jp1 = jp0 + jinc;                 // :242 / :291
+            clk = clk1;
+            jphase = jp1;
+            f2 CLK, JP;
+            CLK.x = clk0; CLK.y = clk1; JP.x = jp0; JP.y = jp1;
+            f2 ratio = CLK * inv_bl;
+            if constexpr (ANYBL) {
+                const f2 rem = vfma(-blend_length * one2, ratio, CLK);
+                const f2 quot = vfma(rem, inv_blend_length * one2, ratio);     // RN(clk / blend_length)
+                ratio = blend_pow2 ? ratio : quot;
+            }
+            f2 alpha;                                                          // :899/:908/:917
+            if constexpr (ANYBL) {
+                alpha.x = silent_pair ? 1.0f : __builtin_fminf(ratio.x, 1.0f);
+                alpha.y = silent_pair ? 1.0f : __builtin_fminf(ratio.y, 1.0f);
+            } else {
+                // a both-silent pair emits silent() itself (alpha = 1, :926): its reciprocal blend length was
+                // replaced by +inf for this tile (inv_bl below), the clock is positive in a calm tile, and
+                // min(+inf, 1) = 1 — no select per sample
+                alpha.x = __builtin_fminf(ratio.x, 1.0f);
+                alpha.y = __builtin_fminf(ratio.y, 1.0f);
+            }
+            const f2 oma = 1.0f - alpha;
+            const f2 jomp = 1.0f - JP;
+            frequency = X.frequency * oma + Y.frequency * alpha;               // :404-414
+            const f2 n_freq = fn_cur * jomp + fn_next * JP;                    // :254
+            frequency = frequency + n_freq * d_freq;                           // :763
+            // :520-525  `p += f; if p >= 1 { p -= 1 }` is fract(p + f) for 0 <= p < 1, 0 < f <= 1: both
+            // branches are exact (x - 1 for x in [1, 2) loses nothing)
+            const float ph0 = phase;
+            const float ph1 = __builtin_amdgcn_fractf(ph0 + frequency.x);
+            phase = __builtin_amdgcn_fractf(ph1 + frequency.y);
+            PH.x = ph0; PH.y = ph1;
+        };
 #pragma unroll 1
         for (int ts = 0; ts < T; ts += TS) {
             if (!(have_slopes && ts == 0)) endpoint(std::true_type(), (float)(TS + 1), inv_ts, D, xe);
@@ -1354,52 +1429,24 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 const float nm[2] = {
                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nm1_of_lane), tc)),
                     __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nm1_of_lane), tc + 1))};
-                // ---- the per-utterance chain of samples tc, tc+1: exact (see scalar_packed_steps)
-                const float clk0 = clk - dt, clk1 = clk0 - dt;                     // :861
-                const float jp0 = jphase + jinc, jp1 = jp0 + jinc;                 // :242 / :291
-                clk = clk1;
-                jphase = jp1;
-                f2 CLK, JP;
-                CLK.x = clk0; CLK.y = clk1; JP.x = jp0; JP.y = jp1;
-                f2 ratio = CLK * inv_blend_length;
-                if constexpr (ANYBL) {
-                    const f2 rem = vfma(-blend_length * one2, ratio, CLK);
-                    const f2 quot = vfma(rem, inv_blend_length * one2, ratio);     // RN(clk / blend_length)
-                    ratio = blend_pow2 ? ratio : quot;
-                }
-                f2 alpha;                                                          // :899/:908/:917
-                alpha.x = silent_pair ? 1.0f : __builtin_fminf(ratio.x, 1.0f);
-                alpha.y = silent_pair ? 1.0f : __builtin_fminf(ratio.y, 1.0f);
-                const f2 oma = 1.0f - alpha;
-                const f2 jomp = 1.0f - JP;
-                f2 frequency = X.frequency * oma + Y.frequency * alpha;            // :404-414
-                const f2 n_freq = fn_cur * jomp + fn_next * JP;                    // :254
-                frequency = frequency + n_freq * d_freq;                           // :763
-                const f2 omf = 1.0f - frequency;                                   // carrier :503-525
-                const float ph0 = phase;
-                const bool head0 = ph0 < frequency.x, tail0 = ph0 > omf.x;
-                float ph1 = ph0 + frequency.x;
-                ph1 = (ph1 >= 1.0f) ? ph1 - 1.0f : ph1;
-                const bool head1 = ph1 < frequency.y, tail1 = ph1 > omf.y;
-                const float ph2 = ph1 + frequency.y;
-                phase = (ph2 >= 1.0f) ? ph2 - 1.0f : ph2;
-                f2 PH;
-                PH.x = ph0; PH.y = ph1;
-                const f2 phm1 = PH - 1.0f;
-                f2 dividend;
-                dividend.x = head0 ? ph0 : phm1.x;
-                dividend.y = head1 ? ph1 : phm1.y;
-                const f2 tt = dividend * vrcp(frequency);                          // tolerance: 1 ulp quotient
-                f2 s_tt2, sgn, polyblep;
-                const f2 tt2 = tt * tt;
-                s_tt2.x = __uint_as_float(__float_as_uint(tt2.x) ^ (head0 ? 0x80000000u : 0u));
-                s_tt2.y = __uint_as_float(__float_as_uint(tt2.y) ^ (head1 ? 0x80000000u : 0u));
-                sgn.x = head0 ? -1.0f : 1.0f;
-                sgn.y = head1 ? -1.0f : 1.0f;
-                const f2 pb = vfma(vsplat(2.0f, f2()), tt, s_tt2) + sgn;
-                polyblep.x = (head0 | tail0) ? pb.x : 0.0f;
-                polyblep.y = (head1 | tail1) ? pb.y : 0.0f;
-                const f2 saw2 = vfma(vsplat(2.0f, f2()), PH, -one2) - polyblep;    // :517
+                f2 PH, frequency;
+                chain_pair(PH, frequency);
+                // polyBLEP :503-517 without branches or selects: with d_h = f - p (> 0: the head test
+                // p < f) and d_t = p - (1 - f) (> 0: the tail test p > 1 - f; never both), u = max(d_h, d_t, 0) / f
+                // is 1 - t for the head (:505) and 1 + t for the tail (:509), and the correction is -u^2 or
+                // +u^2 (:506, :510) — zero when neither test holds.  d_h - d_t = 1 - 2p = -(2p - 1): the sign
+                // of the uncorrected saw says which.  Same tests as the reference, quotient by v_rcp.
+                const f2 omf = 1.0f - frequency;
+                const f2 d_h = frequency - PH, d_t = PH - omf;
+                f2 u;
+                u.x = __builtin_fmaxf(__builtin_fmaxf(d_h.x, d_t.x), 0.0f);
+                u.y = __builtin_fmaxf(__builtin_fmaxf(d_h.y, d_t.y), 0.0f);
+                u = u * vrcp(frequency);
+                const f2 saw_nb = vfma(vsplat(2.0f, f2()), PH, -one2);             // 2 p - 1
+                f2 su;    // u with the sign of -saw_nb: + for the head (saw + u^2), - for the tail (saw - u^2)
+                su.x = __uint_as_float((__float_as_uint(u.x) & 0x7FFFFFFFu) | (~__float_as_uint(saw_nb.x) & 0x80000000u));
+                su.y = __uint_as_float((__float_as_uint(u.y) & 0x7FFFFFFFu) | (~__float_as_uint(saw_nb.y) & 0x80000000u));
+                const f2 saw2 = vfma(su, u, saw_nb);                               // :517
                 // ---- the formants, sample by sample, coefficients by interpolation
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -1500,6 +1547,8 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                         const float r_first = (clk - dt) * inv_blend_length;
                         const float r_next = (clk - (float)(T + 1) * dt) * inv_blend_length;
                         calm = calm & !((r_first > 1.0f) & (r_next < 1.0f));
+                        // fast_tile's polyBLEP form needs the head and tail tests to exclude each other: pitch < 1/2
+                        calm = calm & (__builtin_fmaxf(X.frequency, Y.frequency) + __builtin_fabsf(d_freq) < 0.5f);
                     }
                     calm_tile = __builtin_amdgcn_ballot_w64(!(calm | idle)) == 0;
                 }
@@ -1858,12 +1907,12 @@ static void launch_one(const SynthArgs &args, hipStream_t stream)
         }
     }
     if (args.fast && !args.state) {
-        // tolerance mode: the same kernels with the fast calm tile; ANYBL folded in (one instantiation
-        // per layout keeps the library small), HALF only where the exact policy uses it
+        // tolerance mode: the same kernels with the fast calm tile; HALF only where the exact policy uses it
         // (64-sample tiles at L = 1 were measured: slower — a tile with an event takes the general step
         // for all of its samples, and twice as many samples share a tile with each event)
         if (L == 1 && args.half_capable) start<L, T, WAVES, MINW, false, true, true, NF, false, true>(args, grid, block, stream);
-        else start<L, T, WAVES, MINW, false, false, true, NF, false, true>(args, grid, block, stream);
+        else if (args.any_blend) start<L, T, WAVES, MINW, false, false, true, NF, false, true>(args, grid, block, stream);
+        else start<L, T, WAVES, MINW, false, false, false, NF, false, true>(args, grid, block, stream);
         return;
     }
     if (args.state) {
