@@ -846,8 +846,9 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         const float polyblep = (head | tail) ? pb : 0.0f;
         // :517  2*phase is exact (0 <= phase < 1), so the fma rounds the same difference once
         const float saw = vfma(2.0f, phase, -1.0f) - polyblep;
-        phase += frequency;                                                // :520
-        phase = (phase >= 1.0f) ? phase - 1.0f : phase;                    // :523-525
+        // :520-525  `p += f; if p >= 1 { p -= 1 }` == fract(p + f) for 0 <= p < 1, 0 < f <= 1 (pair_is_safe):
+        // x - 1 is exact for x in [1, 2), so both branches give the reference's bits in one instruction
+        phase = __builtin_amdgcn_fractf(phase + frequency);
         float noise;                                                       // :528
         if constexpr (CALM) noise = noise_in;
         else noise = lcg_f32(noise_seed);
@@ -935,11 +936,9 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             const f2 omf = 1.0f - frequency;
             const float ph0 = phase;
             const bool head0 = ph0 < frequency.x, tail0 = ph0 > omf.x;
-            float ph1 = ph0 + frequency.x;
-            ph1 = (ph1 >= 1.0f) ? ph1 - 1.0f : ph1;
+            const float ph1 = __builtin_amdgcn_fractf(ph0 + frequency.x);     // see quiet_step
             const bool head1 = ph1 < frequency.y, tail1 = ph1 > omf.y;
-            float ph2 = ph1 + frequency.y;
-            phase = (ph2 >= 1.0f) ? ph2 - 1.0f : ph2;
+            phase = __builtin_amdgcn_fractf(ph1 + frequency.y);
             f2 PH;
             PH.x = ph0; PH.y = ph1;
             const f2 phm1 = PH - 1.0f;
@@ -1009,11 +1008,9 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             const f2 omf = 1.0f - frequency;
             const float ph0 = phase;
             const bool head0 = ph0 < frequency.x, tail0 = ph0 > omf.x;
-            float ph1 = ph0 + frequency.x;
-            ph1 = (ph1 >= 1.0f) ? ph1 - 1.0f : ph1;
+            const float ph1 = __builtin_amdgcn_fractf(ph0 + frequency.x);     // see quiet_step
             const bool head1 = ph1 < frequency.y, tail1 = ph1 > omf.y;
-            const float ph2 = ph1 + frequency.y;
-            phase = (ph2 >= 1.0f) ? ph2 - 1.0f : ph2;
+            phase = __builtin_amdgcn_fractf(ph1 + frequency.y);
             f2 PH;
             PH.x = ph0; PH.y = ph1;
             const f2 phm1 = PH - 1.0f;
@@ -1136,11 +1133,9 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         const f2 omf = 1.0f - frequency;
         const float ph0 = phase;
         const bool head0 = ph0 < frequency.x, tail0 = ph0 > omf.x;
-        float ph1 = ph0 + frequency.x;
-        ph1 = (ph1 >= 1.0f) ? ph1 - 1.0f : ph1;
+        const float ph1 = __builtin_amdgcn_fractf(ph0 + frequency.x);         // see quiet_step
         const bool head1 = ph1 < frequency.y, tail1 = ph1 > omf.y;
-        const float ph2 = ph1 + frequency.y;
-        phase = (ph2 >= 1.0f) ? ph2 - 1.0f : ph2;
+        phase = __builtin_amdgcn_fractf(ph1 + frequency.y);
         f2 PH;
         PH.x = ph0; PH.y = ph1;
         const f2 phm1 = PH - 1.0f;
