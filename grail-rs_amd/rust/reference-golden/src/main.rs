@@ -1,5 +1,5 @@
-//! Writes, for every parity case of tests/golden/make_golden.py, what the reference crate itself
-//! renders: `<case>.f32` (little-endian f32 samples of the whole track) and `voice_44k.f32` /
+//! Writes, for every parity case of tests/golden/make_golden.py and for the first six utterances of the
+//! bench corpus at full length (BASELINE config 3), what the reference crate itself renders: `<case>.f32` (little-endian f32 samples of the whole track) and `voice_44k.f32` /
 //! `voice_48k.f32` (the voice tables in the field order of `grail_voice`, include/grail_hip.h),
 //! plus `manifest.txt` (`name length` per line) and `toolchain.txt`.
 //!
@@ -105,7 +105,32 @@ fn main() {
         ("wrap_48k", 48000.0, vec![seg(A, 0.07, 0.07, f48), seg(E, 0.07, 0.07, 0.0031)], 4242),
     ];
 
+    // the first six utterances of the bench corpus at full length (BASELINE config 3: 4 x 0.5 s at
+    // 48 kHz, grail_hip/workload.py::make_batch): utterance u hashes with the crate's own LCG step
+    // (src/lib.rs:40) from 0x9E3779B9 ^ u; segment 0 is Silence, the others draw from (A, E, Silence);
+    // pitch 100..200 Hz; jitter seed = u.
+    let lcg = |s: u32| s.wrapping_mul(16807).wrapping_add(1);
+    let mut bench_cases: Vec<(String, f32, Vec<PhonemeElem>, u32)> = Vec::new();
+    for u in 0u32..6 {
+        let mut s = u ^ 0x9E37_79B9;
+        let mut segs = Vec::new();
+        for i in 0..4 {
+            s = lcg(s);
+            let ph = if i == 0 { S } else { [A, E, S][((s >> 16) % 3) as usize] };
+            s = lcg(s);
+            let hz = (100 + (s >> 16) % 101) as f32;
+            segs.push(seg(ph, 0.5, 0.5, hz / 48000.0));
+        }
+        bench_cases.push((format!("bench_u{u}"), 48000.0, segs, u));
+    }
+
     let mut manifest = String::new();
+    for (name, rate, segs, seed) in bench_cases {
+        let v = voice_at(rate);
+        let pcm: Vec<f32> = segs.into_iter().select(v).sequence(v).jitter(seed, v).synthesize().collect();
+        write_f32(&dir.join(format!("{name}.f32")), &pcm);
+        manifest.push_str(&format!("{name} {}\n", pcm.len()));
+    }
     for (name, rate, segs, seed) in cases {
         let v = voice_at(rate);
         let pcm: Vec<f32> = segs.into_iter().select(v).sequence(v).jitter(seed, v).synthesize().collect();

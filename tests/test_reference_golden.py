@@ -33,7 +33,16 @@ def golden_cases():
     spec = importlib.util.spec_from_file_location("make_golden", os.path.join(sys_path_golden, "make_golden.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
-    return {name: (rate, segs, seed) for name, rate, segs, seed in m.cases()}
+    cases = {name: (rate, segs, seed) for name, rate, segs, seed in m.cases()}
+    # bench_u0..5: the first six utterances of the bench corpus at full length (BASELINE config 3, 4 x 0.5 s
+    # at 48 kHz) — reference-golden/src/main.rs builds the same segments with the crate's own LCG step
+    from grail_hip import workload as W
+    segs, offs, _, seeds = W.make_batch(6)
+    for u in range(6):
+        sg = segs[offs[u]:offs[u + 1]]
+        cases[f"bench_u{u}"] = (48000.0, [(int(a["phoneme"]), float(a["length"]), float(a["blend_length"]),
+                                            float(a["frequency"])) for a in sg], int(seeds[u]))
+    return cases
 
 
 @pytest.mark.parametrize("name,length", manifest())
@@ -51,3 +60,31 @@ def test_voice_tables_match_the_reference_crate(tag, rate):
     want = np.fromfile(os.path.join(REF_DIR, f"voice_{tag}.f32"), dtype="<f4")
     got = np.frombuffer(bytes(O.voice_generic(rate)), dtype=np.float32)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,length", manifest())
+def test_hip_path_reproduces_the_reference_crate(gpu_ctx, name, length):
+    """The product itself (HIP kernels through the C ABI), not just the oracle, against the crate's samples:
+    exact mode bit for bit, fast mode within its stated tolerance."""
+    import grail_hip as G
+    rate, segs, seed = golden_cases()[name]
+    want = np.fromfile(os.path.join(REF_DIR, name + ".f32"), dtype="<f4")
+    gpu_ctx.set_voices([G.voice_generic(rate)])
+    sa = G.segments(segs)
+    stride = (length + 63) // 64 * 64 + 64
+    try:
+        for lanes in (0, 1, 2, 4, 8):
+            gpu_ctx.set_option("lanes_per_utterance", lanes)
+            out, n = gpu_ctx.synthesize(sa, [0, len(sa)], jitter_seeds=[seed], out_stride=stride)
+            assert int(n[0]) == length
+            assert np.array_equal(out[0, :length].view(np.uint32), want.view(np.uint32)), (name, lanes)
+        gpu_ctx.set_option("lanes_per_utterance", 0)
+        gpu_ctx.set_option("arithmetic", 1)
+        out, n = gpu_ctx.synthesize(sa, [0, len(sa)], jitter_seeds=[seed], out_stride=stride)
+        assert int(n[0]) == length
+        assert np.max(np.abs(out[0, :length].astype(np.float64) - want)) <= G.FAST_TOLERANCE
+    finally:
+        gpu_ctx.set_option("arithmetic", 0)
+        gpu_ctx.set_option("lanes_per_utterance", 0)
+        gpu_ctx.set_voices([G.voice_generic(48000.0)])
