@@ -1,14 +1,24 @@
+#!/bin/bash
+# The round's evidence, collected on the GPU box: bench lines, rocprofv3 kernel stats of the default
+# bench command, PMC counters for every reported workload (tools/collect_counters.py), tool outputs.
+# usage (through gpurun): tools/profile_round.sh <tag>     -> gpurun_out/<tag>/
+tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r
-python bench.py > gpurun_out/r/bench_n1.json 2> gpurun_out/r/bench_n1.err
-python bench.py --voices 8 --cpu-utts 0 > gpurun_out/r/bench_n1_config4.json 2>/dev/null
-python bench.py --literal --cpu-utts 0 > gpurun_out/r/bench_n1_literal.json 2>/dev/null
-python bench.py --pcm16 --cpu-utts 0 > gpurun_out/r/bench_n1_pcm16.json 2>/dev/null
-rm -rf gpurun_out/prof/stats; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats -- python3 bench.py --cpu-utts 0 > gpurun_out/r/stats.log 2>&1
-cp gpurun_out/prof/stats/*/*kernel_stats.csv gpurun_out/r/kernel_stats.csv
-tools/pmc.sh w3 "--steps 2 --warmup 0" WRITE_SIZE > gpurun_out/r/pmc.txt
-tools/pmc.sh f3 "--steps 2 --warmup 0" FETCH_SIZE >> gpurun_out/r/pmc.txt
-tools/pmc.sh s3 "--steps 1 --warmup 0" SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE >> gpurun_out/r/pmc.txt
-tools/pmc.sh s4 "--steps 1 --warmup 0 --voices 8" SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE >> gpurun_out/r/pmc.txt
-tools/pmc.sh s3b "--steps 1 --warmup 0" SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM >> gpurun_out/r/pmc.txt
-cat gpurun_out/r/pmc.txt
+out=gpurun_out/$tag; mkdir -p $out
+python3 tools/collect_counters.py $out/traffic.json > $out/collect_counters.log 2>&1
+cp $out/traffic.json profiles/traffic.json            # so that the bench lines below carry the counters
+python3 bench.py > $out/bench_n1.json 2> $out/bench_n1.err
+python3 bench.py --config 4 --cpu-utts 0 > $out/bench_n1_config4.json 2>/dev/null
+python3 bench.py --config 2 --cpu-utts 0 > $out/bench_n1_config2.json 2>/dev/null
+python3 bench.py --mode fast --cpu-utts 0 > $out/bench_n1_fast.json 2>/dev/null
+python3 bench.py --pcm16 --cpu-utts 0 > $out/bench_n1_pcm16.json 2>/dev/null
+python3 bench.py --verify --cpu-utts 0 --fast-leg 0 > $out/bench_n1_verify.json 2>/dev/null
+rm -rf gpurun_out/prof/stats
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats -- python3 bench.py --cpu-utts 0 > $out/stats.log 2>&1
+cp gpurun_out/prof/stats/*/*kernel_stats.csv $out/kernel_stats.csv
+python3 tools/small_batch_bench.py > $out/small_batch.txt 2>&1
+python3 tools/stream_latency.py 2>/dev/null | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" > $out/stream_latency.txt
+python3 tools/host_output_bench.py > $out/host_output.txt 2>&1
+python3 tools/ragged_bench.py > $out/ragged.txt 2>&1
+./tools/dpp_check.bin > $out/dpp_check.txt 2>&1
+ls -la $out
