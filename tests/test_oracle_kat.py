@@ -360,7 +360,7 @@ def test_reference_golden_reader_round_trip(tmp_path):
     for tag, rate in (("44k", None), ("48k", 48000.0)):
         np.frombuffer(bytes(O.voice_generic(rate)), dtype="<f4").tofile(str(tmp_path / f"voice_{tag}.f32"))
     env = dict(os.environ, GRAIL_REFERENCE_GOLDEN_DIR=str(tmp_path))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x",
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "not gpu",
                         os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_reference_golden.py")],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-1500:]
