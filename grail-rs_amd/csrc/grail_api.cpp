@@ -121,6 +121,7 @@ struct grail_ctx {
     bool voices_live4_ok = false;     // ... and parameters that keep their output at exactly +0 (live4_ok)
     bool voices_scan_ok = false;      // every formant of every voice inside the safe window (scan_voice_ok)
     int scan_debug = 0;
+    int sort_option = 1;              // ragged batches: fill launch slots in order of decreasing length
     int64_t pipe8_max_groups = 512;   // eight-formant pipelined workgroups: up to two per CU
     int scan_option = 1;              // fast arithmetic: small batches go to the time-parallel scan kernel
     int64_t scan_max_utts = 3072;     // ... up to this many utterances
@@ -159,6 +160,7 @@ struct grail_batch {
     uint32_t *d_offsets = nullptr;
     uint32_t *d_voice_ids = nullptr;
     uint32_t *d_seeds = nullptr;
+    uint32_t *d_perm = nullptr;   // ragged batches: launch slot -> utterance, longest first
     float *d_elems = nullptr;  // elem mode only
     uint32_t n_utt = 0;
     uint32_t n_segs = 0;
@@ -195,6 +197,7 @@ void free_batch_buffers(grail_batch *b)
     if (b->d_offsets) (void)hipFree(b->d_offsets);
     if (b->d_voice_ids) (void)hipFree(b->d_voice_ids);
     if (b->d_seeds) (void)hipFree(b->d_seeds);
+    if (b->d_perm) (void)hipFree(b->d_perm);
     if (b->d_elems) (void)hipFree(b->d_elems);
 }
 
@@ -214,6 +217,30 @@ int check_offsets(const uint32_t *seg_offsets, uint32_t n_utt, uint32_t *n_segs)
         if (seg_offsets[u + 1] < seg_offsets[u])
             return fail(GRAIL_ERR_INVALID_ARG, "seg_offsets must be non-decreasing");
     *n_segs = seg_offsets[n_utt];
+    return GRAIL_OK;
+}
+
+// Ragged batches: the lanes of a wave run in lockstep, so a wave lasts as long as its longest utterance.
+// Launch slots are therefore filled in order of decreasing length (sum of the segment lengths, in seconds
+// — close enough to the sample count for sorting): the utterances of a wave end together, and when the
+// batch is larger than the machine the longest waves start first.  Results do not depend on the slot
+// (batch invariance), rows stay where the caller put them.  Aligned batches (all sums equal) keep the
+// identity assignment and pay nothing.
+int upload_length_order(grail_ctx *ctx, grail_batch *b, const std::vector<float> &seconds, uint32_t n_utt)
+{
+    if (n_utt < 2 || !ctx->sort_option) return GRAIL_OK;
+    float lo = seconds[0], hi = seconds[0];
+    for (uint32_t u = 1; u < n_utt; ++u) {
+        lo = std::fmin(lo, seconds[u]);
+        hi = std::fmax(hi, seconds[u]);
+    }
+    if (!(hi - lo > 0.002f)) return GRAIL_OK;       // aligned (or NaN lengths): nothing to gain
+    std::vector<uint32_t> perm(n_utt);
+    for (uint32_t u = 0; u < n_utt; ++u) perm[u] = u;
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t c) { return seconds[a] > seconds[c]; });
+    int rc = upload(&b->d_perm, perm.data(), n_utt, ctx->stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return GRAIL_OK;
 }
 
@@ -472,6 +499,10 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         ctx->scan_option = value ? 1 : 0;
         return GRAIL_OK;
     }
+    if (std::strcmp(name, "sort_by_length") == 0) {    // applies to batches uploaded afterwards
+        ctx->sort_option = value ? 1 : 0;
+        return GRAIL_OK;
+    }
     if (std::strcmp(name, "pipeline8_max_groups") == 0) {   // tuning: 0 keeps eight-formant batches off the pipeline
         ctx->pipe8_max_groups = value;
         return GRAIL_OK;
@@ -584,8 +615,12 @@ int grail_batch_upload(grail_ctx *ctx, const grail_phoneme_elem *segs, const uin
     b->min_length = min_length;
     b->min_pitch = min_pitch;
     b->n_segs = n_segs;
+    std::vector<float> seconds(n_utt, 0.0f);
+    for (uint32_t u = 0; u < n_utt; ++u)
+        for (uint32_t i = seg_offsets[u]; i < seg_offsets[u + 1]; ++i) seconds[u] += segs[i].length;
     if ((rc = upload(&b->d_segs, segs, n_segs, ctx->stream)) ||
-        (rc = upload_common(ctx, b, seg_offsets, voice_ids, jitter_seeds, n_utt))) {
+        (rc = upload_common(ctx, b, seg_offsets, voice_ids, jitter_seeds, n_utt)) ||
+        (rc = upload_length_order(ctx, b, seconds, n_utt))) {
         free_batch_buffers(b);
         delete b;
         return rc;
@@ -622,9 +657,13 @@ int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
     b->phoneme_mode = false;
     b->any_blend = any_blend;
     b->n_segs = n_segs;
+    std::vector<float> seconds(n_utt, 0.0f);
+    for (uint32_t u = 0; u < n_utt; ++u)
+        for (uint32_t i = seg_offsets[u]; i < seg_offsets[u + 1]; ++i) seconds[u] += segs[i].length;
     if ((rc = upload(&b->d_segs, ds.data(), n_segs, ctx->stream)) ||
         (rc = upload(&b->d_elems, elems.data(), elems.size(), ctx->stream)) ||
-        (rc = upload_common(ctx, b, seg_offsets, voice_ids, jitter_seeds, n_utt))) {
+        (rc = upload_common(ctx, b, seg_offsets, voice_ids, jitter_seeds, n_utt)) ||
+        (rc = upload_length_order(ctx, b, seconds, n_utt))) {
         free_batch_buffers(b);
         delete b;
         return rc;
@@ -720,6 +759,8 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     a.seg_offsets = batch->d_offsets + first;      // the offsets themselves are absolute into segs
     a.voice_ids = batch->d_voice_ids ? batch->d_voice_ids + first : nullptr;
     a.seeds = batch->d_seeds ? batch->d_seeds + first : nullptr;
+    // the length-sorted slot assignment covers the whole batch: row-block launches keep launch order
+    a.perm = (first == 0 && count == batch->n_utt) ? batch->d_perm : nullptr;
     a.elems = batch->phoneme_mode ? ctx->d_voice_elems : batch->d_elems;
     a.voices = ctx->d_voices;
     a.out = out_dev;
@@ -849,6 +890,7 @@ static int stream_next(grail_ctx *ctx, grail_stream *stream, uint32_t max_sample
     a.seg_offsets = batch->d_offsets;
     a.voice_ids = batch->d_voice_ids;
     a.seeds = batch->d_seeds;
+    a.perm = batch->d_perm;
     a.elems = batch->phoneme_mode ? ctx->d_voice_elems : batch->d_elems;
     a.voices = ctx->d_voices;
     a.out = out_dev;

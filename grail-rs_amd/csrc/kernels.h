@@ -45,6 +45,8 @@ struct SynthArgs {
     const uint32_t *seg_offsets;  // [n_utt + 1]
     const uint32_t *voice_ids;    // [n_utt] or nullptr (voice 0)
     const uint32_t *seeds;        // [n_utt] or nullptr (seed 0)
+    const uint32_t *perm;         // [n_utt] or nullptr: launch slot -> utterance (ragged batches: sorted by
+                                  // length on upload, so the lanes of a wave end together)
     const float *elems;           // phoneme mode: voice elem table; elem mode: batch elem table
     const DevVoice *voices;
     float *out;

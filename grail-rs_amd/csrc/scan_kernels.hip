@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64 * (NP + 1)) void scan_kernel(const SynthArgs A)
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const uint32_t u = blockIdx.x;
+    const uint32_t u = A.perm ? A.perm[blockIdx.x] : blockIdx.x;   // longest utterances first (ragged batches)
     if (threadIdx.x == 0) last_tile = 0x7fffffff;
     __syncthreads();
 

@@ -391,9 +391,16 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     const int j = lane % L;
     const int f0 = j * FPL;
     const uint32_t u0 = PIPE ? blockIdx.x * S : (blockIdx.x * WAVES + wave) * S;
-    const uint32_t u = u0 + slot;
-    bool done = u >= A.n_utt;
+    // which utterance this slot renders: its position in the launch, or — ragged batches — the host's
+    // length-sorted assignment (A.perm), so that the lanes of a wave end together; rows, lengths and
+    // per-utterance inputs always belong to utterance `u`
+    const bool slot_used = u0 + slot < A.n_utt;
+    const uint32_t u = !slot_used ? A.n_utt : (A.perm ? A.perm[u0 + slot] : u0 + slot);
+    bool done = !slot_used;
     const uint32_t uc = done ? 0u : u;
+    __shared__ uint32_t rowid_all[PIPE ? 1 : WAVES][S];
+    uint32_t *rowid = rowid_all[PIPE ? 0 : wave];
+    if (A.perm && j == L - 1) rowid[slot] = uc;
 
     uint32_t vid = A.voice_ids ? A.voice_ids[uc] : 0u;
     if (vid >= A.n_voices) vid = 0u;
@@ -1714,7 +1721,8 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 #pragma unroll
                 for (int i = 0; i < S / ROWS_PER_IT; ++i) {
                     const int r = i * ROWS_PER_IT + rr;
-                    *reinterpret_cast<float4 *>(A.out + (uint64_t)(u0 + r) * A.out_stride + base + rl * 4) = v[i];
+                    const uint32_t row = A.perm ? rowid[r] : u0 + r;
+                    *reinterpret_cast<float4 *>(A.out + (uint64_t)row * A.out_stride + base + rl * 4) = v[i];
                 }
                 wave_lds_sync();
                 if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
@@ -1730,7 +1738,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             const uint32_t c = cnt[r];
             const int t0 = rl * 4;
             if ((uint32_t)t0 < c) {
-                const uint64_t at = (uint64_t)(u0 + r) * A.out_stride + base + t0;
+                const uint64_t at = (uint64_t)(A.perm ? rowid[r] : u0 + r) * A.out_stride + base + t0;
                 auto sample_at = [&](const int tt) __attribute__((always_inline)) -> float {
                     if constexpr (FOLD_IN_FLUSH) {
                         // v1.sum() * 0.5: the left fold from 0.0 over formants 0..7  :574, :123-125

@@ -195,6 +195,9 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       live) whose every parameter is inside the safe window run one workgroup per utterance with
  *       the time axis across the lanes and the filter recurrences solved by parallel scans
  *       (csrc/scan_kernels.hip): 256 utterances x 2 s in 2.3 ms instead of 11.8 ms.
+ *   "sort_by_length": 1 (default) / 0 — batches uploaded afterwards whose utterances differ in
+ *       length fill the launch slots in order of decreasing length (lanes of a wave run in lockstep:
+ *       a wave lasts as long as its longest utterance).  Rows stay where the caller put them.
  *   "kernel_variant": experiments only.
  * Read-only statistics: "slow_division_wave_steps", "fast_wave_tiles" (wave-tiles rendered in fast
  * arithmetic), "general_wave_steps", "last_launch_formants" (4 or 8), "last_launch_lanes",

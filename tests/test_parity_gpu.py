@@ -513,3 +513,28 @@ def test_small_batch_pipeline_with_eight_live_formants_is_bit_exact(gpu_ctx, n_u
     finally:
         gpu_ctx.set_option("small_batch_pipeline", 1)
         gpu_ctx.set_voices(W.single_voice())
+
+
+@pytest.mark.parametrize("lanes", [0, 1, 2, 4, 8])
+def test_length_sorted_slot_assignment_is_invisible(gpu_ctx, lanes):
+    """Ragged batches fill the launch slots in order of decreasing length (grail_api.cpp
+    upload_length_order); every row still belongs to the caller's utterance and every sample is the
+    oracle's, with the option on and off, one-shot and streamed."""
+    rng = np.random.default_rng(7)
+    voices = W.single_voice()
+    n_utt = 150
+    segs, offs, vids, seeds = W.make_batch(n_utt, length=0.02, blend_length=0.015625)
+    segs["length"] = rng.uniform(0.004, 0.03, len(segs)).astype(np.float32)
+    stride = 8192
+    ref, ref_len = O.synthesize_batch(ovoices(voices), segs, offs, vids, seeds, stride)
+    assert len(set(ref_len.tolist())) > 50
+    gpu_ctx.set_voices(voices)
+    try:
+        for sort in (1, 0):
+            gpu_ctx.set_option("sort_by_length", sort)
+            gpu_ctx.set_option("lanes_per_utterance", lanes)
+            out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+            assert_bit_identical(out, out_len, ref, ref_len, f"sort={sort} lanes={lanes}")
+    finally:
+        gpu_ctx.set_option("sort_by_length", 1)
+        gpu_ctx.set_option("lanes_per_utterance", 0)

@@ -12,7 +12,10 @@ import grail_hip as G
 from grail_hip import workload as W
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+sort = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = G.Context(0)
+ctx.set_option("sort_by_length", sort)
+print(f"n = {n} utterances, sort_by_length = {sort}", flush=True)
 rng = np.random.default_rng(1)
 for label, ragged_len, ragged_jit, n_voices in (("aligned 1 voice", False, False, 1),
                                                  ("ragged lengths, 1 voice", True, False, 1),
@@ -40,7 +43,7 @@ for label, ragged_len, ragged_jit, n_voices in (("aligned 1 voice", False, False
     ctx.d2h(lens, d_len, lens.nbytes)
     total = int(lens.astype(np.uint64).sum())
     print(f"{label:45s} kernel {min(ms):7.2f} ms  {total / (min(ms) * 1e-3):.3e} samples/s  "
-          f"(max row {int(lens.max())} samples)", flush=True)
+          f"(max row {int(lens.max())} samples, mean {total / n:.0f})  {ctx.last_kernel_name()}", flush=True)
     ctx.device_free(d_out)
     ctx.device_free(d_len)
     batch.free()
