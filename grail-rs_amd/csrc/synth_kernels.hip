@@ -1694,10 +1694,8 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         }
 
         // ---- flush the staged tile: row `slot` holds samples [base, base+T)
-        if (!emit) {      // PIPE: only the rendering wave has something to flush
-            if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
-            continue;
-        }
+        // PIPE: the rendering wave parked the tile; all four waves (identical state, same decisions) flush a
+        // share of its rows each instead of waiting for wave 0 to do it alone, between two workgroup barriers
         const uint32_t mine = n_out > base ? n_out - base : 0u;
         constexpr int ROW_LANES = T / 4;
         constexpr int ROWS_PER_IT = 64 / ROW_LANES;
@@ -1729,10 +1727,13 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 continue;
             }
         }
-        if (j == L - 1) cnt[slot] = mine;
-        wave_lds_sync();
+        if (emit && j == L - 1) cnt[slot] = mine;
+        if constexpr (PIPE) __syncthreads();
+        else wave_lds_sync();
+        const int r_first = PIPE ? wave * ROWS_PER_IT : 0;
+        constexpr int R_STEP = PIPE ? ROWS_PER_IT * WAVES : ROWS_PER_IT;
 #pragma unroll 1
-        for (int r0 = 0; r0 < S; r0 += ROWS_PER_IT) {
+        for (int r0 = r_first; r0 < S; r0 += R_STEP) {
             const int r = r0 + rr;
             if (ROWS_PER_IT > S && r >= S) continue;
             const uint32_t c = cnt[r];
@@ -1784,7 +1785,8 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 }
             }
         }
-        wave_lds_sync();
+        if constexpr (PIPE) __syncthreads();     // the rendering wave may not park the next tile before all have read
+        else wave_lds_sync();
         if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
     }
 

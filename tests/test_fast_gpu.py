@@ -293,3 +293,27 @@ def test_scan_kernel_gate_sends_unsafe_tables_elsewhere(gpu_ctx):
     segs, offs, vids, seeds = W.make_batch(8, length=0.05, blend_length=0.03)
     out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, 16384)
     assert not gpu_ctx.last_kernel_name().startswith("scan_kernel")
+
+
+def test_fast_mode_pcm16_rows_are_the_conversion_of_the_fast_f32_rows(gpu_ctx):
+    """i16 rows in fast mode (lane kernels and scan kernel): exactly `(x * 32767) as i16` of the f32 rows the
+    same kernels produce (examples/cli.rs:49), i.e. the conversion is fused, not a different rendering."""
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
+    for n_utt, scan in ((24, 1), (24, 0)):
+        segs, offs, vids, seeds = W.make_batch(n_utt, length=0.05, blend_length=0.0625)
+        stride = 16384
+        gpu_ctx.set_option("arithmetic", 1)
+        gpu_ctx.set_option("time_parallel_scan", scan)
+        try:
+            f32, n32 = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+            name32 = gpu_ctx.last_kernel_name()
+            i16, n16 = gpu_ctx.synthesize_pcm16(segs, offs, vids, seeds, out_stride=stride)
+            assert gpu_ctx.last_kernel_name() == name32 and name32.startswith("scan_kernel") == bool(scan)
+        finally:
+            gpu_ctx.set_option("arithmetic", 0)
+            gpu_ctx.set_option("time_parallel_scan", 1)
+        assert np.array_equal(n32, n16)
+        want = np.clip(np.trunc(f32.astype(np.float32) * np.float32(32767.0)), -32768, 32767).astype(np.int16)
+        for u in range(n_utt):
+            assert np.array_equal(i16[u, :n16[u]], want[u, :n16[u]]), (scan, u)

@@ -538,3 +538,33 @@ def test_length_sorted_slot_assignment_is_invisible(gpu_ctx, lanes):
     finally:
         gpu_ctx.set_option("sort_by_length", 1)
         gpu_ctx.set_option("lanes_per_utterance", 0)
+
+
+def test_host_destinations_pinned_and_pageable_get_the_same_rows(gpu_ctx):
+    """GRAIL_OUT_HOST renders row blocks while the previous block leaves over PCIe: a pinned destination
+    (direct copies) and a pageable one (staging ring + copier threads) receive the oracle's rows, zero tails
+    included, also when the batch spans several blocks and when rows are cut at out_stride."""
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
+    n_utt = 4096 + 700                                     # two row blocks (4096 + a partly filled one)
+    segs, offs, vids, seeds = W.make_batch(n_utt, length=0.004, blend_length=0.00390625)
+    stride = W.max_samples(length=0.004)
+    ref, ref_len = O.synthesize_batch(ovoices(voices), segs, offs, vids, seeds, stride)
+    out_len = np.zeros(n_utt, dtype=np.uint32)
+    pinned = gpu_ctx.host_alloc((n_utt, stride), np.float32)
+    try:
+        for dst in (pinned, np.full((n_utt, stride), 7.0, dtype=np.float32)):
+            dst[:] = 7.0
+            gpu_ctx.synthesize_into(dst, out_len, segs, offs, vids, seeds)
+            assert np.array_equal(out_len, ref_len)
+            assert np.array_equal(dst.view(np.uint32), ref.view(np.uint32))      # samples, then zeros
+    finally:
+        gpu_ctx.host_free(pinned)
+    # rows cut at out_stride: reported, lengths capped, the samples that fit are the oracle's
+    short = 256
+    dst = np.zeros((n_utt, short), dtype=np.float32)
+    with pytest.raises(G.GrailError) as ei:
+        gpu_ctx.synthesize_into(dst, out_len, segs, offs, vids, seeds)
+    assert ei.value.status == G.ERR_BUFFER_TOO_SMALL
+    assert np.array_equal(out_len, np.minimum(ref_len, short))
+    assert np.array_equal(dst.view(np.uint32), ref[:, :short].view(np.uint32))
