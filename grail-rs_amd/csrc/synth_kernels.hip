@@ -1716,11 +1716,16 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     v[i] = make_float4(stage[(t0 + 0) * SP + r], stage[(t0 + 1) * SP + r], stage[(t0 + 2) * SP + r],
                                        stage[(t0 + 3) * SP + r]);
                 }
+                if (A.perm) {     // (two copies of the loop: the usual one without any LDS look-up)
 #pragma unroll
-                for (int i = 0; i < S / ROWS_PER_IT; ++i) {
-                    const int r = i * ROWS_PER_IT + rr;
-                    const uint32_t row = A.perm ? rowid[r] : u0 + r;
-                    *reinterpret_cast<float4 *>(A.out + (uint64_t)row * A.out_stride + base + rl * 4) = v[i];
+                    for (int i = 0; i < S / ROWS_PER_IT; ++i)
+                        *reinterpret_cast<float4 *>(A.out + (uint64_t)rowid[i * ROWS_PER_IT + rr] * A.out_stride + base +
+                                                    rl * 4) = v[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < S / ROWS_PER_IT; ++i)
+                        *reinterpret_cast<float4 *>(A.out + (uint64_t)(u0 + i * ROWS_PER_IT + rr) * A.out_stride + base +
+                                                    rl * 4) = v[i];
                 }
                 wave_lds_sync();
                 if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
