@@ -238,6 +238,9 @@ def main():
                     help="after the timed region: per-utterance digests of every rank's rows must equal "
                          "the digests rank 0 gets when it renders the same global utterances itself "
                          "(GPU-count invariance), and a re-batched subset must match (batch invariance)")
+    ap.add_argument("--ramp", type=int, default=1, choices=[0, 1],
+                    help="0 skips the clock-ramp launches of a small sub-batch before the warm-up "
+                         "(counter passes: only the measured kernel should appear)")
     ap.add_argument("--cpu-utts", type=int, default=512,
                     help="utterances for the CPU baseline (0 = skip); 512 is ~4-7 s of CPU on one "
                          "thread (samples/s does not depend on it)")
@@ -389,7 +392,7 @@ def main():
     # 43 for the very first launch, seen in rocprofv3's per-kernel average).  A few launches of a small
     # sub-batch — a different kernel instantiation, so it has its own row in the profiler's statistics —
     # bring the clocks up before the W warm-up steps of the real batch.  Untimed, like the warm-up.
-    if n_utt > 8192:
+    if args.ramp and n_utt > 8192:
         r_segs, r_offs, r_vids, r_seeds = W.make_batch(4096, n_voices=len(voices))
         ramp = ctx.upload(r_segs, r_offs, r_vids, r_seeds)
         for _ in range(4):

@@ -27,7 +27,7 @@ WORKLOADS = [   # key (as bench.py builds it), bench arguments
     ("config3_utts65536_pcm16", ["--config", "3", "--mode", "exact", "--pcm16"]),
 ]
 PASSES = [["WRITE_SIZE"], ["FETCH_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_BUSY_CYCLES"]]
-COMMON = ["--fast-leg", "0", "--cpu-utts", "0", "--steps", "2", "--warmup", "0"]
+COMMON = ["--fast-leg", "0", "--cpu-utts", "0", "--steps", "2", "--warmup", "0", "--ramp", "0"]
 env = dict(os.environ, TMPDIR="/tmp")
 
 
