@@ -908,6 +908,7 @@ static int stream_next(grail_ctx *ctx, grail_stream *stream, uint32_t max_sample
     a.half_capable = stream->half_capable ? 1u : 0u;
     a.any_blend = stream->any_blend ? 1u : 0u;
     a.live4 = stream->live4 ? 1u : 0u;
+    a.fast = ctx->fast_option ? 1u : 0u;     // may change between calls: both flavours share the state layout
     a.state = stream->d_state;
     a.state_stride = stream->lanes;
     a.resume = stream->started ? 1u : 0u;

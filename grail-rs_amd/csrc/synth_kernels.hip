@@ -1905,7 +1905,8 @@ static void launch_one(const SynthArgs &args, hipStream_t stream)
     const dim3 grid((args.n_utt + per_block - 1) / per_block), block(64 * WAVES);
     if constexpr (L <= 4) {
         if (args.state && !args.any_blend && args.live4) {
-            start<L, T, WAVES, MINW, true, false, false, 4>(args, grid, block, stream);
+            if (args.fast) start<L, T, WAVES, MINW, true, false, false, 4, false, true>(args, grid, block, stream);
+            else start<L, T, WAVES, MINW, true, false, false, 4>(args, grid, block, stream);
             return;
         }
         if (!args.state && !args.any_blend && args.live4) {
@@ -1923,6 +1924,12 @@ static void launch_one(const SynthArgs &args, hipStream_t stream)
         if (L == 1 && args.half_capable) start<L, T, WAVES, MINW, false, true, true, NF, false, true>(args, grid, block, stream);
         else if (args.any_blend) start<L, T, WAVES, MINW, false, false, true, NF, false, true>(args, grid, block, stream);
         else start<L, T, WAVES, MINW, false, false, false, NF, false, true>(args, grid, block, stream);
+        return;
+    }
+    if (args.state && args.fast) {
+        // resumable streams in tolerance mode (chunks concatenate to the one-shot rendering within the
+        // tolerance, not bit for bit: the interpolation ends restart with every call)
+        start<L, T, WAVES, MINW, true, false, true, NF, false, true>(args, grid, block, stream);
         return;
     }
     if (args.state) {

@@ -250,7 +250,9 @@ const char *grail_last_kernel_name(grail_ctx *ctx);
  * lives in HBM between launches.  Each call renders the NEXT max_samples (<= out_stride)
  * samples of every utterance to out_dev + u*out_stride (from index 0) and the count to
  * out_len_dev[u] (0 once the utterance has ended).  Concatenating the chunks gives exactly the
- * one-shot result, whatever the chunk sizes.  The batch must outlive the stream. */
+ * one-shot result, whatever the chunk sizes ("arithmetic" = 0; in fast mode the chunks follow the
+ * exact state to the bit — same lengths, same boundaries — and the samples agree with the one-shot
+ * rendering within the fast-mode tolerance).  The batch must outlive the stream. */
 int grail_stream_open(grail_ctx *ctx, const grail_batch *batch, grail_stream **out);
 int grail_stream_next_async(grail_ctx *ctx, grail_stream *stream, uint32_t max_samples,
                             float *out_dev, uint64_t out_stride, uint32_t *out_len_dev);

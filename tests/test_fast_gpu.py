@@ -317,3 +317,49 @@ def test_fast_mode_pcm16_rows_are_the_conversion_of_the_fast_f32_rows(gpu_ctx):
         want = np.clip(np.trunc(f32.astype(np.float32) * np.float32(32767.0)), -32768, 32767).astype(np.int16)
         for u in range(n_utt):
             assert np.array_equal(i16[u, :n16[u]], want[u, :n16[u]]), (scan, u)
+
+
+@pytest.mark.parametrize("lanes", [0, 1, 4, 8])
+def test_fast_mode_streams(gpu_ctx, lanes):
+    """Resumable streams in fast mode: ragged chunk sizes, f32; the concatenation has the oracle's
+    lengths and is within the fast-mode tolerance of the oracle's samples."""
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
+    n_utt = 70
+    segs, offs, vids, seeds = W.make_batch(n_utt, length=0.06, blend_length=0.0625)
+    total = W.max_samples(length=0.06)
+    ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, total)
+    gpu_ctx.set_option("lanes_per_utterance", lanes)
+    gpu_ctx.set_option("arithmetic", 1)
+    batch = gpu_ctx.upload(segs, offs, vids, seeds)
+    chunk_cap = 1024
+    d_out = gpu_ctx.device_alloc(n_utt * chunk_cap * 4)
+    d_len = gpu_ctx.device_alloc(n_utt * 4)
+    got = np.zeros((n_utt, total), dtype=np.float32)
+    pos = np.zeros(n_utt, dtype=np.int64)
+    try:
+        st = G.Stream(batch)
+        for chunk in [96, 33, 1000, 7, 512] * 20:
+            st.next_async(chunk, d_out, chunk_cap, d_len)
+            gpu_ctx.sync()
+            assert "FAST" in gpu_ctx.last_kernel_name() and "STREAM" in gpu_ctx.last_kernel_name()
+            lens = np.zeros(n_utt, dtype=np.uint32)
+            gpu_ctx.d2h(lens, d_len, n_utt * 4)
+            buf = np.zeros((n_utt, chunk_cap), dtype=np.float32)
+            gpu_ctx.d2h(buf, d_out, buf.nbytes)
+            for u in range(n_utt):
+                got[u, pos[u]:pos[u] + lens[u]] = buf[u, :lens[u]]
+            pos += lens
+            if not lens.any():
+                break
+        st.close()
+    finally:
+        gpu_ctx.set_option("arithmetic", 0)
+        gpu_ctx.set_option("lanes_per_utterance", 0)
+        gpu_ctx.device_free(d_out)
+        gpu_ctx.device_free(d_len)
+        batch.free()
+    assert np.array_equal(pos.astype(np.uint32), ref_len)
+    k = _worst(got, ref, ref_len)
+    print(f"fast streams, lanes={lanes}: {k:.1f} * 2^-23")
+    assert 0.0 < k * ULP <= TOL
