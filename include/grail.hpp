@@ -84,6 +84,11 @@ public:
     grail_ctx *ctx() const { return ctx_; }
     const std::vector<Voice> &voices() const { return voices_; }
 
+    // Exact (default): every sample bit-identical to the reference arithmetic.  Fast: the stated-tolerance
+    // mode (|fast - exact| <= GRAIL_FAST_TOLERANCE; clocks, phases, wraps and noise generators stay exact).
+    enum class Arithmetic { Exact = 0, Fast = 1 };
+    void set_arithmetic(Arithmetic a) const { check(grail_set_option(ctx_, "arithmetic", (int64_t)a)); }
+
     // utterances.map(|u| u.phonemes.select(v).sequence(v).jitter(seed, v).synthesize().collect())
     std::vector<std::vector<float>> synthesize(const std::vector<Utterance> &utts) const
     {
