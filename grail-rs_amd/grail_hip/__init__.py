@@ -35,7 +35,7 @@ ERR_NO_VOICES = -7
 OUT_HOST = 0
 OUT_DEVICE = 1
 # "arithmetic" = 1 (fast mode): GRAIL_FAST_TOLERANCE of include/grail_hip.h
-FAST_TOLERANCE_ULPS = 256
+FAST_TOLERANCE_ULPS = 64
 FAST_TOLERANCE = FAST_TOLERANCE_ULPS * 2.0 ** -23
 FAST_TOLERANCE_NOTE = (f"fast mode: max |fast - exact| <= {FAST_TOLERANCE_ULPS} * 2^-23 = {FAST_TOLERANCE:.3g} of "
                        "full scale vs the oracle (tests/test_fast_gpu.py asserts it on configs 2, 3, 4 "

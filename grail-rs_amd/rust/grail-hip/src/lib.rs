@@ -128,7 +128,7 @@ impl<I: IntoIterator<Item = Utterance>> IntoSynthesizeBatch for I {
 }
 
 /// Arithmetic of the synthesis kernels: `Exact` (default) is bit-identical to the CPU iterator chain;
-/// `Fast` is the stated-tolerance mode (|fast - exact| <= GRAIL_FAST_TOLERANCE = 256 * 2^-23 of full
+/// `Fast` is the stated-tolerance mode (|fast - exact| <= GRAIL_FAST_TOLERANCE = 64 * 2^-23 of full
 /// scale, measured 18 * 2^-23; clock, phases, wraps and noise generators stay exact): 2.4x the
 /// throughput on large batches, 5x on batches of a few hundred utterances (time-parallel scan kernel).
 pub enum Arithmetic { Exact, Fast }

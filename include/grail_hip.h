@@ -41,7 +41,7 @@ extern "C" {
 
 #define GRAIL_ABI_VERSION 1
 /* fast mode ("arithmetic" = 1): bound on |fast - exact| per sample, full scale = 1.0; k * 2^-23 */
-#define GRAIL_FAST_TOLERANCE_ULPS 256
+#define GRAIL_FAST_TOLERANCE_ULPS 64
 #define GRAIL_FAST_TOLERANCE (GRAIL_FAST_TOLERANCE_ULPS * 1.1920928955078125e-07f)
 
 /* src/lib.rs:24  NUM_FORMANTS, src/lib.rs:21 DEFAULT_SAMPLE_RATE */

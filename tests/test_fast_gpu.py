@@ -1,6 +1,6 @@
 """Fast mode ("arithmetic" = 1, the tolerance north_star allows) against the oracle.
 
-Contract (include/grail_hip.h): |fast - reference| <= GRAIL_FAST_TOLERANCE = 256 * 2^-23 of full
+Contract (include/grail_hip.h): |fast - reference| <= GRAIL_FAST_TOLERANCE = 64 * 2^-23 of full
 scale, sample for sample; lengths identical; the discontinuous state (segment boundaries, jitter
 wraps, saw edges) never moves, so the error is rounding-level everywhere, never an O(1) glitch.
 The yardstick printed beside it is the reference's own rounding noise: the oracle's binary32
@@ -16,7 +16,7 @@ from grail_hip import workload as W
 pytestmark = pytest.mark.gpu
 
 ULP = 2.0 ** -23
-TOL = G.FAST_TOLERANCE          # 256 * 2^-23
+TOL = G.FAST_TOLERANCE          # 64 * 2^-23
 
 
 def _ovoices(voices):
