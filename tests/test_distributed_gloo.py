@@ -114,3 +114,46 @@ def test_file_rendezvous_three_ranks():
         p.join(30)
     assert sorted(results) == [(0, "ok"), (1, "ok"), (2, "ok")], results
     assert not os.path.exists(os.path.join("/tmp", f"grail_rdzv_{key}"))
+
+
+def _stale_worker(rank, world, key, q):
+    sys.path.insert(0, os.path.join(ROOT, "grail-rs_amd"))
+    from grail_hip.rendezvous import FileGroup
+    try:
+        g = FileGroup(rank, world, key=key, timeout=60)
+        blob = g.broadcast_bytes(b"fresh-id" if rank == 0 else None)
+        g.barrier()
+        g.close()
+        q.put((rank, blob.decode(), g.dir))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e), ""))
+
+
+def test_file_rendezvous_ignores_leftovers_of_a_crashed_launch():
+    """A crashed earlier launch with the same key left a directory full of barrier / broadcast files and
+    a pointer to it (written by a process that no longer exists).  The new launch must not read any of
+    it: rank 0 creates a fresh directory, the others accept only a pointer written by a live rank 0."""
+    import multiprocessing as mp
+    import subprocess
+    key = f"pytest_stale_{os.getpid()}"
+    stale = f"/tmp/grail_rdzv_{key}_stale"
+    os.makedirs(stale, exist_ok=True)
+    for name in ("bar1.0", "bar1.1", "bc1", "bar2.0", "bar2.1"):
+        with open(os.path.join(stale, name), "wb") as f:
+            f.write(b"stale-id")
+    dead = subprocess.Popen([sys.executable, "-c", "pass"])
+    dead.wait()
+    with open(f"/tmp/grail_rdzv_{key}.ptr", "w") as f:
+        f.write(f"{stale}\n{dead.pid}\n{__import__('time').time()!r}\n")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stale_worker, args=(r, 2, key, q)) for r in (1, 0)]   # rank 1 first
+    procs[0].start()
+    __import__("time").sleep(0.5)              # rank 1 is already polling the stale pointer
+    procs[1].start()
+    results = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+    assert [r[1] for r in results] == ["fresh-id", "fresh-id"], results
+    assert all(r[2] != stale for r in results)
+    __import__("shutil").rmtree(stale, ignore_errors=True)
