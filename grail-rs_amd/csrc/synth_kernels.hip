@@ -52,6 +52,9 @@
 #ifndef GRAIL_SCALAR_PACK
 #define GRAIL_SCALAR_PACK 1
 #endif
+#ifndef GRAIL_FAST_G_SCALE
+#define GRAIL_FAST_G_SCALE 1048576.0f   // 2^22 / 4: interpolation error of G, H <= 2^-22 (fast_tile's guard)
+#endif
 #ifndef PIPE_PAIRS_PER_PHASE
 #define PIPE_PAIRS_PER_PHASE 2     // PIPE kernels: sample pairs per coefficient wave between barriers
 #endif
@@ -1362,7 +1365,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             }
             // halvings needed: r / 2^s <= 2^-9.5 (error ~ r^2 / 16), |.| / 4 / 4^s <= 2^-22
             const int la = __builtin_amdgcn_frexp_expf(ra * 724.0773439350247f);      // 2^9.5
-            const int lg = (__builtin_amdgcn_frexp_expf(rg * 1048576.0f) + 1) >> 1;    // 2^22 / 4
+            const int lg = (__builtin_amdgcn_frexp_expf(rg * GRAIL_FAST_G_SCALE) + 1) >> 1;
             int level = la > lg ? la : lg;
             level = level < 0 ? 0 : level;
             if (!(ra == ra) || !(rg == rg)) level = 99;                                // NaN: not here
