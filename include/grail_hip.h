@@ -24,7 +24,11 @@
  * function of (its segments, its voice, its jitter seed) — independent of the
  * batch size, its position in the batch, the lane mapping and the GPU count —
  * and are bit-identical to the reference's IEEE-754 binary32 arithmetic
- * (no FMA contraction, correctly rounded division, denormals kept).
+ * (no FMA contraction, correctly rounded division, denormals kept).  That is the
+ * default, "arithmetic" = 0.  With grail_set_option(ctx, "arithmetic", 1) the
+ * samples are within GRAIL_FAST_TOLERANCE of those bits instead (lengths,
+ * segment boundaries, noise wraps and saw edges still exactly the reference's),
+ * deterministic for a given batch, 2.4x faster.
  *
  * There is no CPU fallback: every compute entry point fails with
  * GRAIL_ERR_NO_DEVICE when no gfx950-capable HIP device is usable.
