@@ -243,25 +243,38 @@ __global__ __launch_bounds__(64 * (NP + 1)) void scan_kernel(const SynthArgs A)
                         if (lane == 0) { pb.d_ffreq = VO.jitter_delta_formant_frequency; pb.amp_scale = 0.5f * VO.jitter_delta_amplitude; }
                         params_dirty = false;
                     }
-                    // ---- the clock and the jitter phase of samples 1.. by closed form.  Samples 1 and 2 are
-                    // plain serial steps; from there on the sequence moves by the quantum q = v1 - v2 as long
-                    // as the values stay in the binade of v2 (RN(v - d) = v - RN_grid(d) when v lies on the
-                    // result's grid) and d is not exactly half-way between two grid points.
-                    const float c1 = clk_first - dt, c2 = c1 - dt, qc = c1 - c2;
-                    const float p1 = jp_first + jinc, p2 = p1 + jinc, qp = p2 - p1;
-                    const float lm2 = (float)(lane - 2);
-                    float cj = lane == 0 ? clk_first : lane == 1 ? c1 : lane == 2 ? c2 : __builtin_fmaf(-lm2, qc, c2);
-                    float pj = lane == 0 ? jp_first : lane == 1 ? p1 : lane == 2 ? p2 : __builtin_fmaf(lm2, qp, p2);
-                    const uint32_t ec = __float_as_uint(c2) >> 23, ep = __float_as_uint(p2) >> 23;
-                    const float ulp_c = __uint_as_float(ec > 23u ? (ec - 23u) << 23 : 0u);
-                    const float ulp_p = __uint_as_float(ep > 23u ? (ep - 23u) << 23 : 0u);
-                    const bool regular_c = (__builtin_fabsf(dt - qc) != 0.5f * ulp_c) && ec > 24u;
-                    const bool regular_p = (__builtin_fabsf(jinc - qp) != 0.5f * ulp_p) && ep > 24u &&
-                                           (__float_as_uint(p1) >> 23) == ep;
-                    bool ok = true;
-                    if (lane >= 1) ok = (cj >= 0.0f) && (pj <= 1.0f);
-                    if (lane >= 3) ok = ok && regular_c && regular_p && (__float_as_uint(cj) >> 23) == ec &&
-                                        (__float_as_uint(pj) >> 23) == ep;
+                    // ---- the clock and the jitter phase of samples 1.. by closed form.  From a known value v0
+                    // (lane b) the next two are plain serial steps v1, v2; from there on the sequence moves by
+                    // the quantum q = v1 - v2 as long as the values stay in the binade of v2 (RN(v - d) =
+                    // v - RN_grid(d) when v lies on the result's grid) and d is not exactly half-way between two
+                    // grid points.  Where the binade ends the same construction starts again from the last
+                    // exact lane (up to two more times per tile), so tiles are cut by events, not by binades.
+                    // `step` = -dt for the clock, +jinc for the jitter phase; `need_same_start`: an increasing
+                    // sequence is regular only if v1 already lies in v2's binade (else v1 is off v2's grid).
+                    auto extend = [&](float &v, int &nv, const float step, const bool need_same_start) __attribute__((always_inline)) {
+                        // lanes < nv hold exact values; make lanes >= nv exact as far as one binade reaches
+                        const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), nv - 1));
+                        const float v1 = v0 + step, v2 = v1 + step, q = v2 - v1;
+                        const int rel = lane - nv;                       // 0: v1, 1: v2, k >= 2: v2 + (k - 1) q
+                        const float cand = rel <= 0 ? v1 : rel == 1 ? v2 : __builtin_fmaf((float)(rel - 1), q, v2);
+                        const uint32_t e2 = __float_as_uint(v2) >> 23;
+                        const float ulp = __uint_as_float(e2 > 23u ? (e2 - 23u) << 23 : 0u);
+                        const bool regular = (__builtin_fabsf(step - q) != 0.5f * ulp) && e2 > 24u &&
+                                             (!need_same_start || (__float_as_uint(v1) >> 23) == e2);
+                        const bool good = lane < nv || rel <= 1 || (regular && (__float_as_uint(cand) >> 23) == e2);
+                        v = lane >= nv ? cand : v;
+                        const uint64_t bad_ = ~__builtin_amdgcn_ballot_w64(good);
+                        nv = bad_ ? __builtin_ctzll(bad_) : TL;
+                    };
+                    float cj = clk_first, pj = jp_first;
+                    int nc = 1, np_ = 1;
+#pragma unroll 1
+                    for (int pass = 0; pass < 3 && (nc < TL || np_ < TL); ++pass) {
+                        if (nc < TL) extend(cj, nc, -dt, false);
+                        if (np_ < TL) extend(pj, np_, jinc, true);
+                    }
+                    // the tile ends before the first event: a clock below zero (:864) or a phase above one (:245)
+                    const bool ok = lane == 0 || (lane < nc && lane < np_ && cj >= 0.0f && pj <= 1.0f);
                     const uint64_t bad = ~__builtin_amdgcn_ballot_w64(ok);
                     int n = bad ? __builtin_ctzll(bad) : TL;
                     const uint32_t room = cap32 - n_out;
