@@ -1313,22 +1313,26 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 x.mu[k] = mul;
                 x.tb[k] = et;
             }
+            float oml_here = 1.0f;
+            if constexpr (SU) {
+                const float es = __builtin_fmaf(vget(Y.smooth[0], 0), alpha, vget(X.smooth[0], 0) * oma);
+                oml_here = 1.0f - exp_approx(es);
+            }
 #pragma unroll
             for (int k = 0; k < NLP; ++k) {
-                put(e.b[k], FS.b[k], vfma(Y.breath[k], vsplat(alpha, V()), X.breath[k] * oma));
+                const V br = vfma(Y.breath[k], vsplat(alpha, V()), X.breath[k] * oma);
                 if constexpr (!SU) {
+                    put(e.b[k], FS.b[k], br);
                     const V es = vfma(Y.smooth[k], vsplat(alpha, V()), X.smooth[k] * oma);
                     put(e.om[k], FS.om[k], 1.0f - exp_approx(es));
                 } else {
+                    // shared smoothness: the low-pass is used as a' = (1-k) a + k saw + (k breath)(noise - saw),
+                    // so the interpolated per-formant quantity is k * breath
+                    put(e.b[k], FS.b[k], br * oml_here);
                     e.om[k] = one;
                 }
             }
-            e.oml = 1.0f;
-            if constexpr (SU) {
-                const float es = __builtin_fmaf(vget(Y.smooth[0], 0), alpha, vget(X.smooth[0], 0) * oma);
-                const float v = 1.0f - exp_approx(es);
-                e.oml = SLOPE ? (v - FS.oml) * scale : v;
-            }
+            e.oml = SU ? (SLOPE ? (oml_here - FS.oml) * scale : oml_here) : 1.0f;
         };
         FastEnds D;              // per-sample slopes of the sub-tile
         FastAux xe;
@@ -1453,6 +1457,12 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 su.y = __uint_as_float((__float_as_uint(u.y) & 0x7FFFFFFFu) | (~__float_as_uint(saw_nb.y) & 0x80000000u));
                 const f2 saw2 = vfma(su, u, saw_nb);                               // :517
                 // ---- the formants, sample by sample, coefficients by interpolation
+                f2 keep2 = one2, ksaw2 = one2;          // shared smoothness: 1 - k and k * saw of both samples
+                if constexpr (SU) {
+                    const f2 k2 = vfma(vsplat(D.oml, f2()), TI, vsplat(FS.oml, f2()));
+                    keep2 = 1.0f - k2;
+                    ksaw2 = k2 * saw2;
+                }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const float ti = vget(TI, h), saw = vget(saw2, h);
@@ -1460,15 +1470,17 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     const V nms = vsplat(nz[h] - saw, V());
                     const V nm1 = vsplat(nm[h], V());
                     const V sawv = vsplat(saw, V());
-                    V oml_v = one;
-                    if constexpr (SU) oml_v = vsplat(__builtin_fmaf(D.oml, ti, FS.oml), V());
                     V acc = vsplat(0.0f, V());
 #pragma unroll
                     for (int k = 0; k < NLP; ++k) {
                         const V b = vfma(D.b[k], tiv, FS.b[k]);
-                        const V nw = vfma(b, nms, sawv);                            // :531
-                        if constexpr (!SU) oml_v = vfma(D.om[k], tiv, FS.om[k]);
-                        st_a[k] = vfma(oml_v, nw - st_a[k], st_a[k]);               // :538
+                        if constexpr (SU) {             // :531 + :538:  a' = (1-k) a + k saw + (k breath)(noise - saw)
+                            st_a[k] = vfma(b, nms, vfma(vsplat(vget(keep2, h), V()), st_a[k], vsplat(vget(ksaw2, h), V())));
+                        } else {
+                            const V nw = vfma(b, nms, sawv);                        // :531
+                            const V oml_v = vfma(D.om[k], tiv, FS.om[k]);
+                            st_a[k] = vfma(oml_v, nw - st_a[k], st_a[k]);           // :538
+                        }
                     }
 #pragma unroll
                     for (int k = 0; k < NLIVE; ++k) {
