@@ -2,33 +2,40 @@
 //
 // The lane-per-utterance kernels of synth_kernels.hip need tens of thousands of utterances to fill an
 // MI355X; with a few hundred most SIMDs idle and the time per batch is the serial length of one
-// utterance.  This kernel turns the mapping around: ONE WORKGROUP PER UTTERANCE, LANES = TIME.  A tile is
-// up to 64 consecutive samples, one per lane.
+// utterance.  This kernel turns the mapping around: ONE WORKGROUP PER UTTERANCE, LANES = TIME.
+// The unit of work is a SUPER-TILE of up to 512 consecutive samples without an event inside.
 //
 //   wave 0 ("chain")      the per-utterance state of the reference, EXACT: Sequencer clock and segment
 //                         advances (src/lib.rs:859-932), jitter phase, wraps and redraws (:240-306,
 //                         :753-777), the pitch track, the carrier phase with its wrap (:520-525), the
-//                         carrier-noise LCG (:36-55, closed-form skip-ahead).  The clock `clk -= dt` and the
-//                         jitter phase `p += inc` are serial f32 accumulations; inside one binade they
-//                         move by a constant quantum (the increment rounded to that binade's grid), so
-//                         lane j gets its value as one fma, exactly, and a tile simply ends where the
-//                         binade (or a tie case, or an event) ends.  The carrier phase is the one truly
-//                         serial quantity: fract(p + f_j) handed down the lanes with DPP wave_shr:1.
-//   waves 1..NP ("pairs") two formants each (packed f32).  Every lane evaluates its sample's filter
-//                         coefficients directly (no interpolation), then the recurrences are solved for the
-//                         whole tile by inclusive scans over the lanes: the one-pole low-pass (:538) is the
-//                         affine map a -> (1-k) a + k x, the Cytomic SVF (:565-571) the 2x2 affine map
+//                         carrier-noise LCG (:36-55, closed-form skip-ahead).  It walks the super-tile in
+//                         tiles of 64 samples, one per lane.  The clock `clk -= dt` and the jitter phase
+//                         `p += inc` are serial f32 accumulations; inside one binade they move by a constant
+//                         quantum (the increment rounded to that binade's grid), so lane j gets its value
+//                         as one fma, exactly; quantum and binade are kept from tile to tile and derived
+//                         afresh only after an event or where the binade ends.  The carrier phase is the one
+//                         truly serial quantity: fract(p + f_j) handed down the lanes with DPP wave_shr:1.
+//   wave 1 ("filters")    one super-tile behind, formant pair by formant pair (two formants = one packed
+//                         f32 vector; two pairs when formants 5-8 are provably dead, else four).  Lane j
+//                         owns the EIGHT consecutive samples 8j .. 8j+7: it evaluates their coefficients directly
+//                         (no interpolation), composes its eight steps of each recurrence into one affine
+//                         map, the 64 maps are combined by an inclusive scan over the lanes (six DPP steps:
+//                         row_shr 1/2/4/8, row_bcast 15/31 — north_star's "first-order-section parallel
+//                         scan"), and from the state the scan hands it the lane runs its eight samples with
+//                         the plain recurrence.  The one-pole low-pass (:538) is the map a -> (1-k) a + k x,
+//                         the Cytomic SVF (:565-571) the 2x2 affine map
 //                           [b'; c'] = [[2 a1 - 1, -2 a2], [2 a2, 1 - 2 a3]] [b; c] + v0 [2 a2; 2 a3],
-//                         composed as (M2, u2) o (M1, u1) = (M2 M1, M2 u1 + u2) in six DPP steps
-//                         (row_shr 1/2/4/8, row_bcast 15/31) — north_star's "first-order-section parallel
-//                         scan".  The tile's last state is the next tile's start.
-//   wave 0 again          adds the pairs' band-pass outputs (:574) and stores the tile.
+//                         composed as (M2, u2) o (M1, u1) = (M2 M1, M2 u1 + u2).  Work per sample: 8/8 of a
+//                         serial filter step + 1/8 of a scan, instead of a whole scan per 64 samples.
+//                         The pairs' band-pass outputs add up in formant order (:574) in registers and the
+//                         lane stores its eight samples (a wave writes 2 KB runs).
 //
-// Three pipeline stages one tile apart, LDS buffers in between, one workgroup barrier per tile.
-// Tolerance mode only (the scans reassociate the recurrences); the discontinuous state is the reference's
-// to the bit, so lengths and every boundary / wrap / saw edge sit where the reference puts them.
-// The host only sends batches here whose every parameter is inside the proven-safe window
-// (grail_api.cpp scan_ok): no NaN / Inf special cases exist on this path.
+// Two pipeline stages one super-tile apart, double-buffered LDS in between, ONE workgroup barrier per
+// super-tile.  Two waves per utterance keep eight workgroups resident per CU, so that mid-size batches
+// (thousands of utterances) are bound by instruction issue, not by the latency of the serial chain.  Tolerance mode only (the scans reassociate the recurrences); the discontinuous state is
+// the reference's to the bit, so lengths and every boundary / wrap / saw edge sit where the reference puts
+// them.  The host only sends batches here whose every parameter is inside the proven-safe window
+// (grail_api.cpp scan_voice_ok): no NaN / Inf special cases exist on this path.
 #include <cstdio>
 
 #include <type_traits>
@@ -40,13 +47,18 @@
 namespace grail {
 namespace {
 
-constexpr int TL = 64;   // samples per tile = lanes per wave
+constexpr int TL = 64;        // lanes per wave = samples per chain tile
+constexpr int CK = 8;         // consecutive samples owned by one lane of a pair wave
+constexpr int ST = TL * CK;   // samples per super-tile
 
-struct TileIn {
-    float alpha[TL], jp[TL], saw[TL], nz[TL];
-    int n;        // valid samples (lanes) of this tile
-    int epoch;    // which parameter block applies
-    int pad[2];
+struct __attribute__((aligned(16))) TileIn {
+    float alpha[ST], jp[ST], saw[ST], nz[ST];
+};
+struct TileMeta {
+    int n;          // samples of the super-tile
+    int epoch;      // which parameter block applies
+    uint32_t at;    // row position of its first sample
+    int pad;
 };
 
 // what the pair waves need of the current segment pair and jitter period (written by the chain wave)
@@ -69,41 +81,68 @@ __device__ __forceinline__ f2 dpp(f2 old, f2 x)
     r.y = dpp<CTRL, ROW_MASK>(old.y, x.y);
     return r;
 }
+// wave-uniform by construction; says so to the compiler (scalar registers, scalar branches)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ bool uni(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
+__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
 
-// one level of the inclusive scans: combine with the element CTRL lanes earlier in time
+// One level of the inclusive scans over the lanes: combine with the element CTRL lanes earlier in time
+// (lanes without a source take the identity through DPP's `old` operand).
 //   low-pass   (P, Q):  a -> P a + Q
 //   band-pass  (M, U):  s -> M s + U
-struct ScanElem {
+struct LpMap {
     f2 P, Q;
+};
+struct BpMap {
     f2 m11, m12, m21, m22, u1, u2;
 };
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void scan_level(ScanElem &e)
+__device__ __forceinline__ void scan_level(LpMap &e)
 {
     const f2 one = vsplat(1.0f, f2()), zero = vsplat(0.0f, f2());
     const f2 eP = dpp<CTRL, ROW_MASK>(one, e.P), eQ = dpp<CTRL, ROW_MASK>(zero, e.Q);
+    e.Q = vfma(e.P, eQ, e.Q);
+    e.P = e.P * eP;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void scan_level(BpMap &e)
+{
+    const f2 one = vsplat(1.0f, f2()), zero = vsplat(0.0f, f2());
     const f2 e11 = dpp<CTRL, ROW_MASK>(one, e.m11), e12 = dpp<CTRL, ROW_MASK>(zero, e.m12);
     const f2 e21 = dpp<CTRL, ROW_MASK>(zero, e.m21), e22 = dpp<CTRL, ROW_MASK>(one, e.m22);
     const f2 eu1 = dpp<CTRL, ROW_MASK>(zero, e.u1), eu2 = dpp<CTRL, ROW_MASK>(zero, e.u2);
-    e.Q = vfma(e.P, eQ, e.Q);
-    e.P = e.P * eP;
     const f2 n11 = vfma(e.m12, e21, e.m11 * e11), n12 = vfma(e.m12, e22, e.m11 * e12);
     const f2 n21 = vfma(e.m22, e21, e.m21 * e11), n22 = vfma(e.m22, e22, e.m21 * e12);
     e.u1 = vfma(e.m12, eu2, vfma(e.m11, eu1, e.u1));
     e.u2 = vfma(e.m22, eu2, vfma(e.m21, eu1, e.u2));
     e.m11 = n11; e.m12 = n12; e.m21 = n21; e.m22 = n22;
 }
+template <typename MAP>
+__device__ __forceinline__ void scan_lanes(MAP &e)
+{
+    scan_level<0x111, 0xF>(e);   // row_shr:1
+    scan_level<0x112, 0xF>(e);   // row_shr:2
+    scan_level<0x114, 0xF>(e);   // row_shr:4
+    scan_level<0x118, 0xF>(e);   // row_shr:8
+    scan_level<0x142, 0xA>(e);   // row_bcast:15 into rows 1 and 3
+    scan_level<0x143, 0xC>(e);   // row_bcast:31 into rows 2 and 3
+}
 
-template <int NP>   // pair waves: 2 (formants 5-8 proven dead, see live4_ok) or 4
-__global__ __launch_bounds__(64 * (NP + 1)) void scan_kernel(const SynthArgs A)
+typedef float vf4u __attribute__((ext_vector_type(4), aligned(4)));       // 16-byte stores at 4-byte alignment
+typedef short vs8u __attribute__((ext_vector_type(8), aligned(2)));
+
+template <int NP>   // formant pairs: 2 (formants 5-8 proven dead, see live4_ok) or 4
+__global__ __launch_bounds__(128) void scan_kernel(const SynthArgs A)
 {
     __shared__ TileIn tin[2];
     __shared__ ParamBlock par[2];
-    __shared__ float yout[2][NP][TL];
-    __shared__ int last_tile;                 // index of the utterance's last tile, known once the chain ends
+    __shared__ TileMeta meta[4];
+    __shared__ int last_tile;                 // index of the utterance's last super-tile, known once the chain ends
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform, and the compiler knows
     const uint32_t u = A.perm ? A.perm[blockIdx.x] : blockIdx.x;   // longest utterances first (ragged batches)
     if (threadIdx.x == 0) last_tile = 0x7fffffff;
     __syncthreads();
@@ -153,6 +192,12 @@ __global__ __launch_bounds__(64 * (NP + 1)) void scan_kernel(const SynthArgs A)
         float phase = 0.0f;
         uint32_t noise_seed = 0u;                                   // :594
         const uint32_t skip_mul = LCG_SKIP.mul[lane + 1], skip_add = LCG_SKIP.add[lane + 1];
+        const float lane_p1 = (float)(lane + 1);
+
+        // closed forms kept from tile to tile: signed quantum, binade (biased exponent), still valid?
+        float c_q = 0.0f, j_q = 0.0f;
+        uint32_t c_e2 = 0u, j_e2 = 0u;
+        bool c_reg = false, j_reg = false;
 
         const uint64_t cap = A.cap;
         const uint32_t cap32 = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;
@@ -160,125 +205,147 @@ __global__ __launch_bounds__(64 * (NP + 1)) void scan_kernel(const SynthArgs A)
         bool finished = false, truncated = false;
         int epoch = 0;
         bool params_dirty = true;
-        int hist_n[2] = {0, 0};
-        uint32_t hist_at[2] = {0u, 0u};
+        uint32_t quick_tiles = 0, derived_tiles = 0;   // statistics: tiles on the kept closed forms / derived afresh
 
         for (int step = 0;; ++step) {
-            // ---- stage 3: add up and store the tile the pair waves finished in the previous step
-            if (step >= 2 && step - 2 <= last_tile) {
-                const int b = (step - 2) & 1;
-                float y = 0.0f;
-#pragma unroll
-                for (int w = 0; w < NP; ++w) y += yout[b][w][lane];
-                if (lane < hist_n[b]) {
-                    const uint64_t at = (uint64_t)u * A.out_stride + hist_at[b] + (uint32_t)lane;
-                    const float sample = y * 0.5f;                  // :574
-                    if (A.out_pcm16) A.out_pcm16[at] = (int16_t)pcm16_from_f32(sample);
-                    else A.out[at] = sample;
-                }
-            }
-            // ---- stage 1: the next tile of the chain
             if (!finished) {
                 TileIn &ti = tin[step & 1];
-                // the first sample of the tile: the reference's own control flow
-                float clk_first = clk - dt;                                     // :861
-                if (clk_first < 0.0f) {                                         // :864
-                    if (cur.some && nxt.some) {                                 // :868
-                        cur = nxt;
-                        fetch_seg(nxt, A.segs, seg_pos, seg_end, true, VO.elem_base);
-                        clk_first += cur.length;                                // :873
-                    } else if (!cur.some && !nxt.some) {                        // :876
-                        fetch_seg(cur, A.segs, seg_pos, seg_end, true, VO.elem_base);
-                        fetch_seg(nxt, A.segs, seg_pos, seg_end, true, VO.elem_base);
-                        if (cur.some) clk_first += cur.length;                  // :881-883
-                    } else {
-                        finished = true;                                        // :886
-                    }
-                    if (!finished && cur.some) {                                // the match at :891-931
-                        const bool has_b = cur.elem >= 0, has_c = nxt.some && nxt.elem >= 0;
-                        silent_pair = !has_b && !has_c;
-                        inv_bl = 1.0f / cur.blend_length;                       // blend lengths are +-2^k here
-                        if (has_b && has_c) { x_row = nxt.elem; y_row = cur.elem; xf = nxt.frequency; yf = cur.frequency; x_mute = y_mute = false; }
-                        else if (has_b) { x_row = y_row = cur.elem; xf = yf = cur.frequency; x_mute = true; y_mute = false; }
-                        else if (has_c) { x_row = y_row = nxt.elem; xf = yf = nxt.frequency; x_mute = false; y_mute = true; }
-                        else { x_row = y_row = -1; xf = yf = 0.25f; x_mute = y_mute = false; }
-                        params_dirty = true;
-                    }
-                }
-                if (!cur.some) finished = true;                                 // :930
-                if (!finished && n_out >= cap) { truncated = true; finished = true; }
-                if (finished) {
-                    if (lane == 0) last_tile = step - 1;
-                } else {
-                    float jp_first = jphase + jinc;                             // :242 / :291
-                    if (jp_first > 1.0f) {                                      // :245 / :294
-                        jp_first -= 1.0f;
-                        fn_cur = fn_next;
-                        fn_next = lcg_f32(fn_state);
-                        ff_cur = ff_next;
-                        fa_cur = fa_next;
-                        uint32_t s1 = ff_state, s2 = fa_state;
-#pragma unroll
-                        for (int i = 0; i < NF; ++i) {                          // from_func order :301
-                            const float r1 = lcg_f32(s1), r2 = lcg_f32(s2);
-                            if ((lane & 7) == i) { ff_next = r1; fa_next = r2; }
-                        }
-                        ff_state = s1;
-                        fa_state = s2;
-                        params_dirty = true;
-                    }
-                    if (params_dirty) {
-                        ++epoch;
-                        ParamBlock &pb = par[epoch & 1];
-                        if (lane < ELEM_FLOATS) {
-                            // SynthesisElem::silent() :367-377, copy_silent() :454-459
-                            const float sil = lane == 0 ? 0.25f : (lane < F_BREATH ? 0.25f : 0.0f);
-                            float xv = x_row >= 0 ? elems[(size_t)x_row * ELEM_FLOATS + lane] : sil;
-                            float yv = y_row >= 0 ? elems[(size_t)y_row * ELEM_FLOATS + lane] : sil;
-                            if (lane >= F_AMP) { xv = x_mute ? 0.0f : xv; yv = y_mute ? 0.0f : yv; }
-                            pb.X[lane] = xv;
-                            pb.Y[lane] = yv;
-                        }
-                        if (lane < NF) { pb.ffc[lane] = ff_cur; pb.ffn[lane] = ff_next; pb.fac[lane] = fa_cur; pb.fan[lane] = fa_next; }
-                        if (lane == 0) { pb.d_ffreq = VO.jitter_delta_formant_frequency; pb.amp_scale = 0.5f * VO.jitter_delta_amplitude; }
-                        params_dirty = false;
-                    }
-                    // ---- the clock and the jitter phase of samples 1.. by closed form.  From a known value v0
-                    // (lane b) the next two are plain serial steps v1, v2; from there on the sequence moves by
-                    // the quantum q = v1 - v2 as long as the values stay in the binade of v2 (RN(v - d) =
+                const uint32_t at0 = n_out;
+                int S = 0;                                                      // samples of this super-tile so far
+                while (S <= ST - TL) {
+                    // ---- the clock and the jitter phase of the tile by closed form.  From a known value v0
+                    // the next two are plain serial steps v1, v2; from there on the sequence moves by the
+                    // quantum q = v2 - v1 as long as the values stay in the binade of v2 (RN(v - d) =
                     // v - RN_grid(d) when v lies on the result's grid) and d is not exactly half-way between two
-                    // grid points.  Where the binade ends the same construction starts again from the last
-                    // exact lane (up to two more times per tile), so tiles are cut by events, not by binades.
-                    // `step` = -dt for the clock, +jinc for the jitter phase; `need_same_start`: an increasing
-                    // sequence is regular only if v1 already lies in v2's binade (else v1 is off v2's grid).
-                    auto extend = [&](float &v, int &nv, const float step, const bool need_same_start) __attribute__((always_inline)) {
-                        // lanes < nv hold exact values; make lanes >= nv exact as far as one binade reaches
-                        const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), nv - 1));
-                        const float v1 = v0 + step, v2 = v1 + step, q = v2 - v1;
-                        const int rel = lane - nv;                       // 0: v1, 1: v2, k >= 2: v2 + (k - 1) q
-                        const float cand = rel <= 0 ? v1 : rel == 1 ? v2 : __builtin_fmaf((float)(rel - 1), q, v2);
-                        const uint32_t e2 = __float_as_uint(v2) >> 23;
-                        const float ulp = __uint_as_float(e2 > 23u ? (e2 - 23u) << 23 : 0u);
-                        const bool regular = (__builtin_fabsf(step - q) != 0.5f * ulp) && e2 > 24u &&
-                                             (!need_same_start || (__float_as_uint(v1) >> 23) == e2);
-                        const bool good = lane < nv || rel <= 1 || (regular && (__float_as_uint(cand) >> 23) == e2);
-                        v = lane >= nv ? cand : v;
-                        const uint64_t bad_ = ~__builtin_amdgcn_ballot_w64(good);
-                        nv = bad_ ? __builtin_ctzll(bad_) : TL;
-                    };
-                    float cj = clk_first, pj = jp_first;
-                    int nc = 1, np_ = 1;
-#pragma unroll 1
-                    for (int pass = 0; pass < 3 && (nc < TL || np_ < TL); ++pass) {
-                        if (nc < TL) extend(cj, nc, -dt, false);
-                        if (np_ < TL) extend(pj, np_, jinc, true);
+                    // grid points.  (q, binade) stay valid from tile to tile, so the usual tile is QUICK: one
+                    // fma per sequence and a test that all 64 values are still in the binade — which also says
+                    // that no clock went below zero (:864) and no phase above one (:245): no event in the tile.
+                    float cj = 0.0f, pj = 0.0f;
+                    int n = TL;
+                    bool quick = false;
+                    if (uni(c_reg && j_reg && cap32 - n_out >= (uint32_t)TL)) {
+                        cj = __builtin_fmaf(lane_p1, c_q, clk);
+                        pj = __builtin_fmaf(lane_p1, j_q, jphase);
+                        const bool in = (__float_as_uint(cj) >> 23) == c_e2 && (__float_as_uint(pj) >> 23) == j_e2;
+                        quick = __builtin_amdgcn_ballot_w64(in) == ~0ull;
                     }
-                    // the tile ends before the first event: a clock below zero (:864) or a phase above one (:245)
-                    const bool ok = lane == 0 || (lane < nc && lane < np_ && cj >= 0.0f && pj <= 1.0f);
-                    const uint64_t bad = ~__builtin_amdgcn_ballot_w64(ok);
-                    int n = bad ? __builtin_ctzll(bad) : TL;
-                    const uint32_t room = cap32 - n_out;
-                    n = (uint32_t)n > room ? (int)room : n;
+                    if (quick) {
+                        ++quick_tiles;
+                    } else {
+                        // ---- the first sample of the tile: the reference's own control flow.  An event ends the
+                        // super-tile that is under way (its parameter block applies to every sample of it)
+                        float clk_first = clk - dt;                                 // :861
+                        float jp_first = jphase + jinc;                             // :242 / :291
+                        if (uni(S > 0 && (clk_first < 0.0f || jp_first > 1.0f || n_out >= cap))) break;
+                        if (uni(clk_first < 0.0f)) {                                // :864
+                            if (cur.some && nxt.some) {                             // :868
+                                cur = nxt;
+                                fetch_seg(nxt, A.segs, seg_pos, seg_end, true, VO.elem_base);
+                                clk_first += cur.length;                            // :873
+                            } else if (!cur.some && !nxt.some) {                    // :876
+                                fetch_seg(cur, A.segs, seg_pos, seg_end, true, VO.elem_base);
+                                fetch_seg(nxt, A.segs, seg_pos, seg_end, true, VO.elem_base);
+                                if (cur.some) clk_first += cur.length;              // :881-883
+                            } else {
+                                finished = true;                                    // :886
+                            }
+                            if (!finished && cur.some) {                            // the match at :891-931
+                                const bool has_b = cur.elem >= 0, has_c = nxt.some && nxt.elem >= 0;
+                                silent_pair = !has_b && !has_c;
+                                inv_bl = 1.0f / cur.blend_length;                   // blend lengths are +-2^k here
+                                if (has_b && has_c) { x_row = nxt.elem; y_row = cur.elem; xf = nxt.frequency; yf = cur.frequency; x_mute = y_mute = false; }
+                                else if (has_b) { x_row = y_row = cur.elem; xf = yf = cur.frequency; x_mute = true; y_mute = false; }
+                                else if (has_c) { x_row = y_row = nxt.elem; xf = yf = nxt.frequency; x_mute = false; y_mute = true; }
+                                else { x_row = y_row = -1; xf = yf = 0.25f; x_mute = y_mute = false; }
+                                params_dirty = true;
+                            }
+                            c_reg = false;
+                        }
+                        if (!cur.some) finished = true;                             // :930
+                        if (!finished && n_out >= cap) { truncated = true; finished = true; }
+                        if (uni(finished)) break;
+                        if (uni(jp_first > 1.0f)) {                                 // :245 / :294
+                            jp_first -= 1.0f;
+                            fn_cur = fn_next;
+                            fn_next = lcg_f32(fn_state);
+                            ff_cur = ff_next;
+                            fa_cur = fa_next;
+                            uint32_t s1 = ff_state, s2 = fa_state;
+    #pragma unroll
+                            for (int i = 0; i < NF; ++i) {                          // from_func order :301
+                                const float r1 = lcg_f32(s1), r2 = lcg_f32(s2);
+                                if ((lane & 7) == i) { ff_next = r1; fa_next = r2; }
+                            }
+                            ff_state = s1;
+                            fa_state = s2;
+                            params_dirty = true;
+                            j_reg = false;
+                        }
+                        if (params_dirty) {
+                            ++epoch;
+                            ParamBlock &pb = par[epoch & 1];
+                            if (lane < ELEM_FLOATS) {
+                                // SynthesisElem::silent() :367-377, copy_silent() :454-459
+                                const float sil = lane == 0 ? 0.25f : (lane < F_BREATH ? 0.25f : 0.0f);
+                                float xv = x_row >= 0 ? elems[(size_t)x_row * ELEM_FLOATS + lane] : sil;
+                                float yv = y_row >= 0 ? elems[(size_t)y_row * ELEM_FLOATS + lane] : sil;
+                                if (lane >= F_AMP) { xv = x_mute ? 0.0f : xv; yv = y_mute ? 0.0f : yv; }
+                                pb.X[lane] = xv;
+                                pb.Y[lane] = yv;
+                            }
+                            if (lane < NF) { pb.ffc[lane] = ff_cur; pb.ffn[lane] = ff_next; pb.fac[lane] = fa_cur; pb.fan[lane] = fa_next; }
+                            if (lane == 0) { pb.d_ffreq = VO.jitter_delta_formant_frequency; pb.amp_scale = 0.5f * VO.jitter_delta_amplitude; }
+                            params_dirty = false;
+                        }
+                        // Where the binade ends, or after an event, the closed form is derived afresh from the last
+                        // exact lane (up to three times per tile).  `step` = -dt for the clock, +jinc for the jitter
+                        // phase; `need_same_start`: an increasing sequence is regular only if v1 already lies in
+                        // v2's binade (else v1 is off v2's grid).
+                        auto extend = [&](float &v, int &nv, const float step_, const bool need_same_start,
+                                          float &q_out, uint32_t &e2_out, bool &reg_out) __attribute__((always_inline)) {
+                            // lanes < nv hold exact values; make lanes >= nv exact as far as one binade reaches
+                            const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), nv - 1));
+                            const float v1 = v0 + step_, v2 = v1 + step_, q = v2 - v1;
+                            const int rel = lane - nv;                       // 0: v1, 1: v2, k >= 2: v2 + (k - 1) q
+                            const float cand = rel <= 0 ? v1 : rel == 1 ? v2 : __builtin_fmaf((float)(rel - 1), q, v2);
+                            const uint32_t e2 = __float_as_uint(v2) >> 23;
+                            const float ulp = __uint_as_float(e2 > 23u ? (e2 - 23u) << 23 : 0u);
+                            const bool regular = (__builtin_fabsf(step_ - q) != 0.5f * ulp) && e2 > 24u &&
+                                                 (!need_same_start || (__float_as_uint(v1) >> 23) == e2);
+                            const bool good = lane < nv || rel <= 1 || (regular && (__float_as_uint(cand) >> 23) == e2);
+                            v = lane >= nv ? cand : v;
+                            const uint64_t bad_ = ~__builtin_amdgcn_ballot_w64(good);
+                            const int nv_before = nv;
+                            nv = bad_ ? __builtin_ctzll(bad_) : TL;
+                            // the closed form carries over to the next tile if lane 63 was reached inside v2's binade
+                            q_out = q;
+                            e2_out = e2;
+                            reg_out = regular && nv == TL && nv_before <= TL - 2;
+                        };
+                        ++derived_tiles;
+                        cj = clk_first;
+                        pj = jp_first;
+                        int nc = 1, np_ = 1;
+                        c_reg = j_reg = false;
+#pragma unroll 1
+                        for (int pass = 0; pass < 3 && (nc < TL || np_ < TL); ++pass) {
+                            if (nc < TL) extend(cj, nc, -dt, false, c_q, c_e2, c_reg);
+                            if (np_ < TL) extend(pj, np_, jinc, true, j_q, j_e2, j_reg);
+                        }
+                        // the tile ends before the first event: a clock below zero (:864) or a phase above one (:245)
+                        const bool ok = lane == 0 || (lane < nc && lane < np_ && cj >= 0.0f && pj <= 1.0f);
+                        const uint64_t bad = ~__builtin_amdgcn_ballot_w64(ok);
+                        n = bad ? __builtin_ctzll(bad) : TL;
+                        const uint32_t room = cap32 - n_out;
+                        n = uni((uint32_t)n > room ? (int)room : n);
+                        if (n <= 0) break;
+                        // the closed forms carry over only if the value the next tile starts from lies in their
+                        // binades (a tile cut short may end in the binade before) and the phase binade is below one
+                        const float c_last = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cj), n - 1));
+                        const float j_last = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pj), n - 1));
+                        c_reg = c_reg && (__float_as_uint(c_last) >> 23) == c_e2;
+                        j_reg = j_reg && (__float_as_uint(j_last) >> 23) == j_e2 && j_e2 < 127u;
+                    }
                     // ---- per lane: alpha, the pitch (exact: :404-414, :254, :763)
                     float alpha = __builtin_fminf(cj * inv_bl, 1.0f);           // :899/:908/:917
                     alpha = silent_pair ? 1.0f : alpha;
@@ -308,11 +375,11 @@ __global__ __launch_bounds__(64 * (NP + 1)) void scan_kernel(const SynthArgs A)
                     // ---- carrier noise :528: lane j is j + 1 draws after the tile's start state
                     const uint32_t sk = noise_seed * skip_mul + skip_add;
                     const float nz = (__uint_as_float((sk >> 9) | 0x3F800000u) - 1.5f) * 2.0f;
-                    ti.alpha[lane] = alpha;
-                    ti.jp[lane] = pj;
-                    ti.saw[lane] = saw;
-                    ti.nz[lane] = nz;
-                    if (lane == 0) { ti.n = n; ti.epoch = epoch; }
+                    // lanes >= n write beyond the tile: the next tile overwrites them, or nobody reads them
+                    ti.alpha[S + lane] = alpha;
+                    ti.jp[S + lane] = pj;
+                    ti.saw[S + lane] = saw;
+                    ti.nz[S + lane] = nz;
                     // ---- carry the chain to the tile's end
                     const int last = n - 1;
                     clk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cj), last));
@@ -321,154 +388,226 @@ __global__ __launch_bounds__(64 * (NP + 1)) void scan_kernel(const SynthArgs A)
                     const float f_l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, frequency), last));
                     phase = __builtin_amdgcn_fractf(ph_l + f_l);
                     noise_seed = (uint32_t)__builtin_amdgcn_readlane((int)sk, last);
-                    hist_n[step & 1] = n;
-                    hist_at[step & 1] = n_out;
                     n_out += (uint32_t)n;
+                    S += n;
+                }
+                if (S > 0) {
+                    if (lane == 0) { TileMeta &m = meta[step & 3]; m.n = S; m.epoch = epoch; m.at = at0; }
+                } else {
+                    finished = true;                    // nothing left (or no room): the previous super-tile was the last
+                    if (lane == 0) last_tile = step - 1;
                 }
             }
             __syncthreads();
-            if (step >= 1 && step - 1 > last_tile) break;     // the tile stored above was the last one
+            if (step - 1 >= last_tile) break;           // the filter wave stored the last super-tile in this step
         }
         if (lane == 0) {
             if (A.out_len) A.out_len[u] = n_out;
             if (truncated) atomicOr(A.truncated, 1u);
+            atomicAdd(A.truncated + 2, quick_tiles);
+            atomicAdd(A.truncated + 3, derived_tiles);
         }
         return;
     }
 
-    // =============================== a pair wave: formants f0, f0 + 1 ===============================
-    const int pw = wave - 1;
-    const int f0 = 2 * pw;
-    f2 a_in = vsplat(0.0f, f2()), b_in = a_in, c_in = a_in;       // filter states at the tile's start
-    f2 Xf, Xb, Xs, Xr, Xt, Xa, Yf, Yb, Ys, Yr, Yt, Ya, ffc, ffn, fac, fan;
-    Xf = Xb = Xs = Xr = Xt = Xa = Yf = Yb = Ys = Yr = Yt = Ya = ffc = ffn = fac = fan = a_in;
+    // =============================== the filter wave ===============================
+    // filter states at the super-tile's start, formant f in lane f of three registers
+    float st_a = 0.0f, st_b = 0.0f, st_c = 0.0f;
+    // the parameter block of the epoch, one value per lane: X[lane], Y[lane], the four noise arrays
+    float vX = 0.0f, vY = 0.0f, vN = 0.0f;
     float d_ffreq = 0.0f, amp_scale = 0.0f;
     int have_epoch = -1;
     const f2 one = vsplat(1.0f, f2()), zero = vsplat(0.0f, f2());
-    const f2 five = vsplat(5.0f, f2()), m4 = vsplat(-4.0f, f2());
-    for (int step = 0;; ++step) {
-        if (step >= 1 && step - 1 <= last_tile) {
-            const TileIn &ti = tin[(step - 1) & 1];
-            const int n = ti.n;
-            if (ti.epoch != have_epoch) {
-                have_epoch = ti.epoch;
-                const ParamBlock &pb = par[have_epoch & 1];
-                auto two = [&](const float *p, int off) __attribute__((always_inline)) { f2 r; r.x = p[off + f0]; r.y = p[off + f0 + 1]; return r; };
-                Xf = two(pb.X, F_FREQ); Xb = two(pb.X, F_BW); Xs = two(pb.X, F_SMOOTH);
-                Xr = two(pb.X, F_BREATH); Xt = two(pb.X, F_TURB); Xa = two(pb.X, F_AMP);
-                Yf = two(pb.Y, F_FREQ); Yb = two(pb.Y, F_BW); Ys = two(pb.Y, F_SMOOTH);
-                Yr = two(pb.Y, F_BREATH); Yt = two(pb.Y, F_TURB); Ya = two(pb.Y, F_AMP);
-                ffc = two(pb.ffc, 0); ffn = two(pb.ffn, 0); fac = two(pb.fac, 0); fan = two(pb.fan, 0);
-                d_ffreq = pb.d_ffreq;
-                amp_scale = pb.amp_scale;
+    const f2 five = vsplat(5.0f, f2()), m4 = vsplat(-4.0f, f2()), two_ = vsplat(2.0f, f2());
+    auto at_lane = [](const float v, const int l) __attribute__((always_inline)) {
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+    };
+    auto put_lane = [&](float &v, const int l, const float x) __attribute__((always_inline)) { v = lane == l ? x : v; };
+
+    // one super-tile: FULL = all 512 samples present (no lane needs identity padding)
+    auto super_tile = [&](const TileIn &ti, const TileMeta m, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int S = m.n;
+        const int mine = S - CK * lane;                                    // my samples: k < mine
+        float y[CK];
+#pragma unroll
+        for (int k = 0; k < CK; ++k) y[k] = 0.0f;
+#pragma unroll 1
+        for (int p = 0; p < NP; ++p) {
+            const int f0 = 2 * p;
+            // every pair reads the tile's samples again (eight registers per sample kept across a pair's
+            // whole computation would cost a wave of occupancy): the offset is opaque to the optimiser
+            int off = CK * lane;
+            asm volatile("" : "+v"(off));
+            const float4 *pa = reinterpret_cast<const float4 *>(&ti.alpha[off]);
+            const float4 *pj = reinterpret_cast<const float4 *>(&ti.jp[off]);
+            const float4 *ps = reinterpret_cast<const float4 *>(&ti.saw[off]);
+            const float4 *pn = reinterpret_cast<const float4 *>(&ti.nz[off]);
+            f2 a_in, b_in, c_in;
+            a_in.x = at_lane(st_a, f0); a_in.y = at_lane(st_a, f0 + 1);
+            b_in.x = at_lane(st_b, f0); b_in.y = at_lane(st_b, f0 + 1);
+            c_in.x = at_lane(st_c, f0); c_in.y = at_lane(st_c, f0 + 1);
+            auto two = [&](const float v, const int off) __attribute__((always_inline)) { f2 r; r.x = at_lane(v, off + f0); r.y = at_lane(v, off + f0 + 1); return r; };
+            const f2 Xf = two(vX, F_FREQ), Xb = two(vX, F_BW), Xs = two(vX, F_SMOOTH), Xr = two(vX, F_BREATH), Xt = two(vX, F_TURB), Xa = two(vX, F_AMP);
+            const f2 Yf = two(vY, F_FREQ), Yb = two(vY, F_BW), Ys = two(vY, F_SMOOTH), Yr = two(vY, F_BREATH), Yt = two(vY, F_TURB), Ya = two(vY, F_AMP);
+            const f2 ffc = two(vN, 0), ffn = two(vN, NF), fac = two(vN, 2 * NF), fan = two(vN, 3 * NF);
+            // v0_k = PW_k a_start + QW_k: my low-pass steps up to sample k composed, times w_k (:544-550)
+            f2 PW[CK], QW[CK], A1[CK], TG[CK];
+            // ---- coefficients of my eight samples; the low-pass steps composed into one map
+            LpMap lp;
+            lp.P = one;
+            lp.Q = zero;
+            float4 a4, j4, s4, n4;
+#pragma unroll
+            for (int k = 0; k < CK; ++k) {
+                if (k % 4 == 0) { a4 = pa[k / 4]; j4 = pj[k / 4]; s4 = ps[k / 4]; n4 = pn[k / 4]; }
+                const float alpha = k % 4 == 0 ? a4.x : k % 4 == 1 ? a4.y : k % 4 == 2 ? a4.z : a4.w;
+                const float jpk = k % 4 == 0 ? j4.x : k % 4 == 1 ? j4.y : k % 4 == 2 ? j4.z : j4.w;
+                const float swk = k % 4 == 0 ? s4.x : k % 4 == 1 ? s4.y : k % 4 == 2 ? s4.z : s4.w;
+                const float nzk = k % 4 == 0 ? n4.x : k % 4 == 1 ? n4.y : k % 4 == 2 ? n4.z : n4.w;
+                const float oma = 1.0f - alpha, jomp = 1.0f - jpk;
+                const f2 av = vsplat(alpha, f2()), jpv = vsplat(jpk, f2());
+                // SynthesisElem::blend :404-414 and Jitter::next :763-773 with fused multiply-adds
+                f2 ef = vfma(Yf, av, Xf * oma);
+                const f2 eb = vfma(Yb, av, Xb * oma);
+                const f2 es = vfma(Ys, av, Xs * oma);
+                const f2 er = vfma(Yr, av, Xr * oma);
+                const f2 et = vfma(Yt, av, Xt * oma);
+                const f2 ea = vfma(Ya, av, Xa * oma);
+                const f2 nff = vfma(ffn, jpv, ffc * jomp);
+                const f2 nfa = vfma(fan, jpv, fac * jomp);
+                ef = vfma(nff, vsplat(d_ffreq, f2()), ef);
+                const f2 G = ea * vfma(nfa + 1.0f, vsplat(-amp_scale, f2()), one);
+                const f2 H = et * G;
+                // tan_approx :63-70, k :558, a1 :560 — reciprocals by v_rcp + one Newton step
+                const f2 omx = 1.0f - ef, xph = ef + 0.5f, hmx = 0.5f - ef;
+                const f2 ox = omx * ef, ph_ = xph * hmx;
+                const f2 num = ox * vfma(m4, ph_, five);
+                const f2 den = (xph * vfma(m4, ox, five)) * hmx;
+                f2 rd = vrcp(den), rx = vrcp(ef);
+                rd = vfma(vfma(-den, rd, one), rd, rd);
+                rx = vfma(vfma(-ef, rx, one), rx, rx);
+                f2 tg = num * rd;
+                const f2 kq = eb * rx;
+                const f2 d3 = vfma(tg, tg + kq, one);
+                f2 a1 = vrcp(d3);
+                a1 = vfma(vfma(-d3, a1, one), a1, a1);
+                const f2 oml = 1.0f - exp_approx(es);                          // :535
+                const f2 nw = vfma(er, vsplat(nzk - swk, f2()), vsplat(swk, f2()));   // :531
+                f2 pk = 1.0f - oml, qk = oml * nw;
+                f2 w = vfma(H, vsplat(nzk - 1.0f, f2()), G);                   // v0 = a w :544-550
+                if constexpr (!FULL) {
+                    const bool live = k < mine;                                // identity steps beyond the end
+                    pk = live ? pk : one;
+                    qk = live ? qk : zero;
+                    a1 = live ? a1 : one;
+                    tg = live ? tg : zero;
+                    w = live ? w : zero;
+                }
+                lp.Q = vfma(pk, lp.Q, qk);
+                lp.P = lp.P * pk;
+                PW[k] = lp.P * w; QW[k] = lp.Q * w; A1[k] = a1; TG[k] = tg;
             }
-            const bool live = lane < n;
-            const float alpha = ti.alpha[lane], jp = ti.jp[lane], saw = ti.saw[lane], nz = ti.nz[lane];
-            const float oma = 1.0f - alpha, jomp = 1.0f - jp;
-            const f2 al = vsplat(alpha, f2()), jpv = vsplat(jp, f2());
-            // SynthesisElem::blend :404-414 and Jitter::next :763-773 with fused multiply-adds
-            f2 ef = vfma(Yf, al, Xf * oma);
-            const f2 eb = vfma(Yb, al, Xb * oma);
-            const f2 es = vfma(Ys, al, Xs * oma);
-            const f2 er = vfma(Yr, al, Xr * oma);
-            const f2 et = vfma(Yt, al, Xt * oma);
-            const f2 ea = vfma(Ya, al, Xa * oma);
-            const f2 nff = vfma(ffn, jpv, ffc * jomp);
-            const f2 nfa = vfma(fan, jpv, fac * jomp);
-            ef = vfma(nff, vsplat(d_ffreq, f2()), ef);
-            const f2 G = ea * vfma(nfa + 1.0f, vsplat(-amp_scale, f2()), one);
-            const f2 H = et * G;
-            // tan_approx :63-70, k :558, a1 :560 — reciprocals by v_rcp + one Newton step
-            const f2 omx = 1.0f - ef, xph = ef + 0.5f, hmx = 0.5f - ef;
-            const f2 ox = omx * ef, ph_ = xph * hmx;
-            const f2 num = ox * vfma(m4, ph_, five);
-            const f2 den = (xph * vfma(m4, ox, five)) * hmx;
-            f2 rd = vrcp(den), rx = vrcp(ef);
-            rd = vfma(vfma(-den, rd, one), rd, rd);
-            rx = vfma(vfma(-ef, rx, one), rx, rx);
-            const f2 tg = num * rd;
-            const f2 kq = eb * rx;
-            const f2 d3 = vfma(tg, tg + kq, one);
-            f2 a1 = vrcp(d3);
-            a1 = vfma(vfma(-d3, a1, one), a1, a1);
-            const f2 oml = 1.0f - exp_approx(es);                          // :535
-            const f2 nw = vfma(er, vsplat(nz - saw, f2()), vsplat(saw, f2()));   // :531
-            // ---- the one-pole low-pass :538 as an affine scan
-            ScanElem e;
-            e.P = live ? 1.0f - oml : one;
-            e.Q = live ? oml * nw : zero;
-            // the band-pass needs v0 = a (G + H (noise - 1)) :544-550, i.e. the low-pass result first:
-            // scan the low-pass alone, then build the band-pass elements and scan those
-            {
-                f2 P = e.P, Q = e.Q;
-                auto lvl = [&](auto ctrl, auto rmask) __attribute__((always_inline)) {
-                    constexpr int C = decltype(ctrl)::value, R = decltype(rmask)::value;
-                    const f2 eP = dpp<C, R>(one, P), eQ = dpp<C, R>(zero, Q);
-                    Q = vfma(P, eQ, Q);
-                    P = P * eP;
-                };
-                lvl(std::integral_constant<int, 0x111>(), std::integral_constant<int, 0xF>());
-                lvl(std::integral_constant<int, 0x112>(), std::integral_constant<int, 0xF>());
-                lvl(std::integral_constant<int, 0x114>(), std::integral_constant<int, 0xF>());
-                lvl(std::integral_constant<int, 0x118>(), std::integral_constant<int, 0xF>());
-                lvl(std::integral_constant<int, 0x142>(), std::integral_constant<int, 0xA>());
-                lvl(std::integral_constant<int, 0x143>(), std::integral_constant<int, 0xC>());
-                e.P = P;
-                e.Q = Q;
+            // ---- the low-pass :538: scan the lanes' maps; my samples start from the state of the lane below
+            const f2 myP = lp.P, myQ = lp.Q;
+            scan_lanes(lp);
+            const f2 Pb = dpp<0x138, 0xF>(one, lp.P), Qb = dpp<0x138, 0xF>(zero, lp.Q);   // the lanes before me
+            const f2 a_start = vfma(Pb, a_in, Qb);
+            const f2 a_end = vfma(myP, a_start, myQ);
+            BpMap bp;
+            bp.m11 = one; bp.m12 = zero; bp.m21 = zero; bp.m22 = one; bp.u1 = zero; bp.u2 = zero;
+#pragma unroll
+            for (int k = 0; k < CK; ++k) {
+                const f2 v0 = vfma(PW[k], a_start, QW[k]);
+                PW[k] = v0;
+                // the band-pass step :560-571 as a 2x2 affine map, composed onto my earlier steps
+                const f2 A2 = A1[k] * TG[k];                                   // a2 = g a1
+                const f2 A3 = A2 * TG[k];                                      // a3 = g a2
+                const f2 m11 = vfma(two_, A1[k], -one), m21 = A2 + A2, m22 = vfma(-two_, A3, one);
+                const f2 u1 = m21 * v0, u2 = (A3 + A3) * v0;                   // m12 = -m21
+                const f2 n11 = vfma(-m21, bp.m21, m11 * bp.m11), n12 = vfma(-m21, bp.m22, m11 * bp.m12);
+                const f2 n21 = vfma(m22, bp.m21, m21 * bp.m11), n22 = vfma(m22, bp.m22, m21 * bp.m12);
+                const f2 nu1 = vfma(-m21, bp.u2, vfma(m11, bp.u1, u1));
+                const f2 nu2 = vfma(m22, bp.u2, vfma(m21, bp.u1, u2));
+                bp.m11 = n11; bp.m12 = n12; bp.m21 = n21; bp.m22 = n22; bp.u1 = nu1; bp.u2 = nu2;
             }
-            const f2 a_t = vfma(e.P, a_in, e.Q);                           // low-pass state after this sample
-            const f2 v0 = a_t * vfma(H, vsplat(nz - 1.0f, f2()), G);       // :544-550
-            // ---- the band-pass :560-571 as a 2x2 affine scan
-            const f2 A2 = a1 * tg;                                         // a2 = g a1
-            const f2 A3 = A2 * tg;                                         // a3 = g a2
-            e.m11 = live ? vfma(vsplat(2.0f, f2()), a1, -one) : one;
-            e.m12 = live ? -2.0f * A2 : zero;
-            e.m21 = live ? 2.0f * A2 : zero;
-            e.m22 = live ? vfma(vsplat(-2.0f, f2()), A3, one) : one;
-            e.u1 = live ? (2.0f * A2) * v0 : zero;
-            e.u2 = live ? (2.0f * A3) * v0 : zero;
-            e.P = one;
-            e.Q = zero;
-            scan_level<0x111, 0xF>(e);
-            scan_level<0x112, 0xF>(e);
-            scan_level<0x114, 0xF>(e);
-            scan_level<0x118, 0xF>(e);
-            scan_level<0x142, 0xA>(e);
-            scan_level<0x143, 0xC>(e);
-            const f2 b_t = vfma(e.m12, c_in, vfma(e.m11, b_in, e.u1));    // states after this sample
-            const f2 c_t = vfma(e.m22, c_in, vfma(e.m21, b_in, e.u2));
-            // the output uses the states BEFORE the sample: the lane below, or the tile's start
-            const f2 b_p = dpp<0x138, 0xF>(b_in, b_t), c_p = dpp<0x138, 0xF>(c_in, c_t);
-            const f2 w1 = vfma(A2, v0 - c_p, a1 * b_p);                    // :566
-            float y_lane = live ? w1.x + w1.y : 0.0f;
-            if (A.resume) {   // development aid ("scan_debug" option): a chain quantity instead of the audio
-                const float dv = A.resume == 1 ? alpha : A.resume == 2 ? jp : A.resume == 3 ? saw : A.resume == 4 ? nz :
-                                 A.resume == 5 ? a1.x : A.resume == 6 ? tg.x : A.resume == 7 ? a_t.x :
-                                 A.resume == 8 ? v0.x : A.resume == 9 ? ef.x : A.resume == 10 ? G.x :
-                                 A.resume == 12 ? ef.y : A.resume == 13 ? G.y : A.resume == 14 ? a1.y :
-                                 A.resume == 15 ? tg.y : A.resume == 16 ? a_t.y : A.resume == 17 ? v0.y : w1.x;
-                y_lane = (pw == 0 && live) ? 2.0f * dv : 0.0f;
-                if (A.resume >= 100) {      // 100 + f: the band-pass output of formant f alone
-                    const int f = (int)A.resume - 100;
-                    y_lane = (live && f / 2 == pw) ? 2.0f * (f % 2 ? w1.y : w1.x) : 0.0f;
+            scan_lanes(bp);
+            const f2 e11 = dpp<0x138, 0xF>(one, bp.m11), e12 = dpp<0x138, 0xF>(zero, bp.m12);
+            const f2 e21 = dpp<0x138, 0xF>(zero, bp.m21), e22 = dpp<0x138, 0xF>(one, bp.m22);
+            const f2 eu1 = dpp<0x138, 0xF>(zero, bp.u1), eu2 = dpp<0x138, 0xF>(zero, bp.u2);
+            f2 b = vfma(e12, c_in, vfma(e11, b_in, eu1));
+            f2 c = vfma(e22, c_in, vfma(e21, b_in, eu2));
+#pragma unroll
+            for (int k = 0; k < CK; ++k) {
+                const f2 v3 = PW[k] - c;                                       // :565
+                const f2 v1 = A1[k] * vfma(TG[k], v3, b);                      // :566 with a2 = g a1
+                const f2 v2 = vfma(TG[k], v1, c);                              // :567 with a2 = g a1, a3 = g a2
+                b = vfma(two_, v1, -b);                                        // :570
+                c = vfma(two_, v2, -c);                                        // :571
+                const float yp = v1.x + v1.y;
+                y[k] += yp;                                                    // :574, in formant order
+            }
+            if (A.resume && A.resume < 200 && p == 0) {   // development aid ("scan_debug" option): a chain quantity instead of the audio
+#pragma unroll
+                for (int k = 0; k < CK; ++k) {
+                    const float dv = A.resume == 1 ? ti.alpha[CK * lane + k] : A.resume == 2 ? ti.jp[CK * lane + k] :
+                                     A.resume == 3 ? ti.saw[CK * lane + k] : A.resume == 4 ? ti.nz[CK * lane + k] :
+                                     A.resume == 5 ? A1[k].x : A.resume == 6 ? TG[k].x : PW[k].x;
+                    y[k] = 2.0f * dv;
                 }
             }
-            yout[(step - 1) & 1][pw][lane] = y_lane;
-            // the tile's end (lanes >= n carried identities) is the next tile's start
-            // (components go through named floats: bit-casting `v.y` of a by-value vector argument in place
-            // made hipcc 7.2 read lane 63 of v.x for both halves)
-            auto last_of = [](const float vx, const float vy) __attribute__((always_inline)) {
-                f2 r;
-                r.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vx), 63));
-                r.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vy), 63));
-                return r;
-            };
-            a_in = last_of(a_t.x, a_t.y);
-            b_in = last_of(b_t.x, b_t.y);
-            c_in = last_of(c_t.x, c_t.y);
+            // the super-tile's end (lanes beyond it carried identities) is the next one's start
+            put_lane(st_a, f0, lane63(a_end.x)); put_lane(st_a, f0 + 1, lane63(a_end.y));
+            put_lane(st_b, f0, lane63(b.x)); put_lane(st_b, f0 + 1, lane63(b.y));
+            put_lane(st_c, f0, lane63(c.x)); put_lane(st_c, f0 + 1, lane63(c.y));
+            if (A.resume && A.resume < 200) break;
+        }
+        // ---- my eight samples of the row
+        const uint64_t at = (uint64_t)u * A.out_stride + m.at + (uint32_t)(CK * lane);
+        if constexpr (FULL) {
+            if (A.out_pcm16) {
+                vs8u v;
+#pragma unroll
+                for (int k = 0; k < CK; ++k) v[k] = (short)pcm16_from_f32(y[k] * 0.5f);
+                *reinterpret_cast<vs8u *>(A.out_pcm16 + at) = v;
+            } else {
+#pragma unroll
+                for (int h = 0; h < CK / 4; ++h) {
+                    vf4u v;
+                    v.x = y[4 * h] * 0.5f; v.y = y[4 * h + 1] * 0.5f; v.z = y[4 * h + 2] * 0.5f; v.w = y[4 * h + 3] * 0.5f;
+                    *reinterpret_cast<vf4u *>(A.out + at + 4 * h) = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < CK; ++k) {
+                if (k < mine) {
+                    const float sample = y[k] * 0.5f;                          // :574
+                    if (A.out_pcm16) A.out_pcm16[at + k] = (int16_t)pcm16_from_f32(sample);
+                    else A.out[at + k] = sample;
+                }
+            }
+        }
+    };
+
+    for (int step = 0;; ++step) {
+        if (step >= 1 && step - 1 <= last_tile && !(A.resume >= 200 && (A.resume & 1))) {
+            const TileMeta m = meta[(step - 1) & 3];
+            if (m.epoch != have_epoch) {
+                have_epoch = m.epoch;
+                const ParamBlock &pb = par[have_epoch & 1];
+                vX = pb.X[lane < ELEM_FLOATS ? lane : 0];
+                vY = pb.Y[lane < ELEM_FLOATS ? lane : 0];
+                vN = pb.ffc[lane & 31];                  // ffc, ffn, fac, fan: 4 x NF consecutive floats
+                d_ffreq = uni(pb.d_ffreq);
+                amp_scale = uni(pb.amp_scale);
+            }
+            const TileIn &ti = tin[(step - 1) & 1];
+            if (m.n == ST) super_tile(ti, m, std::true_type());
+            else super_tile(ti, m, std::false_type());
         }
         __syncthreads();
-        if (step >= 1 && step - 1 > last_tile) break;
+        if (step - 1 >= last_tile) break;
     }
 }
 
@@ -477,8 +616,8 @@ __global__ __launch_bounds__(64 * (NP + 1)) void scan_kernel(const SynthArgs A)
 hipError_t launch_scan(const SynthArgs &args, hipStream_t stream)
 {
     if (args.n_utt == 0) return hipSuccess;
-    if (args.live4) hipLaunchKernelGGL((scan_kernel<2>), dim3(args.n_utt), dim3(192), 0, stream, args);
-    else hipLaunchKernelGGL((scan_kernel<4>), dim3(args.n_utt), dim3(320), 0, stream, args);
+    if (args.live4) hipLaunchKernelGGL((scan_kernel<2>), dim3(args.n_utt), dim3(128), 0, stream, args);
+    else hipLaunchKernelGGL((scan_kernel<4>), dim3(args.n_utt), dim3(128), 0, stream, args);
     return hipGetLastError();
 }
 
