@@ -124,7 +124,8 @@ struct grail_ctx {
     int sort_option = 1;              // ragged batches: fill launch slots in order of decreasing length
     int64_t pipe8_max_groups = 512;   // eight-formant pipelined workgroups: up to two per CU
     int scan_option = 1;              // fast arithmetic: small batches go to the time-parallel scan kernel
-    int64_t scan_max_utts = 3072;     // ... up to this many utterances
+    int64_t scan_max_utts = 7680;     // ... up to this many utterances (x 4/7 with eight live formants)
+    int64_t scan_split_max = 1536;    // ... and up to this many with the carrier phase on a wave of its own
     float max_dt = 0.0f;              // largest 1/sample_rate of the table
     float max_pitch_jitter = 0.0f;    // largest |jitter_delta_frequency| of the table
     int last_formants = 8, last_lanes = 0, last_pipe = 0;   // what the last synthesis launch used (statistics)
@@ -511,6 +512,11 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         ctx->scan_debug = (int)value;
         return GRAIL_OK;
     }
+    if (std::strcmp(name, "time_parallel_scan_split_max_utterances") == 0) {
+        if (value < 0) return fail(GRAIL_ERR_INVALID_ARG, "negative limit");
+        ctx->scan_split_max = value;
+        return GRAIL_OK;
+    }
     if (std::strcmp(name, "time_parallel_scan_max_utterances") == 0) {
         if (value < 0) return fail(GRAIL_ERR_INVALID_ARG, "negative limit");
         ctx->scan_max_utts = value;
@@ -549,6 +555,10 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
     }
     if (std::strcmp(name, "time_parallel_scan_max_utterances") == 0) {
         *value = ctx->scan_max_utts;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "time_parallel_scan_split_max_utterances") == 0) {
+        *value = ctx->scan_split_max;
         return GRAIL_OK;
     }
     if (std::strcmp(name, "slow_division_wave_steps") == 0) {  // read-only statistic
@@ -802,10 +812,11 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     // fast arithmetic, few utterances: the machine is mostly idle under the lane-per-utterance mapping;
     // one workgroup per utterance with the time axis across the lanes and the filter recurrences solved by
     // parallel scans (scan_kernels.hip).  Needs every parameter inside the safe window (no IEEE fallback).
-    // (measured crossover against the lane-per-utterance fast kernels: ~3000 utterances with four live
-    // formants — two pair waves each — and half that with eight; profiles/r02_small_batch.txt)
+    // (measured crossover against the lane-per-utterance fast kernels: ~7800 utterances with four live
+    // formants, ~4400 with eight — the filter wave then has four formant pairs to go through;
+    // profiles/r02_small_batch.txt)
     const bool scan = a.fast && ctx->scan_option && !ctx->lanes_option &&
-                      (int64_t)count * (batch_live4(ctx, batch) ? 1 : 2) <= ctx->scan_max_utts &&
+                      (int64_t)count * (batch_live4(ctx, batch) ? 4 : 7) <= 4 * ctx->scan_max_utts &&
                       batch->phoneme_mode && ctx->voices_scan_ok && batch->plain && !batch->any_blend &&
                       batch->min_length >= 2.0f * ctx->max_dt &&
                       batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f;
@@ -818,8 +829,12 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
         a.live4 = batch_live4(ctx, batch) ? 1u : 0u;     // (the L = 8 rule above may have cleared it)
         ctx->last_formants = a.live4 ? 4 : 8;
         a.resume = (uint32_t)ctx->scan_debug;
+        // three-stage workgroups for few utterances (tools/scan_split_crossover.py: up to ~1500 with four
+        // live formants, half that with eight, where the filter wave is the slower stage either way)
+        a.pipe = (int64_t)count * (a.live4 ? 1 : 2) <= ctx->scan_split_max ? 1u : 0u;
         e = launch_scan(a, ctx->stream);
-        ctx->last_kernel = a.live4 ? "scan_kernel<pairs=2,FAST>" : "scan_kernel<pairs=4,FAST>";
+        ctx->last_kernel = a.live4 ? (a.pipe ? "scan_kernel<pairs=2,SPLIT,FAST>" : "scan_kernel<pairs=2,FAST>")
+                                   : (a.pipe ? "scan_kernel<pairs=4,SPLIT,FAST>" : "scan_kernel<pairs=4,FAST>");
     } else {
         e = launch_synth(a, L, ctx->variant_option, ctx->stream);
         ctx->last_kernel = last_kernel_name();

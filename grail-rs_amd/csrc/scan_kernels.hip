@@ -83,7 +83,6 @@ __device__ __forceinline__ f2 dpp(f2 old, f2 x)
 }
 // wave-uniform by construction; says so to the compiler (scalar registers, scalar branches)
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ bool uni(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
 __device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
@@ -133,10 +132,16 @@ __device__ __forceinline__ void scan_lanes(MAP &e)
 typedef float vf4u __attribute__((ext_vector_type(4), aligned(4)));       // 16-byte stores at 4-byte alignment
 typedef short vs8u __attribute__((ext_vector_type(8), aligned(2)));
 
-template <int NP>   // formant pairs: 2 (formants 5-8 proven dead, see live4_ok) or 4
-__global__ __launch_bounds__(128) void scan_kernel(const SynthArgs A)
+// NP: formant pairs, 2 (formants 5-8 proven dead, see live4_ok) or 4.
+// SPLIT: the carrier phase, saw and carrier noise run on a wave of their own, between the chain wave and the
+// filter wave (three pipeline stages): the serial phase loop is a third of the chain wave's time, and with few
+// utterances the time per batch IS the chain wave's time.
+template <int NP, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_eu(4))) void scan_kernel(const SynthArgs A)
 {
-    __shared__ TileIn tin[2];
+    constexpr int NBUF = SPLIT ? 3 : 2;        // super-tiles in flight
+    constexpr int W_FILT = SPLIT ? 2 : 1;      // the filter wave; it works W_FILT super-tiles behind the chain
+    __shared__ TileIn tin[NBUF];
     __shared__ ParamBlock par[2];
     __shared__ TileMeta meta[4];
     __shared__ int last_tile;                 // index of the utterance's last super-tile, known once the chain ends
@@ -151,6 +156,41 @@ __global__ __launch_bounds__(128) void scan_kernel(const SynthArgs A)
     if (vid >= A.n_voices) vid = 0u;
     const DevVoice VO = A.voices[vid];
     const float *__restrict__ elems = A.elems;
+
+    // ---- the carrier: phase, saw, noise of up to 64 consecutive samples (lane = sample), from their pitch.
+    // Runs in the chain wave, or in the phase wave of the SPLIT flavour.
+    float phase = 0.0f;
+    uint32_t noise_seed = 0u;                                       // :594
+    const uint32_t skip_mul = LCG_SKIP.mul[lane + 1], skip_add = LCG_SKIP.add[lane + 1];
+    auto carrier = [&](const float frequency, const int n, float &saw, float &nz) __attribute__((always_inline)) {
+        // the carrier phase: p_j = fract(p_{j-1} + f_{j-1}), exact (:520-525), handed down the lanes: after
+        // k rounds lanes <= k hold their phase.  Lane 0 has no lane below: the shifted-in value is 0 there
+        // (bound_ctrl) and its addend is the phase the tile starts from, fract(0 + phase) = phase.  Rounds
+        // beyond n - 1 only touch lanes >= n, so the trip count is rounded up to whole groups of eight.
+        const float f_below = dpp<0x138, 0xF>(0.0f, frequency);     // wave_shr:1
+        const float addend = lane == 0 ? phase : f_below;
+        float ph = phase;
+        for (int k = 1; k < n; k += 8) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                ph = __builtin_amdgcn_fractf(
+                    __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ph), 0x138, 0xF, 0xF, true)) + addend);
+        }
+        // saw with polyBLEP (:503-517), quotient by v_rcp (tolerance)
+        const bool head = ph < frequency, tail = ph > (1.0f - frequency);
+        const float tt = (head ? ph : ph - 1.0f) * __builtin_amdgcn_rcpf(frequency);
+        const float pb_ = head ? ((2.0f * tt - tt * tt) - 1.0f) : ((tt * tt + 2.0f * tt) + 1.0f);
+        saw = __builtin_fmaf(2.0f, ph, -1.0f) - ((head | tail) ? pb_ : 0.0f);
+        // carrier noise :528: lane j is j + 1 draws after the tile's start state
+        const uint32_t sk = noise_seed * skip_mul + skip_add;
+        nz = (__uint_as_float((sk >> 9) | 0x3F800000u) - 1.5f) * 2.0f;
+        // carry both to the tile's end
+        const int last = n - 1;
+        const float ph_l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ph), last));
+        const float f_l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, frequency), last));
+        phase = __builtin_amdgcn_fractf(ph_l + f_l);
+        noise_seed = (uint32_t)__builtin_amdgcn_readlane((int)sk, last);
+    };
 
     if (wave == 0) {
         // =============================== the chain wave ===============================
@@ -189,9 +229,6 @@ __global__ __launch_bounds__(128) void scan_kernel(const SynthArgs A)
         const float jinc = VO.jitter_frequency;
         const float d_freq = VO.jitter_delta_frequency;
 
-        float phase = 0.0f;
-        uint32_t noise_seed = 0u;                                   // :594
-        const uint32_t skip_mul = LCG_SKIP.mul[lane + 1], skip_add = LCG_SKIP.add[lane + 1];
         const float lane_p1 = (float)(lane + 1);
 
         // closed forms kept from tile to tile: signed quantum, binade (biased exponent), still valid?
@@ -209,7 +246,7 @@ __global__ __launch_bounds__(128) void scan_kernel(const SynthArgs A)
 
         for (int step = 0;; ++step) {
             if (!finished) {
-                TileIn &ti = tin[step & 1];
+                TileIn &ti = tin[step % NBUF];
                 const uint32_t at0 = n_out;
                 int S = 0;                                                      // samples of this super-tile so far
                 while (S <= ST - TL) {
@@ -353,41 +390,21 @@ __global__ __launch_bounds__(128) void scan_kernel(const SynthArgs A)
                     float frequency = xf * oma + yf * alpha;
                     const float n_freq = fn_cur * jomp + fn_next * pj;
                     frequency = frequency + n_freq * d_freq;
-                    // ---- the carrier phase: p_j = fract(p_{j-1} + f_{j-1}), exact (:520-525), handed down
-                    // the lanes: after k rounds lanes <= k hold their phase
-                    // lane 0 has no lane below: the shifted-in value is 0 there (bound_ctrl) and its addend is
-                    // the phase the tile starts from, fract(0 + phase) = phase.  Rounds beyond n - 1 only touch
-                    // lanes >= n, so the trip count is rounded up to whole groups of eight.
-                    const float f_below = dpp<0x138, 0xF>(0.0f, frequency);     // wave_shr:1
-                    const float addend = lane == 0 ? phase : f_below;
-                    float ph = phase;
-                    for (int k = 1; k < n; k += 8) {
-#pragma unroll
-                        for (int r = 0; r < 8; ++r)
-                            ph = __builtin_amdgcn_fractf(
-                                __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ph), 0x138, 0xF, 0xF, true)) + addend);
-                    }
-                    // ---- saw with polyBLEP (:503-517), quotient by v_rcp (tolerance)
-                    const bool head = ph < frequency, tail = ph > (1.0f - frequency);
-                    const float tt = (head ? ph : ph - 1.0f) * __builtin_amdgcn_rcpf(frequency);
-                    const float pb_ = head ? ((2.0f * tt - tt * tt) - 1.0f) : ((tt * tt + 2.0f * tt) + 1.0f);
-                    const float saw = __builtin_fmaf(2.0f, ph, -1.0f) - ((head | tail) ? pb_ : 0.0f);
-                    // ---- carrier noise :528: lane j is j + 1 draws after the tile's start state
-                    const uint32_t sk = noise_seed * skip_mul + skip_add;
-                    const float nz = (__uint_as_float((sk >> 9) | 0x3F800000u) - 1.5f) * 2.0f;
                     // lanes >= n write beyond the tile: the next tile overwrites them, or nobody reads them
                     ti.alpha[S + lane] = alpha;
                     ti.jp[S + lane] = pj;
-                    ti.saw[S + lane] = saw;
-                    ti.nz[S + lane] = nz;
+                    if constexpr (SPLIT) {
+                        ti.saw[S + lane] = frequency;                           // the phase wave turns it into the saw
+                    } else {
+                        float saw, nz;
+                        carrier(frequency, n, saw, nz);
+                        ti.saw[S + lane] = saw;
+                        ti.nz[S + lane] = nz;
+                    }
                     // ---- carry the chain to the tile's end
                     const int last = n - 1;
                     clk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cj), last));
                     jphase = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pj), last));
-                    const float ph_l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ph), last));
-                    const float f_l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, frequency), last));
-                    phase = __builtin_amdgcn_fractf(ph_l + f_l);
-                    noise_seed = (uint32_t)__builtin_amdgcn_readlane((int)sk, last);
                     n_out += (uint32_t)n;
                     S += n;
                 }
@@ -399,7 +416,7 @@ __global__ __launch_bounds__(128) void scan_kernel(const SynthArgs A)
                 }
             }
             __syncthreads();
-            if (step - 1 >= last_tile) break;           // the filter wave stored the last super-tile in this step
+            if (step - W_FILT >= last_tile) break;      // the filter wave stored the last super-tile in this step
         }
         if (lane == 0) {
             if (A.out_len) A.out_len[u] = n_out;
@@ -408,6 +425,30 @@ __global__ __launch_bounds__(128) void scan_kernel(const SynthArgs A)
             atomicAdd(A.truncated + 3, derived_tiles);
         }
         return;
+    }
+
+    if constexpr (SPLIT) {
+        if (wave == 1) {
+            // =============================== the phase wave ===============================
+            // one super-tile behind the chain wave: 64 samples at a time, whatever tiles the chain cut
+            for (int step = 0;; ++step) {
+                if (step >= 1 && step - 1 <= last_tile) {
+                    const int S = uni(meta[(step - 1) & 3].n);
+                    TileIn &ti = tin[(step - 1) % NBUF];
+                    for (int r = 0; r < S; r += TL) {
+                        const int n = S - r < TL ? S - r : TL;
+                        const float frequency = ti.saw[r + lane];              // lanes >= n: stale values, unused
+                        float saw = 0.0f, nz = 0.0f;
+                        if (A.resume != 205) carrier(frequency, n, saw, nz);   // 205: development probe, the chain wave alone
+                        ti.saw[r + lane] = saw;
+                        ti.nz[r + lane] = nz;
+                    }
+                }
+                __syncthreads();
+                if (step - W_FILT >= last_tile) break;
+            }
+            return;
+        }
     }
 
     // =============================== the filter wave ===============================
@@ -457,28 +498,24 @@ __global__ __launch_bounds__(128) void scan_kernel(const SynthArgs A)
             LpMap lp;
             lp.P = one;
             lp.Q = zero;
-            float4 a4, j4, s4, n4;
-#pragma unroll
-            for (int k = 0; k < CK; ++k) {
-                if (k % 4 == 0) { a4 = pa[k / 4]; j4 = pj[k / 4]; s4 = ps[k / 4]; n4 = pn[k / 4]; }
-                const float alpha = k % 4 == 0 ? a4.x : k % 4 == 1 ? a4.y : k % 4 == 2 ? a4.z : a4.w;
-                const float jpk = k % 4 == 0 ? j4.x : k % 4 == 1 ? j4.y : k % 4 == 2 ? j4.z : j4.w;
-                const float swk = k % 4 == 0 ? s4.x : k % 4 == 1 ? s4.y : k % 4 == 2 ? s4.z : s4.w;
-                const float nzk = k % 4 == 0 ? n4.x : k % 4 == 1 ? n4.y : k % 4 == 2 ? n4.z : n4.w;
+            struct Coef { f2 keep, breath, a1, tg, G, H; };               // keep = exp_approx(smooth) = 1 - k of :535-538
+            // everything that is a smooth function of (alpha, jitter phase), evaluated directly
+            auto eval = [&](const float alpha, const float jpk, Coef &c, f2 &ea, f2 &mu, f2 &et) __attribute__((always_inline)) {
                 const float oma = 1.0f - alpha, jomp = 1.0f - jpk;
                 const f2 av = vsplat(alpha, f2()), jpv = vsplat(jpk, f2());
                 // SynthesisElem::blend :404-414 and Jitter::next :763-773 with fused multiply-adds
                 f2 ef = vfma(Yf, av, Xf * oma);
                 const f2 eb = vfma(Yb, av, Xb * oma);
                 const f2 es = vfma(Ys, av, Xs * oma);
-                const f2 er = vfma(Yr, av, Xr * oma);
-                const f2 et = vfma(Yt, av, Xt * oma);
-                const f2 ea = vfma(Ya, av, Xa * oma);
+                c.breath = vfma(Yr, av, Xr * oma);
+                et = vfma(Yt, av, Xt * oma);
+                ea = vfma(Ya, av, Xa * oma);
                 const f2 nff = vfma(ffn, jpv, ffc * jomp);
                 const f2 nfa = vfma(fan, jpv, fac * jomp);
                 ef = vfma(nff, vsplat(d_ffreq, f2()), ef);
-                const f2 G = ea * vfma(nfa + 1.0f, vsplat(-amp_scale, f2()), one);
-                const f2 H = et * G;
+                mu = vfma(nfa + 1.0f, vsplat(-amp_scale, f2()), one);
+                c.G = ea * mu;
+                c.H = et * c.G;
                 // tan_approx :63-70, k :558, a1 :560 — reciprocals by v_rcp + one Newton step
                 const f2 omx = 1.0f - ef, xph = ef + 0.5f, hmx = 0.5f - ef;
                 const f2 ox = omx * ef, ph_ = xph * hmx;
@@ -487,26 +524,87 @@ __global__ __launch_bounds__(128) void scan_kernel(const SynthArgs A)
                 f2 rd = vrcp(den), rx = vrcp(ef);
                 rd = vfma(vfma(-den, rd, one), rd, rd);
                 rx = vfma(vfma(-ef, rx, one), rx, rx);
-                f2 tg = num * rd;
+                c.tg = num * rd;
                 const f2 kq = eb * rx;
-                const f2 d3 = vfma(tg, tg + kq, one);
+                const f2 d3 = vfma(c.tg, c.tg + kq, one);
                 f2 a1 = vrcp(d3);
-                a1 = vfma(vfma(-d3, a1, one), a1, a1);
-                const f2 oml = 1.0f - exp_approx(es);                          // :535
-                const f2 nw = vfma(er, vsplat(nzk - swk, f2()), vsplat(swk, f2()));   // :531
-                f2 pk = 1.0f - oml, qk = oml * nw;
-                f2 w = vfma(H, vsplat(nzk - 1.0f, f2()), G);                   // v0 = a w :544-550
+                c.a1 = vfma(vfma(-d3, a1, one), a1, a1);
+                c.keep = exp_approx(es);                                       // :535
+            };
+            // one sample: the low-pass step composed onto my earlier ones, the band-pass coefficients kept
+            auto sample = [&](const int k, Coef c, const float swk, const float nzk) __attribute__((always_inline)) {
+                const f2 nw = vfma(c.breath, vsplat(nzk - swk, f2()), vsplat(swk, f2()));   // :531
+                f2 pk = c.keep, qk = vfma(-c.keep, nw, nw);                    // a -> keep a + (1 - keep) nw :538
+                f2 w = vfma(c.H, vsplat(nzk - 1.0f, f2()), c.G);               // v0 = a w :544-550
                 if constexpr (!FULL) {
                     const bool live = k < mine;                                // identity steps beyond the end
                     pk = live ? pk : one;
                     qk = live ? qk : zero;
-                    a1 = live ? a1 : one;
-                    tg = live ? tg : zero;
+                    c.a1 = live ? c.a1 : one;
+                    c.tg = live ? c.tg : zero;
                     w = live ? w : zero;
                 }
                 lp.Q = vfma(pk, lp.Q, qk);
                 lp.P = lp.P * pk;
-                PW[k] = lp.P * w; QW[k] = lp.Q * w; A1[k] = a1; TG[k] = tg;
+                PW[k] = lp.P * w; QW[k] = lp.Q * w; A1[k] = c.a1; TG[k] = c.tg;
+            };
+            auto part = [](const float4 v, const int i) __attribute__((always_inline)) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; };
+            float4 a4, j4, s4, n4;
+            // In a full super-tile alpha and the jitter phase are linear in time, so the coefficients are
+            // evaluated at my first and last sample and interpolated in between — under fast_tile's error
+            // guard (synth_kernels.hip): no kink of alpha = min(clk / blend, 1) among my samples, relative
+            // change of a1, g and the low-pass factor r <= 2^-9.5 (error r^2 / 16 <= 2^-23), the products of
+            // linear functions G and H within 2^-22.  Seven samples apart instead of 32: the guard only
+            // fails for parameters moving ~20x faster than the reference's front end makes them, and then
+            // (any lane of the wave) every sample is evaluated directly.
+            bool interpolate = false;
+            Coef C0, D;
+            if constexpr (FULL) {
+                Coef C7;
+                f2 ea0, mu0, et0, ea7, mu7, et7;
+                const float al0 = ti.alpha[off], al7 = ti.alpha[off + CK - 1];
+                eval(al0, ti.jp[off], C0, ea0, mu0, et0);
+                eval(al7, ti.jp[off + CK - 1], C7, ea7, mu7, et7);
+                D.keep = C7.keep - C0.keep; D.breath = C7.breath - C0.breath; D.a1 = C7.a1 - C0.a1;
+                D.tg = C7.tg - C0.tg; D.G = C7.G - C0.G; D.H = C7.H - C0.H;
+                float ra = 0.0f, rg = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(D.a1, c)) * __builtin_amdgcn_rcpf(vget(C0.a1, c)));
+                    ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(D.tg, c)) * __builtin_amdgcn_rcpf(vget(C0.tg, c)));
+                    ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(D.keep, c)) * __builtin_amdgcn_rcpf(1.0f - vget(C0.keep, c)));
+                    rg = __builtin_fmaxf(rg, __builtin_fabsf((vget(ea7, c) - vget(ea0, c)) * (vget(mu7, c) - vget(mu0, c))));
+                    rg = __builtin_fmaxf(rg, __builtin_fabsf((vget(et7, c) - vget(et0, c)) * vget(D.G, c)));
+                }
+                const bool kink = (al0 == 1.0f) != (al7 == 1.0f);
+                const bool good = !kink && ra <= 0.0013810679f && rg <= 9.5367431640625e-07f;   // 2^-9.5, 2^-20
+                interpolate = __builtin_amdgcn_ballot_w64(good) == ~0ull;
+            }
+            if (interpolate) {
+                const f2 seventh = vsplat(1.0f / 7.0f, f2());
+                D.keep = D.keep * seventh; D.breath = D.breath * seventh; D.a1 = D.a1 * seventh;
+                D.tg = D.tg * seventh; D.G = D.G * seventh; D.H = D.H * seventh;
+#pragma unroll
+                for (int k = 0; k < CK; ++k) {
+                    if (k % 4 == 0) { s4 = ps[k / 4]; n4 = pn[k / 4]; }
+                    Coef c = C0;
+                    if (k > 0) {
+                        const f2 kf = vsplat((float)k, f2());
+                        c.keep = vfma(kf, D.keep, C0.keep); c.breath = vfma(kf, D.breath, C0.breath);
+                        c.a1 = vfma(kf, D.a1, C0.a1); c.tg = vfma(kf, D.tg, C0.tg);
+                        c.G = vfma(kf, D.G, C0.G); c.H = vfma(kf, D.H, C0.H);
+                    }
+                    sample(k, c, part(s4, k % 4), part(n4, k % 4));
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < CK; ++k) {
+                    if (k % 4 == 0) { a4 = pa[k / 4]; j4 = pj[k / 4]; s4 = ps[k / 4]; n4 = pn[k / 4]; }
+                    Coef c;
+                    f2 ea, mu, et;
+                    eval(part(a4, k % 4), part(j4, k % 4), c, ea, mu, et);
+                    sample(k, c, part(s4, k % 4), part(n4, k % 4));
+                }
             }
             // ---- the low-pass :538: scan the lanes' maps; my samples start from the state of the lane below
             const f2 myP = lp.P, myQ = lp.Q;
@@ -591,8 +689,8 @@ __global__ __launch_bounds__(128) void scan_kernel(const SynthArgs A)
     };
 
     for (int step = 0;; ++step) {
-        if (step >= 1 && step - 1 <= last_tile && !(A.resume >= 200 && (A.resume & 1))) {
-            const TileMeta m = meta[(step - 1) & 3];
+        if (step >= W_FILT && step - W_FILT <= last_tile && !(A.resume >= 200 && (A.resume & 1))) {
+            const TileMeta m = meta[(step - W_FILT) & 3];
             if (m.epoch != have_epoch) {
                 have_epoch = m.epoch;
                 const ParamBlock &pb = par[have_epoch & 1];
@@ -602,12 +700,12 @@ __global__ __launch_bounds__(128) void scan_kernel(const SynthArgs A)
                 d_ffreq = uni(pb.d_ffreq);
                 amp_scale = uni(pb.amp_scale);
             }
-            const TileIn &ti = tin[(step - 1) & 1];
+            const TileIn &ti = tin[(step - W_FILT) % NBUF];
             if (m.n == ST) super_tile(ti, m, std::true_type());
             else super_tile(ti, m, std::false_type());
         }
         __syncthreads();
-        if (step - 1 >= last_tile) break;
+        if (step - W_FILT >= last_tile) break;
     }
 }
 
@@ -616,8 +714,15 @@ __global__ __launch_bounds__(128) void scan_kernel(const SynthArgs A)
 hipError_t launch_scan(const SynthArgs &args, hipStream_t stream)
 {
     if (args.n_utt == 0) return hipSuccess;
-    if (args.live4) hipLaunchKernelGGL((scan_kernel<2>), dim3(args.n_utt), dim3(128), 0, stream, args);
-    else hipLaunchKernelGGL((scan_kernel<4>), dim3(args.n_utt), dim3(128), 0, stream, args);
+    // few utterances: the time per batch is the chain's; three-stage workgroups halve it.  Many: two waves
+    // per utterance keep more utterances resident per CU (args.pipe: the host's choice, grail_api.cpp)
+    if (args.pipe) {
+        if (args.live4) hipLaunchKernelGGL((scan_kernel<2, true>), dim3(args.n_utt), dim3(192), 0, stream, args);
+        else hipLaunchKernelGGL((scan_kernel<4, true>), dim3(args.n_utt), dim3(192), 0, stream, args);
+    } else {
+        if (args.live4) hipLaunchKernelGGL((scan_kernel<2, false>), dim3(args.n_utt), dim3(128), 0, stream, args);
+        else hipLaunchKernelGGL((scan_kernel<4, false>), dim3(args.n_utt), dim3(128), 0, stream, args);
+    }
     return hipGetLastError();
 }
 

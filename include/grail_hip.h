@@ -195,17 +195,22 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       for parameters like voices::generic()'s (DESIGN.md "Fast mode"; tests/test_fast_gpu.py).
  *       This is the ONE knob that changes result bits.
  *   "time_parallel_scan": 1 (default) / 0 — fast arithmetic only: batches of up to
- *       "time_parallel_scan_max_utterances" (default 3072; half that when all eight formants are
+ *       "time_parallel_scan_max_utterances" (default 7680; 4/7 of that when all eight formants are
  *       live) whose every parameter is inside the safe window run one workgroup per utterance with
  *       the time axis across the lanes and the filter recurrences solved by parallel scans
- *       (csrc/scan_kernels.hip): 256 utterances x 2 s in 2.3 ms instead of 11.8 ms.
+ *       (csrc/scan_kernels.hip): 256 utterances x 2 s in 1.2 ms instead of 11.5 ms, 4096 in 6.7 ms.
+ *       Up to "time_parallel_scan_split_max_utterances" (default 1536; half with eight live
+ *       formants) the workgroups have three pipeline stages (the serial carrier phase on a wave of
+ *       its own: lowest time per batch), above it two (more utterances resident per CU: highest
+ *       throughput).  Same results either way.
  *   "sort_by_length": 1 (default) / 0 — batches uploaded afterwards whose utterances differ in
  *       length fill the launch slots in order of decreasing length (lanes of a wave run in lockstep:
  *       a wave lasts as long as its longest utterance).  Rows stay where the caller put them.
  *   "kernel_variant": experiments only.
  * Read-only statistics: "slow_division_wave_steps", "fast_wave_tiles" (wave-tiles rendered in fast
- * arithmetic), "general_wave_steps", "last_launch_formants" (4 or 8), "last_launch_lanes",
- * "last_launch_pipelined". */
+ * arithmetic; scan kernel: 64-sample chain tiles on the closed forms kept from the tile before),
+ * "general_wave_steps" (scan kernel: chain tiles whose closed forms were derived afresh),
+ * "last_launch_formants" (4 or 8), "last_launch_lanes", "last_launch_pipelined". */
 int grail_set_option(grail_ctx *ctx, const char *name, int64_t value);
 int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value);
 

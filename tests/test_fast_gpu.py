@@ -220,17 +220,25 @@ def test_fast_mode_full_size_against_exact_mode_on_the_device(gpu_ctx, config):
 
 
 # ---- the time-parallel scan kernel (small batches, fast arithmetic) ------------------------------
+@pytest.mark.parametrize("split", [1, 0])
 @pytest.mark.parametrize("n_voices", [1, 8])
-def test_scan_kernel_small_batch_within_tolerance(gpu_ctx, n_voices):
+def test_scan_kernel_small_batch_within_tolerance(gpu_ctx, n_voices, split):
     """Few utterances in fast mode go to scan_kernels.hip: lanes = time, recurrences by parallel scan.
-    Lengths equal the oracle's (the chain is exact), samples within the fast-mode tolerance."""
+    Lengths equal the oracle's (the chain is exact), samples within the fast-mode tolerance.  Both
+    flavours: three-stage workgroups (the carrier phase on a wave of its own, few utterances) and
+    two-stage ones (many utterances)."""
     voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
     gpu_ctx.set_voices(voices)
     n_utt = 48
     segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=n_voices)          # full 2 s utterances
     stride = W.max_samples()
-    out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
-    assert gpu_ctx.last_kernel_name().startswith("scan_kernel<pairs=%d" % (2 if n_voices == 1 else 4))
+    split_default = gpu_ctx.get_option("time_parallel_scan_split_max_utterances")
+    gpu_ctx.set_option("time_parallel_scan_split_max_utterances", split_default if split else 0)
+    try:
+        out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
+    finally:
+        gpu_ctx.set_option("time_parallel_scan_split_max_utterances", split_default)
+    assert gpu_ctx.last_kernel_name() == "scan_kernel<pairs=%d,%sFAST>" % (2 if n_voices == 1 else 4, "SPLIT," if split else "")
     ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, stride)
     assert np.array_equal(out_len, ref_len)
     k = _worst(out, ref, ref_len)
@@ -265,18 +273,21 @@ def test_scan_kernel_edge_cases(gpu_ctx):
     segs = G.segments([s for u in utts for s in u])
     offs = np.cumsum([0] + [len(u) for u in utts]).astype(np.uint32)
     seeds = np.arange(len(utts), dtype=np.uint32) * 1234567
-    for stride in (40000, 2048):                      # the second cuts the long rows
+    split_default = gpu_ctx.get_option("time_parallel_scan_split_max_utterances")
+    for stride, split in ((40000, 1), (2048, 1), (40000, 0), (2048, 0)):    # 2048 cuts the long rows
         ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, None, seeds, stride)
         ref_len = np.minimum(ref_len, stride)
         gpu_ctx.set_option("arithmetic", 1)
+        gpu_ctx.set_option("time_parallel_scan_split_max_utterances", split_default if split else 0)
         try:
             out, out_len = gpu_ctx.synthesize(segs, offs, None, seeds, out_stride=stride, allow_truncation=True)
         finally:
             gpu_ctx.set_option("arithmetic", 0)
-        assert gpu_ctx.last_kernel_name().startswith("scan_kernel")
+            gpu_ctx.set_option("time_parallel_scan_split_max_utterances", split_default)
+        assert gpu_ctx.last_kernel_name().startswith("scan_kernel") and ("SPLIT" in gpu_ctx.last_kernel_name()) == bool(split)
         assert np.array_equal(out_len, ref_len), stride
         k = _worst(out, ref, ref_len)
-        print(f"scan kernel edge cases, stride {stride}: {k:.1f} * 2^-23")
+        print(f"scan kernel edge cases, stride {stride}, split {split}: {k:.1f} * 2^-23")
         assert k * ULP <= TOL
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Development probe: scan kernel time with stages switched off (scan_debug 200 + bits: 1 = pair waves idle,
-2 = no carrier-phase loop)."""
+"""Development probe: scan kernel time, two-stage and three-stage (SPLIT) workgroups, with the filter wave
+switched off (scan_debug 201)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "grail-rs_amd"))
@@ -18,12 +18,14 @@ for n_voices in (1, 8):
         ctx.set_option("arithmetic", 1); ctx.set_option("time_parallel_scan", 1)
         ctx.set_option("time_parallel_scan_max_utterances", 1 << 20)
         row = [f"voices={n_voices} n={n:5d}:"]
-        for mode in (0, 201, 202, 203):
-            ctx.set_option("scan_debug", mode)
-            ms = []
-            for _ in range(3):
-                batch.synthesize_async(d_out, stride, d_len); ctx.sync(); ms.append(ctx.last_kernel_ms())
-            row.append(f"mode {mode}: {min(ms):6.2f} ms")
+        for split in (0, 1):
+            ctx.set_option("time_parallel_scan_split_max_utterances", (1 << 20) if split else 0)
+            for mode in ((0, 201, 205) if split else (0, 201)):
+                ctx.set_option("scan_debug", mode)
+                ms = []
+                for _ in range(3):
+                    batch.synthesize_async(d_out, stride, d_len); ctx.sync(); ms.append(ctx.last_kernel_ms())
+                row.append(f"split {split} mode {mode}: {min(ms):6.2f} ms")
         print("  ".join(row), flush=True)
         ctx.set_option("scan_debug", 0)
         ctx.device_free(d_out); ctx.device_free(d_len); batch.free()
