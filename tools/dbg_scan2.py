@@ -36,7 +36,7 @@ with np.errstate(over="ignore"):
         if phase >= 1: phase = f32(phase - f32(1))
         s = np.uint32(s * np.uint32(16807) + np.uint32(1))
         nz[i] = f32(f32((np.uint32((s >> np.uint32(9)) | np.uint32(0x3F800000))).view(np.float32) - f32(1.5)) * f32(2))
-fi = 1
+fi = 0      # scan_debug modes 5 - 7 show formant 0: a1, g, v0 (1 - 4: alpha, jitter phase, saw, carrier noise)
 x = tr[:, 1 + fi].astype(np.float64); bw = tr[:, 9 + fi].astype(np.float64); sm = tr[:, 17 + fi].astype(np.float64)
 br = tr[:, 25 + fi].astype(np.float64); tb = tr[:, 33 + fi].astype(np.float64); am = tr[:, 41 + fi].astype(np.float64)
 g = ((1 - x) * x * (5 - 4 * (x + .5) * (.5 - x))) / ((x + .5) * (5 - 4 * (1 - x) * x) * (.5 - x))
@@ -51,7 +51,7 @@ for i in range(n):
     a_t[i] = a
     v0[i] = a * ((1 - tb[i]) + nz[i] * tb[i]) * am[i]
 ctx.set_option("arithmetic", 1)
-for mode, name, ref in ((12, "ef.y", x), (13, "G.y", am), (14, "a1.y", a1), (15, "tg.y", g), (16, "a_t.y", a_t), (17, "v0.y", v0)):
+for mode, name, ref in ((3, "saw", saw.astype(np.float64)), (4, "noise", nz.astype(np.float64)), (5, "a1.x", a1), (6, "tg.x", g), (7, "v0.x", v0)):
     ctx.set_option("scan_debug", mode)
     out, ol = ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
     d = np.abs(out[u, :n].astype(np.float64) - ref)

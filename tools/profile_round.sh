@@ -21,4 +21,6 @@ python3 tools/stream_latency.py 2>/dev/null | grep -v "^RCCL\|^HIP\|^ROCm\|^Host
 python3 tools/host_output_bench.py > $out/host_output.txt 2>&1
 python3 tools/ragged_bench.py > $out/ragged.txt 2>&1
 ./tools/dpp_check.bin > $out/dpp_check.txt 2>&1
+python3 tools/scan_split_crossover.py > $out/scan_split.txt 2>&1
+./tools/phase_chain_mb.bin > $out/phase_chain.txt 2>&1
 ls -la $out

@@ -14,7 +14,7 @@ ctx = G.Context(0)
 stride = W.max_samples()
 for n_voices in (1, 8):
     ctx.set_voices(W.single_voice() if n_voices == 1 else W.preset_voices(8))
-    for n in (1, 64, 256, 1024, 2048, 4096, 8192, 16384, 32768):
+    for n in (1, 64, 256, 1024, 1536, 2048, 4096, 6144, 8192, 16384, 32768):
         segs, offs, vids, seeds = W.make_batch(n, n_voices=n_voices)
         batch = ctx.upload(segs, offs, vids, seeds)
         d_out = ctx.device_alloc(n * stride * 4)
