@@ -124,7 +124,7 @@ struct grail_ctx {
     int sort_option = 1;              // ragged batches: fill launch slots in order of decreasing length
     int64_t pipe8_max_groups = 512;   // eight-formant pipelined workgroups: up to two per CU
     int scan_option = 1;              // fast arithmetic: small batches go to the time-parallel scan kernel
-    int64_t scan_max_utts = 7680;     // ... up to this many utterances (x 4/7 with eight live formants)
+    int64_t scan_max_utts = 8704;     // ... up to this many utterances (x 4/7 with eight live formants)
     int64_t scan_split_max = 1536;    // ... and up to this many with the carrier phase on a wave of its own
     float max_dt = 0.0f;              // largest 1/sample_rate of the table
     float max_pitch_jitter = 0.0f;    // largest |jitter_delta_frequency| of the table
@@ -812,8 +812,8 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     // fast arithmetic, few utterances: the machine is mostly idle under the lane-per-utterance mapping;
     // one workgroup per utterance with the time axis across the lanes and the filter recurrences solved by
     // parallel scans (scan_kernels.hip).  Needs every parameter inside the safe window (no IEEE fallback).
-    // (measured crossover against the lane-per-utterance fast kernels: ~7800 utterances with four live
-    // formants, ~4400 with eight — the filter wave then has four formant pairs to go through;
+    // (measured crossover against the lane-per-utterance fast kernels: ~9000 utterances with four live
+    // formants, ~5000 with eight — the filter wave then has four formant pairs to go through;
     // profiles/r02_small_batch.txt)
     const bool scan = a.fast && ctx->scan_option && !ctx->lanes_option &&
                       (int64_t)count * (batch_live4(ctx, batch) ? 4 : 7) <= 4 * ctx->scan_max_utts &&

@@ -259,13 +259,18 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
                     // that no clock went below zero (:864) and no phase above one (:245): no event in the tile.
                     float cj = 0.0f, pj = 0.0f;
                     int n = TL;
-                    bool quick = false;
-                    if (uni(c_reg && j_reg && cap32 - n_out >= (uint32_t)TL)) {
-                        cj = __builtin_fmaf(lane_p1, c_q, clk);
-                        pj = __builtin_fmaf(lane_p1, j_q, jphase);
-                        const bool in = (__float_as_uint(cj) >> 23) == c_e2 && (__float_as_uint(pj) >> 23) == j_e2;
-                        quick = __builtin_amdgcn_ballot_w64(in) == ~0ull;
+                    bool c_ok = false, j_ok = false;                            // this tile's 64 values by the kept form?
+                    if (uni(cap32 - n_out >= (uint32_t)TL)) {
+                        if (uni(c_reg)) {
+                            cj = __builtin_fmaf(lane_p1, c_q, clk);
+                            c_ok = __builtin_amdgcn_ballot_w64((__float_as_uint(cj) >> 23) == c_e2) == ~0ull;
+                        }
+                        if (uni(j_reg)) {
+                            pj = __builtin_fmaf(lane_p1, j_q, jphase);
+                            j_ok = __builtin_amdgcn_ballot_w64((__float_as_uint(pj) >> 23) == j_e2) == ~0ull;
+                        }
                     }
+                    const bool quick = c_ok && j_ok;
                     if (quick) {
                         ++quick_tiles;
                     } else {
@@ -335,7 +340,8 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
                             params_dirty = false;
                         }
                         // Where the binade ends, or after an event, the closed form is derived afresh from the last
-                        // exact lane (up to three times per tile).  `step` = -dt for the clock, +jinc for the jitter
+                        // exact lane (up to six times per tile: the first tile after a jitter wrap crosses six
+                        // binades).  `step` = -dt for the clock, +jinc for the jitter
                         // phase; `need_same_start`: an increasing sequence is regular only if v1 already lies in
                         // v2's binade (else v1 is off v2's grid).
                         auto extend = [&](float &v, int &nv, const float step_, const bool need_same_start,
@@ -359,13 +365,14 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
                             e2_out = e2;
                             reg_out = regular && nv == TL && nv_before <= TL - 2;
                         };
+                        // (a sequence whose kept form held for all 64 lanes — it then had no event either — stays as
+                        // it is: usually only one of the two leaves its binade)
                         ++derived_tiles;
-                        cj = clk_first;
-                        pj = jp_first;
-                        int nc = 1, np_ = 1;
-                        c_reg = j_reg = false;
+                        int nc = TL, np_ = TL;
+                        if (!c_ok) { cj = clk_first; nc = 1; c_reg = false; }
+                        if (!j_ok) { pj = jp_first; np_ = 1; j_reg = false; }
 #pragma unroll 1
-                        for (int pass = 0; pass < 3 && (nc < TL || np_ < TL); ++pass) {
+                        for (int pass = 0; pass < 6 && (nc < TL || np_ < TL); ++pass) {
                             if (nc < TL) extend(cj, nc, -dt, false, c_q, c_e2, c_reg);
                             if (np_ < TL) extend(pj, np_, jinc, true, j_q, j_e2, j_reg);
                         }
@@ -435,9 +442,11 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
                 if (step >= 1 && step - 1 <= last_tile) {
                     const int S = uni(meta[(step - 1) & 3].n);
                     TileIn &ti = tin[(step - 1) % NBUF];
+                    float f_next = ti.saw[lane];                               // the pitch, one tile ahead of its use
                     for (int r = 0; r < S; r += TL) {
                         const int n = S - r < TL ? S - r : TL;
-                        const float frequency = ti.saw[r + lane];              // lanes >= n: stale values, unused
+                        const float frequency = f_next;                        // lanes >= n: stale values, unused
+                        if (r + TL < S) f_next = ti.saw[r + TL + lane];
                         float saw = 0.0f, nz = 0.0f;
                         if (A.resume != 205) carrier(frequency, n, saw, nz);   // 205: development probe, the chain wave alone
                         ti.saw[r + lane] = saw;

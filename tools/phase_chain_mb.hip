@@ -19,6 +19,24 @@ __device__ __forceinline__ float chain_dpp(float phase, float f, int lane)
         ph = __builtin_amdgcn_fractf(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ph), 0x138, 0xF, 0xF, true)) + addend);
     return ph;
 }
+// variant 1: the same dependent add + fract chain without the lane shift (not the recurrence: the cost of DPP)
+__device__ __forceinline__ float chain_plain(float phase, float f)
+{
+    float ph = phase;
+#pragma unroll
+    for (int r = 0; r < 64; ++r) ph = __builtin_amdgcn_fractf(ph + f);
+    return ph;
+}
+// variant 2: the shift inside 16-lane rows only (row_shr:1; not the recurrence either)
+__device__ __forceinline__ float chain_row(float phase, float f, int lane)
+{
+    float ph = phase;
+#pragma unroll
+    for (int r = 0; r < 64; ++r)
+        ph = __builtin_amdgcn_fractf(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ph), 0x111, 0xF, 0xF, true)) + f);
+    return ph;
+}
+
 template <int V>
 __global__ void bench(const float *fin, float *out, long long *cycles, int tiles)
 {
@@ -27,7 +45,7 @@ __global__ void bench(const float *fin, float *out, long long *cycles, int tiles
     const long long t0 = clock64();
     for (int t = 0; t < tiles; ++t) {
         const float f = fin[(t & 63) * 64 + lane];
-        const float ph = chain_dpp(phase, f, lane);
+        const float ph = V == 0 ? chain_dpp(phase, f, lane) : V == 1 ? chain_plain(phase, f) : chain_row(phase, f, lane);
         const float ph_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ph), 63));
         const float f_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), 63));
         phase = __builtin_amdgcn_fractf(ph_l + f_l);
@@ -49,9 +67,21 @@ int main()
     hipMalloc(&d_f, f.size() * 4); hipMemcpy(d_f, f.data(), f.size() * 4, hipMemcpyHostToDevice);
     hipMalloc(&d_c, 8);
     hipMalloc(&d_o, 65 * 64 * 4);
-    for (int rep = 0; rep < 2; ++rep) {
-        hipLaunchKernelGGL(bench<0>, dim3(1), dim3(64), 0, 0, d_f, d_o, d_c, tiles);
-        hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int v = 2; v >= 0; --v) {
+        float ms = 0.0f;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0, 0);
+            if (v == 0) hipLaunchKernelGGL(bench<0>, dim3(1), dim3(64), 0, 0, d_f, d_o, d_c, tiles);
+            else if (v == 1) hipLaunchKernelGGL(bench<1>, dim3(1), dim3(64), 0, 0, d_f, d_o, d_c, tiles);
+            else hipLaunchKernelGGL(bench<2>, dim3(1), dim3(64), 0, 0, d_f, d_o, d_c, tiles);
+            hipEventRecord(e1, 0);
+            hipDeviceSynchronize();
+            hipEventElapsedTime(&ms, e0, e1);
+        }
+        long long cv; hipMemcpy(&cv, d_c, 8, hipMemcpyDeviceToHost);
+        printf("%s: %.2f ns per sample (%.2f s_memtime ticks)\n", v == 0 ? "wave_shr:1 + fract (the recurrence)" : v == 1 ? "add + fract without a lane shift" : "row_shr:1 + fract",
+               ms * 1e6 / ((double)tiles * 64), (double)cv / tiles / 64);
     }
     long long c; hipMemcpy(&c, d_c, 8, hipMemcpyDeviceToHost);
     std::vector<float> o(65 * 64); hipMemcpy(o.data(), d_o, 65 * 64 * 4, hipMemcpyDeviceToHost);
@@ -67,7 +97,6 @@ int main()
         }
         phase = p;
     }
-    printf("carrier-phase chain: %.1f s_memtime ticks per tile of 64 samples, %.2f per sample; %d of 4096 values differ from the serial loop\n",
-           (double)c / tiles, (double)c / tiles / 64, bad);
+    printf("the recurrence: %d of 4096 values differ from the serial loop\n", bad);
     return bad != 0;
 }
