@@ -123,6 +123,7 @@ struct grail_ctx {
     int scan_debug = 0;
     int sort_option = 1;              // ragged batches: fill launch slots in order of decreasing length
     int64_t pipe8_max_groups = 512;   // eight-formant pipelined workgroups: up to two per CU
+    int64_t pipe4_max_groups = 512;   // four-formant pipelined workgroups (16 utterances each): up to two per CU
     int scan_option = 1;              // fast arithmetic: small batches go to the time-parallel scan kernel
     int64_t scan_max_utts = 8704;     // ... up to this many utterances (x 4/7 with eight live formants)
     int64_t scan_split_max = 1536;    // ... and up to this many with the carrier phase on a wave of its own
@@ -504,6 +505,10 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         ctx->sort_option = value ? 1 : 0;
         return GRAIL_OK;
     }
+    if (std::strcmp(name, "pipeline4_max_groups") == 0) {   // tuning: four-formant batches, 16 utterances per workgroup
+        ctx->pipe4_max_groups = value;
+        return GRAIL_OK;
+    }
     if (std::strcmp(name, "pipeline8_max_groups") == 0) {   // tuning: 0 keeps eight-formant batches off the pipeline
         ctx->pipe8_max_groups = value;
         return GRAIL_OK;
@@ -788,9 +793,10 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     a.fast = ctx->fast_option ? 1u : 0u;
     int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(count);
     // small batches leave SIMDs idle: four-wave workgroups (one wave renders 16 utterances, one carries
-    // the per-utterance chain, two prepare the filter coefficients) while there is a CU for each
+    // the per-utterance chain, two prepare the filter coefficients), up to two per CU (tools/pipe4_range.py:
+    // 11.5 ms up to 4 096 utterances, 15.7 up to 8 192 where the lane kernels take 18.0; three per CU lose)
     if (a.live4 && !a.fast && !ctx->lanes_option && ctx->pipeline_option &&
-        ((uint64_t)count + 15) / 16 <= 256) {             // one workgroup per CU
+        ((uint64_t)count + 15) / 16 <= (uint64_t)ctx->pipe4_max_groups) {
         a.pipe = 1u;
         L = 4;
     } else if (!a.live4 && !a.fast && !ctx->lanes_option && ctx->pipeline_option && !batch->any_blend &&

@@ -206,6 +206,9 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *   "sort_by_length": 1 (default) / 0 — batches uploaded afterwards whose utterances differ in
  *       length fill the launch slots in order of decreasing length (lanes of a wave run in lockstep:
  *       a wave lasts as long as its longest utterance).  Rows stay where the caller put them.
+ *   "pipeline4_max_groups" (default 512), "pipeline8_max_groups" (default 512): exact arithmetic, how many
+ *       four-wave pipelined workgroups (16 / 8 utterances each, four / eight live formants) a batch may
+ *       need to still take them: two per CU.
  *   "kernel_variant": experiments only.
  * Read-only statistics: "slow_division_wave_steps", "fast_wave_tiles" (wave-tiles rendered in fast
  * arithmetic; scan kernel: 64-sample chain tiles on the closed forms kept from the tile before),

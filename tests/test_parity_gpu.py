@@ -493,6 +493,20 @@ def test_small_batch_pipeline_is_bit_exact(gpu_ctx, n_utt):
         gpu_ctx.set_option("small_batch_pipeline", 1)
 
 
+def test_small_batch_pipeline_with_two_workgroups_per_cu_is_bit_exact(gpu_ctx):
+    """4 097 - 8 192 utterances with four live formants keep the pipelined workgroups, two per CU
+    ("pipeline4_max_groups" = 512): 4 200 short utterances against the oracle."""
+    voices = W.single_voice()
+    n_utt = 4200
+    segs, offs, vids, seeds = W.make_batch(n_utt, length=0.06, blend_length=0.0625)
+    stride = W.max_samples(length=0.06)
+    ref, ref_len = O.synthesize_batch(ovoices(voices), segs, offs, vids, seeds, stride)
+    gpu_ctx.set_voices(voices)
+    out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+    assert gpu_ctx.get_option("last_launch_pipelined") == 1
+    assert_bit_identical(out, out_len, ref, ref_len, "pipeline, 263 workgroups")
+
+
 @pytest.mark.parametrize("n_utt", [13, 40])
 def test_small_batch_pipeline_with_eight_live_formants_is_bit_exact(gpu_ctx, n_utt):
     """Tables whose eight formants are all audible (config 4's presets) take the same four-wave
