@@ -55,6 +55,9 @@
 #ifndef GRAIL_FAST_G_SCALE
 #define GRAIL_FAST_G_SCALE 1048576.0f   // 2^22 / 4: interpolation error of G, H <= 2^-22 (fast_tile's guard)
 #endif
+#ifndef PIPE_MAX_TILES
+#define PIPE_MAX_TILES 8          // PIPE kernels: consecutive calm tiles rendered without draining the pipeline
+#endif
 #ifndef PIPE_PAIRS_PER_PHASE
 #define PIPE_PAIRS_PER_PHASE 2     // PIPE kernels: sample pairs per coefficient wave between barriers
 #endif
@@ -1534,6 +1537,75 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         return true;
     };
 
+    // ---- the staged tile's rows to memory: row `slot` holds samples [base_, base_ + T), mine_ of them valid
+    // (the general flush; the main loop below has a shortcut for the usual full tile of the lane kernels)
+    auto flush_rows = [&](const uint32_t base_, const uint32_t mine_) __attribute__((always_inline)) {
+        constexpr int ROW_LANES = T / 4;
+        constexpr int ROWS_PER_IT = 64 / ROW_LANES;
+        const int rl = lane % ROW_LANES;
+        const int rr = lane / ROW_LANES;
+        if (emit && j == L - 1) cnt[slot] = mine_;
+        if constexpr (PIPE) __syncthreads();
+        else wave_lds_sync();
+        const int r_first = PIPE ? wave * ROWS_PER_IT : 0;
+        constexpr int R_STEP = PIPE ? ROWS_PER_IT * WAVES : ROWS_PER_IT;
+#pragma unroll 1
+        for (int r0 = r_first; r0 < S; r0 += R_STEP) {
+            const int r = r0 + rr;
+            if (ROWS_PER_IT > S && r >= S) continue;
+            const uint32_t c = cnt[r];
+            const int t0 = rl * 4;
+            if ((uint32_t)t0 < c) {
+                const uint64_t at = (uint64_t)(A.perm ? rowid[r] : u0 + r) * A.out_stride + base_ + t0;
+                auto sample_at = [&](const int tt) __attribute__((always_inline)) -> float {
+                    if constexpr (FOLD_IN_FLUSH) {
+                        // v1.sum() * 0.5: the left fold from 0.0 over formants 0..7  :574, :123-125
+                        const float *p = stage + (tt * S + r) * NFA;
+                        float run = 0.0f;
+#pragma unroll
+                        for (int f = 0; f < NFA; ++f) run = run + p[f];
+                        if (NFA < NF) run = run + 0.0f;   // formants 5-8: literal +0.0 terms
+                        return run * 0.5f;
+                    } else {
+                        return stage[tt * SP + r];
+                    }
+                };
+                const float s0 = sample_at(t0 + 0);
+                const float s1 = sample_at(t0 + 1);
+                const float s2 = sample_at(t0 + 2);
+                const float s3 = sample_at(t0 + 3);
+                if (A.out_pcm16) {
+                    // the WAV sink's `(x * i16::MAX as f32) as i16` (examples/cli.rs:49) on the way out
+                    int16_t *dst = A.out_pcm16 + at;
+                    const int p0 = pcm16_from_f32(s0), p1 = pcm16_from_f32(s1);
+                    const int p2 = pcm16_from_f32(s2), p3 = pcm16_from_f32(s3);
+                    if (vec16_ok && (uint32_t)(t0 + 4) <= c) {
+                        *reinterpret_cast<uint2 *>(dst) =
+                            make_uint2((uint32_t)(p0 & 0xFFFF) | ((uint32_t)p1 << 16),
+                                       (uint32_t)(p2 & 0xFFFF) | ((uint32_t)p3 << 16));
+                    } else {
+                        dst[0] = (int16_t)p0;
+                        if ((uint32_t)(t0 + 1) < c) dst[1] = (int16_t)p1;
+                        if ((uint32_t)(t0 + 2) < c) dst[2] = (int16_t)p2;
+                        if ((uint32_t)(t0 + 3) < c) dst[3] = (int16_t)p3;
+                    }
+                    continue;
+                }
+                float *dst = A.out + at;
+                if (vec_ok && (uint32_t)(t0 + 4) <= c) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(s0, s1, s2, s3);
+                } else {
+                    dst[0] = s0;
+                    if ((uint32_t)(t0 + 1) < c) dst[1] = s1;
+                    if ((uint32_t)(t0 + 2) < c) dst[2] = s2;
+                    if ((uint32_t)(t0 + 3) < c) dst[3] = s3;
+                }
+            }
+        }
+        if constexpr (PIPE) __syncthreads();     // the rendering wave may not park the next tile before all have read
+        else wave_lds_sync();
+    };
+
     for (uint32_t base = 0;; base += T) {
         int t = 0;
         while (t < T) {
@@ -1548,6 +1620,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             // implies RN(clk - dt) >= (m - 1.01)*dt (RN is monotone), so clk > (T+8)*dt leaves
             // > 7*dt after T <= 64 steps; the phase grows by at most jinc*(1 + 2^-23) per step.
             bool calm_tile = false;
+            int pipe_tiles = 1;                            // PIPE: calm tiles the pipeline runs through in one go
             const bool idle = STREAM ? finished : done;   // a paused stream lane resumes: not idle
             uint32_t tile_seed = 0u;                       // the carrier-noise state the tile starts from
             if (t == 0) {
@@ -1568,6 +1641,23 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                         calm = calm & (__builtin_fmaxf(X.frequency, Y.frequency) + __builtin_fabsf(d_freq) < 0.5f);
                     }
                     calm_tile = __builtin_amdgcn_ballot_w64(!(calm | idle)) == 0;
+                    if constexpr (PIPE) {
+                        // how many calm tiles in a row (every wave of the workgroup finds the same number): the
+                        // pipeline then runs through them without draining.  The margins of the single tile
+                        // for N = k T steps: each step lowers the bound on the clock by at most 1.01 dt.
+                        pipe_tiles = 1;
+                        if (calm_tile) {
+#pragma unroll 1
+                            for (int k = 2; k <= PIPE_MAX_TILES; ++k) {
+                                const float nsteps = (float)(k * T);
+                                const bool ok = (clk > (nsteps * 1.0125f + 8.0f) * dt) &
+                                                (jphase + (nsteps + 1.0f) * jinc < 0.999f) &
+                                                (cap32 - n_out >= (uint32_t)(k * T));
+                                if (__builtin_amdgcn_ballot_w64(!(ok | idle)) != 0) break;
+                                pipe_tiles = k;
+                            }
+                        }
+                    }
                 }
             }
             auto quiet_run = [&](auto nlive_tag, auto su_tag) __attribute__((always_inline)) {
@@ -1592,23 +1682,35 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                         constexpr int SPR = 4 * QP;              // samples per round
                         constexpr int ROUNDS = T / SPR;
                         static_assert(T % SPR == 0, "whole rounds");
-                        auto noise_at = [&](const int step) __attribute__((always_inline)) {
+                        // Consecutive calm tiles (pipe_tiles of them) go through without draining the pipeline:
+                        // when the rendering wave has parked a tile all four waves flush it, then carry on.
+                        // The chain wave is two rounds ahead: it draws the next tile's carrier noise itself.
+                        uint32_t sk_chain = sk;
+                        float noise_chain = noise_of_lane;
+                        auto noise_at_chain = [&](const int step) __attribute__((always_inline)) {
                             return __builtin_bit_cast(
-                                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), step));
+                                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_chain), step));
                         };
+                        const int all_rounds = pipe_tiles * ROUNDS;
 #pragma unroll 1
-                        for (int ph_ = -2; ph_ < ROUNDS; ++ph_) {
+                        for (int ph_ = -2; ph_ < all_rounds; ++ph_) {
                             if (role == 1) {
                                 const int m = ph_ + 2;
-                                if (m < ROUNDS) {
+                                if (m < all_rounds) {
+                                    const int ml = m % ROUNDS;
+                                    if (ml == 0 && m > 0) {          // on to the next tile: its noise, T draws further
+                                        const uint32_t seed_next = (uint32_t)__builtin_amdgcn_readlane((int)sk_chain, T - 1);
+                                        sk_chain = seed_next * LCG_SKIP.mul[ahead] + LCG_SKIP.add[ahead];
+                                        noise_chain = (__uint_as_float((sk_chain >> 9) | 0x3F800000u) - 1.5f) * 2.0f;
+                                    }
 #pragma unroll
                                     for (int q = 0; q < 2 * QP; ++q)
-                                        pipe_chain(chain_all[m & 1][q], noise_at(SPR * m + 2 * q),
-                                                   noise_at(SPR * m + 2 * q + 1));
+                                        pipe_chain(chain_all[m & 1][q], noise_at_chain(SPR * ml + 2 * q),
+                                                   noise_at_chain(SPR * ml + 2 * q + 1));
                                 }
                             } else if (role >= 2) {
                                 const int m = ph_ + 1;
-                                if (m >= 0 && m < ROUNDS) {
+                                if (m >= 0 && m < all_rounds) {
 #pragma unroll
                                     for (int q = 0; q < QP; ++q) {
                                         const int pair = 2 * q + (role - 2);
@@ -1617,9 +1719,18 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                                 }
                             } else if (ph_ >= 0) {
 #pragma unroll
-                                for (int q = 0; q < 2 * QP; ++q) pipe_render(ring_all[ph_ & 1][q], SPR * ph_ + 2 * q);
+                                for (int q = 0; q < 2 * QP; ++q)
+                                    pipe_render(ring_all[ph_ & 1][q], SPR * (ph_ % ROUNDS) + 2 * q);
                             }
                             __syncthreads();
+                            if (ph_ >= 0 && ph_ % ROUNDS == ROUNDS - 1 && ph_ != all_rounds - 1) {
+                                // a tile inside the run is complete: what the main loop does after a calm tile
+                                n_out += idle ? 0u : (uint32_t)T;
+                                noise_seed = (uint32_t)__builtin_amdgcn_readlane((int)sk, T - 1);
+                                sk = noise_seed * LCG_SKIP.mul[ahead] + LCG_SKIP.add[ahead];
+                                flush_rows(base, n_out > base ? n_out - base : 0u);
+                                base += T;
+                            }
                         }
                         // every wave takes over the clocks the chain wave arrived at
                         if (role == 1) {
@@ -1747,66 +1858,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 continue;
             }
         }
-        if (emit && j == L - 1) cnt[slot] = mine;
-        if constexpr (PIPE) __syncthreads();
-        else wave_lds_sync();
-        const int r_first = PIPE ? wave * ROWS_PER_IT : 0;
-        constexpr int R_STEP = PIPE ? ROWS_PER_IT * WAVES : ROWS_PER_IT;
-#pragma unroll 1
-        for (int r0 = r_first; r0 < S; r0 += R_STEP) {
-            const int r = r0 + rr;
-            if (ROWS_PER_IT > S && r >= S) continue;
-            const uint32_t c = cnt[r];
-            const int t0 = rl * 4;
-            if ((uint32_t)t0 < c) {
-                const uint64_t at = (uint64_t)(A.perm ? rowid[r] : u0 + r) * A.out_stride + base + t0;
-                auto sample_at = [&](const int tt) __attribute__((always_inline)) -> float {
-                    if constexpr (FOLD_IN_FLUSH) {
-                        // v1.sum() * 0.5: the left fold from 0.0 over formants 0..7  :574, :123-125
-                        const float *p = stage + (tt * S + r) * NFA;
-                        float run = 0.0f;
-#pragma unroll
-                        for (int f = 0; f < NFA; ++f) run = run + p[f];
-                        if (NFA < NF) run = run + 0.0f;   // formants 5-8: literal +0.0 terms
-                        return run * 0.5f;
-                    } else {
-                        return stage[tt * SP + r];
-                    }
-                };
-                const float s0 = sample_at(t0 + 0);
-                const float s1 = sample_at(t0 + 1);
-                const float s2 = sample_at(t0 + 2);
-                const float s3 = sample_at(t0 + 3);
-                if (A.out_pcm16) {
-                    // the WAV sink's `(x * i16::MAX as f32) as i16` (examples/cli.rs:49) on the way out
-                    int16_t *dst = A.out_pcm16 + at;
-                    const int p0 = pcm16_from_f32(s0), p1 = pcm16_from_f32(s1);
-                    const int p2 = pcm16_from_f32(s2), p3 = pcm16_from_f32(s3);
-                    if (vec16_ok && (uint32_t)(t0 + 4) <= c) {
-                        *reinterpret_cast<uint2 *>(dst) =
-                            make_uint2((uint32_t)(p0 & 0xFFFF) | ((uint32_t)p1 << 16),
-                                       (uint32_t)(p2 & 0xFFFF) | ((uint32_t)p3 << 16));
-                    } else {
-                        dst[0] = (int16_t)p0;
-                        if ((uint32_t)(t0 + 1) < c) dst[1] = (int16_t)p1;
-                        if ((uint32_t)(t0 + 2) < c) dst[2] = (int16_t)p2;
-                        if ((uint32_t)(t0 + 3) < c) dst[3] = (int16_t)p3;
-                    }
-                    continue;
-                }
-                float *dst = A.out + at;
-                if (vec_ok && (uint32_t)(t0 + 4) <= c) {
-                    *reinterpret_cast<float4 *>(dst) = make_float4(s0, s1, s2, s3);
-                } else {
-                    dst[0] = s0;
-                    if ((uint32_t)(t0 + 1) < c) dst[1] = s1;
-                    if ((uint32_t)(t0 + 2) < c) dst[2] = s2;
-                    if ((uint32_t)(t0 + 3) < c) dst[3] = s3;
-                }
-            }
-        }
-        if constexpr (PIPE) __syncthreads();     // the rendering wave may not park the next tile before all have read
-        else wave_lds_sync();
+        flush_rows(base, mine);
         if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
     }
 

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 __device__ __forceinline__ float chain_dpp(float phase, float f, int lane)
@@ -57,24 +58,25 @@ __global__ void bench(const float *fin, float *out, long long *cycles, int tiles
     if (lane == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
-int main()
+int main(int argc, char **argv)
 {
     const int tiles = 4096;
+    const int blocks = argc > 1 ? atoi(argv[1]) : 1;   // more than one: the same chain on many CUs at once (clock under load)
     std::vector<float> f(64 * 64);
     uint32_t s = 12345u;
     for (auto &x : f) { s = s * 1664525u + 1013904223u; x = 0.002f + 0.004f * (float)(s >> 8) / 16777216.0f; }
     float *d_f, *d_o; long long *d_c;
     hipMalloc(&d_f, f.size() * 4); hipMemcpy(d_f, f.data(), f.size() * 4, hipMemcpyHostToDevice);
-    hipMalloc(&d_c, 8);
+    hipMalloc(&d_c, 8 * (size_t)blocks);
     hipMalloc(&d_o, 65 * 64 * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int v = 2; v >= 0; --v) {
         float ms = 0.0f;
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0, 0);
-            if (v == 0) hipLaunchKernelGGL(bench<0>, dim3(1), dim3(64), 0, 0, d_f, d_o, d_c, tiles);
-            else if (v == 1) hipLaunchKernelGGL(bench<1>, dim3(1), dim3(64), 0, 0, d_f, d_o, d_c, tiles);
-            else hipLaunchKernelGGL(bench<2>, dim3(1), dim3(64), 0, 0, d_f, d_o, d_c, tiles);
+            if (v == 0) hipLaunchKernelGGL(bench<0>, dim3(blocks), dim3(64), 0, 0, d_f, d_o, d_c, tiles);
+            else if (v == 1) hipLaunchKernelGGL(bench<1>, dim3(blocks), dim3(64), 0, 0, d_f, d_o, d_c, tiles);
+            else hipLaunchKernelGGL(bench<2>, dim3(blocks), dim3(64), 0, 0, d_f, d_o, d_c, tiles);
             hipEventRecord(e1, 0);
             hipDeviceSynchronize();
             hipEventElapsedTime(&ms, e0, e1);
