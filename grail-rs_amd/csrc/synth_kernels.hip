@@ -58,9 +58,6 @@
 #ifndef PIPE_MAX_TILES
 #define PIPE_MAX_TILES 8          // PIPE kernels: consecutive calm tiles rendered without draining the pipeline
 #endif
-#ifndef PIPE_PAIRS_PER_PHASE
-#define PIPE_PAIRS_PER_PHASE 2     // PIPE kernels: sample pairs per coefficient wave between barriers
-#endif
 
 namespace grail {
 
@@ -362,7 +359,7 @@ struct StateIO {
 // arithmetic uses fused multiply-adds, one uncorrected reciprocal per formant, and filter
 // coefficients interpolated linearly across the tile.  Tiles with an event run the exact steps.
 template <int L, int T, int WAVES, int MIN_WAVES_PER_SIMD, bool STREAM, bool HALF, bool ANYBL, int NFA = NF,
-          bool PIPE = false, bool FAST = false>
+          bool PIPE = false, bool FAST = false, int PQP = 2>
 __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(const SynthArgs A)
 {
     static_assert(!FAST || !PIPE, "FAST");
@@ -995,19 +992,43 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     //                         turbulence mix, the jittered amplitude and a1, a2, a3 from that chain
     //   pipe_render (wave 0): the two filter recurrence steps and the band-pass outputs
     // Same operations on the same operands in the same order as time_packed_steps.
-    constexpr int QP = PIPE_PAIRS_PER_PHASE;     // sample pairs each coefficient wave handles per phase
-    __shared__ float4 chain_all[PIPE ? 2 : 1][PIPE ? 2 * QP : 1][PIPE ? 3 : 1][PIPE ? 64 : 1];   // [round&1][pair][q][lane]
+    // PIPE: a round is 2 * QP sample pairs.  QP = 2: each coefficient wave takes two of its four pairs.  QP = 4
+    // (16 samples between barriers; 95 KB of LDS, one workgroup per CU): the coefficient waves take three pairs
+    // each and the chain wave — the lightest stage — the last two of the round it wrote one phase before.
+    constexpr int QP = PQP;
+    __shared__ float4 chain_all[PIPE ? 2 : 1][PIPE ? (QP + 1) / 2 : 1][PIPE ? 3 : 1][PIPE ? 64 : 1];   // [round&1][four pairs][q][lane]: lane (quad | pair) holds the pair's chain
     __shared__ float4 ring_all[PIPE ? 2 : 1][PIPE ? 2 * QP : 1][PIPE ? 4 : 1][PIPE ? 64 : 1];
     __shared__ float hand_all[PIPE ? 3 : 1][PIPE ? 64 : 1];
-    auto pipe_chain = [&](float4 (*dst)[64], const float nz0, const float nz1) __attribute__((always_inline)) {
+    // One round = four sample pairs.  The four lanes of a quad carry the same utterance (L = 4: its four
+    // formants; L = 8: half of its eight), so the quad shares the round: quad lane i takes pair i.  Only what
+    // is serial — the clock, the jitter phase, the carrier phase — is stepped through all eight samples by
+    // every lane (the reference's operations in the reference's order; a lane latches the values of its pair);
+    // alpha, pitch, polyBLEP and saw are evaluated once per pair instead of once per lane and pair.
+    auto quad_bcast = [](const float x, auto sel_tag) __attribute__((always_inline)) {
+        constexpr int I = decltype(sel_tag)::value;
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), I * 0x55, 0xF, 0xF, true));   // quad_perm:[I,I,I,I]
+    };
+    auto pipe_chain = [&](float4 (*dst)[64], const float noise_of_step, const int first_step) __attribute__((always_inline)) {
         if constexpr (PIPE) {
+            static_assert(!PIPE || QP % 2 == 0, "a quad shares four pairs");
             const f2 one2 = vsplat(1.0f, f2());
-            const float clk0 = clk - dt, clk1 = clk0 - dt;                     // :861
-            const float jp0 = jphase + jinc, jp1 = jp0 + jinc;                 // :242 / :291
-            clk = clk1;
-            jphase = jp1;
-            f2 CLK, JP;
-            CLK.x = clk0; CLK.y = clk1; JP.x = jp0; JP.y = jp1;
+            const int jq = lane & 3;
+            float c = clk, p = jphase;
+            f2 CLK = vsplat(0.0f, f2()), JP = CLK;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool me = jq == i;
+                c = c - dt;                                                    // :861
+                p = p + jinc;                                                  // :242 / :291
+                CLK.x = me ? c : CLK.x;
+                JP.x = me ? p : JP.x;
+                c = c - dt;
+                p = p + jinc;
+                CLK.y = me ? c : CLK.y;
+                JP.y = me ? p : JP.y;
+            }
+            clk = c;
+            jphase = p;
             const f2 ratio = CLK * inv_blend_length;
             f2 alpha;                                                          // :899/:908/:917
             alpha.x = silent_pair ? 1.0f : __builtin_fminf(ratio.x, 1.0f);
@@ -1017,19 +1038,29 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             f2 frequency = X.frequency * oma + Y.frequency * alpha;            // :404-414
             const f2 n_freq = fn_cur * jomp + fn_next * JP;                    // :254
             frequency = frequency + n_freq * d_freq;                           // :763
-            // carrier :503-525
+            // carrier :503-525: the phase goes through the eight samples in order, pitch by pitch
+            float ph = phase;
+            f2 PH = vsplat(0.0f, f2());
+            auto two_steps = [&](auto sel_tag) __attribute__((always_inline)) {
+                constexpr int I = decltype(sel_tag)::value;
+                const bool me = jq == I;
+                PH.x = me ? ph : PH.x;
+                ph = __builtin_amdgcn_fractf(ph + quad_bcast(frequency.x, sel_tag));     // see quiet_step
+                PH.y = me ? ph : PH.y;
+                ph = __builtin_amdgcn_fractf(ph + quad_bcast(frequency.y, sel_tag));
+            };
+            two_steps(std::integral_constant<int, 0>());
+            two_steps(std::integral_constant<int, 1>());
+            two_steps(std::integral_constant<int, 2>());
+            two_steps(std::integral_constant<int, 3>());
+            phase = ph;
             const f2 omf = 1.0f - frequency;
-            const float ph0 = phase;
-            const bool head0 = ph0 < frequency.x, tail0 = ph0 > omf.x;
-            const float ph1 = __builtin_amdgcn_fractf(ph0 + frequency.x);     // see quiet_step
-            const bool head1 = ph1 < frequency.y, tail1 = ph1 > omf.y;
-            phase = __builtin_amdgcn_fractf(ph1 + frequency.y);
-            f2 PH;
-            PH.x = ph0; PH.y = ph1;
+            const bool head0 = PH.x < frequency.x, tail0 = PH.x > omf.x;
+            const bool head1 = PH.y < frequency.y, tail1 = PH.y > omf.y;
             const f2 phm1 = PH - 1.0f;
             f2 dividend;
-            dividend.x = head0 ? ph0 : phm1.x;
-            dividend.y = head1 ? ph1 : phm1.y;
+            dividend.x = head0 ? PH.x : phm1.x;
+            dividend.y = head1 ? PH.y : phm1.y;
             const f2 tt = div_exact<true>(dividend, frequency);
             const f2 tt2 = tt * tt;
             f2 s_tt2, sgn, polyblep;                                           // see quiet_step
@@ -1041,14 +1072,19 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             polyblep.x = (head0 | tail0) ? pb.x : 0.0f;
             polyblep.y = (head1 | tail1) ? pb.y : 0.0f;
             const f2 saw = vfma(vsplat(2.0f, f2()), PH, -one2) - polyblep;     // :517
+            // the carrier noise of my two samples: lane t of noise_of_step holds the tile's step t
+            const int at = first_step + 2 * jq;
+            const float nz0 = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * at, __float_as_int(noise_of_step)));
+            const float nz1 = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * at + 4, __float_as_int(noise_of_step)));
             dst[0][lane] = make_float4(alpha.x, alpha.y, oma.x, oma.y);
             dst[1][lane] = make_float4(JP.x, JP.y, jomp.x, jomp.y);
             dst[2][lane] = make_float4(saw.x, saw.y, nz0, nz1);
         }
     };
-    auto pipe_coeffs = [&](const float4 (*src)[64], float4 (*dst)[64]) __attribute__((always_inline)) {
+    auto pipe_coeffs = [&](const float4 (*src)[64], const int pair, float4 (*dst)[64]) __attribute__((always_inline)) {
         if constexpr (PIPE) {
-            const float4 c0 = src[0][lane], c1 = src[1][lane], c2 = src[2][lane];
+            const int from = (lane & ~3) | pair;                               // the quad lane that worked out this pair
+            const float4 c0 = src[0][from], c1 = src[1][from], c2 = src[2][from];
             f2 alpha, oma, JP, jomp, saw, NZ;
             alpha.x = c0.x; alpha.y = c0.y; oma.x = c0.z; oma.y = c0.w;
             JP.x = c1.x; JP.y = c1.y; jomp.x = c1.z; jomp.y = c1.w;
@@ -1687,10 +1723,6 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                         // The chain wave is two rounds ahead: it draws the next tile's carrier noise itself.
                         uint32_t sk_chain = sk;
                         float noise_chain = noise_of_lane;
-                        auto noise_at_chain = [&](const int step) __attribute__((always_inline)) {
-                            return __builtin_bit_cast(
-                                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_chain), step));
-                        };
                         const int all_rounds = pipe_tiles * ROUNDS;
 #pragma unroll 1
                         for (int ph_ = -2; ph_ < all_rounds; ++ph_) {
@@ -1704,17 +1736,22 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                                         noise_chain = (__uint_as_float((sk_chain >> 9) | 0x3F800000u) - 1.5f) * 2.0f;
                                     }
 #pragma unroll
-                                    for (int q = 0; q < 2 * QP; ++q)
-                                        pipe_chain(chain_all[m & 1][q], noise_at_chain(SPR * ml + 2 * q),
-                                                   noise_at_chain(SPR * ml + 2 * q + 1));
+                                    for (int g = 0; g < QP / 2; ++g) pipe_chain(chain_all[m & 1][g], noise_chain, SPR * ml + 8 * g);
+                                }
+                                if constexpr (QP == 4) {             // and the last two pairs of the round before
+                                    const int mc = ph_ + 1;
+                                    if (mc >= 0 && mc < all_rounds) {
+                                        pipe_coeffs(chain_all[mc & 1][1], 2, ring_all[mc & 1][6]);
+                                        pipe_coeffs(chain_all[mc & 1][1], 3, ring_all[mc & 1][7]);
+                                    }
                                 }
                             } else if (role >= 2) {
                                 const int m = ph_ + 1;
                                 if (m >= 0 && m < all_rounds) {
 #pragma unroll
-                                    for (int q = 0; q < QP; ++q) {
-                                        const int pair = 2 * q + (role - 2);
-                                        pipe_coeffs(chain_all[m & 1][pair], ring_all[m & 1][pair]);
+                                    for (int q = 0; q < (QP == 4 ? 3 : QP); ++q) {
+                                        const int pair = QP == 4 ? 3 * (role - 2) + q : 2 * q + (role - 2);
+                                        pipe_coeffs(chain_all[m & 1][pair / 4], pair % 4, ring_all[m & 1][pair]);
                                     }
                                 }
                             } else if (ph_ >= 0) {
@@ -1955,14 +1992,14 @@ static thread_local char g_kernel_name[96] = "none";
 const char *last_kernel_name() { return g_kernel_name; }
 
 template <int L, int T, int WAVES, int MINW, bool STREAM, bool HALF, bool ANYBL, int NFA = NF, bool PIPE = false,
-          bool FAST = false>
+          bool FAST = false, int PQP = 2>
 static void start(const SynthArgs &args, dim3 grid, dim3 block, hipStream_t stream)
 {
-    std::snprintf(g_kernel_name, sizeof g_kernel_name, "synth_kernel<L=%d,T=%d,W=%d,%d,%s%s%sNFA=%d%s%s>", L, T, WAVES,
+    std::snprintf(g_kernel_name, sizeof g_kernel_name, "synth_kernel<L=%d,T=%d,W=%d,%d,%s%s%sNFA=%d%s%s%s>", L, T, WAVES,
                   MINW, STREAM ? "STREAM," : "", HALF ? "HALF," : "", ANYBL ? "ANYBL," : "", NFA,
-                  PIPE ? ",PIPE" : "", FAST ? ",FAST" : "");
-    hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, STREAM, HALF, ANYBL, NFA, PIPE, FAST>), grid, block, 0, stream,
-                       args);
+                  PIPE ? ",PIPE" : "", FAST ? ",FAST" : "", PQP == 4 ? ",R16" : "");
+    hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, STREAM, HALF, ANYBL, NFA, PIPE, FAST, PQP>), grid, block, 0,
+                       stream, args);
 }
 
 template <int L, int T, int WAVES, int MINW>
@@ -2019,13 +2056,16 @@ hipError_t launch_synth(const SynthArgs &args, int L, int variant, hipStream_t s
     if (args.n_utt == 0) return hipSuccess;
     if (args.pipe && !args.state && !args.any_blend && !args.fast) {
         // workgroups of four waves — render, chain, 2 x coefficients — share 16 utterances (four live
-        // formants, 4 lanes each) or 8 utterances (eight formants, 8 lanes each)
+        // formants, 4 lanes each) or 8 utterances (eight formants, 8 lanes each).  While there is a CU per
+        // workgroup: rounds of 16 samples (95 KB of LDS); two workgroups per CU: rounds of 8.
         if (args.live4) {
             const dim3 grid((args.n_utt + 15) / 16), block(256);
-            start<4, 64, 4, 1, false, false, false, 4, true>(args, grid, block, stream);
+            if (grid.x <= 256) start<4, 64, 4, 1, false, false, false, 4, true, false, 4>(args, grid, block, stream);
+            else start<4, 64, 4, 1, false, false, false, 4, true>(args, grid, block, stream);
         } else {
             const dim3 grid((args.n_utt + 7) / 8), block(256);
-            start<8, 64, 4, 1, false, false, false, NF, true>(args, grid, block, stream);
+            if (grid.x <= 256) start<8, 64, 4, 1, false, false, false, NF, true, false, 4>(args, grid, block, stream);
+            else start<8, 64, 4, 1, false, false, false, NF, true>(args, grid, block, stream);
         }
         return hipGetLastError();
     }
