@@ -993,11 +993,11 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     //   pipe_render (wave 0): the two filter recurrence steps and the band-pass outputs
     // Same operations on the same operands in the same order as time_packed_steps.
     // PIPE: a round is 2 * QP sample pairs.  QP = 2: each coefficient wave takes two of its four pairs.  QP = 4
-    // (16 samples between barriers; 95 KB of LDS, one workgroup per CU): the coefficient waves take three pairs
+    // (16 samples between barriers; the one in use): the coefficient waves take three pairs
     // each and the chain wave — the lightest stage — the last two of the round it wrote one phase before.
     constexpr int QP = PQP;
-    __shared__ float4 chain_all[PIPE ? 2 : 1][PIPE ? (QP + 1) / 2 : 1][PIPE ? 3 : 1][PIPE ? 64 : 1];   // [round&1][four pairs][q][lane]: lane (quad | pair) holds the pair's chain
-    __shared__ float4 ring_all[PIPE ? 2 : 1][PIPE ? 2 * QP : 1][PIPE ? 4 : 1][PIPE ? 64 : 1];
+    __shared__ float4 chain_all[PIPE ? 2 : 1][PIPE ? (QP + 1) / 2 : 1][PIPE ? 2 : 1][PIPE ? 64 : 1];   // [round&1][four pairs][q][lane]: lane (quad | pair) holds the pair's chain
+    __shared__ float4 ring_all[PIPE ? 2 : 1][PIPE ? 2 * QP : 1][PIPE ? 3 : 1][PIPE ? 64 : 1];
     __shared__ float hand_all[PIPE ? 3 : 1][PIPE ? 64 : 1];
     // One round = four sample pairs.  The four lanes of a quad carry the same utterance (L = 4: its four
     // formants; L = 8: half of its eight), so the quad shares the round: quad lane i takes pair i.  Only what
@@ -1076,19 +1076,19 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             const int at = first_step + 2 * jq;
             const float nz0 = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * at, __float_as_int(noise_of_step)));
             const float nz1 = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * at + 4, __float_as_int(noise_of_step)));
-            dst[0][lane] = make_float4(alpha.x, alpha.y, oma.x, oma.y);
-            dst[1][lane] = make_float4(JP.x, JP.y, jomp.x, jomp.y);
-            dst[2][lane] = make_float4(saw.x, saw.y, nz0, nz1);
+            dst[0][lane] = make_float4(alpha.x, alpha.y, JP.x, JP.y);
+            dst[1][lane] = make_float4(saw.x, saw.y, nz0, nz1);
         }
     };
     auto pipe_coeffs = [&](const float4 (*src)[64], const int pair, float4 (*dst)[64]) __attribute__((always_inline)) {
         if constexpr (PIPE) {
             const int from = (lane & ~3) | pair;                               // the quad lane that worked out this pair
-            const float4 c0 = src[0][from], c1 = src[1][from], c2 = src[2][from];
-            f2 alpha, oma, JP, jomp, saw, NZ;
-            alpha.x = c0.x; alpha.y = c0.y; oma.x = c0.z; oma.y = c0.w;
-            JP.x = c1.x; JP.y = c1.y; jomp.x = c1.z; jomp.y = c1.w;
+            const float4 c0 = src[0][from], c2 = src[1][from];
+            f2 alpha, JP, saw, NZ;
+            alpha.x = c0.x; alpha.y = c0.y; JP.x = c0.z; JP.y = c0.w;
             saw.x = c2.x; saw.y = c2.y; NZ.x = c2.z; NZ.y = c2.w;
+            const f2 oma = 1.0f - alpha;                                       // as the chain has them
+            const f2 jomp = 1.0f - JP;
             f2 e_freq = X.freq[0] * oma + Y.freq[0] * alpha;                   // :404-414
             const f2 e_bw = X.bw[0] * oma + Y.bw[0] * alpha;
             const f2 e_smooth = X.smooth[0] * oma + Y.smooth[0] * alpha;
@@ -1109,21 +1109,20 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             const f2 g = div_exact<true>(num, den);                            // :555
             const f2 kq = div_exact<true>(e_bw, e_freq);                       // :558
             const f2 a1 = rcp_exact<true>(1.0f + g * (g + kq));                // :560
-            const f2 a2 = g * a1;                                              // :561
-            const f2 a3 = g * a2;                                              // :562
             const f2 tmix = (1.0f - e_turb) + NZ * e_turb;                     // :544-545
             const f2 nw = saw * (1.0f - e_breath) + NZ * e_breath;             // :531
             dst[0][lane] = make_float4(oml.x, oml.y, nw.x, nw.y);
             dst[1][lane] = make_float4(tmix.x, tmix.y, e_amp.x, e_amp.y);
-            dst[2][lane] = make_float4(a1.x, a1.y, a2.x, a2.y);
-            dst[3][lane] = make_float4(a3.x, a3.y, 0.0f, 0.0f);
+            dst[2][lane] = make_float4(a1.x, a1.y, g.x, g.y);                  // a2, a3: the render wave's two products
         }
     };
     auto pipe_render = [&](const float4 (*src)[64], const int tc) __attribute__((always_inline)) {
         if constexpr (PIPE) {
-            const float4 q0 = src[0][lane], q1 = src[1][lane], q2 = src[2][lane], q3 = src[3][lane];
+            const float4 q0 = src[0][lane], q1 = src[1][lane], q2 = src[2][lane];
             const float oml[2] = {q0.x, q0.y}, nw[2] = {q0.z, q0.w}, tmix[2] = {q1.x, q1.y};
-            const float amp[2] = {q1.z, q1.w}, a1[2] = {q2.x, q2.y}, a2[2] = {q2.z, q2.w}, a3[2] = {q3.x, q3.y};
+            const float amp[2] = {q1.z, q1.w}, a1[2] = {q2.x, q2.y}, g[2] = {q2.z, q2.w};
+            const float a2[2] = {g[0] * a1[0], g[1] * a1[1]};                  // :561
+            const float a3[2] = {g[0] * a2[0], g[1] * a2[1]};                  // :562
 #pragma unroll
             for (int h = 0; h < 2; ++h) {                                      // :538-571
                 float sa = st_a[0], sb = st_b[0], sc = st_c[0];
@@ -2056,16 +2055,14 @@ hipError_t launch_synth(const SynthArgs &args, int L, int variant, hipStream_t s
     if (args.n_utt == 0) return hipSuccess;
     if (args.pipe && !args.state && !args.any_blend && !args.fast) {
         // workgroups of four waves — render, chain, 2 x coefficients — share 16 utterances (four live
-        // formants, 4 lanes each) or 8 utterances (eight formants, 8 lanes each).  While there is a CU per
-        // workgroup: rounds of 16 samples (95 KB of LDS); two workgroups per CU: rounds of 8.
+        // formants, 4 lanes each) or 8 utterances (eight formants, 8 lanes each); rounds of 16 samples (73 KB of
+        // LDS: two workgroups fit a CU)
         if (args.live4) {
             const dim3 grid((args.n_utt + 15) / 16), block(256);
-            if (grid.x <= 256) start<4, 64, 4, 1, false, false, false, 4, true, false, 4>(args, grid, block, stream);
-            else start<4, 64, 4, 1, false, false, false, 4, true>(args, grid, block, stream);
+            start<4, 64, 4, 1, false, false, false, 4, true, false, 4>(args, grid, block, stream);
         } else {
             const dim3 grid((args.n_utt + 7) / 8), block(256);
-            if (grid.x <= 256) start<8, 64, 4, 1, false, false, false, NF, true, false, 4>(args, grid, block, stream);
-            else start<8, 64, 4, 1, false, false, false, NF, true>(args, grid, block, stream);
+            start<8, 64, 4, 1, false, false, false, NF, true, false, 4>(args, grid, block, stream);
         }
         return hipGetLastError();
     }
