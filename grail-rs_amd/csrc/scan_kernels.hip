@@ -1,41 +1,46 @@
-// scan_kernels.hip — time-parallel synthesis for SMALL batches in fast (tolerance) arithmetic, gfx950.
+// scan_kernels.hip — time-parallel synthesis for small and mid-size batches in fast (tolerance) arithmetic, gfx950.
 //
 // The lane-per-utterance kernels of synth_kernels.hip need tens of thousands of utterances to fill an
-// MI355X; with a few hundred most SIMDs idle and the time per batch is the serial length of one
+// MI355X; with a few thousand most SIMDs idle and the time per batch is the serial length of one
 // utterance.  This kernel turns the mapping around: ONE WORKGROUP PER UTTERANCE, LANES = TIME.
 // The unit of work is a SUPER-TILE of up to 512 consecutive samples without an event inside.
 //
-//   wave 0 ("chain")      the per-utterance state of the reference, EXACT: Sequencer clock and segment
+//   chain wave            the per-utterance state of the reference, EXACT: Sequencer clock and segment
 //                         advances (src/lib.rs:859-932), jitter phase, wraps and redraws (:240-306,
-//                         :753-777), the pitch track, the carrier phase with its wrap (:520-525), the
-//                         carrier-noise LCG (:36-55, closed-form skip-ahead).  It walks the super-tile in
-//                         tiles of 64 samples, one per lane.  The clock `clk -= dt` and the jitter phase
-//                         `p += inc` are serial f32 accumulations; inside one binade they move by a constant
-//                         quantum (the increment rounded to that binade's grid), so lane j gets its value
-//                         as one fma, exactly; quantum and binade are kept from tile to tile and derived
-//                         afresh only after an event or where the binade ends.  The carrier phase is the one
-//                         truly serial quantity: fract(p + f_j) handed down the lanes with DPP wave_shr:1.
-//   wave 1 ("filters")    one super-tile behind, formant pair by formant pair (two formants = one packed
-//                         f32 vector; two pairs when formants 5-8 are provably dead, else four).  Lane j
-//                         owns the EIGHT consecutive samples 8j .. 8j+7: it evaluates their coefficients directly
-//                         (no interpolation), composes its eight steps of each recurrence into one affine
-//                         map, the 64 maps are combined by an inclusive scan over the lanes (six DPP steps:
-//                         row_shr 1/2/4/8, row_bcast 15/31 — north_star's "first-order-section parallel
-//                         scan"), and from the state the scan hands it the lane runs its eight samples with
-//                         the plain recurrence.  The one-pole low-pass (:538) is the map a -> (1-k) a + k x,
-//                         the Cytomic SVF (:565-571) the 2x2 affine map
+//                         :753-777), the pitch track.  It walks the super-tile in tiles of 64 samples, one per
+//                         lane.  The clock `clk -= dt` and the jitter phase `p += inc` are serial f32
+//                         accumulations; inside one binade they move by a constant quantum (the increment
+//                         rounded to that binade's grid), so lane j gets its value as one fma, exactly;
+//                         quantum and binade are kept from tile to tile and derived afresh only after an
+//                         event or where the binade ends.
+//   carrier               the carrier phase with its wrap (:520-525) is the one truly serial quantity:
+//                         fract(p + f_j) handed down the lanes with DPP wave_shr:1; then saw with polyBLEP
+//                         (:503-517) and the carrier-noise LCG (:36-55, closed-form skip-ahead).  In the chain
+//                         wave (two-stage workgroups, many utterances) or on a wave of its own, one super-tile
+//                         behind (three-stage workgroups, few utterances: the phase loop bounds the time).
+//   filter wave           one super-tile further behind, formant pair by formant pair (two formants = one
+//                         packed f32 vector; two pairs when formants 5-8 are provably dead, else four).
+//                         Lane j owns the EIGHT consecutive samples 8j .. 8j+7: it evaluates their
+//                         coefficients (at its first and last sample, interpolated in between under the
+//                         fast-tile error guard; directly where the guard fails), composes its eight steps of
+//                         each recurrence into one affine map, the 64 maps are combined by an inclusive scan
+//                         over the lanes (six DPP steps: row_shr 1/2/4/8, row_bcast 15/31 — north_star's
+//                         "first-order-section parallel scan"), and from the state the scan hands it the
+//                         lane runs its eight samples with the plain recurrence.  The one-pole low-pass
+//                         (:538) is the map a -> (1-k) a + k x, the Cytomic SVF (:565-571) the 2x2 affine map
 //                           [b'; c'] = [[2 a1 - 1, -2 a2], [2 a2, 1 - 2 a3]] [b; c] + v0 [2 a2; 2 a3],
 //                         composed as (M2, u2) o (M1, u1) = (M2 M1, M2 u1 + u2).  Work per sample: 8/8 of a
 //                         serial filter step + 1/8 of a scan, instead of a whole scan per 64 samples.
 //                         The pairs' band-pass outputs add up in formant order (:574) in registers and the
 //                         lane stores its eight samples (a wave writes 2 KB runs).
 //
-// Two pipeline stages one super-tile apart, double-buffered LDS in between, ONE workgroup barrier per
+// Pipeline stages one super-tile apart, double- or triple-buffered LDS in between, ONE workgroup barrier per
 // super-tile.  Two waves per utterance keep eight workgroups resident per CU, so that mid-size batches
-// (thousands of utterances) are bound by instruction issue, not by the latency of the serial chain.  Tolerance mode only (the scans reassociate the recurrences); the discontinuous state is
-// the reference's to the bit, so lengths and every boundary / wrap / saw edge sit where the reference puts
-// them.  The host only sends batches here whose every parameter is inside the proven-safe window
-// (grail_api.cpp scan_voice_ok): no NaN / Inf special cases exist on this path.
+// (thousands of utterances) are bound by instruction issue, not by the latency of the serial chain.
+// Tolerance mode only (the scans reassociate the recurrences); the discontinuous state is the reference's
+// to the bit, so lengths and every boundary / wrap / saw edge sit where the reference puts them.  The host
+// only sends batches here whose every parameter is inside the proven-safe window (grail_api.cpp
+// scan_voice_ok): no NaN / Inf special cases exist on this path.
 #include <cstdio>
 
 #include <type_traits>
@@ -48,7 +53,7 @@ namespace grail {
 namespace {
 
 constexpr int TL = 64;        // lanes per wave = samples per chain tile
-constexpr int CK = 8;         // consecutive samples owned by one lane of a pair wave
+constexpr int CK = 8;         // consecutive samples owned by one lane of the filter wave
 constexpr int ST = TL * CK;   // samples per super-tile
 
 struct __attribute__((aligned(16))) TileIn {
@@ -61,7 +66,7 @@ struct TileMeta {
     int pad;
 };
 
-// what the pair waves need of the current segment pair and jitter period (written by the chain wave)
+// what the filter wave needs of the current segment pair and jitter period (written by the chain wave)
 struct ParamBlock {
     float X[ELEM_FLOATS], Y[ELEM_FLOATS];      // emitted elem = X (1 - alpha) + Y alpha
     float ffc[NF], ffn[NF], fac[NF], fan[NF];  // formant-frequency / amplitude noise: current, next
@@ -134,8 +139,9 @@ typedef short vs8u __attribute__((ext_vector_type(8), aligned(2)));
 
 // NP: formant pairs, 2 (formants 5-8 proven dead, see live4_ok) or 4.
 // SPLIT: the carrier phase, saw and carrier noise run on a wave of their own, between the chain wave and the
-// filter wave (three pipeline stages): the serial phase loop is a third of the chain wave's time, and with few
+// filter wave (three pipeline stages): the serial phase loop is half of the chain wave's time, and with few
 // utterances the time per batch IS the chain wave's time.
+// amdgpu_waves_per_eu(4): 128 VGPRs (a handful spilled), so that eight two-wave workgroups fit a CU.
 template <int NP, bool SPLIT>
 __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_eu(4))) void scan_kernel(const SynthArgs A)
 {
