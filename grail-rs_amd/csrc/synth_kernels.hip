@@ -348,11 +348,13 @@ struct StateIO {
 // arithmetic keeps their band-pass state and output at exactly +0 for the whole batch, so the fold
 // only gains literal +0.0 terms.
 // PIPE: the four waves of a workgroup share ONE set of 16 utterances (small batches, idle SIMDs).
-// In calm tiles wave 0 runs the filter recurrences, wave 1 the per-utterance chain, waves 2 and 3 the
-// filter coefficients of alternate sample pairs, each stage handing its results on through LDS one
-// round behind the previous one (pipe_chain / pipe_coeffs / pipe_render below).  Outside calm tiles
-// every wave runs the whole step redundantly (only wave 0 stores), so all four carry the same
-// per-utterance state, take the same decisions and meet at the same barriers.
+// In calm tiles wave 0 runs the filter recurrences, wave 1 the per-utterance chain (its four lanes per
+// utterance sharing the sample pairs of a round) and a quarter of the filter coefficients, waves 2 and 3
+// the other coefficients, each stage handing its results on through LDS one round of 16 samples behind
+// the previous one (pipe_chain / pipe_coeffs / pipe_render below); runs of up to PIPE_MAX_TILES calm
+// tiles go through without draining the pipeline.  Outside calm tiles every wave runs the whole step
+// redundantly (only wave 0 stores), so all four carry the same per-utterance state, take the same
+// decisions and meet at the same barriers.
 // FAST: calm tiles run the tolerance-mode arithmetic (fast_tile below): the discontinuous per-utterance
 // state (Sequencer clock, jitter phase, carrier phase, the LCGs) is advanced exactly as in the exact
 // kernels, so no segment boundary, noise wrap or saw edge ever moves; the continuous per-formant
@@ -987,16 +989,17 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 
     // ---- PIPE: time_packed_steps cut in three, one piece per role, handed on through LDS.
     //   pipe_chain  (wave 1): clock, alpha, jitter phase, pitch blend and jitter, carrier phase, polyBLEP
-    //                         and saw of samples tc, tc+1 — the per-utterance chain, once for all formants
-    //   pipe_coeffs (waves 2, 3, alternate pairs): blend, jitter, 1-exp(smooth), the low-pass input, the
-    //                         turbulence mix, the jittered amplitude and a1, a2, a3 from that chain
-    //   pipe_render (wave 0): the two filter recurrence steps and the band-pass outputs
+    //                         and saw of four sample pairs — the per-utterance chain, once for all formants
+    //   pipe_coeffs (waves 2, 3; wave 1): blend, jitter, 1-exp(smooth), the low-pass input, the
+    //                         turbulence mix, the jittered amplitude, a1 and g from that chain
+    //   pipe_render (wave 0): a2 = g a1, a3 = g a2, the two filter recurrence steps and the band-pass outputs
     // Same operations on the same operands in the same order as time_packed_steps.
     // PIPE: a round is 2 * QP sample pairs.  QP = 2: each coefficient wave takes two of its four pairs.  QP = 4
     // (16 samples between barriers; the one in use): the coefficient waves take three pairs
     // each and the chain wave — the lightest stage — the last two of the round it wrote one phase before.
     constexpr int QP = PQP;
-    __shared__ float4 chain_all[PIPE ? 2 : 1][PIPE ? (QP + 1) / 2 : 1][PIPE ? 2 : 1][PIPE ? 64 : 1];   // [round&1][four pairs][q][lane]: lane (quad | pair) holds the pair's chain
+    // [round & 1][group of four pairs][q][lane]: lane (quad | pair) holds the pair's chain
+    __shared__ float4 chain_all[PIPE ? 2 : 1][PIPE ? (QP + 1) / 2 : 1][PIPE ? 2 : 1][PIPE ? 64 : 1];
     __shared__ float4 ring_all[PIPE ? 2 : 1][PIPE ? 2 * QP : 1][PIPE ? 3 : 1][PIPE ? 64 : 1];
     __shared__ float hand_all[PIPE ? 3 : 1][PIPE ? 64 : 1];
     // One round = four sample pairs.  The four lanes of a quad carry the same utterance (L = 4: its four
