@@ -269,6 +269,9 @@ def test_scan_kernel_edge_cases(gpu_ctx):
         [(A, 2.5 / 48000.0, 0.5, f), (E, 0.05, 0.0625, f)],
         [(A, 0.7, 0.25, 0.9 * f)],
         [(G.PH_STOP, 0.03, 0.03125, f), (G.PH_GLIDE, 0.03, 0.03125, f), (E, 0.06, 0.0625, 2 * f)],
+        # 4 ms blends: the coefficients move too fast for the eight-sample interpolation, its guard sends
+        # the super-tiles of the blend to the direct evaluation
+        [(A, 0.2, 0.00390625, f), (E, 0.2, 0.00390625, 1.2 * f), (A, 0.1, 0.00390625, 0.8 * f)],
     ] * 3
     segs = G.segments([s for u in utts for s in u])
     offs = np.cumsum([0] + [len(u) for u in utts]).astype(np.uint32)
