@@ -896,30 +896,12 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     // phase and the filter state links sample tc to tc+1, so everything else — blend, jitter,
     // tan_approx, the divisions, polyBLEP — is evaluated for both samples at once (.x = tc,
     // .y = tc+1): the same operations on the same operands as two quiet steps, two per issue slot.
-    auto time_packed_steps = [&](const int tc, const float nz0, const float nz1) __attribute__((always_inline)) {
+    // The per-formant part of two calm samples (.x = tc, .y = tc+1) from their chain values: blend, jitter,
+    // coefficients, the two filter steps.
+    auto formant_pair = [&](const f2 alpha, const f2 oma, const f2 JP, const f2 jomp, const f2 saw, const f2 NZ,
+                            const int tc) __attribute__((always_inline)) {
         if constexpr (W == 1 && NV == 1 && FOLD_IN_FLUSH) {
-            const f2 one2 = vsplat(1.0f, f2());
-            const float clk0 = clk - dt, clk1 = clk0 - dt;                     // :861
-            const float jp0 = jphase + jinc, jp1 = jp0 + jinc;                 // :242 / :291
-            clk = clk1;
-            jphase = jp1;
-            f2 CLK, JP, NZ;
-            CLK.x = clk0; CLK.y = clk1; JP.x = jp0; JP.y = jp1; NZ.x = nz0; NZ.y = nz1;
-            f2 ratio = CLK * inv_blend_length;
-            if constexpr (ANYBL) {
-                const f2 rem = vfma(-blend_length * one2, ratio, CLK);
-                const f2 quot = vfma(rem, inv_blend_length * one2, ratio);     // RN(clk / blend_length)
-                ratio = blend_pow2 ? ratio : quot;
-            }
-            f2 alpha;                                                          // :899/:908/:917
-            alpha.x = silent_pair ? 1.0f : __builtin_fminf(ratio.x, 1.0f);
-            alpha.y = silent_pair ? 1.0f : __builtin_fminf(ratio.y, 1.0f);
-            const f2 oma = 1.0f - alpha;
-            const f2 jomp = 1.0f - JP;
             // SynthesisElem::blend :404-414, Jitter::next :753-777
-            f2 frequency = X.frequency * oma + Y.frequency * alpha;
-            const f2 n_freq = fn_cur * jomp + fn_next * JP;                    // :254
-            frequency = frequency + n_freq * d_freq;                           // :763
             f2 e_freq = X.freq[0] * oma + Y.freq[0] * alpha;
             const f2 e_bw = X.bw[0] * oma + Y.bw[0] * alpha;
             const f2 e_smooth = X.smooth[0] * oma + Y.smooth[0] * alpha;
@@ -944,30 +926,6 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             const f2 a2 = g * a1;                                              // :561
             const f2 a3 = g * a2;                                              // :562
             const f2 tmix = (1.0f - e_turb) + NZ * e_turb;                     // :544-545
-            // carrier :503-525: the phase is the one carried quantity, two short serial steps
-            const f2 omf = 1.0f - frequency;
-            const float ph0 = phase;
-            const bool head0 = ph0 < frequency.x, tail0 = ph0 > omf.x;
-            const float ph1 = __builtin_amdgcn_fractf(ph0 + frequency.x);     // see quiet_step
-            const bool head1 = ph1 < frequency.y, tail1 = ph1 > omf.y;
-            phase = __builtin_amdgcn_fractf(ph1 + frequency.y);
-            f2 PH;
-            PH.x = ph0; PH.y = ph1;
-            const f2 phm1 = PH - 1.0f;
-            f2 dividend;
-            dividend.x = head0 ? ph0 : phm1.x;
-            dividend.y = head1 ? ph1 : phm1.y;
-            const f2 tt = div_exact<true>(dividend, frequency);
-            const f2 tt2 = tt * tt;
-            f2 s_tt2, sgn, polyblep;                                           // see quiet_step
-            s_tt2.x = __uint_as_float(__float_as_uint(tt2.x) ^ (head0 ? 0x80000000u : 0u));
-            s_tt2.y = __uint_as_float(__float_as_uint(tt2.y) ^ (head1 ? 0x80000000u : 0u));
-            sgn.x = head0 ? -1.0f : 1.0f;
-            sgn.y = head1 ? -1.0f : 1.0f;
-            const f2 pb = vfma(vsplat(2.0f, f2()), tt, s_tt2) + sgn;
-            polyblep.x = (head0 | tail0) ? pb.x : 0.0f;
-            polyblep.y = (head1 | tail1) ? pb.y : 0.0f;
-            const f2 saw = vfma(vsplat(2.0f, f2()), PH, -one2) - polyblep;     // :517
             const f2 nw = saw * (1.0f - e_breath) + NZ * e_breath;             // :531
             // the filter recurrences :538-571, sample tc then tc+1
 #pragma unroll
@@ -987,6 +945,110 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         }
     };
 
+    // One formant per lane, eight calm samples: the four lanes of a quad carry the same utterance, so the quad
+    // shares the per-utterance chain — quad lane i works out sample pair i (quad_chain), every lane then takes
+    // the four pairs' chain values from their lanes and runs its formant through them.
+    auto quad_bcast = [](const float x, auto sel_tag) __attribute__((always_inline)) {
+        constexpr int I = decltype(sel_tag)::value;
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), I * 0x55, 0xF, 0xF, true));   // quad_perm:[I,I,I,I]
+    };
+    // Only what is serial — the clock, the jitter phase, the carrier phase — is stepped through all eight
+    // samples by every lane (the reference's operations in the reference's order; a lane latches the values of
+    // its pair); alpha, pitch, polyBLEP and saw are evaluated once per pair instead of once per lane and pair.
+    auto quad_chain = [&](const float noise_of_step, const int first_step, f2 &alpha, f2 &JP, f2 &saw,
+                          f2 &NZ) __attribute__((always_inline)) {
+        static_assert(L >= 4 || !PIPE, "a quad of lanes per utterance");
+        const f2 one2 = vsplat(1.0f, f2());
+        const int jq = lane & 3;
+        float c = clk, p = jphase;
+        f2 CLK = vsplat(0.0f, f2());
+        JP = CLK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool me = jq == i;
+            c = c - dt;                                                        // :861
+            p = p + jinc;                                                      // :242 / :291
+            CLK.x = me ? c : CLK.x;
+            JP.x = me ? p : JP.x;
+            c = c - dt;
+            p = p + jinc;
+            CLK.y = me ? c : CLK.y;
+            JP.y = me ? p : JP.y;
+        }
+        clk = c;
+        jphase = p;
+        f2 ratio = CLK * inv_blend_length;
+        if constexpr (ANYBL) {
+            const f2 rem = vfma(-blend_length * one2, ratio, CLK);
+            const f2 quot = vfma(rem, inv_blend_length * one2, ratio);         // RN(clk / blend_length)
+            ratio = blend_pow2 ? ratio : quot;
+        }
+        alpha.x = silent_pair ? 1.0f : __builtin_fminf(ratio.x, 1.0f);         // :899/:908/:917
+        alpha.y = silent_pair ? 1.0f : __builtin_fminf(ratio.y, 1.0f);
+        const f2 oma = 1.0f - alpha;
+        const f2 jomp = 1.0f - JP;
+        f2 frequency = X.frequency * oma + Y.frequency * alpha;                // :404-414
+        const f2 n_freq = fn_cur * jomp + fn_next * JP;                        // :254
+        frequency = frequency + n_freq * d_freq;                               // :763
+        // carrier :503-525: the phase goes through the eight samples in order, pitch by pitch
+        float ph = phase;
+        f2 PH = vsplat(0.0f, f2());
+        auto two_steps = [&](auto sel_tag) __attribute__((always_inline)) {
+            constexpr int I = decltype(sel_tag)::value;
+            const bool me = jq == I;
+            PH.x = me ? ph : PH.x;
+            ph = __builtin_amdgcn_fractf(ph + quad_bcast(frequency.x, sel_tag));         // see quiet_step
+            PH.y = me ? ph : PH.y;
+            ph = __builtin_amdgcn_fractf(ph + quad_bcast(frequency.y, sel_tag));
+        };
+        two_steps(std::integral_constant<int, 0>());
+        two_steps(std::integral_constant<int, 1>());
+        two_steps(std::integral_constant<int, 2>());
+        two_steps(std::integral_constant<int, 3>());
+        phase = ph;
+        const f2 omf = 1.0f - frequency;
+        const bool head0 = PH.x < frequency.x, tail0 = PH.x > omf.x;
+        const bool head1 = PH.y < frequency.y, tail1 = PH.y > omf.y;
+        const f2 phm1 = PH - 1.0f;
+        f2 dividend;
+        dividend.x = head0 ? PH.x : phm1.x;
+        dividend.y = head1 ? PH.y : phm1.y;
+        const f2 tt = div_exact<true>(dividend, frequency);
+        const f2 tt2 = tt * tt;
+        f2 s_tt2, sgn, polyblep;                                               // see quiet_step
+        s_tt2.x = __uint_as_float(__float_as_uint(tt2.x) ^ (head0 ? 0x80000000u : 0u));
+        s_tt2.y = __uint_as_float(__float_as_uint(tt2.y) ^ (head1 ? 0x80000000u : 0u));
+        sgn.x = head0 ? -1.0f : 1.0f;
+        sgn.y = head1 ? -1.0f : 1.0f;
+        const f2 pb = vfma(vsplat(2.0f, f2()), tt, s_tt2) + sgn;
+        polyblep.x = (head0 | tail0) ? pb.x : 0.0f;
+        polyblep.y = (head1 | tail1) ? pb.y : 0.0f;
+        saw = vfma(vsplat(2.0f, f2()), PH, -one2) - polyblep;                  // :517
+        // the carrier noise of my two samples: lane t of noise_of_step holds the tile's step t
+        const int at = first_step + 2 * jq;
+        NZ.x = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * at, __float_as_int(noise_of_step)));
+        NZ.y = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * at + 4, __float_as_int(noise_of_step)));
+    };
+    auto time_packed_block = [&](const int tc, const float noise_of_step) __attribute__((always_inline)) {
+        if constexpr (W == 1 && NV == 1 && FOLD_IN_FLUSH && L >= 4) {
+            f2 alpha, JP, saw, NZ;
+            quad_chain(noise_of_step, tc, alpha, JP, saw, NZ);
+            auto pair_from = [&](auto sel_tag) __attribute__((always_inline)) {
+                constexpr int I = decltype(sel_tag)::value;
+                f2 al, jp, sw, nz;
+                al.x = quad_bcast(alpha.x, sel_tag); al.y = quad_bcast(alpha.y, sel_tag);
+                jp.x = quad_bcast(JP.x, sel_tag); jp.y = quad_bcast(JP.y, sel_tag);
+                sw.x = quad_bcast(saw.x, sel_tag); sw.y = quad_bcast(saw.y, sel_tag);
+                nz.x = quad_bcast(NZ.x, sel_tag); nz.y = quad_bcast(NZ.y, sel_tag);
+                formant_pair(al, 1.0f - al, jp, 1.0f - jp, sw, nz, tc + 2 * I);
+            };
+            pair_from(std::integral_constant<int, 0>());
+            pair_from(std::integral_constant<int, 1>());
+            pair_from(std::integral_constant<int, 2>());
+            pair_from(std::integral_constant<int, 3>());
+        }
+    };
+
     // ---- PIPE: time_packed_steps cut in three, one piece per role, handed on through LDS.
     //   pipe_chain  (wave 1): clock, alpha, jitter phase, pitch blend and jitter, carrier phase, polyBLEP
     //                         and saw of four sample pairs — the per-utterance chain, once for all formants
@@ -1002,85 +1064,14 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     __shared__ float4 chain_all[PIPE ? 2 : 1][PIPE ? (QP + 1) / 2 : 1][PIPE ? 2 : 1][PIPE ? 64 : 1];
     __shared__ float4 ring_all[PIPE ? 2 : 1][PIPE ? 2 * QP : 1][PIPE ? 3 : 1][PIPE ? 64 : 1];
     __shared__ float hand_all[PIPE ? 3 : 1][PIPE ? 64 : 1];
-    // One round = four sample pairs.  The four lanes of a quad carry the same utterance (L = 4: its four
-    // formants; L = 8: half of its eight), so the quad shares the round: quad lane i takes pair i.  Only what
-    // is serial — the clock, the jitter phase, the carrier phase — is stepped through all eight samples by
-    // every lane (the reference's operations in the reference's order; a lane latches the values of its pair);
-    // alpha, pitch, polyBLEP and saw are evaluated once per pair instead of once per lane and pair.
-    auto quad_bcast = [](const float x, auto sel_tag) __attribute__((always_inline)) {
-        constexpr int I = decltype(sel_tag)::value;
-        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), I * 0x55, 0xF, 0xF, true));   // quad_perm:[I,I,I,I]
-    };
+    // One round = groups of four sample pairs, each shared by the quad (quad_chain above).
     auto pipe_chain = [&](float4 (*dst)[64], const float noise_of_step, const int first_step) __attribute__((always_inline)) {
         if constexpr (PIPE) {
             static_assert(!PIPE || QP % 2 == 0, "a quad shares four pairs");
-            const f2 one2 = vsplat(1.0f, f2());
-            const int jq = lane & 3;
-            float c = clk, p = jphase;
-            f2 CLK = vsplat(0.0f, f2()), JP = CLK;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool me = jq == i;
-                c = c - dt;                                                    // :861
-                p = p + jinc;                                                  // :242 / :291
-                CLK.x = me ? c : CLK.x;
-                JP.x = me ? p : JP.x;
-                c = c - dt;
-                p = p + jinc;
-                CLK.y = me ? c : CLK.y;
-                JP.y = me ? p : JP.y;
-            }
-            clk = c;
-            jphase = p;
-            const f2 ratio = CLK * inv_blend_length;
-            f2 alpha;                                                          // :899/:908/:917
-            alpha.x = silent_pair ? 1.0f : __builtin_fminf(ratio.x, 1.0f);
-            alpha.y = silent_pair ? 1.0f : __builtin_fminf(ratio.y, 1.0f);
-            const f2 oma = 1.0f - alpha;
-            const f2 jomp = 1.0f - JP;
-            f2 frequency = X.frequency * oma + Y.frequency * alpha;            // :404-414
-            const f2 n_freq = fn_cur * jomp + fn_next * JP;                    // :254
-            frequency = frequency + n_freq * d_freq;                           // :763
-            // carrier :503-525: the phase goes through the eight samples in order, pitch by pitch
-            float ph = phase;
-            f2 PH = vsplat(0.0f, f2());
-            auto two_steps = [&](auto sel_tag) __attribute__((always_inline)) {
-                constexpr int I = decltype(sel_tag)::value;
-                const bool me = jq == I;
-                PH.x = me ? ph : PH.x;
-                ph = __builtin_amdgcn_fractf(ph + quad_bcast(frequency.x, sel_tag));     // see quiet_step
-                PH.y = me ? ph : PH.y;
-                ph = __builtin_amdgcn_fractf(ph + quad_bcast(frequency.y, sel_tag));
-            };
-            two_steps(std::integral_constant<int, 0>());
-            two_steps(std::integral_constant<int, 1>());
-            two_steps(std::integral_constant<int, 2>());
-            two_steps(std::integral_constant<int, 3>());
-            phase = ph;
-            const f2 omf = 1.0f - frequency;
-            const bool head0 = PH.x < frequency.x, tail0 = PH.x > omf.x;
-            const bool head1 = PH.y < frequency.y, tail1 = PH.y > omf.y;
-            const f2 phm1 = PH - 1.0f;
-            f2 dividend;
-            dividend.x = head0 ? PH.x : phm1.x;
-            dividend.y = head1 ? PH.y : phm1.y;
-            const f2 tt = div_exact<true>(dividend, frequency);
-            const f2 tt2 = tt * tt;
-            f2 s_tt2, sgn, polyblep;                                           // see quiet_step
-            s_tt2.x = __uint_as_float(__float_as_uint(tt2.x) ^ (head0 ? 0x80000000u : 0u));
-            s_tt2.y = __uint_as_float(__float_as_uint(tt2.y) ^ (head1 ? 0x80000000u : 0u));
-            sgn.x = head0 ? -1.0f : 1.0f;
-            sgn.y = head1 ? -1.0f : 1.0f;
-            const f2 pb = vfma(vsplat(2.0f, f2()), tt, s_tt2) + sgn;
-            polyblep.x = (head0 | tail0) ? pb.x : 0.0f;
-            polyblep.y = (head1 | tail1) ? pb.y : 0.0f;
-            const f2 saw = vfma(vsplat(2.0f, f2()), PH, -one2) - polyblep;     // :517
-            // the carrier noise of my two samples: lane t of noise_of_step holds the tile's step t
-            const int at = first_step + 2 * jq;
-            const float nz0 = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * at, __float_as_int(noise_of_step)));
-            const float nz1 = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * at + 4, __float_as_int(noise_of_step)));
+            f2 alpha, JP, saw, NZ;
+            quad_chain(noise_of_step, first_step, alpha, JP, saw, NZ);
             dst[0][lane] = make_float4(alpha.x, alpha.y, JP.x, JP.y);
-            dst[1][lane] = make_float4(saw.x, saw.y, nz0, nz1);
+            dst[1][lane] = make_float4(saw.x, saw.y, NZ.x, NZ.y);
         }
     };
     auto pipe_coeffs = [&](const float4 (*src)[64], const int pair, float4 (*dst)[64]) __attribute__((always_inline)) {
@@ -1784,14 +1775,9 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                             phase = hand_all[2][lane];
                         }
                     } else if constexpr (W == 1 && NV == 1 && FOLD_IN_FLUSH) {
+                        static_assert(!(W == 1 && NV == 1 && FOLD_IN_FLUSH) || (L >= 4 && T % 8 == 0), "blocks of eight, quads");
 #pragma unroll 1
-                        for (int tc = 0; tc < T; tc += 2) {
-                            const float nz0 = __builtin_bit_cast(
-                                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc));
-                            const float nz1 = __builtin_bit_cast(
-                                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc + 1));
-                            time_packed_steps(tc, nz0, nz1);
-                        }
+                        for (int tc = 0; tc < T; tc += 8) time_packed_block(tc, noise_of_lane);
                     } else if constexpr (GRAIL_SCALAR_PACK && STEPS_PER_TRIP == 2) {
 #pragma unroll 1
                         for (int tc = 0; tc < T; tc += 2) {
