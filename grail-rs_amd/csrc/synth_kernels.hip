@@ -1139,62 +1139,21 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     // float2 values (.x = tc, .y = tc+1), exactly as in time_packed_steps; only the carrier phase is
     // carried between the two.  The formant vectors, already packed across formants, then run
     // sample by sample with those scalars.
-    auto scalar_packed_steps = [&](auto nlive_tag, auto su_tag, const int tc, const float nz0,
+    // The per-formant part of two calm samples (.x = tc, .y = tc+1) from their chain values, formant vectors
+    // packed across formants: blend, jitter, coefficients and filters sample by sample.
+    auto scalar_formant_pair = [&](auto nlive_tag, auto su_tag, const f2 alpha, const f2 oma, const f2 JP,
+                                   const f2 jomp, const f2 saw2, const int tc, const float nz0,
                                    const float nz1) __attribute__((always_inline)) {
         constexpr int NLIVE = decltype(nlive_tag)::value;
         constexpr bool SU = decltype(su_tag)::value;
         constexpr bool KEEP_LP = STREAM;
         constexpr int NLP = (NLIVE < NV && !KEEP_LP) ? NLIVE : NV;
         const f2 one2 = vsplat(1.0f, f2());
-        const float clk0 = clk - dt, clk1 = clk0 - dt;                         // :861
-        const float jp0 = jphase + jinc, jp1 = jp0 + jinc;                     // :242 / :291
-        clk = clk1;
-        jphase = jp1;
-        f2 CLK, JP;
-        CLK.x = clk0; CLK.y = clk1; JP.x = jp0; JP.y = jp1;
-        f2 ratio = CLK * inv_blend_length;
-        if constexpr (ANYBL) {
-            const f2 rem = vfma(-blend_length * one2, ratio, CLK);
-            const f2 quot = vfma(rem, inv_blend_length * one2, ratio);         // RN(clk / blend_length)
-            ratio = blend_pow2 ? ratio : quot;
-        }
-        f2 alpha;                                                              // :899/:908/:917
-        alpha.x = silent_pair ? 1.0f : __builtin_fminf(ratio.x, 1.0f);
-        alpha.y = silent_pair ? 1.0f : __builtin_fminf(ratio.y, 1.0f);
-        const f2 oma = 1.0f - alpha;
-        const f2 jomp = 1.0f - JP;
-        f2 frequency = X.frequency * oma + Y.frequency * alpha;                // :404-414
-        const f2 n_freq = fn_cur * jomp + fn_next * JP;                        // :254
-        frequency = frequency + n_freq * d_freq;                               // :763
         f2 oml = one2;
         if constexpr (SU) {   // :404-414, :535 once for all formants (same operands, same bits)
             const f2 es = vget(X.smooth[0], 0) * oma + vget(Y.smooth[0], 0) * alpha;
             oml = 1.0f - exp_approx(es);
         }
-        // carrier :503-525
-        const f2 omf = 1.0f - frequency;
-        const float ph0 = phase;
-        const bool head0 = ph0 < frequency.x, tail0 = ph0 > omf.x;
-        const float ph1 = __builtin_amdgcn_fractf(ph0 + frequency.x);         // see quiet_step
-        const bool head1 = ph1 < frequency.y, tail1 = ph1 > omf.y;
-        phase = __builtin_amdgcn_fractf(ph1 + frequency.y);
-        f2 PH;
-        PH.x = ph0; PH.y = ph1;
-        const f2 phm1 = PH - 1.0f;
-        f2 dividend;
-        dividend.x = head0 ? ph0 : phm1.x;
-        dividend.y = head1 ? ph1 : phm1.y;
-        const f2 tt = div_exact<true>(dividend, frequency);
-        const f2 tt2 = tt * tt;
-        f2 s_tt2, sgn, polyblep;                                               // see quiet_step
-        s_tt2.x = __uint_as_float(__float_as_uint(tt2.x) ^ (head0 ? 0x80000000u : 0u));
-        s_tt2.y = __uint_as_float(__float_as_uint(tt2.y) ^ (head1 ? 0x80000000u : 0u));
-        sgn.x = head0 ? -1.0f : 1.0f;
-        sgn.y = head1 ? -1.0f : 1.0f;
-        const f2 pb = vfma(vsplat(2.0f, f2()), tt, s_tt2) + sgn;
-        polyblep.x = (head0 | tail0) ? pb.x : 0.0f;
-        polyblep.y = (head1 | tail1) ? pb.y : 0.0f;
-        const f2 saw2 = vfma(vsplat(2.0f, f2()), PH, -one2) - polyblep;        // :517
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const float a = vget(alpha, h), om = vget(oma, h), jp = vget(JP, h), jm = vget(jomp, h);
@@ -1251,6 +1210,75 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 }
                 if (j == L - 1) stage[t * SP + slot] = acc * 0.5f;
             }
+        }
+    };
+    auto scalar_packed_steps = [&](auto nlive_tag, auto su_tag, const int tc, const float nz0,
+                                   const float nz1) __attribute__((always_inline)) {
+        const f2 one2 = vsplat(1.0f, f2());
+        const float clk0 = clk - dt, clk1 = clk0 - dt;                         // :861
+        const float jp0 = jphase + jinc, jp1 = jp0 + jinc;                     // :242 / :291
+        clk = clk1;
+        jphase = jp1;
+        f2 CLK, JP;
+        CLK.x = clk0; CLK.y = clk1; JP.x = jp0; JP.y = jp1;
+        f2 ratio = CLK * inv_blend_length;
+        if constexpr (ANYBL) {
+            const f2 rem = vfma(-blend_length * one2, ratio, CLK);
+            const f2 quot = vfma(rem, inv_blend_length * one2, ratio);         // RN(clk / blend_length)
+            ratio = blend_pow2 ? ratio : quot;
+        }
+        f2 alpha;                                                              // :899/:908/:917
+        alpha.x = silent_pair ? 1.0f : __builtin_fminf(ratio.x, 1.0f);
+        alpha.y = silent_pair ? 1.0f : __builtin_fminf(ratio.y, 1.0f);
+        const f2 oma = 1.0f - alpha;
+        const f2 jomp = 1.0f - JP;
+        f2 frequency = X.frequency * oma + Y.frequency * alpha;                // :404-414
+        const f2 n_freq = fn_cur * jomp + fn_next * JP;                        // :254
+        frequency = frequency + n_freq * d_freq;                               // :763
+        // carrier :503-525
+        const f2 omf = 1.0f - frequency;
+        const float ph0 = phase;
+        const bool head0 = ph0 < frequency.x, tail0 = ph0 > omf.x;
+        const float ph1 = __builtin_amdgcn_fractf(ph0 + frequency.x);         // see quiet_step
+        const bool head1 = ph1 < frequency.y, tail1 = ph1 > omf.y;
+        phase = __builtin_amdgcn_fractf(ph1 + frequency.y);
+        f2 PH;
+        PH.x = ph0; PH.y = ph1;
+        const f2 phm1 = PH - 1.0f;
+        f2 dividend;
+        dividend.x = head0 ? ph0 : phm1.x;
+        dividend.y = head1 ? ph1 : phm1.y;
+        const f2 tt = div_exact<true>(dividend, frequency);
+        const f2 tt2 = tt * tt;
+        f2 s_tt2, sgn, polyblep;                                               // see quiet_step
+        s_tt2.x = __uint_as_float(__float_as_uint(tt2.x) ^ (head0 ? 0x80000000u : 0u));
+        s_tt2.y = __uint_as_float(__float_as_uint(tt2.y) ^ (head1 ? 0x80000000u : 0u));
+        sgn.x = head0 ? -1.0f : 1.0f;
+        sgn.y = head1 ? -1.0f : 1.0f;
+        const f2 pb = vfma(vsplat(2.0f, f2()), tt, s_tt2) + sgn;
+        polyblep.x = (head0 | tail0) ? pb.x : 0.0f;
+        polyblep.y = (head1 | tail1) ? pb.y : 0.0f;
+        const f2 saw2 = vfma(vsplat(2.0f, f2()), PH, -one2) - polyblep;        // :517
+        scalar_formant_pair(nlive_tag, su_tag, alpha, oma, JP, jomp, saw2, tc, nz0, nz1);
+    };
+    // L = 4 with two formants per lane: the quad shares the chain over eight calm samples (quad_chain above)
+    auto scalar_packed_block = [&](auto nlive_tag, auto su_tag, const int tc, const float noise_of_step) __attribute__((always_inline)) {
+        if constexpr (L >= 4) {
+            f2 alpha, JP, saw, NZ;
+            quad_chain(noise_of_step, tc, alpha, JP, saw, NZ);
+            auto pair_from = [&](auto sel_tag) __attribute__((always_inline)) {
+                constexpr int I = decltype(sel_tag)::value;
+                f2 al, jp, sw;
+                al.x = quad_bcast(alpha.x, sel_tag); al.y = quad_bcast(alpha.y, sel_tag);
+                jp.x = quad_bcast(JP.x, sel_tag); jp.y = quad_bcast(JP.y, sel_tag);
+                sw.x = quad_bcast(saw.x, sel_tag); sw.y = quad_bcast(saw.y, sel_tag);
+                scalar_formant_pair(nlive_tag, su_tag, al, 1.0f - al, jp, 1.0f - jp, sw, tc + 2 * I,
+                                    quad_bcast(NZ.x, sel_tag), quad_bcast(NZ.y, sel_tag));
+            };
+            pair_from(std::integral_constant<int, 0>());
+            pair_from(std::integral_constant<int, 1>());
+            pair_from(std::integral_constant<int, 2>());
+            pair_from(std::integral_constant<int, 3>());
         }
     };
 
@@ -1778,6 +1806,9 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                         static_assert(!(W == 1 && NV == 1 && FOLD_IN_FLUSH) || (L >= 4 && T % 8 == 0), "blocks of eight, quads");
 #pragma unroll 1
                         for (int tc = 0; tc < T; tc += 8) time_packed_block(tc, noise_of_lane);
+                    } else if constexpr (GRAIL_SCALAR_PACK && STEPS_PER_TRIP == 2 && L >= 4 && T % 8 == 0) {
+#pragma unroll 1
+                        for (int tc = 0; tc < T; tc += 8) scalar_packed_block(nlive_tag, su_tag, tc, noise_of_lane);
                     } else if constexpr (GRAIL_SCALAR_PACK && STEPS_PER_TRIP == 2) {
 #pragma unroll 1
                         for (int tc = 0; tc < T; tc += 2) {
