@@ -2,7 +2,8 @@
 samples — against the oracle, through per-utterance checksums (sum of the samples' bit patterns
 mod 2^64, computed on the device for the HIP rows and on the host for the oracle's).  The oracle
 renders the batch in chunks on all host cores; a few minutes of CPU, so it is not part of the
-default suite.  Last run: profiles/r01_full_parity.txt."""
+default suite.  GRAIL_SOAK_UTTS picks another batch size (another kernel family).  Last runs:
+profiles/r02_full_parity.txt."""
 import os
 
 import numpy as np
