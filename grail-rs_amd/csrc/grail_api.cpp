@@ -823,7 +823,7 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     // profiles/r02_small_batch.txt)
     const bool scan = a.fast && ctx->scan_option && !ctx->lanes_option &&
                       (int64_t)count * (batch_live4(ctx, batch) ? 4 : 7) <= 4 * ctx->scan_max_utts &&
-                      batch->phoneme_mode && ctx->voices_scan_ok && batch->plain && !batch->any_blend &&
+                      batch->phoneme_mode && ctx->voices_scan_ok && batch->plain &&
                       batch->min_length >= 2.0f * ctx->max_dt &&
                       batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f;
     ctx->last_formants = a.live4 ? 4 : 8;

@@ -209,7 +209,8 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
         float clk = 0.0f;
         const float dt = 1.0f / VO.sample_rate;                     // :944
         float xf = 0.25f, yf = 0.25f;                               // pitch of X and Y
-        float inv_bl = 1.0f;
+        float inv_bl = 1.0f, bl = 1.0f;                             // blend length: +-2^k (times the exact reciprocal) or any
+        bool bl_pow2 = true;
         bool silent_pair = true;
         int x_row = -1, y_row = -1;                                 // table rows behind X and Y (-1: silent())
         bool x_mute = false, y_mute = false;                        // copy_silent(): amplitudes zeroed
@@ -300,7 +301,10 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
                             if (!finished && cur.some) {                            // the match at :891-931
                                 const bool has_b = cur.elem >= 0, has_c = nxt.some && nxt.elem >= 0;
                                 silent_pair = !has_b && !has_c;
-                                inv_bl = 1.0f / cur.blend_length;                   // blend lengths are +-2^k here
+                                bl = cur.blend_length;
+                                const uint32_t blb = __float_as_uint(bl), ble = (blb >> 23) & 0xFFu;
+                                bl_pow2 = ((blb & 0x7FFFFFu) == 0u) && ble >= 1u && ble <= 253u;
+                                inv_bl = 1.0f / bl;                                 // exact when the length is +-2^k
                                 if (has_b && has_c) { x_row = nxt.elem; y_row = cur.elem; xf = nxt.frequency; yf = cur.frequency; x_mute = y_mute = false; }
                                 else if (has_b) { x_row = y_row = cur.elem; xf = yf = cur.frequency; x_mute = true; y_mute = false; }
                                 else if (has_c) { x_row = y_row = nxt.elem; xf = yf = nxt.frequency; x_mute = false; y_mute = true; }
@@ -397,7 +401,10 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
                         j_reg = j_reg && (__float_as_uint(j_last) >> 23) == j_e2 && j_e2 < 127u;
                     }
                     // ---- per lane: alpha, the pitch (exact: :404-414, :254, :763)
-                    float alpha = __builtin_fminf(cj * inv_bl, 1.0f);           // :899/:908/:917
+                    // clk / 2^k == clk * 2^-k for every clk; any other blend length takes the IEEE quotient
+                    float ratio = cj * inv_bl;
+                    if (!uni(bl_pow2)) ratio = cj / bl;
+                    float alpha = __builtin_fminf(ratio, 1.0f);                 // :899/:908/:917
                     alpha = silent_pair ? 1.0f : alpha;
                     const float oma = 1.0f - alpha, jomp = 1.0f - pj;
                     float frequency = xf * oma + yf * alpha;

@@ -295,18 +295,25 @@ def test_scan_kernel_edge_cases(gpu_ctx):
 
 
 def test_scan_kernel_gate_sends_unsafe_tables_elsewhere(gpu_ctx):
-    """A table outside the safe window (a formant at frequency 0: the reference emits NaN) and a batch
-    with a blend length that is not a power of two do not take the scan kernel."""
+    """A table outside the safe window (a formant at frequency 0: the reference emits NaN) does not take
+    the scan kernel.  Blend lengths that are not powers of two do (the chain wave then takes the IEEE
+    quotient clk / blend_length instead of the product with the exact reciprocal)."""
     v = G.voice_generic(48000.0)
     v.phonemes[0].formant_freq[7] = 0.0
     gpu_ctx.set_voices([v])
     segs, offs, vids, seeds = W.make_batch(8, length=0.05, blend_length=0.0625)
     out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, 16384)
     assert not gpu_ctx.last_kernel_name().startswith("scan_kernel")
-    gpu_ctx.set_voices(W.single_voice())
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
     segs, offs, vids, seeds = W.make_batch(8, length=0.05, blend_length=0.03)
     out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, 16384)
-    assert not gpu_ctx.last_kernel_name().startswith("scan_kernel")
+    assert gpu_ctx.last_kernel_name().startswith("scan_kernel")
+    ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, 16384)
+    assert np.array_equal(out_len, ref_len)
+    k = _worst(out, ref, ref_len)
+    print(f"scan kernel, blend length 0.03 s: max |d| = {k:.1f} * 2^-23")
+    assert 0.0 < k * ULP <= TOL
 
 
 def test_fast_mode_pcm16_rows_are_the_conversion_of_the_fast_f32_rows(gpu_ctx):
