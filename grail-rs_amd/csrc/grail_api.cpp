@@ -748,11 +748,16 @@ static bool batch_half_capable(const grail_ctx *ctx, const grail_batch *batch)
 // two samples long, so the Sequencer clock never goes negative and alpha stays in [0,1]; and
 // every pitch stays >= 2^-20 under the pitch jitter, so the polyBLEP quotient and with it the
 // saw every formant is fed from stay finite (a dead formant fed +-inf would emit NaN)
-static bool batch_live4(const grail_ctx *ctx, const grail_batch *batch)
+static bool batch_live4_any_blend(const grail_ctx *ctx, const grail_batch *batch)
 {
-    return batch_half_capable(ctx, batch) && ctx->voices_live4_ok && batch->plain && !batch->any_blend &&
+    return batch_half_capable(ctx, batch) && ctx->voices_live4_ok && batch->plain &&
            batch->min_length >= 2.0f * ctx->max_dt &&
            batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f;
+}
+// ... and (the lane kernels' four-formant instantiations) every blend length a power of two
+static bool batch_live4(const grail_ctx *ctx, const grail_batch *batch)
+{
+    return batch_live4_any_blend(ctx, batch) && !batch->any_blend;
 }
 
 // Rows [first, first + count) of the batch (count = 0: all of it).  out_dev / out_len_dev point at the
@@ -822,7 +827,7 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     // formants, ~5000 with eight — the filter wave then has four formant pairs to go through;
     // profiles/r02_small_batch.txt)
     const bool scan = a.fast && ctx->scan_option && !ctx->lanes_option &&
-                      (int64_t)count * (batch_live4(ctx, batch) ? 4 : 7) <= 4 * ctx->scan_max_utts &&
+                      (int64_t)count * (batch_live4_any_blend(ctx, batch) ? 4 : 7) <= 4 * ctx->scan_max_utts &&
                       batch->phoneme_mode && ctx->voices_scan_ok && batch->plain &&
                       batch->min_length >= 2.0f * ctx->max_dt &&
                       batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f;
@@ -832,7 +837,7 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
     hipError_t e;
     if (scan) {
-        a.live4 = batch_live4(ctx, batch) ? 1u : 0u;     // (the L = 8 rule above may have cleared it)
+        a.live4 = batch_live4_any_blend(ctx, batch) ? 1u : 0u;   // (the scan kernel takes any blend length)
         ctx->last_formants = a.live4 ? 4 : 8;
         a.resume = (uint32_t)ctx->scan_debug;
         // three-stage workgroups for few utterances (tools/scan_split_crossover.py: up to ~1500 with four

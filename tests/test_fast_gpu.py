@@ -308,7 +308,7 @@ def test_scan_kernel_gate_sends_unsafe_tables_elsewhere(gpu_ctx):
     gpu_ctx.set_voices(voices)
     segs, offs, vids, seeds = W.make_batch(8, length=0.05, blend_length=0.03)
     out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, 16384)
-    assert gpu_ctx.last_kernel_name().startswith("scan_kernel")
+    assert gpu_ctx.last_kernel_name().startswith("scan_kernel<pairs=2")      # four live formants: two pairs
     ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, 16384)
     assert np.array_equal(out_len, ref_len)
     k = _worst(out, ref, ref_len)
