@@ -198,7 +198,8 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       "time_parallel_scan_max_utterances" (default 8704; 4/7 of that when all eight formants are
  *       live) whose every parameter is inside the safe window run one workgroup per utterance with
  *       the time axis across the lanes and the filter recurrences solved by parallel scans
- *       (csrc/scan_kernels.hip): 256 utterances x 2 s in 1.2 ms instead of 11.5 ms, 4096 in 6.3 ms.
+ *       (csrc/scan_kernels.hip): 256 utterances x 2 s in 1.2 ms instead of 8.1 ms (exact arithmetic),
+ *       4096 in 6.3 ms instead of 8.2 ms.
  *       Up to "time_parallel_scan_split_max_utterances" (default 1536; half with eight live
  *       formants) the workgroups have three pipeline stages (the serial carrier phase on a wave of
  *       its own: lowest time per batch), above it two (more utterances resident per CU: highest
