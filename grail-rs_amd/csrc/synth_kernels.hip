@@ -1162,11 +1162,11 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 oml = 1.0f - exp_approx(es);
             }
         }
+        V E_freq[2][NV], E_bw[2][NV], E_smooth[2][NV], E_breath[2][NV], E_turb[2][NV], E_amp[2][NV];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const float a = vget(alpha, h), om = vget(oma, h), jp = vget(JP, h), jm = vget(jomp, h);
-            const float noise = h == 0 ? nz0 : nz1;
-            V e_freq[NV], e_bw[NV], e_smooth[NV], e_breath[NV], e_turb[NV], e_amp[NV];
+            V (&e_freq)[NV] = E_freq[h]; V (&e_bw)[NV] = E_bw[h]; V (&e_smooth)[NV] = E_smooth[h]; V (&e_breath)[NV] = E_breath[h]; V (&e_turb)[NV] = E_turb[h]; V (&e_amp)[NV] = E_amp[h];
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 if (k < NLP) {
@@ -1194,6 +1194,11 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 const V mul = 1.0f - delta;                                    // :772
                 e_amp[k] = e_amp[k] * mul;                                     // :773
             }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float noise = h == 0 ? nz0 : nz1;
+            V (&e_freq)[NV] = E_freq[h]; V (&e_bw)[NV] = E_bw[h]; V (&e_smooth)[NV] = E_smooth[h]; V (&e_breath)[NV] = E_breath[h]; V (&e_turb)[NV] = E_turb[h]; V (&e_amp)[NV] = E_amp[h];
             V v1[NV];
             formant_filters<true, NV, NLIVE, SU, KEEP_LP, V>(vget(saw2, h), noise, vget(oml, h), e_freq, e_bw,
                                                 e_smooth, e_breath, e_turb, e_amp, st_a, st_b, st_c, v1);
