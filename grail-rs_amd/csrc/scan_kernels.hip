@@ -303,7 +303,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
                                 silent_pair = !has_b && !has_c;
                                 bl = cur.blend_length;
                                 const uint32_t blb = __float_as_uint(bl), ble = (blb >> 23) & 0xFFu;
-                                bl_pow2 = ((blb & 0x7FFFFFu) == 0u) && ble >= 1u && ble <= 253u;
+                                bl_pow2 = uni(((blb & 0x7FFFFFu) == 0u) && ble >= 1u && ble <= 253u);
                                 inv_bl = 1.0f / bl;                                 // exact when the length is +-2^k
                                 if (has_b && has_c) { x_row = nxt.elem; y_row = cur.elem; xf = nxt.frequency; yf = cur.frequency; x_mute = y_mute = false; }
                                 else if (has_b) { x_row = y_row = cur.elem; xf = yf = cur.frequency; x_mute = true; y_mute = false; }
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
                     // ---- per lane: alpha, the pitch (exact: :404-414, :254, :763)
                     // clk / 2^k == clk * 2^-k for every clk; any other blend length takes the IEEE quotient
                     float ratio = cj * inv_bl;
-                    if (!uni(bl_pow2)) ratio = cj / bl;
+                    if (!bl_pow2) ratio = cj / bl;
                     float alpha = __builtin_fminf(ratio, 1.0f);                 // :899/:908/:917
                     alpha = silent_pair ? 1.0f : alpha;
                     const float oma = 1.0f - alpha, jomp = 1.0f - pj;
