@@ -1163,8 +1163,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             }
         }
         V E_freq[2][NV], E_bw[2][NV], E_smooth[2][NV], E_breath[2][NV], E_turb[2][NV], E_amp[2][NV];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        auto blend_h = [&](const int h) __attribute__((always_inline)) {
             const float a = vget(alpha, h), om = vget(oma, h), jp = vget(JP, h), jm = vget(jomp, h);
             V (&e_freq)[NV] = E_freq[h]; V (&e_bw)[NV] = E_bw[h]; V (&e_smooth)[NV] = E_smooth[h]; V (&e_breath)[NV] = E_breath[h]; V (&e_turb)[NV] = E_turb[h]; V (&e_amp)[NV] = E_amp[h];
 #pragma unroll
@@ -1194,9 +1193,8 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 const V mul = 1.0f - delta;                                    // :772
                 e_amp[k] = e_amp[k] * mul;                                     // :773
             }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        };
+        auto filter_h = [&](const int h) __attribute__((always_inline)) {
             const float noise = h == 0 ? nz0 : nz1;
             V (&e_freq)[NV] = E_freq[h]; V (&e_bw)[NV] = E_bw[h]; V (&e_smooth)[NV] = E_smooth[h]; V (&e_breath)[NV] = E_breath[h]; V (&e_turb)[NV] = E_turb[h]; V (&e_amp)[NV] = E_amp[h];
             V v1[NV];
@@ -1223,6 +1221,17 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 }
                 if (j == L - 1) stage[t * SP + slot] = acc * 0.5f;
             }
+        };
+        // two formant vectors: the blends of both samples before the filters of the first (measured: the
+        // better schedule); four: sample by sample (the register file does not hold both sets)
+        if constexpr (NLIVE <= 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) blend_h(h);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) filter_h(h);
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { blend_h(h); filter_h(h); }
         }
     };
     auto scalar_packed_steps = [&](auto nlive_tag, auto su_tag, const int tc, const float nz0,
@@ -1745,7 +1754,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     const float noise_of_lane = (__uint_as_float((sk >> 9) | 0x3F800000u) - 1.5f) * 2.0f;
                     // two steps per trip halve the loop overhead; with all four formant vectors
                     // live the doubled body no longer fits the register file (measured: slower)
-                    constexpr int STEPS_PER_TRIP = decltype(nlive_tag)::value <= 2 ? 2 : 1;
+                    constexpr int STEPS_PER_TRIP = 2;
                     static_assert(T % STEPS_PER_TRIP == 0, "whole trips");
                     bool rendered = true;
                     if constexpr (FAST) {
