@@ -1915,7 +1915,10 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             // No per-row conditions, so the LDS reads of all rows are in flight together (a lone wave has
             // nothing else to hide their latency behind) and the stores follow back to back.
             const bool all_full = __builtin_amdgcn_ballot_w64((j == L - 1) & (mine != (uint32_t)T)) == 0;
-            if (all_full && !A.out_pcm16 && vec_ok) {
+            // (not for the one-lane eight-formant kernels: they hold 256 VGPRs and AGPRs besides, and the extra
+            // path cost their f32 rows 4 %; their i16 rows take the general loop below)
+            constexpr bool PCM_FULL_TILE = !(L == 1 && NFA == NF);
+            if (all_full && (A.out_pcm16 ? (PCM_FULL_TILE && vec16_ok) : vec_ok)) {
                 wave_lds_sync();
                 float4 v[S / ROWS_PER_IT];
 #pragma unroll
@@ -1925,7 +1928,18 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     v[i] = make_float4(stage[(t0 + 0) * SP + r], stage[(t0 + 1) * SP + r], stage[(t0 + 2) * SP + r],
                                        stage[(t0 + 3) * SP + r]);
                 }
-                if (A.perm) {     // (two copies of the loop: the usual one without any LDS look-up)
+                if (PCM_FULL_TILE && A.out_pcm16) {
+                    // the WAV sink's `(x * i16::MAX as f32) as i16` (examples/cli.rs:49) on the way out: 8-byte stores
+#pragma unroll
+                    for (int i = 0; i < S / ROWS_PER_IT; ++i) {
+                        const int p0 = pcm16_from_f32(v[i].x), p1 = pcm16_from_f32(v[i].y);
+                        const int p2 = pcm16_from_f32(v[i].z), p3 = pcm16_from_f32(v[i].w);
+                        const uint64_t row = A.perm ? rowid[i * ROWS_PER_IT + rr] : u0 + i * ROWS_PER_IT + rr;
+                        *reinterpret_cast<uint2 *>(A.out_pcm16 + row * A.out_stride + base + rl * 4) =
+                            make_uint2((uint32_t)(p0 & 0xFFFF) | ((uint32_t)p1 << 16),
+                                       (uint32_t)(p2 & 0xFFFF) | ((uint32_t)p3 << 16));
+                    }
+                } else if (A.perm) {     // (two copies of the loop: the usual one without any LDS look-up)
 #pragma unroll
                     for (int i = 0; i < S / ROWS_PER_IT; ++i)
                         *reinterpret_cast<float4 *>(A.out + (uint64_t)rowid[i * ROWS_PER_IT + rr] * A.out_stride + base +
