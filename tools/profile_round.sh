@@ -16,6 +16,9 @@ python3 bench.py --verify --cpu-utts 0 --fast-leg 0 > $out/bench_n1_verify.json 
 rm -rf gpurun_out/prof/stats
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats -- python3 bench.py --cpu-utts 0 > $out/stats.log 2>&1
 cp gpurun_out/prof/stats/*/*kernel_stats.csv $out/kernel_stats.csv
+rm -rf gpurun_out/prof/stats2
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats2 -- python3 bench.py --config 2 --cpu-utts 0 > $out/stats2.log 2>&1
+cp gpurun_out/prof/stats2/*/*kernel_stats.csv $out/kernel_stats_config2.csv
 python3 tools/small_batch_bench.py > $out/small_batch.txt 2>&1
 python3 tools/stream_latency.py 2>/dev/null | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" > $out/stream_latency.txt
 python3 tools/host_output_bench.py > $out/host_output.txt 2>&1
