@@ -223,7 +223,6 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per utterance (0 = auto)")
     ap.add_argument("--pipeline", type=int, default=1, choices=[0, 1],
                     help="0 disables the small-batch producer/consumer kernels (A/B)")
-    ap.add_argument("--variant", type=int, default=0, help="kernel instantiation (experiments)")
     ap.add_argument("--pcm16", action="store_true",
                     help="i16 PCM rows (the WAV sink's conversion fused into the store), not the "
                          "headline: 2.01 algorithmic bytes per sample")
@@ -379,7 +378,6 @@ def main():
     first, last, segs, offs, vids, seeds = W.shard_inputs(n_utt, rank, world, len(voices))
     batch = ctx.upload(segs, offs, vids, seeds)
     ctx.set_option("lanes_per_utterance", args.lanes)
-    ctx.set_option("kernel_variant", args.variant)
     ctx.set_option("small_batch_pipeline", args.pipeline)
     ctx.set_option("arithmetic", 1 if args.mode == "fast" else 0)
     d_out = ctx.device_alloc(n_utt * stride * (2 if args.pcm16 else 4))

@@ -134,7 +134,6 @@ struct grail_ctx {
     uint64_t slow_steps = 0;          // of the kernels synced so far
     uint64_t fast_tiles = 0, general_steps = 0;
     int lanes_option = 0;             // 0 = auto
-    int variant_option = 0;           // experiments: explicit kernel instantiation
     int skip_silent_option = 1;       // skip band-pass filters of provably silent formants
     int pipeline_option = 1;          // small qualifying batches: producer/consumer workgroups
     uint64_t voices_epoch = 0;        // bumped by every install_voices
@@ -150,7 +149,6 @@ struct grail_stream {
     uint32_t *d_state = nullptr;   // [state_words(L)][lanes]
     uint64_t lanes = 0;
     int L = 1;
-    int variant = 0;
     bool started = false;
     // the kernel flavour, fixed when the stream is opened (the state layout follows it)
     bool live4 = false, half_capable = false, any_blend = false;
@@ -527,11 +525,6 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         ctx->scan_max_utts = value;
         return GRAIL_OK;
     }
-    if (std::strcmp(name, "kernel_variant") == 0) {
-        if (value < 0 || value > 1) return fail(GRAIL_ERR_INVALID_ARG, "kernel_variant out of range");
-        ctx->variant_option = (int)value;
-        return GRAIL_OK;
-    }
     return fail(GRAIL_ERR_INVALID_ARG, std::string("unknown option ") + name);
 }
 
@@ -540,10 +533,6 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
     if (!ctx || !name || !value) return fail(GRAIL_ERR_INVALID_ARG, "NULL argument");
     if (std::strcmp(name, "lanes_per_utterance") == 0) {
         *value = ctx->lanes_option;
-        return GRAIL_OK;
-    }
-    if (std::strcmp(name, "kernel_variant") == 0) {
-        *value = ctx->variant_option;
         return GRAIL_OK;
     }
     if (std::strcmp(name, "skip_silent_formants") == 0) {
@@ -847,7 +836,7 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
         ctx->last_kernel = a.live4 ? (a.pipe ? "scan_kernel<pairs=2,SPLIT,FAST>" : "scan_kernel<pairs=2,FAST>")
                                    : (a.pipe ? "scan_kernel<pairs=4,SPLIT,FAST>" : "scan_kernel<pairs=4,FAST>");
     } else {
-        e = launch_synth(a, L, ctx->variant_option, ctx->stream);
+        e = launch_synth(a, L, ctx->stream);
         ctx->last_kernel = last_kernel_name();
     }
     if (e != hipSuccess) return hip_fail(e, "synth kernel launch");
@@ -888,8 +877,7 @@ int grail_stream_open(grail_ctx *ctx, const grail_batch *batch, grail_stream **o
         else if (!ctx->lanes_option)         // same rule over four formants: the widest one-wave-per-SIMD mapping
             s->L = ((uint64_t)batch->n_utt * 4 + 63) / 64 <= 1024 ? 4 : ((uint64_t)batch->n_utt * 2 + 63) / 64 <= 1024 ? 2 : 1;
     }
-    s->variant = ctx->variant_option;
-    s->lanes = state_lanes(batch->n_utt, s->L, s->variant);
+    s->lanes = state_lanes(batch->n_utt, s->L);
     const size_t bytes = (size_t)state_words(s->L) * s->lanes * sizeof(uint32_t);
     hipError_t e = hipMalloc((void **)&s->d_state, bytes ? bytes : 4);
     if (e != hipSuccess) {
@@ -939,7 +927,7 @@ static int stream_next(grail_ctx *ctx, grail_stream *stream, uint32_t max_sample
     a.state_stride = stream->lanes;
     a.resume = stream->started ? 1u : 0u;
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
-    hipError_t e = launch_synth(a, stream->L, stream->variant, ctx->stream);
+    hipError_t e = launch_synth(a, stream->L, ctx->stream);
     if (e != hipSuccess) return hip_fail(e, "synth kernel launch");
     ctx->last_kernel = last_kernel_name();
     ctx->last_formants = a.live4 ? 4 : 8;

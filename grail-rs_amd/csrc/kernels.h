@@ -89,7 +89,7 @@ struct LenArgs {
 // the instantiation the calling thread's last launch_synth started, e.g. "synth_kernel<L=1,T=32,...>"
 const char *last_kernel_name();
 // lanes_per_utt in {1, 2, 4, 8}; returns hipSuccess or the launch error.
-hipError_t launch_synth(const SynthArgs &args, int lanes_per_utt, int variant, hipStream_t stream);
+hipError_t launch_synth(const SynthArgs &args, int lanes_per_utt, hipStream_t stream);
 hipError_t launch_lengths(const LenArgs &args, hipStream_t stream);
 // small batches, fast arithmetic: one workgroup per utterance, lanes = time, recurrences by parallel scan
 // (scan_kernels.hip).  args.live4 selects two formant-pair waves instead of four.
@@ -107,7 +107,7 @@ hipError_t launch_compare(const float *a, const float *b, uint64_t stride, const
                           hipStream_t stream);
 // resumable synthesis: words per lane and lanes per launch of the state buffer
 uint32_t state_words(int lanes_per_utt);
-uint64_t state_lanes(uint32_t n_utt, int lanes_per_utt, int variant);
+uint64_t state_lanes(uint32_t n_utt, int lanes_per_utt);
 // the choice made when the option is 0 (auto)
 int auto_lanes_per_utt(uint32_t n_utt);
 

@@ -1,0 +1,8 @@
+// synth_inst_fast_l2.hip — synth_kernel instantiations: 2 lane(s) per utterance, fast arithmetic.
+// <L, T, WAVES, MINW>: 64-thread workgroups are admitted 8 per CU (2 waves per SIMD, measured); L = 4 / 8 use
+// 256-thread workgroups so that more waves can be resident.
+#include "synth_launch_impl.h"
+
+namespace grail {
+void launch_fast_l2(const SynthArgs &args, hipStream_t stream) { launch_one_fast<2, 64, 1, 2>(args, stream); }
+}  // namespace grail

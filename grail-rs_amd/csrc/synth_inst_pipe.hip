@@ -1,0 +1,17 @@
+// synth_inst_pipe.hip — synth_kernel instantiations: the four-wave pipelined workgroups of small exact batches.
+// Render, chain, 2 x coefficients share 16 utterances (four live formants, 4 lanes each) or 8 utterances (eight
+// formants, 8 lanes each); rounds of 16 samples (73 KB of LDS: two workgroups fit a CU).
+#include "synth_launch_impl.h"
+
+namespace grail {
+void launch_pipe4(const SynthArgs &args, hipStream_t stream)
+{
+    const dim3 grid((args.n_utt + 15) / 16), block(256);
+    start<4, 64, 4, 1, false, false, false, 4, true, false, 4>(args, grid, block, stream);
+}
+void launch_pipe8(const SynthArgs &args, hipStream_t stream)
+{
+    const dim3 grid((args.n_utt + 7) / 8), block(256);
+    start<8, 64, 4, 1, false, false, false, NF, true, false, 4>(args, grid, block, stream);
+}
+}  // namespace grail

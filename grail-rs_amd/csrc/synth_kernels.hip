@@ -1,1976 +1,14 @@
-// synth_kernels.hip — the fused Selector -> Sequencer -> Jitter -> Synthesize kernel
-// for gfx950 (MI355X, CDNA4, wave64).  Hand-written HIP; no MFMA (the path is a
-// per-sample IIR recurrence, VALU-issue bound, ~4 B of HBM traffic per sample).
-//
-// Reference behaviour (file:line in the grail-rs tree):
-//   Selector::next    src/lib.rs:990-1005     Sequencer::next  src/lib.rs:859-932
-//   Jitter::next      src/lib.rs:753-777      Synthesize::next src/lib.rs:497-578
-//   ValueNoise        src/lib.rs:227-255      ArrayValueNoise  src/lib.rs:270-306
-//   random_f32 :36    tan_approx :63          exp_approx :75   Array::sum :123
-//
-// Mapping.  One wavefront renders S = 64/L utterances; the 8 formants of an
-// utterance are spread over L adjacent lanes (L in {1,2,4,8}, FPL = 8/L formants
-// per lane).  Time is serial (phase, clocks, RNG and filter states all carry
-// sample to sample, exactly as in the reference); the per-utterance scalar
-// state is recomputed identically in each of its L lanes so lanes never wait on
-// each other.  The 8-term `Array::sum` is a left fold and must stay one: for
-// L = 2 it runs as a chain down the lanes with DPP row_shr:1 hand-offs, for
-// L >= 4 the lanes park their band-pass outputs in LDS and the fold runs at
-// flush time.  Samples are staged through LDS for T steps and flushed as
-// 16-B-per-lane row stores, so every utterance row is written in contiguous
-// 4*T-byte runs (8-B stores for i16 PCM rows).
-//
-// Steps.  general_step: the literal control flow of the reference with IEEE
-// divisions, taken whenever some lane has an event (segment boundary, jitter
-// wrap, full row) or its segment pair is outside the proven operand window.
-// quiet_step: the same arithmetic straight-line, short exact divisions, behind
-// one ballot per step.  Calm tiles: T quiet steps without that ballot, when no
-// lane can have an event before the tile ends (see the tile loop).
-//
-// Exactness.  Built with -ffp-contract=off: the compiler never fuses a*b+c, so every
-// multiply and add of the reference is an individually rounded IEEE operation.  The
-// few explicit fma calls are places where a fused form is PROVEN to round the same
-// real number once (the division sequences, 5 - 4*p with an exact 4*p, 2*x - 1 with an
-// exact 2*x); divisions are correctly rounded (hipcc's IEEE sequence, or the
-// proven-equal short sequence div_exact<true>); f32 denormals are kept (the kernel
-// descriptor's default).  The result is bit-identical to the reference arithmetic,
-// whatever L is.
-//
-// Packed math.  A lone wave issues at most one instruction every ~5 cycles, whatever the
-// instruction (measured, tools/valu_microbench.hip), and the headline batch is exactly one
-// wave per SIMD, so the scarce resource is issue slots.  The per-formant arithmetic is
-// therefore written on float2 values, which hipcc lowers to v_pk_mul_f32 / v_pk_add_f32 /
-// v_pk_fma_f32: two formants per issue slot, each component still an individually
-// rounded IEEE operation.
+// synth_kernels.hip — dispatch of the fused Selector -> Sequencer -> Jitter -> Synthesize kernel (synth_kernel.h)
+// to its instantiation units (synth_inst_*.hip), the Sequencer-clock pre-pass, and the launch geometry.
 #include <cstdio>
-#include <type_traits>
 
 #include "device_common.h"
 #include "kernels.h"
-#include "pcm16.h"
-
-#ifndef GRAIL_SCALAR_PACK
-#define GRAIL_SCALAR_PACK 1
-#endif
-#ifndef GRAIL_FAST_G_SCALE
-#define GRAIL_FAST_G_SCALE 1048576.0f   // 2^22 / 4: interpolation error of G, H <= 2^-22 (fast_tile's guard)
-#endif
-#ifndef PIPE_MAX_TILES
-#define PIPE_MAX_TILES 8          // PIPE kernels: consecutive calm tiles rendered without draining the pipeline
-#endif
+#include "synth_launch.h"
 
 namespace grail {
 
 namespace {
-
-// lane i takes lane i-1's value (within its row of 16 lanes)
-__device__ __forceinline__ float dpp_from_lane_below(float x)
-{
-    return __int_as_float(
-        __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111 /* row_shr:1 */, 0xF, 0xF, true));
-}
-
-// LDS hand-off between lanes of ONE wave: same-wave DS operations execute in
-// order, so only compiler reordering has to be fenced.
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// the slice of a SynthesisElem that one lane owns: NV vectors of W formants
-template <int NV, typename V>
-struct Part {
-    float frequency;
-    V freq[NV], bw[NV], smooth[NV], breath[NV], turb[NV], amp[NV];
-};
-
-template <int NV, int W, typename V>
-__device__ __forceinline__ void load_part(Part<NV, V> &p, const float *__restrict__ elems,
-                                          int row, int f0)
-{
-    const float *e = elems + (size_t)row * ELEM_FLOATS + f0;
-    p.frequency = elems[(size_t)row * ELEM_FLOATS];
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-#pragma unroll
-        for (int c = 0; c < W; ++c) {
-            const int i = k * W + c;
-            vset(p.freq[k], c, e[F_FREQ + i]);
-            vset(p.bw[k], c, e[F_BW + i]);
-            vset(p.smooth[k], c, e[F_SMOOTH + i]);
-            vset(p.breath[k], c, e[F_BREATH + i]);
-            vset(p.turb[k], c, e[F_TURB + i]);
-            vset(p.amp[k], c, e[F_AMP + i]);
-        }
-    }
-}
-
-// SynthesisElem::silent(), src/lib.rs:367-377
-template <int NV, typename V>
-__device__ __forceinline__ void silent_part(Part<NV, V> &p)
-{
-    p.frequency = 0.25f;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        p.freq[k] = vsplat(0.25f, p.freq[k]);
-        p.bw[k] = vsplat(0.25f, p.bw[k]);
-        p.smooth[k] = vsplat(0.25f, p.smooth[k]);
-        p.breath[k] = vsplat(0.0f, p.breath[k]);
-        p.turb[k] = vsplat(0.0f, p.turb[k]);
-        p.amp[k] = vsplat(0.0f, p.amp[k]);
-    }
-}
-
-// The parallel formant filters of Synthesize::next, src/lib.rs:531-571, for the NV
-// formant vectors one lane owns.  SAFE selects the division flavour (same bits).
-// Written breadth-first (each step for every k before the next step) so that the NV
-// independent dependency chains interleave and hide each other's VALU latency.
-//
-// NLIVE < NV (quiet step only): vectors k >= NLIVE are "silent" for the whole segment pair —
-// amplitude exactly +0 in both blended elems and band-pass state exactly +0 (see
-// upper_half_is_silent) — so their v0 is +-0, their band-pass output w1 is exactly +0 and the
-// state stays +0 (a1*(+0) + a2*(+-0) = +0, (0 + a2*0) + a3*(+-0) = +0, 2*0 - 0 = +0).  Only
-// their one-pole low-pass state (:538) still has to advance; v1 = +0 is returned for the fold.
-#define FOR_K _Pragma("unroll") for (int k = 0; k < NV; ++k)
-#define FOR_L _Pragma("unroll") for (int k = 0; k < NLIVE; ++k)
-// SU = true (quiet step only): the blended smoothness is the same number for all of the lane's
-// formants (bit-equal table entries), so 1 - exp_approx(smooth) was evaluated once, as a scalar,
-// by the caller (`oml_s`): the same operations on the same operands give the same bits.
-// KEEP_LP = false (one-shot kernels, NLIVE < NV): the silent formants can never become audible in
-// this launch (their amplitude is 0 in every phoneme of the voice table), so even their low-pass
-// state is dead and is not advanced.  Resumable streams keep it (KEEP_LP = true).
-template <bool SAFE, int NV, int NLIVE, bool SU, bool KEEP_LP, typename V>
-__device__ __forceinline__ void formant_filters(const float saw, const float noise, const float oml_s,
-                                                const V (&e_freq)[NV], const V (&e_bw)[NV],
-                                                const V (&e_smooth)[NV], const V (&e_breath)[NV],
-                                                const V (&e_turb)[NV], const V (&e_amp)[NV],
-                                                V (&st_a)[NV], V (&st_b)[NV], V (&st_c)[NV],
-                                                V (&v1)[NV])
-{
-    if constexpr (!SAFE) {
-        static_assert(NLIVE == NV, "the IEEE flavour always runs every formant");
-        // the rare IEEE-division flavour, one formant vector at a time (fewest live registers)
-        FOR_K {
-            const V nw = saw * (1.0f - e_breath[k]) + noise * e_breath[k];      // :531
-            const V lp = exp_approx(e_smooth[k]);                               // :535
-            st_a[k] = st_a[k] + (1.0f - lp) * (nw - st_a[k]);                   // :538
-            const V tw = st_a[k] * ((1.0f - e_turb[k]) + noise * e_turb[k]);    // :544-545
-            const V v0 = tw * e_amp[k];                                         // :550
-            const V g = tan_approx<false>(e_freq[k]);                           // :555
-            const V kq = e_bw[k] / e_freq[k];                                   // :558
-            const V a1 = vsplat(1.0f, g) / (1.0f + g * (g + kq));               // :560
-            const V a2 = g * a1;                                                // :561
-            const V a3 = g * a2;                                                // :562
-            const V v3 = v0 - st_c[k];                                          // :565
-            const V w1 = a1 * st_b[k] + a2 * v3;                                // :566
-            const V w2 = (st_c[k] + a2 * st_b[k]) + a3 * v3;                    // :567
-            st_b[k] = 2.0f * w1 - st_b[k];                                      // :570
-            st_c[k] = 2.0f * w2 - st_c[k];                                      // :571
-            v1[k] = w1;
-        }
-        return;
-    } else {
-        V num[NLIVE], den[NLIVE], g[NLIVE], kq[NLIVE], a1[NLIVE], y[NLIVE], e[NLIVE], q[NLIVE],
-            r[NLIVE], d3[NLIVE], y2[NLIVE], e2[NLIVE], q2[NLIVE], r2[NLIVE];
-        const V one = vsplat(1.0f, st_a[0]);
-        const V five = vsplat(5.0f, st_a[0]);
-        const V m4 = vsplat(-4.0f, st_a[0]);
-        // tan_approx numerator / denominator, src/lib.rs:63-70.  In the SAFE operand window
-        // (4*a)*b == 4*(a*b) exactly (scaling by 4 commutes with rounding, nothing under- or
-        // overflows), so 5 - (4*a)*b == fma(-4, a*b, 5): one rounding of the same real number.
-        FOR_L {
-            const V x = e_freq[k];
-            const V omx = 1.0f - x;
-            const V xph = x + 0.5f;
-            const V hmx = 0.5f - x;
-            const V ox = omx * x;                       // (1-x)*x, shared by both polynomials
-            const V ph = xph * hmx;
-            num[k] = ox * vfma(m4, ph, five);           // ((1-x)*x) * (5 - (4*(x+.5))*(.5-x))
-            den[k] = (xph * vfma(m4, ox, five)) * hmx;  // ((x+.5) * (5 - (4*(1-x))*x)) * (.5-x)
-        }
-        // g = num/den and kq = bw/freq by div_exact<true>, a1 = 1/d3 by rcp_exact<true>,
-        // spelled out step by step across k
-        FOR_L { y[k] = vrcp(den[k]); y2[k] = vrcp(e_freq[k]); }
-        FOR_L { e[k] = vfma(-den[k], y[k], one); e2[k] = vfma(-e_freq[k], y2[k], one); }
-        FOR_L { y[k] = vfma(e[k], y[k], y[k]); y2[k] = vfma(e2[k], y2[k], y2[k]); }
-        FOR_L { q[k] = num[k] * y[k]; q2[k] = e_bw[k] * y2[k]; }
-        FOR_L { r[k] = vfma(-den[k], q[k], num[k]); r2[k] = vfma(-e_freq[k], q2[k], e_bw[k]); }
-        FOR_L { g[k] = vfma(r[k], y[k], q[k]); kq[k] = vfma(r2[k], y2[k], q2[k]); }   // :555, :558
-        FOR_L d3[k] = 1.0f + g[k] * (g[k] + kq[k]);                                   // :560
-        FOR_L y[k] = vrcp(d3[k]);
-        FOR_L e[k] = vfma(-d3[k], y[k], one);
-        FOR_L a1[k] = vfma(e[k], y[k], y[k]);
-        constexpr int NLP = (NLIVE < NV && !KEEP_LP) ? NLIVE : NV;   // low-pass states to advance
-#define FOR_P _Pragma("unroll") for (int k = 0; k < NLP; ++k)
-        V nw[NV];
-        FOR_P nw[k] = saw * (1.0f - e_breath[k]) + noise * e_breath[k];                   // :531
-        if constexpr (SU) {
-            FOR_P st_a[k] = st_a[k] + oml_s * (nw[k] - st_a[k]);                          // :535-538
-        } else {
-            V lp[NV];
-            FOR_P lp[k] = exp_approx(e_smooth[k]);                                        // :535
-            FOR_P st_a[k] = st_a[k] + (1.0f - lp[k]) * (nw[k] - st_a[k]);                 // :538
-        }
-#undef FOR_P
-        V tw[NLIVE], v0[NLIVE], a2[NLIVE], a3[NLIVE], v3[NLIVE], w1[NLIVE], w2[NLIVE];
-        // :544-545  1.0*(1-turb) + noise*turb; the multiply by 1.0 is exact and dropped
-        FOR_L tw[k] = st_a[k] * ((1.0f - e_turb[k]) + noise * e_turb[k]);
-        FOR_L v0[k] = tw[k] * e_amp[k];                                                   // :550
-        FOR_L a2[k] = g[k] * a1[k];                                                       // :561
-        FOR_L a3[k] = g[k] * a2[k];                                                       // :562
-        FOR_L v3[k] = v0[k] - st_c[k];                                                    // :565
-        FOR_L w1[k] = a1[k] * st_b[k] + a2[k] * v3[k];                                    // :566
-        FOR_L w2[k] = (st_c[k] + a2[k] * st_b[k]) + a3[k] * v3[k];                        // :567
-        FOR_L st_b[k] = 2.0f * w1[k] - st_b[k];                                           // :570
-        FOR_L st_c[k] = 2.0f * w2[k] - st_c[k];                                           // :571
-        FOR_L v1[k] = w1[k];
-#pragma unroll
-        for (int k = NLIVE; k < NV; ++k) v1[k] = vsplat(0.0f, st_a[0]);                   // exactly +0
-    }
-}
-#undef FOR_L
-#undef FOR_K
-
-// Can every division of the coming segment pair take the SAFE path?  Bounds every
-// divisor/dividend over the pair: alpha in [0,1] (clk >= 0 for the whole pair once it
-// is >= 0 at its first sample, blend_length > 0), the jitter noises in [-1,1] (0 <=
-// jitter_frequency <= 1 keeps the noise phase in (0,1]), so that
-//   x = formant_freq  in [2^-20, 1/2 - 2^-20]  =>  tan_approx num in [2^-18, 1.25], den in [2^-19, 5]
-//   w = formant_bw    in [2^-40, 2^10]         =>  w/x in [2^-39, 2^30],  1+g(g+w/x) in [1, 2^52]
-// all inside the proven [2^-60, 2^60] window.  Any NaN fails a comparison => false.
-template <int NV, int W, typename V>
-__device__ __forceinline__ bool pair_is_safe(const Part<NV, V> &X, const Part<NV, V> &Y, float clk,
-                                             float blend_length, float jinc, float d_ffreq,
-                                             float d_freq)
-{
-    constexpr float X_LO = 9.5367431640625e-07f;        // 2^-20
-    constexpr float X_HI = 0.5f - 9.5367431640625e-07f;
-    constexpr float W_LO = 1.8189894035458565e-12f;     // 2^-39 (2x margin over 2^-40)
-    constexpr float W_HI = 512.0f;                      // 2^9   (2x margin under 2^10)
-    const float jm = 1.002f * __builtin_fabsf(d_ffreq);
-    // carrier frequency (the polyBLEP divisor, src/lib.rs:505/509): in [2^-20, 1]; the
-    // dividend is the phase or phase-1, a sum of such frequencies: 0 or >= 2^-24 in magnitude
-    const float jf = 1.002f * __builtin_fabsf(d_freq);
-    bool ok = (clk >= 0.0f) && (blend_length > 0.0f) && (jinc >= 0.0f) && (jinc <= 1.0f) &&
-              (jm <= 1.0f) && (jf <= 1.0f) &&
-              (X.frequency * 0.999f - jf >= X_LO) && (Y.frequency * 0.999f - jf >= X_LO) &&
-              (X.frequency * 1.001f + jf <= 1.0f) && (Y.frequency * 1.001f + jf <= 1.0f);
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-#pragma unroll
-        for (int c = 0; c < W; ++c) {
-            const float xf = vget(X.freq[k], c), yf = vget(Y.freq[k], c);
-            const float xb = vget(X.bw[k], c), yb = vget(Y.bw[k], c);
-            ok = ok && (xf * 0.999f - jm >= X_LO) && (yf * 0.999f - jm >= X_LO) &&
-                 (xf * 1.001f + jm <= X_HI) && (yf * 1.001f + jm <= X_HI) &&
-                 (xb >= W_LO) && (yb >= W_LO) && (xb <= W_HI) && (yb <= W_HI);
-        }
-    }
-    return ok;
-}
-
-// Is the upper half of this lane's formant vectors silent for the coming segment pair?  Then the
-// quiet step may skip their band-pass filters (formant_filters<.., NLIVE = NV/2>) and still be
-// bit-identical.  Needs, for every such formant: amplitude exactly +0 in both blended elems and
-// 0 <= 0.5*jitter_delta_amplitude <= 1/4 (so the jittered amplitude 0*(1-delta) is +0, delta <=
-// 1/2), band-pass state b, c exactly +0, and breath / turbulence / smoothness in [0,1] with a
-// finite low-pass state (so tw = a*(..) is finite and v0 = tw*(+0) is +-0, never NaN).  Finite,
-// positive a1, a2, a3 and a finite saw come from pair_is_safe.
-template <int NV, int W, typename V>
-__device__ __forceinline__ bool upper_half_is_silent(const Part<NV, V> &X, const Part<NV, V> &Y,
-                                                     const V (&st_a)[NV], const V (&st_b)[NV],
-                                                     const V (&st_c)[NV], float amp_scale)
-{
-    bool ok = (amp_scale >= 0.0f) && (amp_scale <= 0.25f);
-#pragma unroll
-    for (int k = NV / 2; k < NV; ++k) {
-#pragma unroll
-        for (int c = 0; c < W; ++c) {
-            const float xb = vget(X.breath[k], c), yb = vget(Y.breath[k], c);
-            const float xt = vget(X.turb[k], c), yt = vget(Y.turb[k], c);
-            const float xs = vget(X.smooth[k], c), ys = vget(Y.smooth[k], c);
-            ok = ok && (__float_as_uint(vget(X.amp[k], c)) == 0u) &&
-                 (__float_as_uint(vget(Y.amp[k], c)) == 0u) &&
-                 (__float_as_uint(vget(st_b[k], c)) == 0u) &&
-                 (__float_as_uint(vget(st_c[k], c)) == 0u) &&
-                 (xb >= 0.0f) && (xb <= 1.0f) && (yb >= 0.0f) && (yb <= 1.0f) &&
-                 (xt >= 0.0f) && (xt <= 1.0f) && (yt >= 0.0f) && (yt <= 1.0f) &&
-                 (xs >= 0.0f) && (xs <= 1.0f) && (ys >= 0.0f) && (ys <= 1.0f) &&
-                 (__builtin_fabsf(vget(st_a[k], c)) <= 1.152921504606847e18f);   // 2^60
-        }
-    }
-    return ok;
-}
-
-// Resumable synthesis: the per-lane state that the reference keeps in
-// its Copy iterator structs (Sequencer :839-854, Jitter :724-748, Synthesize :470-488), moved
-// between registers and HBM word by word.  Layout: state[word][global lane], coalesced.
-template <bool LOAD>
-struct StateIO {
-    uint32_t *base;
-    size_t stride, lane;
-    uint32_t w = 0;
-    __device__ __forceinline__ uint32_t &slot() { return base[(size_t)(w++) * stride + lane]; }
-    __device__ __forceinline__ void operator()(uint32_t &v) { if (LOAD) v = slot(); else slot() = v; }
-    __device__ __forceinline__ void operator()(int &v)
-    {
-        if (LOAD) v = (int)slot(); else slot() = (uint32_t)v;
-    }
-    __device__ __forceinline__ void operator()(float &v)
-    {
-        if (LOAD) v = __uint_as_float(slot()); else slot() = __float_as_uint(v);
-    }
-    __device__ __forceinline__ void operator()(bool &v)
-    {
-        if (LOAD) v = slot() != 0u; else slot() = v ? 1u : 0u;
-    }
-    __device__ __forceinline__ void operator()(f2 &v)
-    {
-        float a = v.x, b = v.y;
-        (*this)(a);
-        (*this)(b);
-        v.x = a;
-        v.y = b;
-    }
-};
-
-// HALF: instantiate the quiet loops that skip a silent upper half of the lane's formants.  The
-// host only asks for it when the voice table can make use of it (or for resumable streams), so
-// batches whose formants are all audible run a kernel that does not carry those loops.
-// ANYBL: blend lengths that are not powers of two also take the quiet step (clk / blend_length by
-// the short exact division).  The host asks for it only when the batch holds such a segment, so the
-// usual case (the Intonator always emits 0.5, src/lib.rs:1071) runs a kernel without that code.
-// NFA: formants laid out over the lanes, 8 or 4.  NFA = 4 (phoneme batches only) renders
-// formants 1-4 and nothing else: the host has verified (grail_api.cpp, live4_ok) that formants 5-8
-// of every phoneme of every voice have amplitude +0 and parameters for which the reference's own
-// arithmetic keeps their band-pass state and output at exactly +0 for the whole batch, so the fold
-// only gains literal +0.0 terms.
-// PIPE: the four waves of a workgroup share ONE set of 16 utterances (small batches, idle SIMDs).
-// In calm tiles wave 0 runs the filter recurrences, wave 1 the per-utterance chain (its four lanes per
-// utterance sharing the sample pairs of a round) and a quarter of the filter coefficients, waves 2 and 3
-// the other coefficients, each stage handing its results on through LDS one round of 16 samples behind
-// the previous one (pipe_chain / pipe_coeffs / pipe_render below); runs of up to PIPE_MAX_TILES calm
-// tiles go through without draining the pipeline.  Outside calm tiles every wave runs the whole step
-// redundantly (only wave 0 stores), so all four carry the same per-utterance state, take the same
-// decisions and meet at the same barriers.
-// FAST: calm tiles run the tolerance-mode arithmetic (fast_tile below): the discontinuous per-utterance
-// state (Sequencer clock, jitter phase, carrier phase, the LCGs) is advanced exactly as in the exact
-// kernels, so no segment boundary, noise wrap or saw edge ever moves; the continuous per-formant
-// arithmetic uses fused multiply-adds, one uncorrected reciprocal per formant, and filter
-// coefficients interpolated linearly across the tile.  Tiles with an event run the exact steps.
-template <int L, int T, int WAVES, int MIN_WAVES_PER_SIMD, bool STREAM, bool HALF, bool ANYBL, int NFA = NF,
-          bool PIPE = false, bool FAST = false, int PQP = 2>
-__global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(const SynthArgs A)
-{
-    static_assert(!FAST || !PIPE, "FAST");
-    static_assert(NFA == NF || (NFA == 4 && !HALF), "NFA");
-    static_assert(!PIPE || (WAVES == 4 && NFA / L == 1 && L >= 4 && !STREAM && !HALF && !ANYBL && T % 4 == 0), "PIPE");
-    constexpr int FPL = NFA / L;         // formants per lane
-    constexpr int W = FPL >= 2 ? 2 : 1;  // formants per packed value
-    constexpr int NV = FPL / W;          // packed values per lane and field
-    typedef typename VecOf<W>::type V;
-    constexpr int S = 64 / L;            // utterances per wave
-    constexpr int SP = S + 1;            // padded row of the staging tile
-    static_assert(T % 4 == 0 && (64 % (T / 4)) == 0, "T");
-
-    // every wave of the block works alone on its own S utterances and its own
-    // slice of LDS: there is no inter-wave communication and no block barrier
-    // L >= 4: the lanes park all eight band-pass outputs of a sample and the left fold runs at
-    // flush time, spread over time steps, instead of a serial chain of L DPP hops per sample
-    constexpr bool FOLD_IN_FLUSH = L >= 4;
-    constexpr int STAGE_FLOATS = FOLD_IN_FLUSH ? T * S * NFA : T * SP;
-    __shared__ float stage_all[PIPE ? 1 : WAVES][STAGE_FLOATS];
-    __shared__ uint32_t cnt_all[PIPE ? 1 : WAVES][S];
-    const int wave = threadIdx.x / 64;
-    float *stage = stage_all[PIPE ? 0 : wave];
-    uint32_t *cnt = cnt_all[PIPE ? 0 : wave];
-    // PIPE: role 0 renders (owns stage, counts, output), role 1 carries the per-utterance chain,
-    // roles 2 and 3 prepare coefficients; `emit` is constant true otherwise
-    const int role = PIPE ? wave : 0;
-    const bool emit = !PIPE || role == 0;
-
-    const int lane = threadIdx.x % 64;
-    const int slot = lane / L;
-    const int j = lane % L;
-    const int f0 = j * FPL;
-    const uint32_t u0 = PIPE ? blockIdx.x * S : (blockIdx.x * WAVES + wave) * S;
-    // which utterance this slot renders: its position in the launch, or — ragged batches — the host's
-    // length-sorted assignment (A.perm), so that the lanes of a wave end together; rows, lengths and
-    // per-utterance inputs always belong to utterance `u`
-    const bool slot_used = u0 + slot < A.n_utt;
-    const uint32_t u = !slot_used ? A.n_utt : (A.perm ? A.perm[u0 + slot] : u0 + slot);
-    bool done = !slot_used;
-    const uint32_t uc = done ? 0u : u;
-    __shared__ uint32_t rowid_all[PIPE ? 1 : WAVES][S];
-    uint32_t *rowid = rowid_all[PIPE ? 0 : wave];
-    if (A.perm && j == L - 1) rowid[slot] = uc;
-
-    uint32_t vid = A.voice_ids ? A.voice_ids[uc] : 0u;
-    if (vid >= A.n_voices) vid = 0u;
-    const DevVoice VO = A.voices[vid];
-    const bool phoneme_mode = A.phoneme_mode != 0;
-    const float *__restrict__ elems = A.elems;
-
-    // ---- Sequencer state: IntoSequencer::sequence, src/lib.rs:941-949
-    uint32_t seg_pos = A.seg_offsets[uc];
-    const uint32_t seg_end = A.seg_offsets[uc + 1];
-    Seg cur, nxt;
-    cur.some = false; cur.elem = -1; cur.length = 0.0f; cur.blend_length = 1.0f; cur.frequency = 0.0f;
-    nxt = cur;
-    float clk = 0.0f;                        // Sequencer.time
-    const float dt = 1.0f / VO.sample_rate;  // :944
-    Part<NV, V> X, Y;                        // emitted elem = X*(1-alpha) + Y*alpha
-    silent_part(X);
-    silent_part(Y);
-    float blend_length = 1.0f;
-    float inv_blend_length = 1.0f;           // exact when blend_length is +-2^k
-    bool blend_pow2 = true;
-    bool blend_div_ok = false;               // ANYBL: clk / blend_length may use the short exact division
-    bool silent_pair = true;
-    bool pair_safe = false;                  // every division of this pair may use div_exact<true>
-
-    // ---- Jitter state: IntoJitter::jitter, src/lib.rs:786-797.  One seed is
-    // threaded through the three constructors (2 + 16 + 16 draws), each noise
-    // then keeps its own copy of the state.  The three noises share one phase
-    // sequence (same start, same increment), kept once.
-    uint32_t seed = A.seeds ? A.seeds[uc] : 0u;
-    // a resumed stream call loads all of this from its state block: skip the 34 draws
-    const bool fresh_start = !(STREAM && A.state && A.resume);
-    float fn_cur = 0.0f, fn_next = 0.0f;
-    if (fresh_start) {
-        fn_cur = lcg_f32(seed);              // ValueNoise::new :228-229
-        fn_next = lcg_f32(seed);
-    }
-    uint32_t fn_state = seed;
-    V ff_cur[NV], ff_next[NV], fa_cur[NV], fa_next[NV];
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        ff_cur[k] = vsplat(0.0f, ff_cur[k]); ff_next[k] = ff_cur[k];
-        fa_cur[k] = ff_cur[k]; fa_next[k] = ff_cur[k];
-    }
-    uint32_t ff_state = seed;
-    if (fresh_start) {
-#pragma unroll
-    for (int i = 0; i < NF; ++i) {           // ArrayValueNoise::new :275-278
-        const float c0 = lcg_f32(seed);
-        const float n0 = lcg_f32(seed);
-#pragma unroll
-        for (int k = 0; k < NV; ++k)
-#pragma unroll
-            for (int c = 0; c < W; ++c)
-                if (i == f0 + k * W + c) { vset(ff_cur[k], c, c0); vset(ff_next[k], c, n0); }
-    }
-    ff_state = seed;
-#pragma unroll
-    for (int i = 0; i < NF; ++i) {
-        const float c0 = lcg_f32(seed);
-        const float n0 = lcg_f32(seed);
-#pragma unroll
-        for (int k = 0; k < NV; ++k)
-#pragma unroll
-            for (int c = 0; c < W; ++c)
-                if (i == f0 + k * W + c) { vset(fa_cur[k], c, c0); vset(fa_next[k], c, n0); }
-    }
-    }
-    uint32_t fa_state = seed;
-    float jphase = 0.0f;
-    const float jinc = VO.jitter_frequency;
-    const float d_freq = VO.jitter_delta_frequency;
-    const float d_ffreq = VO.jitter_delta_formant_frequency;
-    const float amp_scale = 0.5f * VO.jitter_delta_amplitude;   // :769
-
-    // ---- Synthesize state: IntoSynthesize::synthesize, src/lib.rs:587-596
-    float phase = 0.0f;
-    V st_a[NV], st_b[NV], st_c[NV];
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        st_a[k] = vsplat(0.0f, st_a[k]);
-        st_b[k] = st_a[k];
-        st_c[k] = st_a[k];
-    }
-    uint32_t noise_seed = 0u;                // :594
-
-    const uint64_t cap = A.cap;              // samples this launch may write per row (<= out_stride)
-    const uint32_t cap32 = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;   // n_out is 32-bit
-    uint32_t n_out = 0;
-    uint32_t slow_steps = 0;                 // wave-steps that took the IEEE-division body
-    uint32_t fast_tiles = 0, general_steps = 0;   // statistics: tiles rendered by fast_tile, general steps taken
-    bool truncated = false;
-    const bool vec_ok = ((reinterpret_cast<uintptr_t>(A.out) & 15u) == 0) && ((A.out_stride & 3u) == 0);
-    const bool vec16_ok = ((reinterpret_cast<uintptr_t>(A.out_pcm16) & 7u) == 0) && ((A.out_stride & 3u) == 0);
-
-    // false while the lane's segment pair needs the IEEE-division body or has a blend
-    // length that is not a power of two: such lanes always take the general step
-    bool quiet_ok = false;
-
-    bool finished = false;   // the chain has returned None (persistent); `done` also covers pauses
-    // one-shot phoneme batches: the lane's upper formants have amplitude +0 in every phoneme of
-    // the voice table, so nothing in this launch can ever make them audible
-    bool upper_never_live = false;
-    if constexpr (HALF && NV >= 2 && !STREAM) {
-        upper_never_live = phoneme_mode;
-#pragma unroll
-        for (int p = 0; p < NUM_VOICED; ++p)
-#pragma unroll
-            for (int i = (NV / 2) * W; i < NV * W; ++i)
-                upper_never_live = upper_never_live &&
-                    (__float_as_uint(elems[(size_t)(VO.elem_base + p) * ELEM_FLOATS + F_AMP + f0 + i]) == 0u);
-    }
-    bool smooth_uniform = false; // this pair: X.smooth and Y.smooth are each one number for all formants
-    bool upper_silent = false;   // this pair: the lane's upper NV/2 formant vectors are silent
-    auto update_silent = [&]() __attribute__((always_inline)) {
-        if constexpr (HALF && NV >= 2)
-            upper_silent = A.skip_silent && pair_safe && (STREAM || upper_never_live) &&
-                           upper_half_is_silent<NV, W>(X, Y, st_a, st_b, st_c, amp_scale);
-        bool su = true;
-        const uint32_t xs0 = __float_as_uint(vget(X.smooth[0], 0));
-        const uint32_t ys0 = __float_as_uint(vget(Y.smooth[0], 0));
-#pragma unroll
-        for (int k = 0; k < NV; ++k)
-#pragma unroll
-            for (int c = 0; c < W; ++c)
-                su = su && (__float_as_uint(vget(X.smooth[k], c)) == xs0) &&
-                     (__float_as_uint(vget(Y.smooth[k], c)) == ys0);
-        smooth_uniform = su;
-    };
-
-    // (cur, nxt) -> X, Y, blend constants: the match of Sequencer::next resolved once per pair
-    auto setup_pair = [&]() __attribute__((always_inline)) {
-        // the match at :891-931, resolved once per segment pair
-        const bool has_b = cur.elem >= 0;
-        const bool has_c = nxt.some && nxt.elem >= 0;
-        blend_length = cur.blend_length;
-        silent_pair = !has_b && !has_c;
-        if (has_b && has_c) {          // c.blend(b, alpha)  :897-903
-            load_part<NV, W>(X, elems, nxt.elem, f0);
-            load_part<NV, W>(Y, elems, cur.elem, f0);
-            X.frequency = nxt.frequency;
-            Y.frequency = cur.frequency;
-        } else if (has_b) {            // b.copy_silent().blend(b, alpha)  :906-912
-            load_part<NV, W>(Y, elems, cur.elem, f0);
-            Y.frequency = cur.frequency;
-            X = Y;
-#pragma unroll
-            for (int k = 0; k < NV; ++k) X.amp[k] = vsplat(0.0f, X.amp[k]);
-        } else if (has_c) {            // c.blend(c.copy_silent(), alpha)  :915-921
-            load_part<NV, W>(X, elems, nxt.elem, f0);
-            X.frequency = nxt.frequency;
-            Y = X;
-#pragma unroll
-            for (int k = 0; k < NV; ++k) Y.amp[k] = vsplat(0.0f, Y.amp[k]);
-        } else {                       // SynthesisElem::silent()  :924-927
-            silent_part(X);
-            silent_part(Y);
-        }
-        // clk / 2^k == clk * 2^-k for every clk (same real number, same rounding)
-        const uint32_t blb = __float_as_uint(blend_length);
-        const uint32_t ble = (blb >> 23) & 0xFFu;
-        blend_pow2 = ((blb & 0x7FFFFFu) == 0u) && ble >= 1u && ble <= 253u;
-        inv_blend_length = 1.0f / blend_length;       // IEEE: RN(1/b), what div_exact<true> starts from
-        // any other blend length: q = clk*RN(1/b), r = fma(-b, q, clk), q' = fma(r, RN(1/b), q) is the
-        // correctly rounded clk/b while b and clk are in the proven window (tools/div_exhaustive.hip);
-        // clk <= length, and steps whose clk is below the window take the general step
-        if constexpr (ANYBL)
-            blend_div_ok = (blend_length >= 0x1p-59f) && (blend_length <= 0x1p59f) &&
-                           (cur.length <= 0x1p59f) && (dt >= 0x1p-59f);
-    };
-
-    constexpr bool streaming = STREAM;       // a separate instantiation: the one-shot kernel
-                                             // carries none of the state traffic or its registers
-    const size_t state_lane = (size_t)(blockIdx.x * WAVES + wave) * 64 + lane;
-    auto visit_state = [&](auto &io) __attribute__((always_inline)) {
-        io(seg_pos);
-        io(cur.some); io(cur.elem); io(cur.length); io(cur.blend_length); io(cur.frequency);
-        io(nxt.some); io(nxt.elem); io(nxt.length); io(nxt.blend_length); io(nxt.frequency);
-        io(clk); io(pair_safe); io(finished);
-        io(fn_cur); io(fn_next); io(fn_state); io(ff_state); io(fa_state); io(jphase);
-        io(phase); io(noise_seed);
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            io(ff_cur[k]); io(ff_next[k]); io(fa_cur[k]); io(fa_next[k]);
-            io(st_a[k]); io(st_b[k]); io(st_c[k]);
-        }
-    };
-    if (streaming && A.state && A.resume && u < A.n_utt) {
-        StateIO<true> io{A.state, A.state_stride, state_lane};
-        visit_state(io);
-        done = finished;
-        if (cur.some) setup_pair();
-        quiet_ok = pair_safe && (blend_pow2 || blend_div_ok);
-        update_silent();
-    }
-
-    // ---- the general sample step: any lane may be finished, advance a segment, wrap its
-    // jitter noise, hit the row capacity, or need the IEEE-division body.
-    auto general_step = [&](const int t) __attribute__((always_inline)) {
-        if (done) return;
-        if (streaming && n_out >= cap32) {   // this call's quota is used up: pause BEFORE advancing
-            done = true;
-            return;
-        }
-
-        // ================= Sequencer::next, src/lib.rs:859-932
-        clk -= dt;                                            // :861
-        if (__builtin_expect(clk < 0.0f, 0)) {                // :864
-            if (cur.some && nxt.some) {                       // :868
-                cur = nxt;
-                fetch_seg(nxt, A.segs, seg_pos, seg_end, phoneme_mode, VO.elem_base);
-                clk += cur.length;                            // :873
-            } else if (!cur.some && !nxt.some) {              // :876
-                fetch_seg(cur, A.segs, seg_pos, seg_end, phoneme_mode, VO.elem_base);
-                fetch_seg(nxt, A.segs, seg_pos, seg_end, phoneme_mode, VO.elem_base);
-                if (cur.some) clk += cur.length;              // :881-883
-            } else {
-                done = true;                                  // :886
-                finished = true;
-            }
-            if (!done && cur.some) {
-                setup_pair();
-                pair_safe = pair_is_safe<NV, W>(X, Y, clk, blend_length, jinc, d_ffreq, d_freq);
-                update_silent();
-            }
-        }
-        if (!cur.some) { done = true; finished = true; }      // :930
-        if (done) return;
-        if (__builtin_expect(n_out >= cap, 0)) {   // the chain would yield another sample: row is full
-            truncated = true;
-            done = true;
-            return;
-        }
-
-        // alpha = (time / blend_length).min(1.0)  :899/:908/:917.  A both-silent
-        // pair emits silent() itself (:926): alpha = 1 selects Y = silent() exactly
-        // (X*0 + Y*1 with finite X).
-        float ratio;
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!blend_pow2) == 0, 1))
-            ratio = clk * inv_blend_length;
-        else
-            ratio = blend_pow2 ? clk * inv_blend_length : clk / blend_length;
-        float alpha = __builtin_fminf(ratio, 1.0f);
-        alpha = silent_pair ? 1.0f : alpha;
-        const float oma = 1.0f - alpha;
-
-        // SynthesisElem::blend, src/lib.rs:404-414
-        float frequency = X.frequency * oma + Y.frequency * alpha;
-        V e_freq[NV], e_bw[NV], e_smooth[NV], e_breath[NV], e_turb[NV], e_amp[NV];
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            e_freq[k] = X.freq[k] * oma + Y.freq[k] * alpha;
-            e_smooth[k] = X.smooth[k] * oma + Y.smooth[k] * alpha;
-            e_bw[k] = X.bw[k] * oma + Y.bw[k] * alpha;
-            e_turb[k] = X.turb[k] * oma + Y.turb[k] * alpha;
-            e_breath[k] = X.breath[k] * oma + Y.breath[k] * alpha;
-            e_amp[k] = X.amp[k] * oma + Y.amp[k] * alpha;
-        }
-
-        // ================= Jitter::next, src/lib.rs:753-777
-        jphase += jinc;                                       // :242 / :291
-        if (__builtin_expect(jphase > 1.0f, 0)) {             // :245 / :294
-            jphase -= 1.0f;
-            fn_cur = fn_next;                                 // :249-250
-            fn_next = lcg_f32(fn_state);
-            uint32_t s1 = ff_state, s2 = fa_state;
-#pragma unroll
-            for (int k = 0; k < NV; ++k) { ff_cur[k] = ff_next[k]; fa_cur[k] = fa_next[k]; }
-#pragma unroll
-            for (int i = 0; i < NF; ++i) {                    // from_func order :301
-                const float r1 = lcg_f32(s1);
-                const float r2 = lcg_f32(s2);
-#pragma unroll
-                for (int k = 0; k < NV; ++k)
-#pragma unroll
-                    for (int c = 0; c < W; ++c)
-                        if (i == f0 + k * W + c) { vset(ff_next[k], c, r1); vset(fa_next[k], c, r2); }
-            }
-            ff_state = s1;
-            fa_state = s2;
-        }
-        const float jomp = 1.0f - jphase;
-        const float n_freq = fn_cur * jomp + fn_next * jphase;         // :254
-        frequency = frequency + n_freq * d_freq;                       // :763
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const V n_ff = ff_cur[k] * jomp + ff_next[k] * jphase;     // :305
-            const V n_fa = fa_cur[k] * jomp + fa_next[k] * jphase;
-            e_freq[k] = e_freq[k] + n_ff * d_ffreq;                    // :764
-            const V delta = (n_fa + 1.0f) * amp_scale;                 // :768-769
-            const V mul = 1.0f - delta;                                // :772
-            e_amp[k] = e_amp[k] * mul;                                 // :773
-        }
-
-        // ================= Synthesize::next, src/lib.rs:497-578
-        // polyBLEP saw: both branches divide by the jittered frequency  :503-514
-        const bool head = phase < frequency;
-        const bool tail = phase > (1.0f - frequency);
-        float polyblep = 0.0f;
-        if (__builtin_expect(head || tail, 0)) {
-            const float tt = (head ? phase : (phase - 1.0f)) / frequency;
-            polyblep = head ? ((2.0f * tt - (tt * tt)) - 1.0f)
-                            : (((tt * tt) + 2.0f * tt) + 1.0f);
-        }
-        const float saw = (2.0f * phase - 1.0f) - polyblep;            // :517
-        phase += frequency;                                            // :520
-        if (phase >= 1.0f) phase -= 1.0f;                              // :523-525
-        const float noise = lcg_f32(noise_seed);                       // :528
-
-        // events are rare: this step always takes the IEEE-division body (same bits)
-        V v1[NV];
-        bool fast_formants = false;
-        if constexpr (FAST) fast_formants = __builtin_amdgcn_ballot_w64(!pair_safe) == 0;
-        if (fast_formants) {
-            // FAST kernels, every lane's pair inside the safe window: the per-formant arithmetic of this
-            // sample in tolerance mode too (the control flow and the chain above stay the reference's) —
-            // reciprocals by v_rcp + one Newton step, fused multiply-adds, v1 = a1 (b + g v3), v2 = c + g v1
-            const V one = vsplat(1.0f, V()), five = vsplat(5.0f, V()), m4 = vsplat(-4.0f, V());
-            const V nms = vsplat(noise - saw, V()), nm1 = vsplat(noise - 1.0f, V()), sawv = vsplat(saw, V());
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                const V x = e_freq[k];
-                const V omx = 1.0f - x, xph = x + 0.5f, hmx = 0.5f - x;
-                const V ox = omx * x, ph_ = xph * hmx;
-                const V num = ox * vfma(m4, ph_, five);
-                const V den = (xph * vfma(m4, ox, five)) * hmx;
-                V rd = vrcp(den), rx = vrcp(x);
-                rd = vfma(vfma(-den, rd, one), rd, rd);
-                rx = vfma(vfma(-x, rx, one), rx, rx);
-                const V tg = num * rd;                                              // :555
-                const V kq = e_bw[k] * rx;                                          // :558
-                const V d3 = vfma(tg, tg + kq, one);
-                V a1 = vrcp(d3);
-                a1 = vfma(vfma(-d3, a1, one), a1, a1);                              // :560
-                const V oml = 1.0f - exp_approx(e_smooth[k]);                       // :535
-                const V nw = vfma(e_breath[k], nms, sawv);                          // :531
-                st_a[k] = vfma(oml, nw - st_a[k], st_a[k]);                         // :538
-                const V v0 = st_a[k] * (e_amp[k] * vfma(e_turb[k], nm1, one));      // :544-550
-                const V v3 = v0 - st_c[k];                                          // :565
-                const V w1 = a1 * vfma(tg, v3, st_b[k]);                            // :566
-                const V w2 = vfma(tg, w1, st_c[k]);                                 // :567
-                st_b[k] = vfma(vsplat(2.0f, V()), w1, -st_b[k]);                    // :570
-                st_c[k] = vfma(vsplat(2.0f, V()), w2, -st_c[k]);                    // :571
-                v1[k] = w1;
-            }
-        } else {
-            formant_filters<false, NV, NV, false, true, V>(saw, noise, 0.0f, e_freq, e_bw, e_smooth, e_breath, e_turb, e_amp,
-                                          st_a, st_b, st_c, v1);
-        }
-        if (!pair_safe) ++slow_steps;
-
-        // v1.sum() * 0.5: a left fold from 0.0 over formants 0..7  :574, :123-125,
-        // carried down the utterance's L lanes.
-        if constexpr (FOLD_IN_FLUSH) {
-#pragma unroll
-            for (int k = 0; k < NV; ++k)
-#pragma unroll
-                for (int c = 0; c < W; ++c)
-                    if (emit) stage[(t * S + slot) * NFA + f0 + k * W + c] = vget(v1[k], c);
-        } else {
-            float acc = 0.0f;
-#pragma unroll
-            for (int step = 0; step < L; ++step) {
-                float run = (step == 0) ? 0.0f : dpp_from_lane_below(acc);
-#pragma unroll
-                for (int k = 0; k < NV; ++k)
-#pragma unroll
-                    for (int c = 0; c < W; ++c) run = run + vget(v1[k], c);
-                if (NFA < NF && step == L - 1) run = run + 0.0f;   // formants 5-8: literal +0.0 terms
-                acc = (j == step) ? run : acc;
-            }
-            if (j == L - 1) stage[t * SP + slot] = acc * 0.5f;
-        }
-        ++n_out;
-    };
-
-    // ---- the quiet sample step: taken when a single ballot shows that NO lane of the wave
-    // has any of those events at this sample.  Same arithmetic, straight-line: the polyBLEP
-    // quotient is evaluated unconditionally with div_exact<true> and selected afterwards.
-    // CALM (calm_tag): the step belongs to a calm tile — no lane that still renders
-    // can have an event within the tile — so finished-lane masking is not needed, and the carrier
-    // noise (the same LCG state in every lane) arrives precomputed in `noise_in`.
-    auto quiet_step = [&](auto nlive_tag, auto su_tag, auto calm_tag, const int t, const float clk_next,
-                          const float jphase_next, const float noise_in) __attribute__((always_inline)) {
-        constexpr int NLIVE = decltype(nlive_tag)::value;   // vectors whose band-pass runs
-        constexpr bool SU = decltype(su_tag)::value;        // one smoothness for every formant
-        constexpr bool CALM = decltype(calm_tag)::value;
-        constexpr bool KEEP_LP = STREAM;                    // silent formants keep their low-pass
-        constexpr int NLP = (NLIVE < NV && !KEEP_LP) ? NLIVE : NV;
-        if constexpr (!CALM) {
-            if (done) return;                                              // finished lanes sit out
-        }
-        clk = clk_next;                                                    // :861
-        float ratio = clk * inv_blend_length;                              // exact quotient for 2^k
-        if constexpr (ANYBL) {
-            const float rem = vfma(-blend_length, ratio, clk);
-            const float quot = vfma(rem, inv_blend_length, ratio);         // RN(clk / blend_length)
-            ratio = blend_pow2 ? ratio : quot;
-        }
-        float alpha = __builtin_fminf(ratio, 1.0f);                        // :899/:908/:917
-        alpha = silent_pair ? 1.0f : alpha;
-        const float oma = 1.0f - alpha;
-        float frequency = X.frequency * oma + Y.frequency * alpha;         // :404-414
-        V e_freq[NV], e_bw[NV], e_smooth[NV], e_breath[NV], e_turb[NV], e_amp[NV];
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            if (k < NLP) {
-                e_breath[k] = X.breath[k] * oma + Y.breath[k] * alpha;
-                e_smooth[k] = SU ? e_breath[k] : X.smooth[k] * oma + Y.smooth[k] * alpha;
-            } else {
-                e_breath[k] = vsplat(0.0f, e_breath[k]);   // unused
-                e_smooth[k] = e_breath[k];
-            }
-            if (k < NLIVE) {
-                e_freq[k] = X.freq[k] * oma + Y.freq[k] * alpha;
-                e_bw[k] = X.bw[k] * oma + Y.bw[k] * alpha;
-                e_turb[k] = X.turb[k] * oma + Y.turb[k] * alpha;
-                e_amp[k] = X.amp[k] * oma + Y.amp[k] * alpha;
-            } else {   // silent vectors: no band-pass
-                e_freq[k] = e_breath[k]; e_bw[k] = e_breath[k]; e_turb[k] = e_breath[k]; e_amp[k] = e_breath[k];
-            }
-        }
-        float oml_s = 0.0f;
-        if constexpr (SU) {   // :404-414, :535 once for all formants (same operands, same bits)
-            const float es = vget(X.smooth[0], 0) * oma + vget(Y.smooth[0], 0) * alpha;
-            oml_s = 1.0f - exp_approx(es);
-        }
-        jphase = jphase_next;                                              // :242 / :291, no wrap
-        const float jomp = 1.0f - jphase;
-        const float n_freq = fn_cur * jomp + fn_next * jphase;             // :254
-        frequency = frequency + n_freq * d_freq;                           // :763
-#pragma unroll
-        for (int k = 0; k < NLIVE; ++k) {
-            const V n_ff = ff_cur[k] * jomp + ff_next[k] * jphase;         // :305
-            const V n_fa = fa_cur[k] * jomp + fa_next[k] * jphase;
-            e_freq[k] = e_freq[k] + n_ff * d_ffreq;                        // :764
-            const V delta = (n_fa + 1.0f) * amp_scale;                     // :768-769
-            const V mul = 1.0f - delta;                                    // :772
-            e_amp[k] = e_amp[k] * mul;                                     // :773
-        }
-        const bool head = phase < frequency;                               // :503
-        const bool tail = phase > (1.0f - frequency);                      // :507
-        const float tt = div_exact<true>(head ? phase : (phase - 1.0f), frequency);
-        // :506 (2t - t*t) - 1  and  :510 (t*t + 2t) + 1  are both (2t + s*(t*t)) + s with s = -1
-        // (head) or +1 (tail): a - b is a + (-b), IEEE addition commutes, s*(t*t) is a sign flip,
-        // and 2t is exact (|t| <= 1 here), so fma(2, t, .) rounds the same sum once
-        const float tt2 = tt * tt;
-        const float s_tt2 = __uint_as_float(__float_as_uint(tt2) ^ (head ? 0x80000000u : 0u));
-        const float pb = vfma(2.0f, tt, s_tt2) + (head ? -1.0f : 1.0f);
-        const float polyblep = (head | tail) ? pb : 0.0f;
-        // :517  2*phase is exact (0 <= phase < 1), so the fma rounds the same difference once
-        const float saw = vfma(2.0f, phase, -1.0f) - polyblep;
-        // :520-525  `p += f; if p >= 1 { p -= 1 }` == fract(p + f) for 0 <= p < 1, 0 < f <= 1 (pair_is_safe):
-        // x - 1 is exact for x in [1, 2), so both branches give the reference's bits in one instruction
-        phase = __builtin_amdgcn_fractf(phase + frequency);
-        float noise;                                                       // :528
-        if constexpr (CALM) noise = noise_in;
-        else noise = lcg_f32(noise_seed);
-        V v1[NV];
-        formant_filters<true, NV, NLIVE, SU, KEEP_LP, V>(saw, noise, oml_s, e_freq, e_bw, e_smooth, e_breath, e_turb,
-                                            e_amp, st_a, st_b, st_c, v1);
-        if constexpr (FOLD_IN_FLUSH) {
-#pragma unroll
-            for (int k = 0; k < NV; ++k)
-#pragma unroll
-                for (int c = 0; c < W; ++c)
-                    if (emit) stage[(t * S + slot) * NFA + f0 + k * W + c] = vget(v1[k], c);   // silent: +0
-        } else {
-            float acc = 0.0f;
-#pragma unroll
-            for (int step = 0; step < L; ++step) {
-                float run = (step == 0) ? 0.0f : dpp_from_lane_below(acc);
-#pragma unroll
-                for (int k = 0; k < NLIVE; ++k)
-#pragma unroll
-                    for (int c = 0; c < W; ++c) run = run + vget(v1[k], c);
-                // the silent formants' terms are literal +0.0: ((x + 0) + 0) + ... == x + 0
-                if (NLIVE < NV || (NFA < NF && step == L - 1)) run = run + 0.0f;
-                acc = (j == step) ? run : acc;
-            }
-            if (j == L - 1) stage[t * SP + slot] = acc * 0.5f;
-        }
-        if constexpr (!CALM) ++n_out;      // a calm tile adds its T samples at once
-    };
-
-    // ---- L = 8 (one formant per lane): the packed slot that holds a second formant for smaller L
-    // takes the SAME formant at the NEXT sample instead.  In a calm tile nothing but the carrier
-    // phase and the filter state links sample tc to tc+1, so everything else — blend, jitter,
-    // tan_approx, the divisions, polyBLEP — is evaluated for both samples at once (.x = tc,
-    // .y = tc+1): the same operations on the same operands as two quiet steps, two per issue slot.
-    // The per-formant part of two calm samples (.x = tc, .y = tc+1) from their chain values: blend, jitter,
-    // coefficients, the two filter steps.
-    auto formant_pair = [&](const f2 alpha, const f2 oma, const f2 JP, const f2 jomp, const f2 saw, const f2 NZ,
-                            const int tc) __attribute__((always_inline)) {
-        if constexpr (W == 1 && NV == 1 && FOLD_IN_FLUSH) {
-            // SynthesisElem::blend :404-414, Jitter::next :753-777
-            f2 e_freq = X.freq[0] * oma + Y.freq[0] * alpha;
-            const f2 e_bw = X.bw[0] * oma + Y.bw[0] * alpha;
-            const f2 e_smooth = X.smooth[0] * oma + Y.smooth[0] * alpha;
-            const f2 e_breath = X.breath[0] * oma + Y.breath[0] * alpha;
-            const f2 e_turb = X.turb[0] * oma + Y.turb[0] * alpha;
-            f2 e_amp = X.amp[0] * oma + Y.amp[0] * alpha;
-            const f2 n_ff = ff_cur[0] * jomp + ff_next[0] * JP;                // :305
-            const f2 n_fa = fa_cur[0] * jomp + fa_next[0] * JP;
-            e_freq = e_freq + n_ff * d_ffreq;                                  // :764
-            const f2 delta = (n_fa + 1.0f) * amp_scale;                        // :768-769
-            e_amp = e_amp * (1.0f - delta);                                    // :772-773
-            // Synthesize::next coefficients :535, :555-562 (as formant_filters<true>)
-            const f2 oml = 1.0f - exp_approx(e_smooth);
-            const f2 omx = 1.0f - e_freq, xph = e_freq + 0.5f, hmx = 0.5f - e_freq;
-            const f2 ox = omx * e_freq, ph = xph * hmx;
-            const f2 five = vsplat(5.0f, f2()), m4 = vsplat(-4.0f, f2());
-            const f2 num = ox * vfma(m4, ph, five);
-            const f2 den = (xph * vfma(m4, ox, five)) * hmx;
-            const f2 g = div_exact<true>(num, den);                            // :555
-            const f2 kq = div_exact<true>(e_bw, e_freq);                       // :558
-            const f2 a1 = rcp_exact<true>(1.0f + g * (g + kq));                // :560
-            const f2 a2 = g * a1;                                              // :561
-            const f2 a3 = g * a2;                                              // :562
-            const f2 tmix = (1.0f - e_turb) + NZ * e_turb;                     // :544-545
-            const f2 nw = saw * (1.0f - e_breath) + NZ * e_breath;             // :531
-            // the filter recurrences :538-571, sample tc then tc+1
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float sa = st_a[0], sb = st_b[0], sc = st_c[0];
-                sa = sa + vget(oml, h) * (vget(nw, h) - sa);                   // :538
-                const float tw = sa * vget(tmix, h);
-                const float v0 = tw * vget(e_amp, h);                          // :550
-                const float v3 = v0 - sc;                                      // :565
-                const float w1 = vget(a1, h) * sb + vget(a2, h) * v3;          // :566
-                const float w2 = (sc + vget(a2, h) * sb) + vget(a3, h) * v3;   // :567
-                st_a[0] = sa;
-                st_b[0] = 2.0f * w1 - sb;                                      // :570
-                st_c[0] = 2.0f * w2 - sc;                                      // :571
-                stage[((tc + h) * S + slot) * NFA + f0] = w1;
-            }
-        }
-    };
-
-    // One formant per lane, eight calm samples: the four lanes of a quad carry the same utterance, so the quad
-    // shares the per-utterance chain — quad lane i works out sample pair i (quad_chain), every lane then takes
-    // the four pairs' chain values from their lanes and runs its formant through them.
-    auto quad_bcast = [](const float x, auto sel_tag) __attribute__((always_inline)) {
-        constexpr int I = decltype(sel_tag)::value;
-        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), I * 0x55, 0xF, 0xF, true));   // quad_perm:[I,I,I,I]
-    };
-    // Only what is serial — the clock, the jitter phase, the carrier phase — is stepped through all eight
-    // samples by every lane (the reference's operations in the reference's order; a lane latches the values of
-    // its pair); alpha, pitch, polyBLEP and saw are evaluated once per pair instead of once per lane and pair.
-    auto quad_chain = [&](const float noise_of_step, const int first_step, f2 &alpha, f2 &JP, f2 &saw,
-                          f2 &NZ) __attribute__((always_inline)) {
-        static_assert(L >= 4 || !PIPE, "a quad of lanes per utterance");
-        const f2 one2 = vsplat(1.0f, f2());
-        const int jq = lane & 3;
-        float c = clk, p = jphase;
-        f2 CLK = vsplat(0.0f, f2());
-        JP = CLK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool me = jq == i;
-            c = c - dt;                                                        // :861
-            p = p + jinc;                                                      // :242 / :291
-            CLK.x = me ? c : CLK.x;
-            JP.x = me ? p : JP.x;
-            c = c - dt;
-            p = p + jinc;
-            CLK.y = me ? c : CLK.y;
-            JP.y = me ? p : JP.y;
-        }
-        clk = c;
-        jphase = p;
-        f2 ratio = CLK * inv_blend_length;
-        if constexpr (ANYBL) {
-            const f2 rem = vfma(-blend_length * one2, ratio, CLK);
-            const f2 quot = vfma(rem, inv_blend_length * one2, ratio);         // RN(clk / blend_length)
-            ratio = blend_pow2 ? ratio : quot;
-        }
-        alpha.x = silent_pair ? 1.0f : __builtin_fminf(ratio.x, 1.0f);         // :899/:908/:917
-        alpha.y = silent_pair ? 1.0f : __builtin_fminf(ratio.y, 1.0f);
-        const f2 oma = 1.0f - alpha;
-        const f2 jomp = 1.0f - JP;
-        f2 frequency = X.frequency * oma + Y.frequency * alpha;                // :404-414
-        const f2 n_freq = fn_cur * jomp + fn_next * JP;                        // :254
-        frequency = frequency + n_freq * d_freq;                               // :763
-        // carrier :503-525: the phase goes through the eight samples in order, pitch by pitch
-        float ph = phase;
-        f2 PH = vsplat(0.0f, f2());
-        auto two_steps = [&](auto sel_tag) __attribute__((always_inline)) {
-            constexpr int I = decltype(sel_tag)::value;
-            const bool me = jq == I;
-            PH.x = me ? ph : PH.x;
-            ph = __builtin_amdgcn_fractf(ph + quad_bcast(frequency.x, sel_tag));         // see quiet_step
-            PH.y = me ? ph : PH.y;
-            ph = __builtin_amdgcn_fractf(ph + quad_bcast(frequency.y, sel_tag));
-        };
-        two_steps(std::integral_constant<int, 0>());
-        two_steps(std::integral_constant<int, 1>());
-        two_steps(std::integral_constant<int, 2>());
-        two_steps(std::integral_constant<int, 3>());
-        phase = ph;
-        const f2 omf = 1.0f - frequency;
-        const bool head0 = PH.x < frequency.x, tail0 = PH.x > omf.x;
-        const bool head1 = PH.y < frequency.y, tail1 = PH.y > omf.y;
-        const f2 phm1 = PH - 1.0f;
-        f2 dividend;
-        dividend.x = head0 ? PH.x : phm1.x;
-        dividend.y = head1 ? PH.y : phm1.y;
-        const f2 tt = div_exact<true>(dividend, frequency);
-        const f2 tt2 = tt * tt;
-        f2 s_tt2, sgn, polyblep;                                               // see quiet_step
-        s_tt2.x = __uint_as_float(__float_as_uint(tt2.x) ^ (head0 ? 0x80000000u : 0u));
-        s_tt2.y = __uint_as_float(__float_as_uint(tt2.y) ^ (head1 ? 0x80000000u : 0u));
-        sgn.x = head0 ? -1.0f : 1.0f;
-        sgn.y = head1 ? -1.0f : 1.0f;
-        const f2 pb = vfma(vsplat(2.0f, f2()), tt, s_tt2) + sgn;
-        polyblep.x = (head0 | tail0) ? pb.x : 0.0f;
-        polyblep.y = (head1 | tail1) ? pb.y : 0.0f;
-        saw = vfma(vsplat(2.0f, f2()), PH, -one2) - polyblep;                  // :517
-        // the carrier noise of my two samples: lane t of noise_of_step holds the tile's step t
-        const int at = first_step + 2 * jq;
-        NZ.x = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * at, __float_as_int(noise_of_step)));
-        NZ.y = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * at + 4, __float_as_int(noise_of_step)));
-    };
-    auto time_packed_block = [&](const int tc, const float noise_of_step) __attribute__((always_inline)) {
-        if constexpr (W == 1 && NV == 1 && FOLD_IN_FLUSH && L >= 4) {
-            f2 alpha, JP, saw, NZ;
-            quad_chain(noise_of_step, tc, alpha, JP, saw, NZ);
-            auto pair_from = [&](auto sel_tag) __attribute__((always_inline)) {
-                constexpr int I = decltype(sel_tag)::value;
-                f2 al, jp, sw, nz;
-                al.x = quad_bcast(alpha.x, sel_tag); al.y = quad_bcast(alpha.y, sel_tag);
-                jp.x = quad_bcast(JP.x, sel_tag); jp.y = quad_bcast(JP.y, sel_tag);
-                sw.x = quad_bcast(saw.x, sel_tag); sw.y = quad_bcast(saw.y, sel_tag);
-                nz.x = quad_bcast(NZ.x, sel_tag); nz.y = quad_bcast(NZ.y, sel_tag);
-                formant_pair(al, 1.0f - al, jp, 1.0f - jp, sw, nz, tc + 2 * I);
-            };
-            pair_from(std::integral_constant<int, 0>());
-            pair_from(std::integral_constant<int, 1>());
-            pair_from(std::integral_constant<int, 2>());
-            pair_from(std::integral_constant<int, 3>());
-        }
-    };
-
-    // ---- PIPE: time_packed_steps cut in three, one piece per role, handed on through LDS.
-    //   pipe_chain  (wave 1): clock, alpha, jitter phase, pitch blend and jitter, carrier phase, polyBLEP
-    //                         and saw of four sample pairs — the per-utterance chain, once for all formants
-    //   pipe_coeffs (waves 2, 3; wave 1): blend, jitter, 1-exp(smooth), the low-pass input, the
-    //                         turbulence mix, the jittered amplitude, a1 and g from that chain
-    //   pipe_render (wave 0): a2 = g a1, a3 = g a2, the two filter recurrence steps and the band-pass outputs
-    // Same operations on the same operands in the same order as time_packed_steps.
-    // PIPE: a round is 2 * QP sample pairs.  QP = 2: each coefficient wave takes two of its four pairs.  QP = 4
-    // (16 samples between barriers; the one in use): the coefficient waves take three pairs
-    // each and the chain wave — the lightest stage — the last two of the round it wrote one phase before.
-    constexpr int QP = PQP;
-    // [round & 1][group of four pairs][q][lane]: lane (quad | pair) holds the pair's chain
-    __shared__ float4 chain_all[PIPE ? 2 : 1][PIPE ? (QP + 1) / 2 : 1][PIPE ? 2 : 1][PIPE ? 64 : 1];
-    __shared__ float4 ring_all[PIPE ? 2 : 1][PIPE ? 2 * QP : 1][PIPE ? 3 : 1][PIPE ? 64 : 1];
-    __shared__ float hand_all[PIPE ? 3 : 1][PIPE ? 64 : 1];
-    // One round = groups of four sample pairs, each shared by the quad (quad_chain above).
-    auto pipe_chain = [&](float4 (*dst)[64], const float noise_of_step, const int first_step) __attribute__((always_inline)) {
-        if constexpr (PIPE) {
-            static_assert(!PIPE || QP % 2 == 0, "a quad shares four pairs");
-            f2 alpha, JP, saw, NZ;
-            quad_chain(noise_of_step, first_step, alpha, JP, saw, NZ);
-            dst[0][lane] = make_float4(alpha.x, alpha.y, JP.x, JP.y);
-            dst[1][lane] = make_float4(saw.x, saw.y, NZ.x, NZ.y);
-        }
-    };
-    auto pipe_coeffs = [&](const float4 (*src)[64], const int pair, float4 (*dst)[64]) __attribute__((always_inline)) {
-        if constexpr (PIPE) {
-            const int from = (lane & ~3) | pair;                               // the quad lane that worked out this pair
-            const float4 c0 = src[0][from], c2 = src[1][from];
-            f2 alpha, JP, saw, NZ;
-            alpha.x = c0.x; alpha.y = c0.y; JP.x = c0.z; JP.y = c0.w;
-            saw.x = c2.x; saw.y = c2.y; NZ.x = c2.z; NZ.y = c2.w;
-            const f2 oma = 1.0f - alpha;                                       // as the chain has them
-            const f2 jomp = 1.0f - JP;
-            f2 e_freq = X.freq[0] * oma + Y.freq[0] * alpha;                   // :404-414
-            const f2 e_bw = X.bw[0] * oma + Y.bw[0] * alpha;
-            const f2 e_smooth = X.smooth[0] * oma + Y.smooth[0] * alpha;
-            const f2 e_breath = X.breath[0] * oma + Y.breath[0] * alpha;
-            const f2 e_turb = X.turb[0] * oma + Y.turb[0] * alpha;
-            f2 e_amp = X.amp[0] * oma + Y.amp[0] * alpha;
-            const f2 n_ff = ff_cur[0] * jomp + ff_next[0] * JP;                // :305
-            const f2 n_fa = fa_cur[0] * jomp + fa_next[0] * JP;
-            e_freq = e_freq + n_ff * d_ffreq;                                  // :764
-            const f2 delta = (n_fa + 1.0f) * amp_scale;                        // :768-769
-            e_amp = e_amp * (1.0f - delta);                                    // :772-773
-            const f2 oml = 1.0f - exp_approx(e_smooth);                        // :535
-            const f2 omx = 1.0f - e_freq, xph = e_freq + 0.5f, hmx = 0.5f - e_freq;
-            const f2 ox = omx * e_freq, ph = xph * hmx;
-            const f2 five = vsplat(5.0f, f2()), m4 = vsplat(-4.0f, f2());
-            const f2 num = ox * vfma(m4, ph, five);
-            const f2 den = (xph * vfma(m4, ox, five)) * hmx;
-            const f2 g = div_exact<true>(num, den);                            // :555
-            const f2 kq = div_exact<true>(e_bw, e_freq);                       // :558
-            const f2 a1 = rcp_exact<true>(1.0f + g * (g + kq));                // :560
-            const f2 tmix = (1.0f - e_turb) + NZ * e_turb;                     // :544-545
-            const f2 nw = saw * (1.0f - e_breath) + NZ * e_breath;             // :531
-            dst[0][lane] = make_float4(oml.x, oml.y, nw.x, nw.y);
-            dst[1][lane] = make_float4(tmix.x, tmix.y, e_amp.x, e_amp.y);
-            dst[2][lane] = make_float4(a1.x, a1.y, g.x, g.y);                  // a2, a3: the render wave's two products
-        }
-    };
-    auto pipe_render = [&](const float4 (*src)[64], const int tc) __attribute__((always_inline)) {
-        if constexpr (PIPE) {
-            const float4 q0 = src[0][lane], q1 = src[1][lane], q2 = src[2][lane];
-            const float oml[2] = {q0.x, q0.y}, nw[2] = {q0.z, q0.w}, tmix[2] = {q1.x, q1.y};
-            const float amp[2] = {q1.z, q1.w}, a1[2] = {q2.x, q2.y}, g[2] = {q2.z, q2.w};
-            const float a2[2] = {g[0] * a1[0], g[1] * a1[1]};                  // :561
-            const float a3[2] = {g[0] * a2[0], g[1] * a2[1]};                  // :562
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {                                      // :538-571
-                float sa = st_a[0], sb = st_b[0], sc = st_c[0];
-                sa = sa + oml[h] * (nw[h] - sa);                               // :538
-                const float tw = sa * tmix[h];
-                const float v0 = tw * amp[h];                                  // :550
-                const float v3 = v0 - sc;                                      // :565
-                const float w1 = a1[h] * sb + a2[h] * v3;                      // :566
-                const float w2 = (sc + a2[h] * sb) + a3[h] * v3;               // :567
-                st_a[0] = sa;
-                st_b[0] = 2.0f * w1 - sb;                                      // :570
-                st_c[0] = 2.0f * w2 - sc;                                      // :571
-                stage[((tc + h) * S + slot) * NFA + f0] = w1;
-            }
-        }
-    };
-
-    // ---- two calm samples per trip, smaller L: the per-utterance chain (clock, alpha, pitch blend and
-    // jitter, shared smoothness, polyBLEP, saw) is evaluated for samples tc and tc+1 at once on
-    // float2 values (.x = tc, .y = tc+1), exactly as in time_packed_steps; only the carrier phase is
-    // carried between the two.  The formant vectors, already packed across formants, then run
-    // sample by sample with those scalars.
-    // The per-formant part of two calm samples (.x = tc, .y = tc+1) from their chain values, formant vectors
-    // packed across formants: blend, jitter, coefficients and filters sample by sample.
-    // where the shared low-pass factor is worked out — before the carrier or after it — is the same arithmetic,
-    // but it moves the compiler's schedule: the two-lane kernels measure 2 - 3 % faster with it first, the
-    // one-lane kernels 2.7 % faster with it last (same-box A/B)
-    constexpr bool OML_EARLY = L == 2;
-    auto scalar_formant_pair = [&](auto nlive_tag, auto su_tag, const f2 alpha, const f2 oma, const f2 JP,
-                                   const f2 jomp, const f2 saw2, const int tc, const float nz0,
-                                   const float nz1, const f2 oml_early) __attribute__((always_inline)) {
-        constexpr int NLIVE = decltype(nlive_tag)::value;
-        constexpr bool SU = decltype(su_tag)::value;
-        constexpr bool KEEP_LP = STREAM;
-        constexpr int NLP = (NLIVE < NV && !KEEP_LP) ? NLIVE : NV;
-        const f2 one2 = vsplat(1.0f, f2());
-        f2 oml = one2;
-        if constexpr (SU) {   // :404-414, :535 once for all formants (same operands, same bits)
-            if constexpr (OML_EARLY) {
-                oml = oml_early;
-            } else {
-                const f2 es = vget(X.smooth[0], 0) * oma + vget(Y.smooth[0], 0) * alpha;
-                oml = 1.0f - exp_approx(es);
-            }
-        }
-        V E_freq[2][NV], E_bw[2][NV], E_smooth[2][NV], E_breath[2][NV], E_turb[2][NV], E_amp[2][NV];
-        auto blend_h = [&](const int h) __attribute__((always_inline)) {
-            const float a = vget(alpha, h), om = vget(oma, h), jp = vget(JP, h), jm = vget(jomp, h);
-            V (&e_freq)[NV] = E_freq[h]; V (&e_bw)[NV] = E_bw[h]; V (&e_smooth)[NV] = E_smooth[h]; V (&e_breath)[NV] = E_breath[h]; V (&e_turb)[NV] = E_turb[h]; V (&e_amp)[NV] = E_amp[h];
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                if (k < NLP) {
-                    e_breath[k] = X.breath[k] * om + Y.breath[k] * a;
-                    e_smooth[k] = SU ? e_breath[k] : X.smooth[k] * om + Y.smooth[k] * a;
-                } else {
-                    e_breath[k] = vsplat(0.0f, e_breath[k]);   // unused
-                    e_smooth[k] = e_breath[k];
-                }
-                if (k < NLIVE) {
-                    e_freq[k] = X.freq[k] * om + Y.freq[k] * a;
-                    e_bw[k] = X.bw[k] * om + Y.bw[k] * a;
-                    e_turb[k] = X.turb[k] * om + Y.turb[k] * a;
-                    e_amp[k] = X.amp[k] * om + Y.amp[k] * a;
-                } else {   // silent vectors: no band-pass
-                    e_freq[k] = e_breath[k]; e_bw[k] = e_breath[k]; e_turb[k] = e_breath[k]; e_amp[k] = e_breath[k];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < NLIVE; ++k) {
-                const V n_ff = ff_cur[k] * jm + ff_next[k] * jp;               // :305
-                const V n_fa = fa_cur[k] * jm + fa_next[k] * jp;
-                e_freq[k] = e_freq[k] + n_ff * d_ffreq;                        // :764
-                const V delta = (n_fa + 1.0f) * amp_scale;                     // :768-769
-                const V mul = 1.0f - delta;                                    // :772
-                e_amp[k] = e_amp[k] * mul;                                     // :773
-            }
-        };
-        auto filter_h = [&](const int h) __attribute__((always_inline)) {
-            const float noise = h == 0 ? nz0 : nz1;
-            V (&e_freq)[NV] = E_freq[h]; V (&e_bw)[NV] = E_bw[h]; V (&e_smooth)[NV] = E_smooth[h]; V (&e_breath)[NV] = E_breath[h]; V (&e_turb)[NV] = E_turb[h]; V (&e_amp)[NV] = E_amp[h];
-            V v1[NV];
-            formant_filters<true, NV, NLIVE, SU, KEEP_LP, V>(vget(saw2, h), noise, vget(oml, h), e_freq, e_bw,
-                                                e_smooth, e_breath, e_turb, e_amp, st_a, st_b, st_c, v1);
-            const int t = tc + h;
-            if constexpr (FOLD_IN_FLUSH) {
-#pragma unroll
-                for (int k = 0; k < NV; ++k)
-#pragma unroll
-                    for (int c = 0; c < W; ++c)
-                        stage[(t * S + slot) * NFA + f0 + k * W + c] = vget(v1[k], c);   // silent: +0
-            } else {
-                float acc = 0.0f;
-#pragma unroll
-                for (int step = 0; step < L; ++step) {
-                    float run = (step == 0) ? 0.0f : dpp_from_lane_below(acc);
-#pragma unroll
-                    for (int k = 0; k < NLIVE; ++k)
-#pragma unroll
-                        for (int c = 0; c < W; ++c) run = run + vget(v1[k], c);
-                    if (NLIVE < NV || (NFA < NF && step == L - 1)) run = run + 0.0f;
-                    acc = (j == step) ? run : acc;
-                }
-                if (j == L - 1) stage[t * SP + slot] = acc * 0.5f;
-            }
-        };
-        // two formant vectors: the blends of both samples before the filters of the first (measured: the
-        // better schedule); four: sample by sample (the register file does not hold both sets)
-        if constexpr (NLIVE <= 2) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) blend_h(h);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) filter_h(h);
-        } else {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) { blend_h(h); filter_h(h); }
-        }
-    };
-    auto scalar_packed_steps = [&](auto nlive_tag, auto su_tag, const int tc, const float nz0,
-                                   const float nz1) __attribute__((always_inline)) {
-        const f2 one2 = vsplat(1.0f, f2());
-        const float clk0 = clk - dt, clk1 = clk0 - dt;                         // :861
-        const float jp0 = jphase + jinc, jp1 = jp0 + jinc;                     // :242 / :291
-        clk = clk1;
-        jphase = jp1;
-        f2 CLK, JP;
-        CLK.x = clk0; CLK.y = clk1; JP.x = jp0; JP.y = jp1;
-        f2 ratio = CLK * inv_blend_length;
-        if constexpr (ANYBL) {
-            const f2 rem = vfma(-blend_length * one2, ratio, CLK);
-            const f2 quot = vfma(rem, inv_blend_length * one2, ratio);         // RN(clk / blend_length)
-            ratio = blend_pow2 ? ratio : quot;
-        }
-        f2 alpha;                                                              // :899/:908/:917
-        alpha.x = silent_pair ? 1.0f : __builtin_fminf(ratio.x, 1.0f);
-        alpha.y = silent_pair ? 1.0f : __builtin_fminf(ratio.y, 1.0f);
-        const f2 oma = 1.0f - alpha;
-        const f2 jomp = 1.0f - JP;
-        f2 frequency = X.frequency * oma + Y.frequency * alpha;                // :404-414
-        const f2 n_freq = fn_cur * jomp + fn_next * JP;                        // :254
-        frequency = frequency + n_freq * d_freq;                               // :763
-        f2 oml_early = one2;
-        if constexpr (OML_EARLY && decltype(su_tag)::value) {   // :404-414, :535 once for all formants
-            const f2 es = vget(X.smooth[0], 0) * oma + vget(Y.smooth[0], 0) * alpha;
-            oml_early = 1.0f - exp_approx(es);
-        }
-        // carrier :503-525
-        const f2 omf = 1.0f - frequency;
-        const float ph0 = phase;
-        const bool head0 = ph0 < frequency.x, tail0 = ph0 > omf.x;
-        const float ph1 = __builtin_amdgcn_fractf(ph0 + frequency.x);         // see quiet_step
-        const bool head1 = ph1 < frequency.y, tail1 = ph1 > omf.y;
-        phase = __builtin_amdgcn_fractf(ph1 + frequency.y);
-        f2 PH;
-        PH.x = ph0; PH.y = ph1;
-        const f2 phm1 = PH - 1.0f;
-        f2 dividend;
-        dividend.x = head0 ? ph0 : phm1.x;
-        dividend.y = head1 ? ph1 : phm1.y;
-        const f2 tt = div_exact<true>(dividend, frequency);
-        const f2 tt2 = tt * tt;
-        f2 s_tt2, sgn, polyblep;                                               // see quiet_step
-        s_tt2.x = __uint_as_float(__float_as_uint(tt2.x) ^ (head0 ? 0x80000000u : 0u));
-        s_tt2.y = __uint_as_float(__float_as_uint(tt2.y) ^ (head1 ? 0x80000000u : 0u));
-        sgn.x = head0 ? -1.0f : 1.0f;
-        sgn.y = head1 ? -1.0f : 1.0f;
-        const f2 pb = vfma(vsplat(2.0f, f2()), tt, s_tt2) + sgn;
-        polyblep.x = (head0 | tail0) ? pb.x : 0.0f;
-        polyblep.y = (head1 | tail1) ? pb.y : 0.0f;
-        const f2 saw2 = vfma(vsplat(2.0f, f2()), PH, -one2) - polyblep;        // :517
-        scalar_formant_pair(nlive_tag, su_tag, alpha, oma, JP, jomp, saw2, tc, nz0, nz1, oml_early);
-    };
-    // L = 4 with two formants per lane: the quad shares the chain over eight calm samples (quad_chain above)
-    auto scalar_packed_block = [&](auto nlive_tag, auto su_tag, const int tc, const float noise_of_step) __attribute__((always_inline)) {
-        if constexpr (L >= 4) {
-            f2 alpha, JP, saw, NZ;
-            quad_chain(noise_of_step, tc, alpha, JP, saw, NZ);
-            auto pair_from = [&](auto sel_tag) __attribute__((always_inline)) {
-                constexpr int I = decltype(sel_tag)::value;
-                f2 al, jp, sw;
-                al.x = quad_bcast(alpha.x, sel_tag); al.y = quad_bcast(alpha.y, sel_tag);
-                jp.x = quad_bcast(JP.x, sel_tag); jp.y = quad_bcast(JP.y, sel_tag);
-                sw.x = quad_bcast(saw.x, sel_tag); sw.y = quad_bcast(saw.y, sel_tag);
-                scalar_formant_pair(nlive_tag, su_tag, al, 1.0f - al, jp, 1.0f - jp, sw, tc + 2 * I,
-                                    quad_bcast(NZ.x, sel_tag), quad_bcast(NZ.y, sel_tag), vsplat(1.0f, f2()));
-            };
-            pair_from(std::integral_constant<int, 0>());
-            pair_from(std::integral_constant<int, 1>());
-            pair_from(std::integral_constant<int, 2>());
-            pair_from(std::integral_constant<int, 3>());
-        }
-    };
-
-
-    // ---- FAST: one calm tile of T samples in tolerance-mode arithmetic.
-    // Exact, as everywhere: clk (:861), alpha, the pitch blend and its jitter (:404, :254, :763), the
-    // jitter phase (:242) and the carrier phase with its wrap (:520-525) — two samples per packed
-    // slot, the same operations on the same operands as the exact kernels.  Within tolerance:
-    //   * the polyBLEP quotient (:505/:509) is dividend * v_rcp(frequency);
-    //   * the band-pass (:560-571) is used in the algebraically equal form a2 = g a1, a3 = g a2 =>
-    //     v1 = a1 (b + g v3),  v2 = c + g v1,  so only a1 and g = tan_approx(x) are needed per sample;
-    //   * per formant, everything that is a smooth function of (alpha, jitter phase) — a1, g, the
-    //     jittered amplitude G, amplitude x turbulence H, breath, 1 - exp_approx(smooth) — is evaluated
-    //     at the ends of sub-tiles of TS <= 32 samples and interpolated linearly in between (alpha and the
-    //     jitter phase are linear in time inside a calm tile; a tile that holds the kink of
-    //     alpha = min(., 1) is not calm).  The end of a sub-tile is the start of the next one.
-    //   * the interpolation error is bounded per wave when a run of calm tiles starts (after every
-    //     event): a relative change r of a1, g or 1 - exp_approx over 32 samples gives an error below
-    //     r^2/16 <= 2^-23 for r <= 2^-9.5 (g is close to linear in x: far below that); G and H are
-    //     products of linear functions, error <= |dA dM| / 4 and |dT dG| / 4 <= 2^-22 absolute.
-    //     Faster parameter motion halves TS (error / 4) until it fits; below TS = 2 the tile takes the
-    //     exact steps.  The reference's own front end always emits 0.5 s blends (Intonator :1070-1071),
-    //     for which TS = 32.
-    //   * :531 as saw + breath (noise - saw), :538 as fma, :544-550 as a (G + H (noise - 1)), the
-    //     eight-term sum (:574) in tree order.
-    struct FastEnds {
-        V a1[NV], tg[NV], g[NV], h[NV], b[NV], om[NV];   // tg = tan_approx(x), g = amplitude
-        float oml;
-    };
-    struct FastAux {
-        V ap[NV], mu[NV], tb[NV];
-    };
-    FastEnds FS;             // the interpolated quantities at the first sample of the NEXT tile, kept while calm
-                             // tiles follow each other
-    int fast_have = -1;      // which flavour (NLIVE * 2 + SU) stored FS; -1: nothing kept
-    int fast_shift = 0;      // sub-tile length 32 >> fast_shift, chosen when a run of calm tiles starts
-    auto fast_tile = [&](auto nlive_tag, auto su_tag, const float noise_of_lane,
-                         const bool idle_lane) __attribute__((always_inline)) -> bool {
-        constexpr int NLIVE = decltype(nlive_tag)::value;
-        constexpr bool SU = decltype(su_tag)::value;
-        constexpr bool KEEP_LP = STREAM;
-        constexpr int NLP = (NLIVE < NV && !KEEP_LP) ? NLIVE : NV;
-        constexpr int TS0 = 32;
-        static_assert(T % TS0 == 0, "whole sub-tiles");
-        constexpr int FLAVOUR = NLIVE * 2 + (SU ? 1 : 0);
-        const V one = vsplat(1.0f, V());
-        const V five = vsplat(5.0f, V()), m4 = vsplat(-4.0f, V());
-        // the smooth quantities `after` samples from now (the clock and the jitter phase extrapolated:
-        // they only feed continuous functions here).  SLOPE: e receives (value - FS) * scale instead.
-        auto endpoint = [&](auto slope_tag, const float after, const float scale, FastEnds &e,
-                            FastAux &x) __attribute__((always_inline)) {
-            constexpr bool SLOPE = decltype(slope_tag)::value;
-            const float c = clk - after * dt;
-            const float jp = jphase + after * jinc;
-            float alpha = __builtin_fminf(c * inv_blend_length, 1.0f);
-            alpha = silent_pair ? 1.0f : alpha;
-            const float oma = 1.0f - alpha, jomp = 1.0f - jp;
-            auto put = [&](V &dst, const V &start, const V value) __attribute__((always_inline)) {
-                if constexpr (SLOPE) dst = (value - start) * scale;
-                else dst = value;
-            };
-#pragma unroll
-            for (int k = 0; k < NLIVE; ++k) {
-                V ef = vfma(Y.freq[k], vsplat(alpha, V()), X.freq[k] * oma);
-                const V eb = vfma(Y.bw[k], vsplat(alpha, V()), X.bw[k] * oma);
-                const V et = vfma(Y.turb[k], vsplat(alpha, V()), X.turb[k] * oma);
-                const V ea = vfma(Y.amp[k], vsplat(alpha, V()), X.amp[k] * oma);
-                const V nff = vfma(ff_next[k], vsplat(jp, V()), ff_cur[k] * jomp);
-                const V nfa = vfma(fa_next[k], vsplat(jp, V()), fa_cur[k] * jomp);
-                ef = vfma(nff, vsplat(d_ffreq, V()), ef);
-                const V mul = vfma(nfa + 1.0f, vsplat(-amp_scale, V()), one);
-                const V omx = 1.0f - ef, xph = ef + 0.5f, hmx = 0.5f - ef;
-                const V ox = omx * ef, ph = xph * hmx;
-                const V num = ox * vfma(m4, ph, five);
-                const V den = (xph * vfma(m4, ox, five)) * hmx;
-                // g = num / den (:555), k = bw / x (:558), a1 = 1 / (1 + g (g + k)) (:560): v_rcp + one
-                // Newton step each (correctly rounded reciprocals; the quotients are within an ulp)
-                V rd = vrcp(den), rx = vrcp(ef);
-                rd = vfma(vfma(-den, rd, one), rd, rd);
-                rx = vfma(vfma(-ef, rx, one), rx, rx);
-                const V tg = num * rd;
-                const V kq = eb * rx;
-                const V d3 = vfma(tg, tg + kq, one);
-                V r3 = vrcp(d3);
-                r3 = vfma(vfma(-d3, r3, one), r3, r3);
-                const V gg = ea * mul;
-                put(e.a1[k], FS.a1[k], r3);
-                put(e.tg[k], FS.tg[k], tg);
-                put(e.g[k], FS.g[k], gg);
-                put(e.h[k], FS.h[k], et * gg);
-                x.ap[k] = ea;
-                x.mu[k] = mul;
-                x.tb[k] = et;
-            }
-            float oml_here = 1.0f;
-            if constexpr (SU) {
-                const float es = __builtin_fmaf(vget(Y.smooth[0], 0), alpha, vget(X.smooth[0], 0) * oma);
-                oml_here = 1.0f - exp_approx(es);
-            }
-#pragma unroll
-            for (int k = 0; k < NLP; ++k) {
-                const V br = vfma(Y.breath[k], vsplat(alpha, V()), X.breath[k] * oma);
-                if constexpr (!SU) {
-                    put(e.b[k], FS.b[k], br);
-                    const V es = vfma(Y.smooth[k], vsplat(alpha, V()), X.smooth[k] * oma);
-                    put(e.om[k], FS.om[k], 1.0f - exp_approx(es));
-                } else {
-                    // shared smoothness: the low-pass is used as a' = (1-k) a + k saw + (k breath)(noise - saw),
-                    // so the interpolated per-formant quantity is k * breath
-                    put(e.b[k], FS.b[k], br * oml_here);
-                    e.om[k] = one;
-                }
-            }
-            e.oml = SU ? (SLOPE ? (oml_here - FS.oml) * scale : oml_here) : 1.0f;
-        };
-        FastEnds D;              // per-sample slopes of the sub-tile
-        FastAux xe;
-        bool have_slopes = false;
-        if (fast_have != FLAVOUR) {
-            // a run of calm tiles starts: the values now, the slopes over 32 samples, and the error guard
-            FastAux xs;
-            endpoint(std::false_type(), 1.0f, 1.0f, FS, xs);
-            endpoint(std::true_type(), (float)(TS0 + 1), 1.0f / (float)TS0, D, xe);
-            float ra = 0.0f, rg = 0.0f;
-#pragma unroll
-            for (int k = 0; k < NLIVE; ++k)
-#pragma unroll
-                for (int c = 0; c < W; ++c) {
-                    // relative change of a1 and g over 32 samples; 32^2 x the products of slopes behind G and H
-                    ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(D.a1[k], c)) * (float)TS0 *
-                                                 __builtin_amdgcn_rcpf(vget(FS.a1[k], c)));
-                    ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(D.tg[k], c)) * (float)TS0 *
-                                                 __builtin_amdgcn_rcpf(vget(FS.tg[k], c)));
-                    rg = __builtin_fmaxf(rg, __builtin_fabsf((vget(xe.ap[k], c) - vget(xs.ap[k], c)) *
-                                                             (vget(xe.mu[k], c) - vget(xs.mu[k], c))));
-                    rg = __builtin_fmaxf(rg, __builtin_fabsf((vget(xe.tb[k], c) - vget(xs.tb[k], c)) *
-                                                             vget(D.g[k], c) * (float)TS0));
-                }
-            if constexpr (SU) {
-                ra = __builtin_fmaxf(ra, __builtin_fabsf(D.oml) * (float)TS0 * __builtin_amdgcn_rcpf(FS.oml));
-            } else {
-#pragma unroll
-                for (int k = 0; k < NLP; ++k)
-#pragma unroll
-                    for (int c = 0; c < W; ++c)
-                        ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(D.om[k], c)) * (float)TS0 *
-                                                     __builtin_amdgcn_rcpf(vget(FS.om[k], c)));
-            }
-            // halvings needed: r / 2^s <= 2^-9.5 (error ~ r^2 / 16), |.| / 4 / 4^s <= 2^-22
-            const int la = __builtin_amdgcn_frexp_expf(ra * 724.0773439350247f);      // 2^9.5
-            const int lg = (__builtin_amdgcn_frexp_expf(rg * GRAIL_FAST_G_SCALE) + 1) >> 1;
-            int level = la > lg ? la : lg;
-            level = level < 0 ? 0 : level;
-            if (!(ra == ra) || !(rg == rg)) level = 99;                                // NaN: not here
-            level = idle_lane ? 0 : level;
-            int lvl = 0;
-            for (; lvl <= 4; ++lvl)
-                if (__builtin_amdgcn_ballot_w64(level > lvl) == 0) break;
-            if (lvl > 4) return false;               // faster than TS = 2 can follow: the exact steps
-            fast_shift = lvl;
-            have_slopes = lvl == 0;
-            fast_have = FLAVOUR;
-        }
-        const int TS = TS0 >> fast_shift;
-        const float inv_ts = __builtin_bit_cast(float, (uint32_t)(127 - 5 + fast_shift) << 23);   // 1 / TS
-        const float nm1_of_lane = noise_of_lane - 1.0f;
-        const f2 one2 = vsplat(1.0f, f2());
-        // ---- the per-utterance chain of samples tc, tc+1: exact (see scalar_packed_steps).  Advances
-        // clk, jphase and phase; returns the phases before the two samples and their pitch.
-        const float inv_bl = (!ANYBL && silent_pair) ? __builtin_inff() : inv_blend_length;
-        auto chain_pair = [&](f2 &PH, f2 &frequency) __attribute__((always_inline)) {
-            const float clk0 = clk - dt, clk1 = clk0 - dt;                     // :861
-            const float jp0 = jphase + jinc, jp1 = jp0 + jinc;                 // :242 / :291
-            clk = clk1;
-            jphase = jp1;
-            f2 CLK, JP;
-            CLK.x = clk0; CLK.y = clk1; JP.x = jp0; JP.y = jp1;
-            f2 ratio = CLK * inv_bl;
-            if constexpr (ANYBL) {
-                const f2 rem = vfma(-blend_length * one2, ratio, CLK);
-                const f2 quot = vfma(rem, inv_blend_length * one2, ratio);     // RN(clk / blend_length)
-                ratio = blend_pow2 ? ratio : quot;
-            }
-            f2 alpha;                                                          // :899/:908/:917
-            if constexpr (ANYBL) {
-                alpha.x = silent_pair ? 1.0f : __builtin_fminf(ratio.x, 1.0f);
-                alpha.y = silent_pair ? 1.0f : __builtin_fminf(ratio.y, 1.0f);
-            } else {
-                // a both-silent pair emits silent() itself (alpha = 1, :926): its reciprocal blend length was
-                // replaced by +inf for this tile (inv_bl below), the clock is positive in a calm tile, and
-                // min(+inf, 1) = 1 — no select per sample
-                alpha.x = __builtin_fminf(ratio.x, 1.0f);
-                alpha.y = __builtin_fminf(ratio.y, 1.0f);
-            }
-            const f2 oma = 1.0f - alpha;
-            const f2 jomp = 1.0f - JP;
-            frequency = X.frequency * oma + Y.frequency * alpha;               // :404-414
-            const f2 n_freq = fn_cur * jomp + fn_next * JP;                    // :254
-            frequency = frequency + n_freq * d_freq;                           // :763
-            // :520-525  `p += f; if p >= 1 { p -= 1 }` is fract(p + f) for 0 <= p < 1, 0 < f <= 1: both
-            // branches are exact (x - 1 for x in [1, 2) loses nothing)
-            const float ph0 = phase;
-            const float ph1 = __builtin_amdgcn_fractf(ph0 + frequency.x);
-            phase = __builtin_amdgcn_fractf(ph1 + frequency.y);
-            PH.x = ph0; PH.y = ph1;
-        };
-#pragma unroll 1
-        for (int ts = 0; ts < T; ts += TS) {
-            if (!(have_slopes && ts == 0)) endpoint(std::true_type(), (float)(TS + 1), inv_ts, D, xe);
-            f2 TI;
-            TI.x = 0.0f; TI.y = 1.0f;
-#pragma unroll 1
-            for (int tc = ts; tc < ts + TS; tc += 2) {
-                const float nz[2] = {
-                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc)),
-                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc + 1))};
-                const float nm[2] = {
-                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nm1_of_lane), tc)),
-                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nm1_of_lane), tc + 1))};
-                f2 PH, frequency;
-                chain_pair(PH, frequency);
-                // polyBLEP :503-517 without branches or selects: with d_h = f - p (> 0: the head test
-                // p < f) and d_t = p - (1 - f) (> 0: the tail test p > 1 - f; never both), u = max(d_h, d_t, 0) / f
-                // is 1 - t for the head (:505) and 1 + t for the tail (:509), and the correction is -u^2 or
-                // +u^2 (:506, :510) — zero when neither test holds.  d_h - d_t = 1 - 2p = -(2p - 1): the sign
-                // of the uncorrected saw says which.  Same tests as the reference, quotient by v_rcp.
-                const f2 omf = 1.0f - frequency;
-                const f2 d_h = frequency - PH, d_t = PH - omf;
-                f2 u;
-                u.x = __builtin_fmaxf(__builtin_fmaxf(d_h.x, d_t.x), 0.0f);
-                u.y = __builtin_fmaxf(__builtin_fmaxf(d_h.y, d_t.y), 0.0f);
-                u = u * vrcp(frequency);
-                const f2 saw_nb = vfma(vsplat(2.0f, f2()), PH, -one2);             // 2 p - 1
-                f2 su;    // u with the sign of -saw_nb: + for the head (saw + u^2), - for the tail (saw - u^2)
-                su.x = __uint_as_float((__float_as_uint(u.x) & 0x7FFFFFFFu) | (~__float_as_uint(saw_nb.x) & 0x80000000u));
-                su.y = __uint_as_float((__float_as_uint(u.y) & 0x7FFFFFFFu) | (~__float_as_uint(saw_nb.y) & 0x80000000u));
-                const f2 saw2 = vfma(su, u, saw_nb);                               // :517
-                // ---- the formants, sample by sample, coefficients by interpolation
-                f2 keep2 = one2, ksaw2 = one2;          // shared smoothness: 1 - k and k * saw of both samples
-                if constexpr (SU) {
-                    const f2 k2 = vfma(vsplat(D.oml, f2()), TI, vsplat(FS.oml, f2()));
-                    keep2 = 1.0f - k2;
-                    ksaw2 = k2 * saw2;
-                }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float ti = vget(TI, h), saw = vget(saw2, h);
-                    const V tiv = vsplat(ti, V());
-                    const V nms = vsplat(nz[h] - saw, V());
-                    const V nm1 = vsplat(nm[h], V());
-                    const V sawv = vsplat(saw, V());
-                    V acc = vsplat(0.0f, V());
-#pragma unroll
-                    for (int k = 0; k < NLP; ++k) {
-                        const V b = vfma(D.b[k], tiv, FS.b[k]);
-                        if constexpr (SU) {             // :531 + :538:  a' = (1-k) a + k saw + (k breath)(noise - saw)
-                            st_a[k] = vfma(b, nms, vfma(vsplat(vget(keep2, h), V()), st_a[k], vsplat(vget(ksaw2, h), V())));
-                        } else {
-                            const V nw = vfma(b, nms, sawv);                        // :531
-                            const V oml_v = vfma(D.om[k], tiv, FS.om[k]);
-                            st_a[k] = vfma(oml_v, nw - st_a[k], st_a[k]);           // :538
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < NLIVE; ++k) {
-                        const V a1 = vfma(D.a1[k], tiv, FS.a1[k]);
-                        const V tg = vfma(D.tg[k], tiv, FS.tg[k]);
-                        const V g_ = vfma(D.g[k], tiv, FS.g[k]);
-                        const V h_ = vfma(D.h[k], tiv, FS.h[k]);
-                        const V v0 = st_a[k] * vfma(h_, nm1, g_);                   // :544-550
-                        const V v3 = v0 - st_c[k];                                  // :565
-                        const V w1 = a1 * vfma(tg, v3, st_b[k]);                    // :566  a1 b + a2 v3
-                        const V w2 = vfma(tg, w1, st_c[k]);                         // :567  c + a2 b + a3 v3
-                        st_b[k] = vfma(vsplat(2.0f, V()), w1, -st_b[k]);            // :570
-                        st_c[k] = vfma(vsplat(2.0f, V()), w2, -st_c[k]);            // :571
-                        acc = acc + w1;
-                    }
-                    float part = vget(acc, 0);
-                    if constexpr (W == 2) part = part + vget(acc, 1);
-                    const int t_ = tc + h;
-                    if constexpr (FOLD_IN_FLUSH) {
-                        // the flush folds NFA parked values per sample: this lane's partial sum, then zeros
-                        if (emit) stage[(t_ * S + slot) * NFA + f0] = part;
-#pragma unroll
-                        for (int i = 1; i < FPL; ++i)
-                            if (emit) stage[(t_ * S + slot) * NFA + f0 + i] = 0.0f;
-                    } else {
-                        float tot = part;
-#pragma unroll
-                        for (int step = 1; step < L; ++step) tot = dpp_from_lane_below(tot) + part;
-                        if (j == L - 1) stage[t_ * SP + slot] = tot * 0.5f;
-                    }
-                }
-                TI = TI + 2.0f;
-            }
-            // the sub-tile's end is the next one's start: start + TS * slope (the end value the slopes were
-            // made from, to within an ulp; every sub-tile's end is evaluated afresh, so nothing accumulates)
-            const float fts = (float)TS;
-#pragma unroll
-            for (int k = 0; k < NLIVE; ++k) {
-                FS.a1[k] = vfma(D.a1[k], vsplat(fts, V()), FS.a1[k]);
-                FS.tg[k] = vfma(D.tg[k], vsplat(fts, V()), FS.tg[k]);
-                FS.g[k] = vfma(D.g[k], vsplat(fts, V()), FS.g[k]);
-                FS.h[k] = vfma(D.h[k], vsplat(fts, V()), FS.h[k]);
-            }
-#pragma unroll
-            for (int k = 0; k < NLP; ++k) {
-                FS.b[k] = vfma(D.b[k], vsplat(fts, V()), FS.b[k]);
-                if constexpr (!SU) FS.om[k] = vfma(D.om[k], vsplat(fts, V()), FS.om[k]);
-            }
-            if constexpr (SU) FS.oml = __builtin_fmaf(D.oml, fts, FS.oml);
-        }
-        return true;
-    };
-
-    // ---- the staged tile's rows to memory: row `slot` holds samples [base_, base_ + T), mine_ of them valid
-    // (the general flush; the main loop below has a shortcut for the usual full tile of the lane kernels)
-    auto flush_rows = [&](const uint32_t base_, const uint32_t mine_) __attribute__((always_inline)) {
-        constexpr int ROW_LANES = T / 4;
-        constexpr int ROWS_PER_IT = 64 / ROW_LANES;
-        const int rl = lane % ROW_LANES;
-        const int rr = lane / ROW_LANES;
-        if (emit && j == L - 1) cnt[slot] = mine_;
-        if constexpr (PIPE) __syncthreads();
-        else wave_lds_sync();
-        const int r_first = PIPE ? wave * ROWS_PER_IT : 0;
-        constexpr int R_STEP = PIPE ? ROWS_PER_IT * WAVES : ROWS_PER_IT;
-#pragma unroll 1
-        for (int r0 = r_first; r0 < S; r0 += R_STEP) {
-            const int r = r0 + rr;
-            if (ROWS_PER_IT > S && r >= S) continue;
-            const uint32_t c = cnt[r];
-            const int t0 = rl * 4;
-            if ((uint32_t)t0 < c) {
-                const uint64_t at = (uint64_t)(A.perm ? rowid[r] : u0 + r) * A.out_stride + base_ + t0;
-                auto sample_at = [&](const int tt) __attribute__((always_inline)) -> float {
-                    if constexpr (FOLD_IN_FLUSH) {
-                        // v1.sum() * 0.5: the left fold from 0.0 over formants 0..7  :574, :123-125
-                        const float *p = stage + (tt * S + r) * NFA;
-                        float run = 0.0f;
-#pragma unroll
-                        for (int f = 0; f < NFA; ++f) run = run + p[f];
-                        if (NFA < NF) run = run + 0.0f;   // formants 5-8: literal +0.0 terms
-                        return run * 0.5f;
-                    } else {
-                        return stage[tt * SP + r];
-                    }
-                };
-                const float s0 = sample_at(t0 + 0);
-                const float s1 = sample_at(t0 + 1);
-                const float s2 = sample_at(t0 + 2);
-                const float s3 = sample_at(t0 + 3);
-                if (A.out_pcm16) {
-                    // the WAV sink's `(x * i16::MAX as f32) as i16` (examples/cli.rs:49) on the way out
-                    int16_t *dst = A.out_pcm16 + at;
-                    const int p0 = pcm16_from_f32(s0), p1 = pcm16_from_f32(s1);
-                    const int p2 = pcm16_from_f32(s2), p3 = pcm16_from_f32(s3);
-                    if (vec16_ok && (uint32_t)(t0 + 4) <= c) {
-                        *reinterpret_cast<uint2 *>(dst) =
-                            make_uint2((uint32_t)(p0 & 0xFFFF) | ((uint32_t)p1 << 16),
-                                       (uint32_t)(p2 & 0xFFFF) | ((uint32_t)p3 << 16));
-                    } else {
-                        dst[0] = (int16_t)p0;
-                        if ((uint32_t)(t0 + 1) < c) dst[1] = (int16_t)p1;
-                        if ((uint32_t)(t0 + 2) < c) dst[2] = (int16_t)p2;
-                        if ((uint32_t)(t0 + 3) < c) dst[3] = (int16_t)p3;
-                    }
-                    continue;
-                }
-                float *dst = A.out + at;
-                if (vec_ok && (uint32_t)(t0 + 4) <= c) {
-                    *reinterpret_cast<float4 *>(dst) = make_float4(s0, s1, s2, s3);
-                } else {
-                    dst[0] = s0;
-                    if ((uint32_t)(t0 + 1) < c) dst[1] = s1;
-                    if ((uint32_t)(t0 + 2) < c) dst[2] = s2;
-                    if ((uint32_t)(t0 + 3) < c) dst[3] = s3;
-                }
-            }
-        }
-        if constexpr (PIPE) __syncthreads();     // the rendering wave may not park the next tile before all have read
-        else wave_lds_sync();
-    };
-
-    for (uint32_t base = 0;; base += T) {
-        int t = 0;
-        while (t < T) {
-            // a run of quiet steps: a tight inner loop, so the loop-carried state keeps its
-            // registers from one sample to the next.  Two flavours of the same loop: every
-            // formant vector live, or (all lanes agree) the upper half silent for this pair.
-            // A calm tile: for every lane that is still rendering, the clock stays >= 0, the
-            // jitter phase <= 1 and the row has room for the T steps of the tile.  Lanes that
-            // will not render again in this launch (chain exhausted, row full, no utterance) ride
-            // along: what they compute is never read and their sample count stands still, so
-            // nothing of theirs is flushed.  clk >= m*dt
-            // implies RN(clk - dt) >= (m - 1.01)*dt (RN is monotone), so clk > (T+8)*dt leaves
-            // > 7*dt after T <= 64 steps; the phase grows by at most jinc*(1 + 2^-23) per step.
-            bool calm_tile = false;
-            int pipe_tiles = 1;                            // PIPE: calm tiles the pipeline runs through in one go
-            const bool idle = STREAM ? finished : done;   // a paused stream lane resumes: not idle
-            uint32_t tile_seed = 0u;                       // the carrier-noise state the tile starts from
-            if (t == 0) {
-                static_assert(T <= 64, "calm-tile margins are written for T <= 64");
-                const uint64_t busy = __builtin_amdgcn_ballot_w64(!idle);
-                if (busy != 0) {
-                    tile_seed = (uint32_t)__builtin_amdgcn_readlane((int)noise_seed, __builtin_ctzll(busy));
-                    bool calm = !done & quiet_ok & (dt > 0.0f) & (clk > (float)(T + 8) * dt) &
-                                (jphase + (float)(T + 1) * jinc < 0.999f) &
-                                (cap32 - n_out >= (uint32_t)T) & (noise_seed == tile_seed);
-                    if constexpr (FAST) {
-                        // the interpolated coefficients need alpha linear in time across the tile:
-                        // a tile that holds the kink of min(clk / blend_length, 1) takes the exact steps
-                        const float r_first = (clk - dt) * inv_blend_length;
-                        const float r_next = (clk - (float)(T + 1) * dt) * inv_blend_length;
-                        calm = calm & !((r_first > 1.0f) & (r_next < 1.0f));
-                        // fast_tile's polyBLEP form needs the head and tail tests to exclude each other: pitch < 1/2
-                        calm = calm & (__builtin_fmaxf(X.frequency, Y.frequency) + __builtin_fabsf(d_freq) < 0.5f);
-                    }
-                    calm_tile = __builtin_amdgcn_ballot_w64(!(calm | idle)) == 0;
-                    if constexpr (PIPE) {
-                        // how many calm tiles in a row (every wave of the workgroup finds the same number): the
-                        // pipeline then runs through them without draining.  The margins of the single tile
-                        // for N = k T steps: each step lowers the bound on the clock by at most 1.01 dt.
-                        pipe_tiles = 1;
-                        if (calm_tile) {
-#pragma unroll 1
-                            for (int k = 2; k <= PIPE_MAX_TILES; ++k) {
-                                const float nsteps = (float)(k * T);
-                                const bool ok = (clk > (nsteps * 1.0125f + 8.0f) * dt) &
-                                                (jphase + (nsteps + 1.0f) * jinc < 0.999f) &
-                                                (cap32 - n_out >= (uint32_t)(k * T));
-                                if (__builtin_amdgcn_ballot_w64(!(ok | idle)) != 0) break;
-                                pipe_tiles = k;
-                            }
-                        }
-                    }
-                }
-            }
-            auto quiet_run = [&](auto nlive_tag, auto su_tag) __attribute__((always_inline)) {
-                if (calm_tile) {
-                    // no lane can have an event before the tile ends: no per-step ballot.  The
-                    // carrier noise of the T steps is drawn here, lane l taking step l (closed-form
-                    // skip-ahead of the LCG :36-55; wrapping u32 arithmetic is exact).
-                    const uint32_t ahead = (uint32_t)(lane < T ? lane : T - 1) + 1u;
-                    uint32_t sk = tile_seed * LCG_SKIP.mul[ahead] + LCG_SKIP.add[ahead];
-                    const float noise_of_lane = (__uint_as_float((sk >> 9) | 0x3F800000u) - 1.5f) * 2.0f;
-                    // two steps per trip halve the loop overhead; with all four formant vectors
-                    // live the doubled body no longer fits the register file (measured: slower)
-                    constexpr int STEPS_PER_TRIP = 2;
-                    static_assert(T % STEPS_PER_TRIP == 0, "whole trips");
-                    bool rendered = true;
-                    if constexpr (FAST) {
-                        rendered = fast_tile(nlive_tag, su_tag, noise_of_lane, idle);
-                    } else if constexpr (PIPE) {
-                        // Rounds of two sample pairs, three stages one round apart: in phase p wave 1
-                        // writes the chain of round p+2, waves 2 and 3 turn the chain of round p+1 into
-                        // coefficients (one pair each), wave 0 renders round p; one barrier per phase.
-                        constexpr int SPR = 4 * QP;              // samples per round
-                        constexpr int ROUNDS = T / SPR;
-                        static_assert(T % SPR == 0, "whole rounds");
-                        // Consecutive calm tiles (pipe_tiles of them) go through without draining the pipeline:
-                        // when the rendering wave has parked a tile all four waves flush it, then carry on.
-                        // The chain wave is two rounds ahead: it draws the next tile's carrier noise itself.
-                        uint32_t sk_chain = sk;
-                        float noise_chain = noise_of_lane;
-                        const int all_rounds = pipe_tiles * ROUNDS;
-#pragma unroll 1
-                        for (int ph_ = -2; ph_ < all_rounds; ++ph_) {
-                            if (role == 1) {
-                                const int m = ph_ + 2;
-                                if (m < all_rounds) {
-                                    const int ml = m % ROUNDS;
-                                    if (ml == 0 && m > 0) {          // on to the next tile: its noise, T draws further
-                                        const uint32_t seed_next = (uint32_t)__builtin_amdgcn_readlane((int)sk_chain, T - 1);
-                                        sk_chain = seed_next * LCG_SKIP.mul[ahead] + LCG_SKIP.add[ahead];
-                                        noise_chain = (__uint_as_float((sk_chain >> 9) | 0x3F800000u) - 1.5f) * 2.0f;
-                                    }
-#pragma unroll
-                                    for (int g = 0; g < QP / 2; ++g) pipe_chain(chain_all[m & 1][g], noise_chain, SPR * ml + 8 * g);
-                                }
-                                if constexpr (QP == 4) {             // and the last two pairs of the round before
-                                    const int mc = ph_ + 1;
-                                    if (mc >= 0 && mc < all_rounds) {
-                                        pipe_coeffs(chain_all[mc & 1][1], 2, ring_all[mc & 1][6]);
-                                        pipe_coeffs(chain_all[mc & 1][1], 3, ring_all[mc & 1][7]);
-                                    }
-                                }
-                            } else if (role >= 2) {
-                                const int m = ph_ + 1;
-                                if (m >= 0 && m < all_rounds) {
-#pragma unroll
-                                    for (int q = 0; q < (QP == 4 ? 3 : QP); ++q) {
-                                        const int pair = QP == 4 ? 3 * (role - 2) + q : 2 * q + (role - 2);
-                                        pipe_coeffs(chain_all[m & 1][pair / 4], pair % 4, ring_all[m & 1][pair]);
-                                    }
-                                }
-                            } else if (ph_ >= 0) {
-#pragma unroll
-                                for (int q = 0; q < 2 * QP; ++q)
-                                    pipe_render(ring_all[ph_ & 1][q], SPR * (ph_ % ROUNDS) + 2 * q);
-                            }
-                            __syncthreads();
-                            if (ph_ >= 0 && ph_ % ROUNDS == ROUNDS - 1 && ph_ != all_rounds - 1) {
-                                // a tile inside the run is complete: what the main loop does after a calm tile
-                                n_out += idle ? 0u : (uint32_t)T;
-                                noise_seed = (uint32_t)__builtin_amdgcn_readlane((int)sk, T - 1);
-                                sk = noise_seed * LCG_SKIP.mul[ahead] + LCG_SKIP.add[ahead];
-                                flush_rows(base, n_out > base ? n_out - base : 0u);
-                                base += T;
-                            }
-                        }
-                        // every wave takes over the clocks the chain wave arrived at
-                        if (role == 1) {
-                            hand_all[0][lane] = clk;
-                            hand_all[1][lane] = jphase;
-                            hand_all[2][lane] = phase;
-                        }
-                        __syncthreads();
-                        if (role != 1) {
-                            clk = hand_all[0][lane];
-                            jphase = hand_all[1][lane];
-                            phase = hand_all[2][lane];
-                        }
-                    } else if constexpr (W == 1 && NV == 1 && FOLD_IN_FLUSH) {
-                        static_assert(!(W == 1 && NV == 1 && FOLD_IN_FLUSH) || (L >= 4 && T % 8 == 0), "blocks of eight, quads");
-#pragma unroll 1
-                        for (int tc = 0; tc < T; tc += 8) time_packed_block(tc, noise_of_lane);
-                    } else if constexpr (GRAIL_SCALAR_PACK && STEPS_PER_TRIP == 2 && L >= 4 && T % 8 == 0) {
-#pragma unroll 1
-                        for (int tc = 0; tc < T; tc += 8) scalar_packed_block(nlive_tag, su_tag, tc, noise_of_lane);
-                    } else if constexpr (GRAIL_SCALAR_PACK && STEPS_PER_TRIP == 2) {
-#pragma unroll 1
-                        for (int tc = 0; tc < T; tc += 2) {
-                            const float nz0 = __builtin_bit_cast(
-                                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc));
-                            const float nz1 = __builtin_bit_cast(
-                                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc + 1));
-                            scalar_packed_steps(nlive_tag, su_tag, tc, nz0, nz1);
-                        }
-                    } else {
-#pragma unroll 1
-                        for (int tc = 0; tc < T; tc += STEPS_PER_TRIP) {
-#pragma unroll
-                            for (int h = 0; h < STEPS_PER_TRIP; ++h) {
-                                const float nz = __builtin_bit_cast(
-                                    float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc + h));
-                                quiet_step(nlive_tag, su_tag, std::true_type(), tc + h, clk - dt, jphase + jinc, nz);
-                            }
-                        }
-                    }
-                    if (rendered) {
-                        if constexpr (FAST) ++fast_tiles;
-                        t = T;
-                        n_out += idle ? 0u : (uint32_t)T;
-                        noise_seed = (uint32_t)__builtin_amdgcn_readlane((int)sk, T - 1);
-                        return;
-                    }
-                }
-                fast_have = -1;          // exact steps follow: the kept interpolation ends go stale
-                // FAST kernels take the general step for every sample of a tile that is not calm (about
-                // one tile in a hundred): without the quiet-step loops the kernel needs far fewer registers
-                if constexpr (FAST) return;
-                for (; t < T; ++t) {
-                    const float clk_next = clk - dt;
-                    const float jphase_next = jphase + jinc;
-                    // bitwise on purpose: no short-circuit, so no exec-mask regions
-                    // ANYBL: a blend length that is not 2^k also sends a clk below the division
-                    // window (2^-59, or zero) to the general step
-                    const float clk_floor = (ANYBL && !blend_pow2) ? 0x1p-59f : 0.0f;
-                    const bool eventful = !done & (!quiet_ok | (clk_next < clk_floor) |
-                                                   (jphase_next > 1.0f) | (n_out >= cap32));
-                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(eventful) != 0, 0)) break;
-                    quiet_step(nlive_tag, su_tag, std::false_type(), t, clk_next, jphase_next, 0.0f);
-                }
-            };
-            const bool all_su = __builtin_amdgcn_ballot_w64(!done & !smooth_uniform) == 0;
-            typedef std::integral_constant<int, NV> FullTag;
-            bool half = false;
-            if constexpr (HALF && NV >= 2) {
-                typedef std::integral_constant<int, NV / 2> HalfTag;
-                half = __builtin_amdgcn_ballot_w64(!done & !upper_silent) == 0;
-                if (half && all_su) quiet_run(HalfTag(), std::true_type());
-                else if (half) quiet_run(HalfTag(), std::false_type());
-            }
-            if (!half) {
-                if (all_su) quiet_run(FullTag(), std::true_type());
-                else quiet_run(FullTag(), std::false_type());
-            }
-            if (t < T) {
-                ++general_steps;
-                general_step(t);
-                quiet_ok = pair_safe && (blend_pow2 || blend_div_ok);
-                ++t;
-            }
-        }
-
-        // ---- flush the staged tile: row `slot` holds samples [base, base+T)
-        // PIPE: the rendering wave parked the tile; all four waves (identical state, same decisions) flush a
-        // share of its rows each instead of waiting for wave 0 to do it alone, between two workgroup barriers
-        const uint32_t mine = n_out > base ? n_out - base : 0u;
-        constexpr int ROW_LANES = T / 4;
-        constexpr int ROWS_PER_IT = 64 / ROW_LANES;
-        const int rl = lane % ROW_LANES;
-        const int rr = lane / ROW_LANES;
-        if constexpr (!FOLD_IN_FLUSH && ROWS_PER_IT <= S) {
-            // the usual tile: every row of the wave received all T samples and the rows take 16-B stores.
-            // No per-row conditions, so the LDS reads of all rows are in flight together (a lone wave has
-            // nothing else to hide their latency behind) and the stores follow back to back.
-            const bool all_full = __builtin_amdgcn_ballot_w64((j == L - 1) & (mine != (uint32_t)T)) == 0;
-            // (not for the one-lane eight-formant kernels: they hold 256 VGPRs and AGPRs besides, and the extra
-            // path cost their f32 rows 4 %; their i16 rows take the general loop below)
-            constexpr bool PCM_FULL_TILE = !(L == 1 && NFA == NF);
-            if (all_full && (A.out_pcm16 ? (PCM_FULL_TILE && vec16_ok) : vec_ok)) {
-                wave_lds_sync();
-                float4 v[S / ROWS_PER_IT];
-#pragma unroll
-                for (int i = 0; i < S / ROWS_PER_IT; ++i) {
-                    const int r = i * ROWS_PER_IT + rr;
-                    const int t0 = rl * 4;
-                    v[i] = make_float4(stage[(t0 + 0) * SP + r], stage[(t0 + 1) * SP + r], stage[(t0 + 2) * SP + r],
-                                       stage[(t0 + 3) * SP + r]);
-                }
-                if (PCM_FULL_TILE && A.out_pcm16) {
-                    // the WAV sink's `(x * i16::MAX as f32) as i16` (examples/cli.rs:49) on the way out: 8-byte stores
-#pragma unroll
-                    for (int i = 0; i < S / ROWS_PER_IT; ++i) {
-                        const int p0 = pcm16_from_f32(v[i].x), p1 = pcm16_from_f32(v[i].y);
-                        const int p2 = pcm16_from_f32(v[i].z), p3 = pcm16_from_f32(v[i].w);
-                        const uint64_t row = A.perm ? rowid[i * ROWS_PER_IT + rr] : u0 + i * ROWS_PER_IT + rr;
-                        *reinterpret_cast<uint2 *>(A.out_pcm16 + row * A.out_stride + base + rl * 4) =
-                            make_uint2((uint32_t)(p0 & 0xFFFF) | ((uint32_t)p1 << 16),
-                                       (uint32_t)(p2 & 0xFFFF) | ((uint32_t)p3 << 16));
-                    }
-                } else if (A.perm) {     // (two copies of the loop: the usual one without any LDS look-up)
-#pragma unroll
-                    for (int i = 0; i < S / ROWS_PER_IT; ++i)
-                        *reinterpret_cast<float4 *>(A.out + (uint64_t)rowid[i * ROWS_PER_IT + rr] * A.out_stride + base +
-                                                    rl * 4) = v[i];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < S / ROWS_PER_IT; ++i)
-                        *reinterpret_cast<float4 *>(A.out + (uint64_t)(u0 + i * ROWS_PER_IT + rr) * A.out_stride + base +
-                                                    rl * 4) = v[i];
-                }
-                wave_lds_sync();
-                if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
-                continue;
-            }
-        }
-        flush_rows(base, mine);
-        if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
-    }
-
-    if (emit && j == L - 1 && u < A.n_utt) {
-        if (A.out_len) A.out_len[u] = n_out;
-        if (truncated) atomicOr(A.truncated, 1u);
-    }
-    if (streaming && A.state && u < A.n_utt) {
-        StateIO<false> io{A.state, A.state_stride, state_lane};
-        visit_state(io);
-    }
-    if (emit && lane == 0 && slow_steps) atomicAdd(A.truncated + 1, slow_steps);
-    if (emit && lane == 0 && fast_tiles) atomicAdd(A.truncated + 2, fast_tiles);
-    if (emit && lane == 0 && general_steps) atomicAdd(A.truncated + 3, general_steps);
-}
 
 // Sequencer clock only (src/lib.rs:861-888, :930): how many elems the
 // Sequencer yields, one utterance per lane.
@@ -2019,18 +57,18 @@ uint32_t state_words(int L)
     return 22u + 7u * (uint32_t)fpl;   // visit_state: 22 scalars + 7 values per formant
 }
 
-static void geometry(int L, int variant, uint32_t &per_block, uint32_t &threads)
+static void geometry(int L, uint32_t &per_block, uint32_t &threads)
 {
-    // must mirror the <L, T, WAVES, MINW> table of launch_synth
-    const int waves = (L >= 4 || variant == 1) ? 4 : 1;
+    // must mirror the <L, T, WAVES, MINW> table of the instantiation units
+    const int waves = L >= 4 ? 4 : 1;
     per_block = (64u / (uint32_t)L) * (uint32_t)waves;
     threads = 64u * (uint32_t)waves;
 }
 
-uint64_t state_lanes(uint32_t n_utt, int L, int variant)
+uint64_t state_lanes(uint32_t n_utt, int L)
 {
     uint32_t per_block, threads;
-    geometry(L, variant, per_block, threads);
+    geometry(L, per_block, threads);
     const uint64_t blocks = (n_utt + per_block - 1) / per_block;
     return blocks * threads;
 }
@@ -2048,104 +86,22 @@ int auto_lanes_per_utt(uint32_t n_utt)
 }
 
 // what the last launch_synth call started, for the bench line and the profile bookkeeping
-static thread_local char g_kernel_name[96] = "none";
+thread_local char g_kernel_name[96] = "none";
 const char *last_kernel_name() { return g_kernel_name; }
 
-template <int L, int T, int WAVES, int MINW, bool STREAM, bool HALF, bool ANYBL, int NFA = NF, bool PIPE = false,
-          bool FAST = false, int PQP = 2>
-static void start(const SynthArgs &args, dim3 grid, dim3 block, hipStream_t stream)
-{
-    std::snprintf(g_kernel_name, sizeof g_kernel_name, "synth_kernel<L=%d,T=%d,W=%d,%d,%s%s%sNFA=%d%s%s%s>", L, T, WAVES,
-                  MINW, STREAM ? "STREAM," : "", HALF ? "HALF," : "", ANYBL ? "ANYBL," : "", NFA,
-                  PIPE ? ",PIPE" : "", FAST ? ",FAST" : "", PQP == 4 ? ",R16" : "");
-    hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, STREAM, HALF, ANYBL, NFA, PIPE, FAST, PQP>), grid, block, 0,
-                       stream, args);
-}
-
-template <int L, int T, int WAVES, int MINW>
-static void launch_one(const SynthArgs &args, hipStream_t stream)
-{
-    const uint32_t per_block = (64u / L) * WAVES;
-    const dim3 grid((args.n_utt + per_block - 1) / per_block), block(64 * WAVES);
-    // one-shot fast kernels at L = 1: 64-step tiles (half as many flushes, calm tests and coefficient end
-    // points per sample: 18.1 -> 17.1 ms on the headline batch; the exact kernel measures slower with them,
-    // 43.1 against 40.4 ms, same box)
-    constexpr int TF = L == 1 ? 64 : T;
-    if constexpr (L <= 4) {
-        if (args.state && !args.any_blend && args.live4) {
-            if (args.fast) start<L, T, WAVES, MINW, true, false, false, 4, false, true>(args, grid, block, stream);
-            else start<L, T, WAVES, MINW, true, false, false, 4>(args, grid, block, stream);
-            return;
-        }
-        if (!args.state && !args.any_blend && args.live4) {
-            // L = 4 parks 4 floats per sample instead of 8: room for the 64-step tiles of L = 8
-            constexpr int T4 = L == 4 ? 64 : T;
-            if (args.fast) start<L, (L == 1 ? TF : T4), WAVES, MINW, false, false, false, 4, false, true>(args, grid, block, stream);
-            else start<L, T4, WAVES, MINW, false, false, false, 4>(args, grid, block, stream);
-            return;
-        }
-    }
-    if (args.fast && !args.state) {
-        // tolerance mode: the same kernels with the fast calm tile; HALF only where the exact policy uses it
-        if (L == 1 && args.half_capable) start<L, TF, WAVES, MINW, false, true, true, NF, false, true>(args, grid, block, stream);
-        else if (args.any_blend) start<L, TF, WAVES, MINW, false, false, true, NF, false, true>(args, grid, block, stream);
-        else start<L, TF, WAVES, MINW, false, false, false, NF, false, true>(args, grid, block, stream);
-        return;
-    }
-    if (args.state && args.fast) {
-        // resumable streams in tolerance mode (chunks concatenate to the one-shot rendering within the
-        // tolerance, not bit for bit: the interpolation ends restart with every call)
-        start<L, T, WAVES, MINW, true, false, true, NF, false, true>(args, grid, block, stream);
-        return;
-    }
-    if (args.state) {
-        // resumable streams: the lean instantiation when the batch allows it (chosen when the stream is
-        // opened: the state layout follows the formant layout), the general one otherwise
-        if (!args.any_blend && !args.half_capable)
-            start<L, T, WAVES, MINW, true, false, false>(args, grid, block, stream);
-        else
-            start<L, T, WAVES, MINW, true, true, true>(args, grid, block, stream);
-    } else if (args.any_blend)
-        start<L, T, WAVES, MINW, false, true, true>(args, grid, block, stream);
-    else if (L == 1 && args.half_capable)
-        start<L, T, WAVES, MINW, false, true, false>(args, grid, block, stream);
-    else
-        start<L, T, WAVES, MINW, false, false, false>(args, grid, block, stream);
-}
-
-hipError_t launch_synth(const SynthArgs &args, int L, int variant, hipStream_t stream)
+hipError_t launch_synth(const SynthArgs &args, int L, hipStream_t stream)
 {
     if (args.n_utt == 0) return hipSuccess;
     if (args.pipe && !args.state && !args.any_blend && !args.fast) {
-        // workgroups of four waves — render, chain, 2 x coefficients — share 16 utterances (four live
-        // formants, 4 lanes each) or 8 utterances (eight formants, 8 lanes each); rounds of 16 samples (73 KB of
-        // LDS: two workgroups fit a CU)
-        if (args.live4) {
-            const dim3 grid((args.n_utt + 15) / 16), block(256);
-            start<4, 64, 4, 1, false, false, false, 4, true, false, 4>(args, grid, block, stream);
-        } else {
-            const dim3 grid((args.n_utt + 7) / 8), block(256);
-            start<8, 64, 4, 1, false, false, false, NF, true, false, 4>(args, grid, block, stream);
-        }
+        if (args.live4) launch_pipe4(args, stream);
+        else launch_pipe8(args, stream);
         return hipGetLastError();
     }
-    // 64-thread workgroups are admitted 8 per CU (2 waves per SIMD, measured); L = 4 / 8 use
-    // 256-thread workgroups so that more waves can be resident.  variant 1 (experiments only):
-    // 256-thread workgroups for L = 1 / 2 as well.
-    if (variant == 1) {
-        switch (L) {
-        case 1: launch_one<1, 32, 4, 1>(args, stream); return hipGetLastError();
-        case 2: launch_one<2, 64, 4, 2>(args, stream); return hipGetLastError();
-        default: break;
-        }
-    } else if (variant != 0) {
-        return hipErrorInvalidValue;
-    }
     switch (L) {
-    case 1: launch_one<1, 32, 1, 1>(args, stream); break;
-    case 2: launch_one<2, 64, 1, 2>(args, stream); break;
-    case 4: launch_one<4, 32, 4, 2>(args, stream); break;
-    case 8: launch_one<8, 64, 4, 2>(args, stream); break;
+    case 1: args.fast ? launch_fast_l1(args, stream) : launch_exact_l1(args, stream); break;
+    case 2: args.fast ? launch_fast_l2(args, stream) : launch_exact_l2(args, stream); break;
+    case 4: args.fast ? launch_fast_l4(args, stream) : launch_exact_l4(args, stream); break;
+    case 8: args.fast ? launch_fast_l8(args, stream) : launch_exact_l8(args, stream); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -1,0 +1,23 @@
+// synth_launch.h — the instantiation units of synth_kernel (internal).  One translation unit per lane mapping
+// and arithmetic, so that the kernel families compile in parallel (synth_kernels.hip dispatches).
+#pragma once
+
+#include "kernels.h"
+
+namespace grail {
+
+// exact arithmetic (one-shot and resumable), lanes per utterance 1 / 2 / 4 / 8
+void launch_exact_l1(const SynthArgs &args, hipStream_t stream);
+void launch_exact_l2(const SynthArgs &args, hipStream_t stream);
+void launch_exact_l4(const SynthArgs &args, hipStream_t stream);
+void launch_exact_l8(const SynthArgs &args, hipStream_t stream);
+// tolerance arithmetic (args.fast)
+void launch_fast_l1(const SynthArgs &args, hipStream_t stream);
+void launch_fast_l2(const SynthArgs &args, hipStream_t stream);
+void launch_fast_l4(const SynthArgs &args, hipStream_t stream);
+void launch_fast_l8(const SynthArgs &args, hipStream_t stream);
+// the four-wave pipelined workgroups of small exact batches (args.pipe): four or eight live formants
+void launch_pipe4(const SynthArgs &args, hipStream_t stream);
+void launch_pipe8(const SynthArgs &args, hipStream_t stream);
+
+}  // namespace grail

@@ -1,0 +1,81 @@
+// synth_launch_impl.h — which instantiation of synth_kernel a launch takes (internal; included by the
+// synth_inst_*.hip units only).
+#pragma once
+
+#include "synth_kernel.h"
+#include "synth_launch.h"
+
+namespace grail {
+namespace {
+
+template <int L, int WAVES>
+dim3 lane_grid(const SynthArgs &args)
+{
+    const uint32_t per_block = (64u / L) * WAVES;
+    return dim3((args.n_utt + per_block - 1) / per_block);
+}
+
+template <int L, int T, int WAVES, int MINW>
+void launch_one_exact(const SynthArgs &args, hipStream_t stream)
+{
+    const dim3 grid = lane_grid<L, WAVES>(args), block(64 * WAVES);
+    if constexpr (L <= 4) {
+        if (args.state && !args.any_blend && args.live4) {
+            start<L, T, WAVES, MINW, true, false, false, 4>(args, grid, block, stream);
+            return;
+        }
+        if (!args.state && !args.any_blend && args.live4) {
+            // L = 4 parks 4 floats per sample instead of 8: room for the 64-step tiles of L = 8
+            constexpr int T4 = L == 4 ? 64 : T;
+            start<L, T4, WAVES, MINW, false, false, false, 4>(args, grid, block, stream);
+            return;
+        }
+    }
+    if (args.state) {
+        // resumable streams: the lean instantiation when the batch allows it (chosen when the stream is
+        // opened: the state layout follows the formant layout), the general one otherwise
+        if (!args.any_blend && !args.half_capable)
+            start<L, T, WAVES, MINW, true, false, false>(args, grid, block, stream);
+        else
+            start<L, T, WAVES, MINW, true, true, true>(args, grid, block, stream);
+    } else if (args.any_blend)
+        start<L, T, WAVES, MINW, false, true, true>(args, grid, block, stream);
+    else if (L == 1 && args.half_capable)
+        start<L, T, WAVES, MINW, false, true, false>(args, grid, block, stream);
+    else
+        start<L, T, WAVES, MINW, false, false, false>(args, grid, block, stream);
+}
+
+template <int L, int T, int WAVES, int MINW>
+void launch_one_fast(const SynthArgs &args, hipStream_t stream)
+{
+    const dim3 grid = lane_grid<L, WAVES>(args), block(64 * WAVES);
+    // one-shot fast kernels at L = 1: 64-step tiles (half as many flushes, calm tests and coefficient end
+    // points per sample: 18.1 -> 17.1 ms on the headline batch; the exact kernel measures slower with them,
+    // 43.1 against 40.4 ms, same box)
+    constexpr int TF = L == 1 ? 64 : T;
+    if constexpr (L <= 4) {
+        if (args.state && !args.any_blend && args.live4) {
+            start<L, T, WAVES, MINW, true, false, false, 4, false, true>(args, grid, block, stream);
+            return;
+        }
+        if (!args.state && !args.any_blend && args.live4) {
+            constexpr int T4 = L == 4 ? 64 : T;
+            start<L, (L == 1 ? TF : T4), WAVES, MINW, false, false, false, 4, false, true>(args, grid, block, stream);
+            return;
+        }
+    }
+    if (!args.state) {
+        // tolerance mode: the same kernels with the fast calm tile; HALF only where the exact policy uses it
+        if (L == 1 && args.half_capable) start<L, TF, WAVES, MINW, false, true, true, NF, false, true>(args, grid, block, stream);
+        else if (args.any_blend) start<L, TF, WAVES, MINW, false, false, true, NF, false, true>(args, grid, block, stream);
+        else start<L, TF, WAVES, MINW, false, false, false, NF, false, true>(args, grid, block, stream);
+        return;
+    }
+    // resumable streams in tolerance mode (chunks concatenate to the one-shot rendering within the
+    // tolerance, not bit for bit: the interpolation ends restart with every call)
+    start<L, T, WAVES, MINW, true, false, true, NF, false, true>(args, grid, block, stream);
+}
+
+}  // namespace
+}  // namespace grail

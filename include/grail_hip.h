@@ -210,7 +210,6 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *   "pipeline4_max_groups" (default 512), "pipeline8_max_groups" (default 512): exact arithmetic, how many
  *       four-wave pipelined workgroups (16 / 8 utterances each, four / eight live formants) a batch may
  *       need to still take them: two per CU.
- *   "kernel_variant": experiments only.
  * Read-only statistics: "slow_division_wave_steps", "fast_wave_tiles" (wave-tiles rendered in fast
  * arithmetic; scan kernel: 64-sample chain tiles on the closed forms kept from the tile before),
  * "general_wave_steps" (scan kernel: chain tiles whose closed forms were derived afresh),
