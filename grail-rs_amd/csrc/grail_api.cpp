@@ -127,6 +127,15 @@ struct grail_ctx {
     int scan_option = 1;              // fast arithmetic: small batches go to the time-parallel scan kernel
     int64_t scan_max_utts = 8704;     // ... up to this many utterances (x 4/7 with eight live formants)
     int64_t scan_split_max = 1536;    // ... and up to this many with the carrier phase on a wave of its own
+    bool voices_split_ok = false;     // every voice has a warm-up length (voice_warmup): time-split fast kernels
+    uint32_t max_warmup = 0;          // ... the longest of them
+    float max_rate = 0.0f;            // highest sample rate of the table
+    int split_option = 1;             // fast arithmetic: mid-size batches split every utterance's time axis over lanes
+    int64_t split_chunks = 0;         // ... into this many chunks (0: as many as fill the machine)
+    int64_t split_span = 0;           // ... laid out over this many samples (0: the batch's longest utterance)
+    int64_t split_ff_permille = 140;  // ... cost of a fast-forwarded sample against a rendered one
+    int64_t split_min_utts = 1025;    // ... batches smaller than this stay with the scan kernel
+    int last_split = 0;               // chunks of the last launch (statistics; 0: not time-split)
     float max_dt = 0.0f;              // largest 1/sample_rate of the table
     float max_pitch_jitter = 0.0f;    // largest |jitter_delta_frequency| of the table
     int last_formants = 8, last_lanes = 0, last_pipe = 0;   // what the last synthesis launch used (statistics)
@@ -168,6 +177,7 @@ struct grail_batch {
     bool phoneme_mode = true;
     bool any_blend = false;    // some segment's blend length is not +-2^k (selects the kernel)
     bool plain = false;        // every length / blend length / pitch finite, blend lengths > 0
+    float max_seconds = 0.0f;  // longest utterance: sum of its segment lengths
     float min_length = 0.0f;   // shortest segment (plain batches)
     float min_pitch = 0.0f;    // lowest frequency.min(0.5) of any segment (plain batches)
 };
@@ -320,6 +330,82 @@ bool scan_voice_ok(const grail_voice &v)
     return ok;
 }
 
+// Time-split fast kernels: how many samples until a filter state that started from zero is within 2^-22 of the
+// state the reference would have (relative to the state's size, which is below full scale)?  The chain of
+// Synthesize::next per formant is a one-pole low-pass with factor exp_approx(smooth) = (1 - smooth)^5 (:535-538)
+// and the trapezoidal state-variable band-pass (:555-571), whose poles are the bilinear images
+// z = (1 + s) / (1 - s) of s = g (-k/2 +- sqrt(k^2/4 - 1)), g = tan_approx(freq), k = bw / freq; for k < 2,
+// |z|^2 = (1 - g k + g^2) / (1 + g k + g^2) ~ exp(-2 pi bw).  The slowest of them over every phoneme (blends
+// move the parameters between phonemes and towards silent()'s 0.25 / 0.25 / 0.25, which decays at once; the
+// formant-frequency jitter hardly moves |z|) with a 10 % margin gives the length.  Formants that are silent in
+// every phoneme have nothing to converge.  0: the voice does not qualify (a parameter outside the window, or a
+// warm-up longer than 16384 samples).
+uint32_t voice_warmup(const grail_voice &v)
+{
+    double slowest = 1e300;   // smallest decay rate, per sample
+    for (int i = 0; i < NF; ++i) {
+        bool audible = false;
+        for (int p = 0; p < NUM_VOICED; ++p) audible = audible || !(v.phonemes[p].formant_amp[i] == 0.0f);
+        if (!audible) continue;
+        for (int p = 0; p < NUM_VOICED; ++p) {
+            const grail_synthesis_elem &e = v.phonemes[p];
+            const double f = e.formant_freq[i], w = e.formant_bw[i], sm = e.formant_smooth[i];
+            if (!(f > 0.0 && f < 0.5 && w > 0.0 && sm > 0.0 && sm < 1.0) || !std::isfinite(w)) return 0;
+            const double g = ((1 - f) * f * (5 - 4 * (f + 0.5) * (0.5 - f))) / ((f + 0.5) * (5 - 4 * (1 - f) * f) * (0.5 - f));
+            const double k = w / f;
+            double z;
+            if (k < 2.0) {
+                z = std::sqrt((1 - g * k + g * g) / (1 + g * k + g * g));
+            } else {
+                const double root = std::sqrt(k * k / 4 - 1);
+                const double s1 = g * (-k / 2 + root), s2 = g * (-k / 2 - root);
+                z = std::fmax(std::fabs((1 + s1) / (1 - s1)), std::fabs((1 + s2) / (1 - s2)));
+            }
+            if (!(z > 0.0 && z < 1.0)) return 0;
+            slowest = std::fmin(slowest, -std::log(z));
+            slowest = std::fmin(slowest, -5.0 * std::log1p(-sm));
+        }
+    }
+    if (slowest >= 1e300) return 64;                        // nothing audible: any state is the right one
+    const double samples = std::log(4194304.0) / (0.9 * slowest);   // 2^-22
+    if (!(samples <= 16384.0)) return 0;
+    return ((uint32_t)std::ceil(samples) + 63u) / 64u * 64u;
+}
+
+// The chunk grid of a time-split launch: K chunks over `span` samples.  Chunk k's lane fast-forwards the chain over
+// b[k] - W samples (cost r per sample, in units of a rendered sample), warms up over W and renders b[k+1] - b[k]:
+// the bounds are spaced so that all lanes take the same time (T below, by bisection).  Bounds are multiples
+// of 64; the last one is left to the caller (the row capacity).  false: K chunks do not fit.
+bool split_grid(uint32_t span, uint32_t warmup, int K, double r, uint32_t *b)
+{
+    auto lay = [&](double T, double *out) {
+        double at = 0.0;
+        for (int k = 0; k < K; ++k) {
+            out[k] = at;
+            const double before = k ? r * std::fmax(at - warmup, 0.0) + std::fmin((double)warmup, at) : 0.0;
+            const double len = T - before;
+            if (len < 64.0) return -1.0;
+            at += len;
+        }
+        return at;
+    };
+    double lo = 0.0, hi = (double)span + warmup + 64.0, pos[SPLIT_MAX_CHUNKS + 1];
+    if (lay(hi, pos) < (double)span) return false;
+    for (int it = 0; it < 60; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        const double end = lay(mid, pos);
+        if (end < 0.0 || end < (double)span) lo = mid;
+        else hi = mid;
+    }
+    if (lay(hi, pos) < 0.0) return false;
+    b[0] = 0;
+    for (int k = 1; k < K; ++k) {
+        b[k] = ((uint32_t)pos[k] + 32u) / 64u * 64u;
+        if (b[k] <= b[k - 1]) return false;
+    }
+    return b[K - 1] < span;
+}
+
 int install_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices)
 {
     if (!voices || n_voices == 0) return fail(GRAIL_ERR_INVALID_ARG, "no voices given");
@@ -332,7 +418,8 @@ int install_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices)
         dv[v].jitter_delta_formant_frequency = voices[v].jitter_delta_formant_frequency;
         dv[v].jitter_delta_amplitude = voices[v].jitter_delta_amplitude;
         dv[v].elem_base = v * NUM_VOICED;
-        dv[v].pad[0] = dv[v].pad[1] = 0;
+        dv[v].warmup = voice_warmup(voices[v]);
+        dv[v].pad = 0;
         std::memcpy(&elems[(size_t)v * NUM_VOICED * ELEM_FLOATS], voices[v].phonemes,
                     sizeof(grail_synthesis_elem) * NUM_VOICED);
     }
@@ -366,8 +453,15 @@ int install_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices)
     for (uint32_t v = 0; v < n_voices; ++v) ctx->voices_scan_ok = ctx->voices_scan_ok && scan_voice_ok(voices[v]);
     ctx->max_dt = 0.0f;
     ctx->max_pitch_jitter = 0.0f;
+    ctx->max_rate = 0.0f;
+    ctx->max_warmup = 0;
+    ctx->voices_split_ok = true;
     for (uint32_t v = 0; v < n_voices; ++v) {
         ctx->voices_live4_ok = ctx->voices_live4_ok && live4_ok(voices[v]);
+        ctx->voices_split_ok = ctx->voices_split_ok && dv[v].warmup != 0u && voices[v].sample_rate > 0.0f &&
+                               std::isfinite(voices[v].sample_rate);
+        if (dv[v].warmup > ctx->max_warmup) ctx->max_warmup = dv[v].warmup;
+        if (voices[v].sample_rate > ctx->max_rate) ctx->max_rate = voices[v].sample_rate;
         const float dt = 1.0f / voices[v].sample_rate;
         if (!(dt <= ctx->max_dt)) ctx->max_dt = dt;       // NaN-proof max
         const float pj = std::fabs(voices[v].jitter_delta_frequency);
@@ -503,6 +597,30 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         ctx->sort_option = value ? 1 : 0;
         return GRAIL_OK;
     }
+    if (std::strcmp(name, "time_split") == 0) {
+        ctx->split_option = value ? 1 : 0;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "time_split_chunks") == 0) {
+        if (value < 0 || value > SPLIT_MAX_CHUNKS) return fail(GRAIL_ERR_INVALID_ARG, "time_split_chunks must be 0 (auto) .. 64");
+        ctx->split_chunks = value;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "time_split_span_samples") == 0) {
+        if (value < 0 || value > 0x7fffffff) return fail(GRAIL_ERR_INVALID_ARG, "time_split_span_samples out of range");
+        ctx->split_span = value;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "time_split_ff_cost_permille") == 0) {
+        if (value < 0 || value > 1000) return fail(GRAIL_ERR_INVALID_ARG, "time_split_ff_cost_permille must be 0 .. 1000");
+        ctx->split_ff_permille = value;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "time_split_min_utterances") == 0) {
+        if (value < 0) return fail(GRAIL_ERR_INVALID_ARG, "negative limit");
+        ctx->split_min_utts = value;
+        return GRAIL_OK;
+    }
     if (std::strcmp(name, "pipeline4_max_groups") == 0) {   // tuning: four-formant batches, 16 utterances per workgroup
         ctx->pipe4_max_groups = value;
         return GRAIL_OK;
@@ -549,6 +667,30 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
     }
     if (std::strcmp(name, "time_parallel_scan_max_utterances") == 0) {
         *value = ctx->scan_max_utts;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "time_split") == 0) {
+        *value = ctx->split_option;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "time_split_chunks") == 0) {
+        *value = ctx->split_chunks;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "time_split_span_samples") == 0) {
+        *value = ctx->split_span;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "time_split_ff_cost_permille") == 0) {
+        *value = ctx->split_ff_permille;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "time_split_min_utterances") == 0) {
+        *value = ctx->split_min_utts;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "last_launch_chunks") == 0) {        // read-only: chunks per utterance (0: not time-split)
+        *value = ctx->last_split;
         return GRAIL_OK;
     }
     if (std::strcmp(name, "time_parallel_scan_split_max_utterances") == 0) {
@@ -622,6 +764,8 @@ int grail_batch_upload(grail_ctx *ctx, const grail_phoneme_elem *segs, const uin
     std::vector<float> seconds(n_utt, 0.0f);
     for (uint32_t u = 0; u < n_utt; ++u)
         for (uint32_t i = seg_offsets[u]; i < seg_offsets[u + 1]; ++i) seconds[u] += segs[i].length;
+    for (uint32_t u = 0; u < n_utt; ++u)
+        if (seconds[u] > b->max_seconds) b->max_seconds = seconds[u];
     if ((rc = upload(&b->d_segs, segs, n_segs, ctx->stream)) ||
         (rc = upload_common(ctx, b, seg_offsets, voice_ids, jitter_seeds, n_utt)) ||
         (rc = upload_length_order(ctx, b, seconds, n_utt))) {
@@ -664,6 +808,8 @@ int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
     std::vector<float> seconds(n_utt, 0.0f);
     for (uint32_t u = 0; u < n_utt; ++u)
         for (uint32_t i = seg_offsets[u]; i < seg_offsets[u + 1]; ++i) seconds[u] += segs[i].length;
+    for (uint32_t u = 0; u < n_utt; ++u)
+        if (seconds[u] > b->max_seconds) b->max_seconds = seconds[u];
     if ((rc = upload(&b->d_segs, ds.data(), n_segs, ctx->stream)) ||
         (rc = upload(&b->d_elems, elems.data(), elems.size(), ctx->stream)) ||
         (rc = upload_common(ctx, b, seg_offsets, voice_ids, jitter_seeds, n_utt)) ||
@@ -785,6 +931,8 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     a.any_blend = batch->any_blend ? 1u : 0u;
     a.live4 = batch_live4(ctx, batch) ? 1u : 0u;
     a.fast = ctx->fast_option ? 1u : 0u;
+    // (the fast lane kernels have four-formant instantiations for every blend length)
+    if (a.fast && batch_live4_any_blend(ctx, batch)) a.live4 = 1u;
     int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(count);
     // small batches leave SIMDs idle: four-wave workgroups (one wave renders 16 utterances, one carries
     // the per-utterance chain, two prepare the filter coefficients), up to two per CU (tools/pipe4_range.py:
@@ -815,11 +963,37 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     // (measured crossover against the lane-per-utterance fast kernels: ~9000 utterances with four live
     // formants, ~5000 with eight — the filter wave then has four formant pairs to go through;
     // profiles/r02_small_batch.txt)
-    const bool scan = a.fast && ctx->scan_option && !ctx->lanes_option &&
+    // fast arithmetic, mid-size batches: one lane per utterance would leave most of the machine idle, so the time
+    // axis of every utterance is cut into chunks with a lane each (synth_kernel<..., SPLIT>): as many chunks as
+    // fill 1024 waves, laid out over the batch's longest utterance so that all lanes finish together
+    int split_k = 0;
+    if (a.fast && ctx->split_option && !ctx->lanes_option && batch->phoneme_mode && ctx->voices_split_ok &&
+        batch->plain && out_stride <= 0xFFFFFFFFull &&
+        (ctx->split_chunks >= 2 || (ctx->split_chunks == 0 && (int64_t)count >= ctx->split_min_utts))) {
+        double span = ctx->split_span ? (double)ctx->split_span
+                                      : std::ceil((double)batch->max_seconds * ctx->max_rate) + 64.0;
+        span = std::fmin(span, (double)out_stride);
+        int K = ctx->split_chunks ? (int)ctx->split_chunks : (int)std::min<uint64_t>(65536u / count, SPLIT_MAX_CHUNKS);
+        K = (int)std::fmin((double)K, span / 512.0);
+        while (K >= 2 && !split_grid((uint32_t)span, ctx->max_warmup, K, 1e-3 * (double)ctx->split_ff_permille, a.split_bounds))
+            --K;
+        if (K >= 2) {
+            split_k = K;
+            a.split_bounds[K] = (uint32_t)out_stride;
+        }
+    }
+    const bool scan = !split_k && a.fast && ctx->scan_option && !ctx->lanes_option &&
                       (int64_t)count * (batch_live4_any_blend(ctx, batch) ? 4 : 7) <= 4 * ctx->scan_max_utts &&
                       batch->phoneme_mode && ctx->voices_scan_ok && batch->plain &&
                       batch->min_length >= 2.0f * ctx->max_dt &&
                       batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f;
+    if (split_k) {
+        a.split_chunks = (uint32_t)split_k;
+        a.live4 = batch_live4_any_blend(ctx, batch) ? 1u : 0u;
+        a.pipe = 0u;
+        L = 1;
+    }
+    ctx->last_split = split_k;
     ctx->last_formants = a.live4 ? 4 : 8;
     ctx->last_lanes = scan ? 0 : L;
     ctx->last_pipe = a.pipe && !scan ? 1 : 0;

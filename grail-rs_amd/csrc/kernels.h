@@ -10,6 +10,7 @@ constexpr int NF = 8;            // NUM_FORMANTS, reference src/lib.rs:24
 constexpr int ELEM_FLOATS = 49;  // SynthesisElem, reference src/lib.rs:316-337
 constexpr int NUM_VOICED = 2;    // VoiceStorage {a, e}, reference src/lib.rs:653-659
 constexpr int PH_FIRST_VOICED = 3;
+constexpr int SPLIT_MAX_CHUNKS = 64;   // time-split fast kernels: chunks per utterance
 
 // field offsets inside a 49-float SynthesisElem (declared order)
 constexpr int F_FREQ = 1, F_BW = 9, F_SMOOTH = 17, F_BREATH = 25, F_TURB = 33, F_AMP = 41;
@@ -36,7 +37,9 @@ struct DevVoice {
     float jitter_delta_formant_frequency;
     float jitter_delta_amplitude;
     uint32_t elem_base;  // row of phonemes.a in the voice elem table
-    uint32_t pad[2];
+    uint32_t warmup;     // time-split fast kernels: samples after which a filter state started from zero has
+                         // decayed below half an ulp of full scale (a multiple of 64; 0: the voice does not qualify)
+    uint32_t pad;
 };
 static_assert(sizeof(DevVoice) == 32, "DevVoice layout");
 
@@ -73,6 +76,10 @@ struct SynthArgs {
     uint32_t *state;              // resumable synthesis: state[word][lane] or nullptr (one-shot)
     uint64_t state_stride;        // lanes of the launch (= state_lanes())
     uint32_t resume;              // 1: load the state first (not the first call of a stream)
+    // time-split fast kernels (synth_kernel<..., SPLIT>): chunk k of every utterance is the samples
+    // [split_bounds[k], split_bounds[k + 1]) (multiples of 64; the last bound is `cap`), one lane each
+    uint32_t split_chunks;        // K, 0: not a time-split launch
+    uint32_t split_bounds[SPLIT_MAX_CHUNKS + 1];
 };
 
 struct LenArgs {

@@ -364,11 +364,21 @@ struct StateIO {
 // kernels, so no segment boundary, noise wrap or saw edge ever moves; the continuous per-formant
 // arithmetic uses fused multiply-adds, one uncorrected reciprocal per formant, and filter
 // coefficients interpolated linearly across the tile.  Tiles with an event run the exact steps.
+// SPLIT (FAST, one lane per utterance): the time axis of every utterance is cut into chunks
+// [split_bounds[k], split_bounds[k + 1]) and each chunk gets a lane of its own, so that a few thousand
+// utterances fill the machine.  A chunk's lane first FAST-FORWARDS the exact per-utterance chain (clock,
+// segment advances, jitter phase and redraws, pitch track, carrier phase: the reference's operations, no
+// filters, nothing stored) from sample 0 to `warmup` samples before its chunk, starts the filters there from
+// zero state — by the chunk's first sample the difference to the true state has decayed below half an ulp of
+// full scale (DevVoice::warmup, from the narrowest bandwidth of the voice) — and then renders like any fast
+// kernel, storing from the chunk's first sample on.  All 64 lanes of a wave work on the same chunk index, so
+// they sit at the same sample position and share the carrier noise of a tile as everywhere else.
 template <int L, int T, int WAVES, int MIN_WAVES_PER_SIMD, bool STREAM, bool HALF, bool ANYBL, int NFA = NF,
-          bool PIPE = false, bool FAST = false, int PQP = 2>
+          bool PIPE = false, bool FAST = false, int PQP = 2, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(const SynthArgs A)
 {
-    static_assert(!FAST || !PIPE, "FAST");
+    static_assert(!FAST || (!PIPE && !HALF), "FAST");
+    static_assert(!SPLIT || (FAST && !STREAM && L == 1 && WAVES == 1 && T == 64), "SPLIT");
     static_assert(NFA == NF || (NFA == 4 && !HALF), "NFA");
     static_assert(!PIPE || (WAVES == 4 && NFA / L == 1 && L >= 4 && !STREAM && !HALF && !ANYBL && T % 4 == 0), "PIPE");
     constexpr int FPL = NFA / L;         // formants per lane
@@ -399,7 +409,11 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     const int slot = lane / L;
     const int j = lane % L;
     const int f0 = j * FPL;
-    const uint32_t u0 = PIPE ? blockIdx.x * S : (blockIdx.x * WAVES + wave) * S;
+    // SPLIT: the waves of the last chunk (longest fast-forward) start first
+    const uint32_t split_groups = SPLIT ? (A.n_utt + S - 1) / S : 1u;
+    const uint32_t chunk = SPLIT ? A.split_chunks - 1u - blockIdx.x / split_groups : 0u;
+    const uint32_t u0 = SPLIT ? (blockIdx.x % split_groups) * S
+                              : PIPE ? blockIdx.x * S : (blockIdx.x * WAVES + wave) * S;
     // which utterance this slot renders: its position in the launch, or — ragged batches — the host's
     // length-sorted assignment (A.perm), so that the lanes of a wave end together; rows, lengths and
     // per-utterance inputs always belong to utterance `u`
@@ -498,6 +512,13 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 
     const uint64_t cap = A.cap;              // samples this launch may write per row (<= out_stride)
     const uint32_t cap32 = cap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap;   // n_out is 32-bit
+    // where this launch stops rendering an utterance that has not ended: a stream call at its quota, a chunk
+    // lane at the first sample of the next chunk (the last chunk runs to the end of the row)
+    constexpr bool PAUSES = STREAM || SPLIT;
+    const uint32_t chunk_lo = SPLIT ? A.split_bounds[chunk] : 0u;
+    const uint32_t pause_at = SPLIT ? (chunk + 1u < A.split_chunks ? A.split_bounds[chunk + 1u] : 0xFFFFFFFFu) : cap32;
+    const uint32_t room_end = SPLIT ? (pause_at < cap32 ? pause_at : cap32) : cap32;
+    bool paused = false;
     uint32_t n_out = 0;
     uint32_t slow_steps = 0;                 // wave-steps that took the IEEE-division body
     uint32_t fast_tiles = 0, general_steps = 0;   // statistics: tiles rendered by fast_tile, general steps taken
@@ -608,10 +629,14 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 
     // ---- the general sample step: any lane may be finished, advance a segment, wrap its
     // jitter noise, hit the row capacity, or need the IEEE-division body.
-    auto general_step = [&](const int t) __attribute__((always_inline)) {
+    // CHAIN_ONLY (SPLIT's fast-forward): the per-utterance chain alone — Sequencer, Jitter state, pitch, carrier
+    // phase — exactly as below; no formant is evaluated and nothing is staged
+    auto general_step = [&](const int t, auto chain_only_tag) __attribute__((always_inline)) {
+        constexpr bool CHAIN_ONLY = decltype(chain_only_tag)::value;
         if (done) return;
-        if (streaming && n_out >= cap32) {   // this call's quota is used up: pause BEFORE advancing
+        if (PAUSES && n_out >= pause_at) {   // this launch's share is used up: pause BEFORE advancing
             done = true;
+            paused = true;
             return;
         }
 
@@ -634,6 +659,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 setup_pair();
                 pair_safe = pair_is_safe<NV, W>(X, Y, clk, blend_length, jinc, d_ffreq, d_freq);
                 update_silent();
+                quiet_ok = pair_safe && (blend_pow2 || blend_div_ok);
             }
         }
         if (!cur.some) { done = true; finished = true; }      // :930
@@ -694,6 +720,12 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         const float jomp = 1.0f - jphase;
         const float n_freq = fn_cur * jomp + fn_next * jphase;         // :254
         frequency = frequency + n_freq * d_freq;                       // :763
+        if constexpr (CHAIN_ONLY) {
+            phase += frequency;                                        // :520
+            if (phase >= 1.0f) phase -= 1.0f;                          // :523-525
+            ++n_out;                                                   // (the carrier noise state follows from n_out)
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const V n_ff = ff_cur[k] * jomp + ff_next[k] * jphase;     // :305
@@ -721,12 +753,11 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 
         // events are rare: this step always takes the IEEE-division body (same bits)
         V v1[NV];
-        bool fast_formants = false;
-        if constexpr (FAST) fast_formants = __builtin_amdgcn_ballot_w64(!pair_safe) == 0;
-        if (fast_formants) {
-            // FAST kernels, every lane's pair inside the safe window: the per-formant arithmetic of this
-            // sample in tolerance mode too (the control flow and the chain above stay the reference's) —
-            // reciprocals by v_rcp + one Newton step, fused multiply-adds, v1 = a1 (b + g v3), v2 = c + g v1
+        // FAST kernels, the lane's pair inside the safe window (its own decision: a lane's samples never depend
+        // on its wave-mates): the per-formant arithmetic of this sample in tolerance mode too (the control
+        // flow and the chain above stay the reference's) — reciprocals by v_rcp + one Newton step, fused
+        // multiply-adds, v1 = a1 (b + g v3), v2 = c + g v1
+        if (FAST && pair_safe) {
             const V one = vsplat(1.0f, V()), five = vsplat(5.0f, V()), m4 = vsplat(-4.0f, V());
             const V nms = vsplat(noise - saw, V()), nm1 = vsplat(noise - 1.0f, V()), sawv = vsplat(saw, V());
 #pragma unroll
@@ -1314,7 +1345,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     };
 
 
-    // ---- FAST: one calm tile of T samples in tolerance-mode arithmetic.
+    // ---- FAST: calm tiles of T samples in tolerance-mode arithmetic.
     // Exact, as everywhere: clk (:861), alpha, the pitch blend and its jitter (:404, :254, :763), the
     // jitter phase (:242) and the carrier phase with its wrap (:520-525) — two samples per packed
     // slot, the same operations on the same operands as the exact kernels.  Within tolerance:
@@ -1326,15 +1357,20 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     //     at the ends of sub-tiles of TS <= 32 samples and interpolated linearly in between (alpha and the
     //     jitter phase are linear in time inside a calm tile; a tile that holds the kink of
     //     alpha = min(., 1) is not calm).  The end of a sub-tile is the start of the next one.
-    //   * the interpolation error is bounded per wave when a run of calm tiles starts (after every
-    //     event): a relative change r of a1, g or 1 - exp_approx over 32 samples gives an error below
+    //   * the interpolation error is bounded when a lane's run of calm tiles starts (after every event of
+    //     ITS OWN): a relative change r of a1, g or 1 - exp_approx over 32 samples gives an error below
     //     r^2/16 <= 2^-23 for r <= 2^-9.5 (g is close to linear in x: far below that); G and H are
     //     products of linear functions, error <= |dA dM| / 4 and |dT dG| / 4 <= 2^-22 absolute.
-    //     Faster parameter motion halves TS (error / 4) until it fits; below TS = 2 the tile takes the
-    //     exact steps.  The reference's own front end always emits 0.5 s blends (Intonator :1070-1071),
+    //     Faster parameter motion halves TS (error / 4) until it fits; below TS = 2 the lane takes the
+    //     general steps.  The reference's own front end always emits 0.5 s blends (Intonator :1070-1071),
     //     for which TS = 32.
     //   * :531 as saw + breath (noise - saw), :538 as fma, :544-550 as a (G + H (noise - 1)), the
     //     eight-term sum (:574) in tree order.
+    // BATCH INVARIANCE.  Whether a tile of a lane is calm, where its runs of calm tiles start, its sub-tile
+    // length and its smoothness flavour are decided from the lane's own state on the utterance's own grid of
+    // T-sample tiles; a lane next to lanes that decide otherwise computes exactly what it would compute among
+    // its like (the mixed tile of the main loop runs the same functions under the lane's own predicate).  The
+    // samples of an utterance therefore do not depend on which utterances share its wave.
     struct FastEnds {
         V a1[NV], tg[NV], g[NV], h[NV], b[NV], om[NV];   // tg = tan_approx(x), g = amplitude
         float oml;
@@ -1342,287 +1378,314 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     struct FastAux {
         V ap[NV], mu[NV], tb[NV];
     };
-    FastEnds FS;             // the interpolated quantities at the first sample of the NEXT tile, kept while calm
-                             // tiles follow each other
-    int fast_have = -1;      // which flavour (NLIVE * 2 + SU) stored FS; -1: nothing kept
-    int fast_shift = 0;      // sub-tile length 32 >> fast_shift, chosen when a run of calm tiles starts
-    auto fast_tile = [&](auto nlive_tag, auto su_tag, const float noise_of_lane,
-                         const bool idle_lane) __attribute__((always_inline)) -> bool {
-        constexpr int NLIVE = decltype(nlive_tag)::value;
+    FastEnds FS;             // the interpolated quantities at the first sample of the lane's next sub-tile
+    FastEnds FD;             // their per-sample slopes over the lane's current sub-tile
+    f2 FTI = vsplat(0.0f, f2());   // position of the next sample pair inside the lane's sub-tile: (i, i + 1)
+    int fast_have = -1;      // the flavour (1: shared smoothness, 0: per formant) of the run FS belongs to; -1: no run
+    int fast_shift = 0;      // the lane's sub-tile length is 32 >> fast_shift, chosen when its run starts
+    bool fast_fresh = false; // FD already holds the slopes of the first sub-tile (made when the run started)
+    constexpr int FAST_TS0 = 32;
+    static_assert(!FAST || T % FAST_TS0 == 0, "whole sub-tiles");
+    // the smooth quantities `after` samples from now (the clock and the jitter phase extrapolated:
+    // they only feed continuous functions here).  SLOPE: e receives (value - FS) * scale instead.
+    auto fast_endpoint = [&](auto su_tag, auto slope_tag, const float after, const float scale, FastEnds &e,
+                             FastAux &x) __attribute__((always_inline)) {
         constexpr bool SU = decltype(su_tag)::value;
-        constexpr bool KEEP_LP = STREAM;
-        constexpr int NLP = (NLIVE < NV && !KEEP_LP) ? NLIVE : NV;
-        constexpr int TS0 = 32;
-        static_assert(T % TS0 == 0, "whole sub-tiles");
-        constexpr int FLAVOUR = NLIVE * 2 + (SU ? 1 : 0);
+        constexpr bool SLOPE = decltype(slope_tag)::value;
         const V one = vsplat(1.0f, V());
         const V five = vsplat(5.0f, V()), m4 = vsplat(-4.0f, V());
-        // the smooth quantities `after` samples from now (the clock and the jitter phase extrapolated:
-        // they only feed continuous functions here).  SLOPE: e receives (value - FS) * scale instead.
-        auto endpoint = [&](auto slope_tag, const float after, const float scale, FastEnds &e,
-                            FastAux &x) __attribute__((always_inline)) {
-            constexpr bool SLOPE = decltype(slope_tag)::value;
-            const float c = clk - after * dt;
-            const float jp = jphase + after * jinc;
-            float alpha = __builtin_fminf(c * inv_blend_length, 1.0f);
-            alpha = silent_pair ? 1.0f : alpha;
-            const float oma = 1.0f - alpha, jomp = 1.0f - jp;
-            auto put = [&](V &dst, const V &start, const V value) __attribute__((always_inline)) {
-                if constexpr (SLOPE) dst = (value - start) * scale;
-                else dst = value;
-            };
-#pragma unroll
-            for (int k = 0; k < NLIVE; ++k) {
-                V ef = vfma(Y.freq[k], vsplat(alpha, V()), X.freq[k] * oma);
-                const V eb = vfma(Y.bw[k], vsplat(alpha, V()), X.bw[k] * oma);
-                const V et = vfma(Y.turb[k], vsplat(alpha, V()), X.turb[k] * oma);
-                const V ea = vfma(Y.amp[k], vsplat(alpha, V()), X.amp[k] * oma);
-                const V nff = vfma(ff_next[k], vsplat(jp, V()), ff_cur[k] * jomp);
-                const V nfa = vfma(fa_next[k], vsplat(jp, V()), fa_cur[k] * jomp);
-                ef = vfma(nff, vsplat(d_ffreq, V()), ef);
-                const V mul = vfma(nfa + 1.0f, vsplat(-amp_scale, V()), one);
-                const V omx = 1.0f - ef, xph = ef + 0.5f, hmx = 0.5f - ef;
-                const V ox = omx * ef, ph = xph * hmx;
-                const V num = ox * vfma(m4, ph, five);
-                const V den = (xph * vfma(m4, ox, five)) * hmx;
-                // g = num / den (:555), k = bw / x (:558), a1 = 1 / (1 + g (g + k)) (:560): v_rcp + one
-                // Newton step each (correctly rounded reciprocals; the quotients are within an ulp)
-                V rd = vrcp(den), rx = vrcp(ef);
-                rd = vfma(vfma(-den, rd, one), rd, rd);
-                rx = vfma(vfma(-ef, rx, one), rx, rx);
-                const V tg = num * rd;
-                const V kq = eb * rx;
-                const V d3 = vfma(tg, tg + kq, one);
-                V r3 = vrcp(d3);
-                r3 = vfma(vfma(-d3, r3, one), r3, r3);
-                const V gg = ea * mul;
-                put(e.a1[k], FS.a1[k], r3);
-                put(e.tg[k], FS.tg[k], tg);
-                put(e.g[k], FS.g[k], gg);
-                put(e.h[k], FS.h[k], et * gg);
-                x.ap[k] = ea;
-                x.mu[k] = mul;
-                x.tb[k] = et;
-            }
-            float oml_here = 1.0f;
-            if constexpr (SU) {
-                const float es = __builtin_fmaf(vget(Y.smooth[0], 0), alpha, vget(X.smooth[0], 0) * oma);
-                oml_here = 1.0f - exp_approx(es);
-            }
-#pragma unroll
-            for (int k = 0; k < NLP; ++k) {
-                const V br = vfma(Y.breath[k], vsplat(alpha, V()), X.breath[k] * oma);
-                if constexpr (!SU) {
-                    put(e.b[k], FS.b[k], br);
-                    const V es = vfma(Y.smooth[k], vsplat(alpha, V()), X.smooth[k] * oma);
-                    put(e.om[k], FS.om[k], 1.0f - exp_approx(es));
-                } else {
-                    // shared smoothness: the low-pass is used as a' = (1-k) a + k saw + (k breath)(noise - saw),
-                    // so the interpolated per-formant quantity is k * breath
-                    put(e.b[k], FS.b[k], br * oml_here);
-                    e.om[k] = one;
-                }
-            }
-            e.oml = SU ? (SLOPE ? (oml_here - FS.oml) * scale : oml_here) : 1.0f;
+        const float c = clk - after * dt;
+        const float jp = jphase + after * jinc;
+        float alpha = __builtin_fminf(c * inv_blend_length, 1.0f);
+        alpha = silent_pair ? 1.0f : alpha;
+        const float oma = 1.0f - alpha, jomp = 1.0f - jp;
+        auto put = [&](V &dst, const V &start, const V value) __attribute__((always_inline)) {
+            if constexpr (SLOPE) dst = (value - start) * scale;
+            else dst = value;
         };
-        FastEnds D;              // per-sample slopes of the sub-tile
-        FastAux xe;
-        bool have_slopes = false;
-        if (fast_have != FLAVOUR) {
-            // a run of calm tiles starts: the values now, the slopes over 32 samples, and the error guard
-            FastAux xs;
-            endpoint(std::false_type(), 1.0f, 1.0f, FS, xs);
-            endpoint(std::true_type(), (float)(TS0 + 1), 1.0f / (float)TS0, D, xe);
-            float ra = 0.0f, rg = 0.0f;
 #pragma unroll
-            for (int k = 0; k < NLIVE; ++k)
-#pragma unroll
-                for (int c = 0; c < W; ++c) {
-                    // relative change of a1 and g over 32 samples; 32^2 x the products of slopes behind G and H
-                    ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(D.a1[k], c)) * (float)TS0 *
-                                                 __builtin_amdgcn_rcpf(vget(FS.a1[k], c)));
-                    ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(D.tg[k], c)) * (float)TS0 *
-                                                 __builtin_amdgcn_rcpf(vget(FS.tg[k], c)));
-                    rg = __builtin_fmaxf(rg, __builtin_fabsf((vget(xe.ap[k], c) - vget(xs.ap[k], c)) *
-                                                             (vget(xe.mu[k], c) - vget(xs.mu[k], c))));
-                    rg = __builtin_fmaxf(rg, __builtin_fabsf((vget(xe.tb[k], c) - vget(xs.tb[k], c)) *
-                                                             vget(D.g[k], c) * (float)TS0));
-                }
-            if constexpr (SU) {
-                ra = __builtin_fmaxf(ra, __builtin_fabsf(D.oml) * (float)TS0 * __builtin_amdgcn_rcpf(FS.oml));
-            } else {
-#pragma unroll
-                for (int k = 0; k < NLP; ++k)
-#pragma unroll
-                    for (int c = 0; c < W; ++c)
-                        ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(D.om[k], c)) * (float)TS0 *
-                                                     __builtin_amdgcn_rcpf(vget(FS.om[k], c)));
-            }
-            // halvings needed: r / 2^s <= 2^-9.5 (error ~ r^2 / 16), |.| / 4 / 4^s <= 2^-22
-            const int la = __builtin_amdgcn_frexp_expf(ra * 724.0773439350247f);      // 2^9.5
-            const int lg = (__builtin_amdgcn_frexp_expf(rg * GRAIL_FAST_G_SCALE) + 1) >> 1;
-            int level = la > lg ? la : lg;
-            level = level < 0 ? 0 : level;
-            if (!(ra == ra) || !(rg == rg)) level = 99;                                // NaN: not here
-            level = idle_lane ? 0 : level;
-            int lvl = 0;
-            for (; lvl <= 4; ++lvl)
-                if (__builtin_amdgcn_ballot_w64(level > lvl) == 0) break;
-            if (lvl > 4) return false;               // faster than TS = 2 can follow: the exact steps
-            fast_shift = lvl;
-            have_slopes = lvl == 0;
-            fast_have = FLAVOUR;
+        for (int k = 0; k < NV; ++k) {
+            V ef = vfma(Y.freq[k], vsplat(alpha, V()), X.freq[k] * oma);
+            const V eb = vfma(Y.bw[k], vsplat(alpha, V()), X.bw[k] * oma);
+            const V et = vfma(Y.turb[k], vsplat(alpha, V()), X.turb[k] * oma);
+            const V ea = vfma(Y.amp[k], vsplat(alpha, V()), X.amp[k] * oma);
+            const V nff = vfma(ff_next[k], vsplat(jp, V()), ff_cur[k] * jomp);
+            const V nfa = vfma(fa_next[k], vsplat(jp, V()), fa_cur[k] * jomp);
+            ef = vfma(nff, vsplat(d_ffreq, V()), ef);
+            const V mul = vfma(nfa + 1.0f, vsplat(-amp_scale, V()), one);
+            const V omx = 1.0f - ef, xph = ef + 0.5f, hmx = 0.5f - ef;
+            const V ox = omx * ef, ph = xph * hmx;
+            const V num = ox * vfma(m4, ph, five);
+            const V den = (xph * vfma(m4, ox, five)) * hmx;
+            // g = num / den (:555), k = bw / x (:558), a1 = 1 / (1 + g (g + k)) (:560): v_rcp + one
+            // Newton step each (correctly rounded reciprocals; the quotients are within an ulp)
+            V rd = vrcp(den), rx = vrcp(ef);
+            rd = vfma(vfma(-den, rd, one), rd, rd);
+            rx = vfma(vfma(-ef, rx, one), rx, rx);
+            const V tg = num * rd;
+            const V kq = eb * rx;
+            const V d3 = vfma(tg, tg + kq, one);
+            V r3 = vrcp(d3);
+            r3 = vfma(vfma(-d3, r3, one), r3, r3);
+            const V gg = ea * mul;
+            put(e.a1[k], FS.a1[k], r3);
+            put(e.tg[k], FS.tg[k], tg);
+            put(e.g[k], FS.g[k], gg);
+            put(e.h[k], FS.h[k], et * gg);
+            x.ap[k] = ea;
+            x.mu[k] = mul;
+            x.tb[k] = et;
         }
-        const int TS = TS0 >> fast_shift;
-        const float inv_ts = __builtin_bit_cast(float, (uint32_t)(127 - 5 + fast_shift) << 23);   // 1 / TS
-        const float nm1_of_lane = noise_of_lane - 1.0f;
-        const f2 one2 = vsplat(1.0f, f2());
-        // ---- the per-utterance chain of samples tc, tc+1: exact (see scalar_packed_steps).  Advances
-        // clk, jphase and phase; returns the phases before the two samples and their pitch.
-        const float inv_bl = (!ANYBL && silent_pair) ? __builtin_inff() : inv_blend_length;
-        auto chain_pair = [&](f2 &PH, f2 &frequency) __attribute__((always_inline)) {
-            const float clk0 = clk - dt, clk1 = clk0 - dt;                     // :861
-            const float jp0 = jphase + jinc, jp1 = jp0 + jinc;                 // :242 / :291
-            clk = clk1;
-            jphase = jp1;
-            f2 CLK, JP;
-            CLK.x = clk0; CLK.y = clk1; JP.x = jp0; JP.y = jp1;
-            f2 ratio = CLK * inv_bl;
-            if constexpr (ANYBL) {
-                const f2 rem = vfma(-blend_length * one2, ratio, CLK);
-                const f2 quot = vfma(rem, inv_blend_length * one2, ratio);     // RN(clk / blend_length)
-                ratio = blend_pow2 ? ratio : quot;
-            }
-            f2 alpha;                                                          // :899/:908/:917
-            if constexpr (ANYBL) {
-                alpha.x = silent_pair ? 1.0f : __builtin_fminf(ratio.x, 1.0f);
-                alpha.y = silent_pair ? 1.0f : __builtin_fminf(ratio.y, 1.0f);
+        float oml_here = 1.0f;
+        if constexpr (SU) {
+            const float es = __builtin_fmaf(vget(Y.smooth[0], 0), alpha, vget(X.smooth[0], 0) * oma);
+            oml_here = 1.0f - exp_approx(es);
+        }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const V br = vfma(Y.breath[k], vsplat(alpha, V()), X.breath[k] * oma);
+            if constexpr (!SU) {
+                put(e.b[k], FS.b[k], br);
+                const V es = vfma(Y.smooth[k], vsplat(alpha, V()), X.smooth[k] * oma);
+                put(e.om[k], FS.om[k], 1.0f - exp_approx(es));
             } else {
-                // a both-silent pair emits silent() itself (alpha = 1, :926): its reciprocal blend length was
-                // replaced by +inf for this tile (inv_bl below), the clock is positive in a calm tile, and
-                // min(+inf, 1) = 1 — no select per sample
-                alpha.x = __builtin_fminf(ratio.x, 1.0f);
-                alpha.y = __builtin_fminf(ratio.y, 1.0f);
+                // shared smoothness: the low-pass is used as a' = (1-k) a + k saw + (k breath)(noise - saw),
+                // so the interpolated per-formant quantity is k * breath
+                put(e.b[k], FS.b[k], br * oml_here);
+                e.om[k] = one;
             }
-            const f2 oma = 1.0f - alpha;
-            const f2 jomp = 1.0f - JP;
-            frequency = X.frequency * oma + Y.frequency * alpha;               // :404-414
-            const f2 n_freq = fn_cur * jomp + fn_next * JP;                    // :254
-            frequency = frequency + n_freq * d_freq;                           // :763
-            // :520-525  `p += f; if p >= 1 { p -= 1 }` is fract(p + f) for 0 <= p < 1, 0 < f <= 1: both
-            // branches are exact (x - 1 for x in [1, 2) loses nothing)
-            const float ph0 = phase;
-            const float ph1 = __builtin_amdgcn_fractf(ph0 + frequency.x);
-            phase = __builtin_amdgcn_fractf(ph1 + frequency.y);
-            PH.x = ph0; PH.y = ph1;
-        };
+        }
+        e.oml = SU ? (SLOPE ? (oml_here - FS.oml) * scale : oml_here) : 1.0f;
+    };
+    // A run of calm tiles of this lane starts: the values now, the slopes over 32 samples, the error guard and
+    // with it the lane's sub-tile length.  false: its parameters move faster than TS = 2 can follow.
+    auto fast_begin_run = [&](auto su_tag) __attribute__((always_inline)) -> bool {
+        constexpr bool SU = decltype(su_tag)::value;
+        constexpr int TS0 = FAST_TS0;
+        FastAux xs, xe;
+        fast_endpoint(su_tag, std::false_type(), 1.0f, 1.0f, FS, xs);
+        fast_endpoint(su_tag, std::true_type(), (float)(TS0 + 1), 1.0f / (float)TS0, FD, xe);
+        float ra = 0.0f, rg = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int c = 0; c < W; ++c) {
+                // relative change of a1 and g over 32 samples; 32^2 x the products of slopes behind G and H
+                ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(FD.a1[k], c)) * (float)TS0 *
+                                             __builtin_amdgcn_rcpf(vget(FS.a1[k], c)));
+                ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(FD.tg[k], c)) * (float)TS0 *
+                                             __builtin_amdgcn_rcpf(vget(FS.tg[k], c)));
+                rg = __builtin_fmaxf(rg, __builtin_fabsf((vget(xe.ap[k], c) - vget(xs.ap[k], c)) *
+                                                         (vget(xe.mu[k], c) - vget(xs.mu[k], c))));
+                rg = __builtin_fmaxf(rg, __builtin_fabsf((vget(xe.tb[k], c) - vget(xs.tb[k], c)) *
+                                                         vget(FD.g[k], c) * (float)TS0));
+            }
+        if constexpr (SU) {
+            ra = __builtin_fmaxf(ra, __builtin_fabsf(FD.oml) * (float)TS0 * __builtin_amdgcn_rcpf(FS.oml));
+        } else {
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+#pragma unroll
+                for (int c = 0; c < W; ++c)
+                    ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(FD.om[k], c)) * (float)TS0 *
+                                                 __builtin_amdgcn_rcpf(vget(FS.om[k], c)));
+        }
+        // halvings needed: r / 2^s <= 2^-9.5 (error ~ r^2 / 16), |.| / 4 / 4^s <= 2^-22
+        const int la = __builtin_amdgcn_frexp_expf(ra * 724.0773439350247f);      // 2^9.5
+        const int lg = (__builtin_amdgcn_frexp_expf(rg * GRAIL_FAST_G_SCALE) + 1) >> 1;
+        int level = la > lg ? la : lg;
+        level = level < 0 ? 0 : level;
+        if (!(ra == ra) || !(rg == rg)) level = 99;                                // NaN: not here
+        // the L lanes of an utterance hold different formants: they take the largest of their levels (they run
+        // in lockstep — the per-sample sum goes down the lanes — and all of them start this run together)
+#pragma unroll
+        for (int m = 1; m < L; m <<= 1) {
+            const int o = __shfl_xor(level, m);
+            level = o > level ? o : level;
+        }
+        if (level > 4) return false;
+        fast_shift = level;
+        fast_fresh = level == 0;
+        fast_have = SU ? 1 : 0;
+        return true;
+    };
+    // ---- the per-utterance chain of samples tc, tc+1: exact (see scalar_packed_steps).  Advances
+    // clk, jphase and phase; returns the phases before the two samples and their pitch.
+    auto chain_pair = [&](f2 &PH, f2 &frequency) __attribute__((always_inline)) {
+        const f2 one2 = vsplat(1.0f, f2());
+        // a both-silent pair emits silent() itself (alpha = 1, :926): its reciprocal blend length is replaced
+        // by +inf, the clock is positive in a calm tile, and min(+inf, 1) = 1 — no select per sample
+        const float inv_bl = (!ANYBL && silent_pair) ? __builtin_inff() : inv_blend_length;
+        const float clk0 = clk - dt, clk1 = clk0 - dt;                     // :861
+        const float jp0 = jphase + jinc, jp1 = jp0 + jinc;                 // :242 / :291
+        clk = clk1;
+        jphase = jp1;
+        f2 CLK, JP;
+        CLK.x = clk0; CLK.y = clk1; JP.x = jp0; JP.y = jp1;
+        f2 ratio = CLK * inv_bl;
+        if constexpr (ANYBL) {
+            const f2 rem = vfma(-blend_length * one2, ratio, CLK);
+            const f2 quot = vfma(rem, inv_blend_length * one2, ratio);     // RN(clk / blend_length)
+            ratio = blend_pow2 ? ratio : quot;
+        }
+        f2 alpha;                                                          // :899/:908/:917
+        if constexpr (ANYBL) {
+            alpha.x = silent_pair ? 1.0f : __builtin_fminf(ratio.x, 1.0f);
+            alpha.y = silent_pair ? 1.0f : __builtin_fminf(ratio.y, 1.0f);
+        } else {
+            alpha.x = __builtin_fminf(ratio.x, 1.0f);
+            alpha.y = __builtin_fminf(ratio.y, 1.0f);
+        }
+        const f2 oma = 1.0f - alpha;
+        const f2 jomp = 1.0f - JP;
+        frequency = X.frequency * oma + Y.frequency * alpha;               // :404-414
+        const f2 n_freq = fn_cur * jomp + fn_next * JP;                    // :254
+        frequency = frequency + n_freq * d_freq;                           // :763
+        // :520-525  `p += f; if p >= 1 { p -= 1 }` is fract(p + f) for 0 <= p < 1, 0 < f <= 1: both
+        // branches are exact (x - 1 for x in [1, 2) loses nothing)
+        const float ph0 = phase;
+        const float ph1 = __builtin_amdgcn_fractf(ph0 + frequency.x);
+        phase = __builtin_amdgcn_fractf(ph1 + frequency.y);
+        PH.x = ph0; PH.y = ph1;
+    };
+    // the lane's next sub-tile: its slopes (made afresh unless the run has just started), position 0
+    auto fast_subtile_begin = [&](auto su_tag, const bool have_slopes) __attribute__((always_inline)) {
+        const float ts = (float)(FAST_TS0 >> fast_shift);
+        const float inv_ts = __builtin_bit_cast(float, (uint32_t)(127 - 5 + fast_shift) << 23);   // 1 / TS
+        if (!have_slopes) {
+            FastAux xe;
+            fast_endpoint(su_tag, std::true_type(), ts + 1.0f, inv_ts, FD, xe);
+        }
+        fast_fresh = false;
+        FTI.x = 0.0f; FTI.y = 1.0f;
+    };
+    // the sub-tile's end is the next one's start: start + TS * slope (the end value the slopes were
+    // made from, to within an ulp; every sub-tile's end is evaluated afresh, so nothing accumulates)
+    auto fast_subtile_end = [&](auto su_tag) __attribute__((always_inline)) {
+        constexpr bool SU = decltype(su_tag)::value;
+        const float fts = (float)(FAST_TS0 >> fast_shift);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            FS.a1[k] = vfma(FD.a1[k], vsplat(fts, V()), FS.a1[k]);
+            FS.tg[k] = vfma(FD.tg[k], vsplat(fts, V()), FS.tg[k]);
+            FS.g[k] = vfma(FD.g[k], vsplat(fts, V()), FS.g[k]);
+            FS.h[k] = vfma(FD.h[k], vsplat(fts, V()), FS.h[k]);
+            FS.b[k] = vfma(FD.b[k], vsplat(fts, V()), FS.b[k]);
+            if constexpr (!SU) FS.om[k] = vfma(FD.om[k], vsplat(fts, V()), FS.om[k]);
+        }
+        if constexpr (SU) FS.oml = __builtin_fmaf(FD.oml, fts, FS.oml);
+    };
+    // two samples tc, tc + 1 of the lane: the chain, polyBLEP, the formants with interpolated coefficients;
+    // nz / nm: the carrier noise of the two samples and noise - 1
+    auto fast_pair = [&](auto su_tag, const int tc, const float nz0, const float nz1, const float nm0,
+                         const float nm1_) __attribute__((always_inline)) {
+        constexpr bool SU = decltype(su_tag)::value;
+        const f2 one2 = vsplat(1.0f, f2());
+        const float nz[2] = {nz0, nz1}, nm[2] = {nm0, nm1_};
+        f2 PH, frequency;
+        chain_pair(PH, frequency);
+        // polyBLEP :503-517 without branches or selects: with d_h = f - p (> 0: the head test
+        // p < f) and d_t = p - (1 - f) (> 0: the tail test p > 1 - f; never both), u = max(d_h, d_t, 0) / f
+        // is 1 - t for the head (:505) and 1 + t for the tail (:509), and the correction is -u^2 or
+        // +u^2 (:506, :510) — zero when neither test holds.  d_h - d_t = 1 - 2p = -(2p - 1): the sign
+        // of the uncorrected saw says which.  Same tests as the reference, quotient by v_rcp.
+        const f2 omf = 1.0f - frequency;
+        const f2 d_h = frequency - PH, d_t = PH - omf;
+        f2 u;
+        u.x = __builtin_fmaxf(__builtin_fmaxf(d_h.x, d_t.x), 0.0f);
+        u.y = __builtin_fmaxf(__builtin_fmaxf(d_h.y, d_t.y), 0.0f);
+        u = u * vrcp(frequency);
+        const f2 saw_nb = vfma(vsplat(2.0f, f2()), PH, -one2);             // 2 p - 1
+        f2 su;    // u with the sign of -saw_nb: + for the head (saw + u^2), - for the tail (saw - u^2)
+        su.x = __uint_as_float((__float_as_uint(u.x) & 0x7FFFFFFFu) | (~__float_as_uint(saw_nb.x) & 0x80000000u));
+        su.y = __uint_as_float((__float_as_uint(u.y) & 0x7FFFFFFFu) | (~__float_as_uint(saw_nb.y) & 0x80000000u));
+        const f2 saw2 = vfma(su, u, saw_nb);                               // :517
+        // ---- the formants, sample by sample, coefficients by interpolation
+        f2 keep2 = one2, ksaw2 = one2;          // shared smoothness: 1 - k and k * saw of both samples
+        if constexpr (SU) {
+            const f2 k2 = vfma(vsplat(FD.oml, f2()), FTI, vsplat(FS.oml, f2()));
+            keep2 = 1.0f - k2;
+            ksaw2 = k2 * saw2;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float ti = vget(FTI, h), saw = vget(saw2, h);
+            const V tiv = vsplat(ti, V());
+            const V nms = vsplat(nz[h] - saw, V());
+            const V nm1 = vsplat(nm[h], V());
+            const V sawv = vsplat(saw, V());
+            V acc = vsplat(0.0f, V());
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const V b = vfma(FD.b[k], tiv, FS.b[k]);
+                if constexpr (SU) {             // :531 + :538:  a' = (1-k) a + k saw + (k breath)(noise - saw)
+                    st_a[k] = vfma(b, nms, vfma(vsplat(vget(keep2, h), V()), st_a[k], vsplat(vget(ksaw2, h), V())));
+                } else {
+                    const V nw = vfma(b, nms, sawv);                        // :531
+                    const V oml_v = vfma(FD.om[k], tiv, FS.om[k]);
+                    st_a[k] = vfma(oml_v, nw - st_a[k], st_a[k]);           // :538
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const V a1 = vfma(FD.a1[k], tiv, FS.a1[k]);
+                const V tg = vfma(FD.tg[k], tiv, FS.tg[k]);
+                const V g_ = vfma(FD.g[k], tiv, FS.g[k]);
+                const V h_ = vfma(FD.h[k], tiv, FS.h[k]);
+                const V v0 = st_a[k] * vfma(h_, nm1, g_);                   // :544-550
+                const V v3 = v0 - st_c[k];                                  // :565
+                const V w1 = a1 * vfma(tg, v3, st_b[k]);                    // :566  a1 b + a2 v3
+                const V w2 = vfma(tg, w1, st_c[k]);                         // :567  c + a2 b + a3 v3
+                st_b[k] = vfma(vsplat(2.0f, V()), w1, -st_b[k]);            // :570
+                st_c[k] = vfma(vsplat(2.0f, V()), w2, -st_c[k]);            // :571
+                acc = acc + w1;
+            }
+            float part = vget(acc, 0);
+            if constexpr (W == 2) part = part + vget(acc, 1);
+            const int t_ = tc + h;
+            if constexpr (FOLD_IN_FLUSH) {
+                // the flush folds NFA parked values per sample: this lane's partial sum, then zeros
+                stage[(t_ * S + slot) * NFA + f0] = part;
+#pragma unroll
+                for (int i = 1; i < FPL; ++i) stage[(t_ * S + slot) * NFA + f0 + i] = 0.0f;
+            } else {
+                float tot = part;
+#pragma unroll
+                for (int step = 1; step < L; ++step) tot = dpp_from_lane_below(tot) + part;
+                if (j == L - 1) stage[t_ * SP + slot] = tot * 0.5f;
+            }
+        }
+        FTI = FTI + 2.0f;
+    };
+    // One whole tile in which every rendering lane is calm with the same flavour and sub-tile length and the
+    // same carrier-noise state: the tight loops.  `noise_of_lane`: lane l holds the noise of the tile's step l.
+    auto fast_tile_uniform = [&](auto su_tag, const int shift, const bool all_fresh,
+                                 const float noise_of_lane) __attribute__((always_inline)) {
+        const int TS = FAST_TS0 >> shift;
+        const float nm1_of_lane = noise_of_lane - 1.0f;
 #pragma unroll 1
         for (int ts = 0; ts < T; ts += TS) {
-            if (!(have_slopes && ts == 0)) endpoint(std::true_type(), (float)(TS + 1), inv_ts, D, xe);
-            f2 TI;
-            TI.x = 0.0f; TI.y = 1.0f;
+            fast_subtile_begin(su_tag, all_fresh && ts == 0);
 #pragma unroll 1
             for (int tc = ts; tc < ts + TS; tc += 2) {
-                const float nz[2] = {
-                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc)),
-                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc + 1))};
-                const float nm[2] = {
-                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nm1_of_lane), tc)),
-                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nm1_of_lane), tc + 1))};
-                f2 PH, frequency;
-                chain_pair(PH, frequency);
-                // polyBLEP :503-517 without branches or selects: with d_h = f - p (> 0: the head test
-                // p < f) and d_t = p - (1 - f) (> 0: the tail test p > 1 - f; never both), u = max(d_h, d_t, 0) / f
-                // is 1 - t for the head (:505) and 1 + t for the tail (:509), and the correction is -u^2 or
-                // +u^2 (:506, :510) — zero when neither test holds.  d_h - d_t = 1 - 2p = -(2p - 1): the sign
-                // of the uncorrected saw says which.  Same tests as the reference, quotient by v_rcp.
-                const f2 omf = 1.0f - frequency;
-                const f2 d_h = frequency - PH, d_t = PH - omf;
-                f2 u;
-                u.x = __builtin_fmaxf(__builtin_fmaxf(d_h.x, d_t.x), 0.0f);
-                u.y = __builtin_fmaxf(__builtin_fmaxf(d_h.y, d_t.y), 0.0f);
-                u = u * vrcp(frequency);
-                const f2 saw_nb = vfma(vsplat(2.0f, f2()), PH, -one2);             // 2 p - 1
-                f2 su;    // u with the sign of -saw_nb: + for the head (saw + u^2), - for the tail (saw - u^2)
-                su.x = __uint_as_float((__float_as_uint(u.x) & 0x7FFFFFFFu) | (~__float_as_uint(saw_nb.x) & 0x80000000u));
-                su.y = __uint_as_float((__float_as_uint(u.y) & 0x7FFFFFFFu) | (~__float_as_uint(saw_nb.y) & 0x80000000u));
-                const f2 saw2 = vfma(su, u, saw_nb);                               // :517
-                // ---- the formants, sample by sample, coefficients by interpolation
-                f2 keep2 = one2, ksaw2 = one2;          // shared smoothness: 1 - k and k * saw of both samples
-                if constexpr (SU) {
-                    const f2 k2 = vfma(vsplat(D.oml, f2()), TI, vsplat(FS.oml, f2()));
-                    keep2 = 1.0f - k2;
-                    ksaw2 = k2 * saw2;
-                }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float ti = vget(TI, h), saw = vget(saw2, h);
-                    const V tiv = vsplat(ti, V());
-                    const V nms = vsplat(nz[h] - saw, V());
-                    const V nm1 = vsplat(nm[h], V());
-                    const V sawv = vsplat(saw, V());
-                    V acc = vsplat(0.0f, V());
-#pragma unroll
-                    for (int k = 0; k < NLP; ++k) {
-                        const V b = vfma(D.b[k], tiv, FS.b[k]);
-                        if constexpr (SU) {             // :531 + :538:  a' = (1-k) a + k saw + (k breath)(noise - saw)
-                            st_a[k] = vfma(b, nms, vfma(vsplat(vget(keep2, h), V()), st_a[k], vsplat(vget(ksaw2, h), V())));
-                        } else {
-                            const V nw = vfma(b, nms, sawv);                        // :531
-                            const V oml_v = vfma(D.om[k], tiv, FS.om[k]);
-                            st_a[k] = vfma(oml_v, nw - st_a[k], st_a[k]);           // :538
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < NLIVE; ++k) {
-                        const V a1 = vfma(D.a1[k], tiv, FS.a1[k]);
-                        const V tg = vfma(D.tg[k], tiv, FS.tg[k]);
-                        const V g_ = vfma(D.g[k], tiv, FS.g[k]);
-                        const V h_ = vfma(D.h[k], tiv, FS.h[k]);
-                        const V v0 = st_a[k] * vfma(h_, nm1, g_);                   // :544-550
-                        const V v3 = v0 - st_c[k];                                  // :565
-                        const V w1 = a1 * vfma(tg, v3, st_b[k]);                    // :566  a1 b + a2 v3
-                        const V w2 = vfma(tg, w1, st_c[k]);                         // :567  c + a2 b + a3 v3
-                        st_b[k] = vfma(vsplat(2.0f, V()), w1, -st_b[k]);            // :570
-                        st_c[k] = vfma(vsplat(2.0f, V()), w2, -st_c[k]);            // :571
-                        acc = acc + w1;
-                    }
-                    float part = vget(acc, 0);
-                    if constexpr (W == 2) part = part + vget(acc, 1);
-                    const int t_ = tc + h;
-                    if constexpr (FOLD_IN_FLUSH) {
-                        // the flush folds NFA parked values per sample: this lane's partial sum, then zeros
-                        if (emit) stage[(t_ * S + slot) * NFA + f0] = part;
-#pragma unroll
-                        for (int i = 1; i < FPL; ++i)
-                            if (emit) stage[(t_ * S + slot) * NFA + f0 + i] = 0.0f;
-                    } else {
-                        float tot = part;
-#pragma unroll
-                        for (int step = 1; step < L; ++step) tot = dpp_from_lane_below(tot) + part;
-                        if (j == L - 1) stage[t_ * SP + slot] = tot * 0.5f;
-                    }
-                }
-                TI = TI + 2.0f;
+                const float nz0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc));
+                const float nz1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc + 1));
+                const float nm0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nm1_of_lane), tc));
+                const float nm1_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nm1_of_lane), tc + 1));
+                fast_pair(su_tag, tc, nz0, nz1, nm0, nm1_);
             }
-            // the sub-tile's end is the next one's start: start + TS * slope (the end value the slopes were
-            // made from, to within an ulp; every sub-tile's end is evaluated afresh, so nothing accumulates)
-            const float fts = (float)TS;
-#pragma unroll
-            for (int k = 0; k < NLIVE; ++k) {
-                FS.a1[k] = vfma(D.a1[k], vsplat(fts, V()), FS.a1[k]);
-                FS.tg[k] = vfma(D.tg[k], vsplat(fts, V()), FS.tg[k]);
-                FS.g[k] = vfma(D.g[k], vsplat(fts, V()), FS.g[k]);
-                FS.h[k] = vfma(D.h[k], vsplat(fts, V()), FS.h[k]);
-            }
-#pragma unroll
-            for (int k = 0; k < NLP; ++k) {
-                FS.b[k] = vfma(D.b[k], vsplat(fts, V()), FS.b[k]);
-                if constexpr (!SU) FS.om[k] = vfma(D.om[k], vsplat(fts, V()), FS.om[k]);
-            }
-            if constexpr (SU) FS.oml = __builtin_fmaf(D.oml, fts, FS.oml);
+            fast_subtile_end(su_tag);
         }
-        return true;
+    };
+    // The lane's share of step t of a mixed tile — its wave-mates may be in general steps, in the other
+    // flavour or on another sub-tile length: the same functions under the lane's own predicates.
+    auto fast_lane_step = [&](auto su_tag, const int t) __attribute__((always_inline)) {
+        if (t & 1) return;                                   // a pair covers t and t + 1
+        const int ts_mask = (FAST_TS0 >> fast_shift) - 1;
+        if ((t & ts_mask) == 0) fast_subtile_begin(su_tag, fast_fresh);
+        const float nz0 = lcg_f32(noise_seed), nz1 = lcg_f32(noise_seed);   // :528, the lane's own draws
+        fast_pair(su_tag, t, nz0, nz1, nz0 - 1.0f, nz1 - 1.0f);
+        if (((t + 2) & ts_mask) == 0) fast_subtile_end(su_tag);
     };
 
     // ---- the staged tile's rows to memory: row `slot` holds samples [base_, base_ + T), mine_ of them valid
@@ -1694,8 +1757,145 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         else wave_lds_sync();
     };
 
-    for (uint32_t base = 0;; base += T) {
+    // ---- FAST: one tile of T steps.  Every lane decides for itself (see BATCH INVARIANCE above); the wave then
+    // takes the tight loops when all its rendering lanes agree, and the mixed tile otherwise.
+    auto fast_render_tile = [&](auto) __attribute__((always_inline)) {   // (generic: instantiated by FAST kernels only)
+        static_assert(T <= 64, "calm-tile margins are written for T <= 64");
+        // lanes that will not render again in this launch (chain exhausted, row full, no utterance) ride along
+        // in the tight loops: what they compute is never read and their sample count stands still.  A lane
+        // that has PAUSED (stream quota, end of its chunk) keeps its state: it is not idle.
+        const bool idle = done && !paused;
+        // calm: no event of this lane before the tile ends (margins as in the exact kernels' calm tiles),
+        // alpha linear in time across the tile (a tile that holds the kink of min(clk / blend_length, 1) takes
+        // the general steps), and pitch < 1/2 (fast_pair's polyBLEP needs the head and tail tests to exclude
+        // each other)
+        bool calm = !done & quiet_ok & (dt > 0.0f) & (clk > (float)(T + 8) * dt) &
+                    (jphase + (float)(T + 1) * jinc < 0.999f) & (room_end - n_out >= (uint32_t)T) & (n_out <= room_end);
+        {
+            const float r_first = (clk - dt) * inv_blend_length;
+            const float r_next = (clk - (float)(T + 1) * dt) * inv_blend_length;
+            calm = calm & !((r_first > 1.0f) & (r_next < 1.0f));
+            calm = calm & (__builtin_fmaxf(X.frequency, Y.frequency) + __builtin_fabsf(d_freq) < 0.5f);
+        }
+        // shared smoothness: all formants of the utterance, whichever of its L lanes holds them
+        int flavour = smooth_uniform ? 1 : 0;
+        if constexpr (L > 1) {
+            const uint64_t su_mask = __builtin_amdgcn_ballot_w64(smooth_uniform);
+            flavour = ((su_mask >> (lane & ~(L - 1))) & ((1ull << L) - 1ull)) == ((1ull << L) - 1ull) ? 1 : 0;
+        }
+        bool lane_fast = calm;
+        const bool starts = calm && fast_have != flavour;          // a run of calm tiles of this lane starts here
+        if (__builtin_amdgcn_ballot_w64(starts) != 0) {
+            if (starts) {
+                const bool ok = flavour ? fast_begin_run(std::true_type()) : fast_begin_run(std::false_type());
+                lane_fast = ok;
+            }
+        }
+        if (!lane_fast) fast_have = -1;                            // general steps end the lane's run
+        // the tight loops: every rendering lane fast, one flavour, one sub-tile length, one carrier-noise state
+        const uint64_t rendering = __builtin_amdgcn_ballot_w64(!idle);
+        bool uniform = false;
+        int shift_u = 0, flavour_u = 0;
+        uint32_t tile_seed = 0u;
+        bool all_fresh = false;
+        if (rendering != 0) {
+            const int first = __builtin_ctzll(rendering);
+            tile_seed = (uint32_t)__builtin_amdgcn_readlane((int)noise_seed, first);
+            shift_u = __builtin_amdgcn_readlane(fast_shift, first);
+            flavour_u = __builtin_amdgcn_readlane(flavour, first);
+            const bool fits = idle | (lane_fast & (noise_seed == tile_seed) & (fast_shift == shift_u) & (flavour == flavour_u));
+            uniform = __builtin_amdgcn_ballot_w64(!fits) == 0;
+            all_fresh = __builtin_amdgcn_ballot_w64(!(idle | fast_fresh)) == 0;
+        }
+        if (uniform) {
+            // the carrier noise of the T steps, lane l taking step l (closed-form skip-ahead of the LCG :36-55)
+            const uint32_t ahead = (uint32_t)(lane < T ? lane : T - 1) + 1u;
+            const uint32_t sk = tile_seed * LCG_SKIP.mul[ahead] + LCG_SKIP.add[ahead];
+            const float noise_of_lane = (__uint_as_float((sk >> 9) | 0x3F800000u) - 1.5f) * 2.0f;
+            if (flavour_u) fast_tile_uniform(std::true_type(), shift_u, all_fresh, noise_of_lane);
+            else fast_tile_uniform(std::false_type(), shift_u, all_fresh, noise_of_lane);
+            ++fast_tiles;
+            n_out += idle ? 0u : (uint32_t)T;
+            noise_seed = (uint32_t)__builtin_amdgcn_readlane((int)sk, T - 1);
+            return;
+        }
+        // the mixed tile: per step, a fast lane runs its share of fast_tile_uniform's work, any other lane the
+        // general step (the reference's control flow; tolerance-mode formants while its pair is inside the
+        // safe window)
+        general_steps += (uint32_t)T;
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) {
+            if (lane_fast) {
+                if (flavour) fast_lane_step(std::true_type(), t);
+                else fast_lane_step(std::false_type(), t);
+            } else {
+                general_step(t, std::false_type());
+            }
+        }
+        n_out += lane_fast ? (uint32_t)T : 0u;
+    };
+
+    // ---- SPLIT: fast-forward the exact per-utterance chain to where this chunk's filters start
+    uint32_t base0 = 0;
+    uint32_t reset_at = 0;       // the tile at which this lane's filters start from zero state
+    if constexpr (SPLIT) {
+        uint32_t w = slot_used ? VO.warmup : 0u, w_max = w;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)w_max, m);
+            w_max = o > w_max ? o : w_max;
+        }
+        w_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)w_max);
+        base0 = chunk_lo > w_max ? chunk_lo - w_max : 0u;
+        reset_at = chunk_lo > w ? chunk_lo - w : 0u;
+        for (;;) {
+            if (__builtin_amdgcn_ballot_w64(!done & (n_out < base0)) == 0) break;
+            const bool calm = !done & quiet_ok & (dt > 0.0f) & (clk > (float)(T + 8) * dt) &
+                              (jphase + (float)(T + 1) * jinc < 0.999f) & (n_out + (uint32_t)T <= base0);
+            if (__builtin_amdgcn_ballot_w64(!(calm | done)) == 0) {
+#pragma unroll 4
+                for (int tc = 0; tc < T; tc += 2) {
+                    f2 PH, frequency;
+                    chain_pair(PH, frequency);
+                }
+                n_out += done ? 0u : (uint32_t)T;
+            } else {
+#pragma unroll 1
+                for (int t = 0; t < T; ++t)
+                    if (n_out < base0) general_step(t, std::true_type());
+            }
+        }
+        // the carrier noise state after n_out draws from seed 0 (:594): s -> 16807 s + 1 composed n_out times
+        {
+            uint32_t mul = 16807u, add = 1u, acc = 0u;
+#pragma unroll 1
+            for (int b = 0; b < 32; ++b) {
+                if ((n_out >> b) & 1u) acc = acc * mul + add;
+                add = add * (mul + 1u);
+                mul = mul * mul;
+            }
+            noise_seed = acc;
+        }
+    }
+
+    for (uint32_t base = base0;; base += T) {
+        if constexpr (SPLIT) {
+            // this lane's warm-up starts here (lanes of other voices may have started theirs earlier)
+            if (chunk > 0u && base == reset_at) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    st_a[k] = vsplat(0.0f, st_a[k]);
+                    st_b[k] = st_a[k];
+                    st_c[k] = st_a[k];
+                }
+                fast_have = -1;
+            }
+        }
         int t = 0;
+        if constexpr (FAST) {
+            fast_render_tile(0);
+            t = T;
+        }
         while (t < T) {
             // a run of quiet steps: a tight inner loop, so the loop-carried state keeps its
             // registers from one sample to the next.  Two flavours of the same loop: every
@@ -1719,15 +1919,6 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     bool calm = !done & quiet_ok & (dt > 0.0f) & (clk > (float)(T + 8) * dt) &
                                 (jphase + (float)(T + 1) * jinc < 0.999f) &
                                 (cap32 - n_out >= (uint32_t)T) & (noise_seed == tile_seed);
-                    if constexpr (FAST) {
-                        // the interpolated coefficients need alpha linear in time across the tile:
-                        // a tile that holds the kink of min(clk / blend_length, 1) takes the exact steps
-                        const float r_first = (clk - dt) * inv_blend_length;
-                        const float r_next = (clk - (float)(T + 1) * dt) * inv_blend_length;
-                        calm = calm & !((r_first > 1.0f) & (r_next < 1.0f));
-                        // fast_tile's polyBLEP form needs the head and tail tests to exclude each other: pitch < 1/2
-                        calm = calm & (__builtin_fmaxf(X.frequency, Y.frequency) + __builtin_fabsf(d_freq) < 0.5f);
-                    }
                     calm_tile = __builtin_amdgcn_ballot_w64(!(calm | idle)) == 0;
                     if constexpr (PIPE) {
                         // how many calm tiles in a row (every wave of the workgroup finds the same number): the
@@ -1760,10 +1951,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     // live the doubled body no longer fits the register file (measured: slower)
                     constexpr int STEPS_PER_TRIP = 2;
                     static_assert(T % STEPS_PER_TRIP == 0, "whole trips");
-                    bool rendered = true;
-                    if constexpr (FAST) {
-                        rendered = fast_tile(nlive_tag, su_tag, noise_of_lane, idle);
-                    } else if constexpr (PIPE) {
+                    if constexpr (PIPE) {
                         // Rounds of two sample pairs, three stages one round apart: in phase p wave 1
                         // writes the chain of round p+2, waves 2 and 3 turn the chain of round p+1 into
                         // coefficients (one pair each), wave 0 renders round p; one barrier per phase.
@@ -1860,18 +2048,11 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                             }
                         }
                     }
-                    if (rendered) {
-                        if constexpr (FAST) ++fast_tiles;
-                        t = T;
-                        n_out += idle ? 0u : (uint32_t)T;
-                        noise_seed = (uint32_t)__builtin_amdgcn_readlane((int)sk, T - 1);
-                        return;
-                    }
+                    t = T;
+                    n_out += idle ? 0u : (uint32_t)T;
+                    noise_seed = (uint32_t)__builtin_amdgcn_readlane((int)sk, T - 1);
+                    return;
                 }
-                fast_have = -1;          // exact steps follow: the kept interpolation ends go stale
-                // FAST kernels take the general step for every sample of a tile that is not calm (about
-                // one tile in a hundred): without the quiet-step loops the kernel needs far fewer registers
-                if constexpr (FAST) return;
                 for (; t < T; ++t) {
                     const float clk_next = clk - dt;
                     const float jphase_next = jphase + jinc;
@@ -1900,7 +2081,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             }
             if (t < T) {
                 ++general_steps;
-                general_step(t);
+                general_step(t, std::false_type());
                 quiet_ok = pair_safe && (blend_pow2 || blend_div_ok);
                 ++t;
             }
@@ -1914,6 +2095,14 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         constexpr int ROWS_PER_IT = 64 / ROW_LANES;
         const int rl = lane % ROW_LANES;
         const int rr = lane / ROW_LANES;
+        if constexpr (SPLIT) {
+            // warm-up tiles: the filters are still converging, nothing is stored (the lanes of the chunk before
+            // render these samples); the stage is per wave and the next tile simply overwrites it
+            if (base < chunk_lo) {
+                if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+                continue;
+            }
+        }
         if constexpr (!FOLD_IN_FLUSH && ROWS_PER_IT <= S) {
             // the usual tile: every row of the wave received all T samples and the rows take 16-B stores.
             // No per-row conditions, so the LDS reads of all rows are in flight together (a lone wave has
@@ -1963,7 +2152,15 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
     }
 
-    if (emit && j == L - 1 && u < A.n_utt) {
+    if constexpr (SPLIT) {
+        // the utterance's length comes from the lane that saw it end — the chain returned None, or the row was
+        // full — inside its own chunk: a lane that stopped at the next chunk's first sample has only paused, and
+        // an utterance that ended before this lane's chunk began belongs to an earlier lane
+        if (u < A.n_utt && done && !paused && n_out >= chunk_lo) {
+            if (A.out_len) A.out_len[u] = n_out;
+            if (truncated) atomicOr(A.truncated, 1u);
+        }
+    } else if (emit && j == L - 1 && u < A.n_utt) {
         if (A.out_len) A.out_len[u] = n_out;
         if (truncated) atomicOr(A.truncated, 1u);
     }
@@ -1977,13 +2174,13 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 }
 
 template <int L, int T, int WAVES, int MINW, bool STREAM, bool HALF, bool ANYBL, int NFA = NF, bool PIPE = false,
-          bool FAST = false, int PQP = 2>
+          bool FAST = false, int PQP = 2, bool SPLIT = false>
 void start(const SynthArgs &args, dim3 grid, dim3 block, hipStream_t stream)
 {
-    std::snprintf(g_kernel_name, sizeof g_kernel_name, "synth_kernel<L=%d,T=%d,W=%d,%d,%s%s%sNFA=%d%s%s%s>", L, T, WAVES,
+    std::snprintf(g_kernel_name, sizeof g_kernel_name, "synth_kernel<L=%d,T=%d,W=%d,%d,%s%s%sNFA=%d%s%s%s%s>", L, T, WAVES,
                   MINW, STREAM ? "STREAM," : "", HALF ? "HALF," : "", ANYBL ? "ANYBL," : "", NFA,
-                  PIPE ? ",PIPE" : "", FAST ? ",FAST" : "", PQP == 4 ? ",R16" : "");
-    hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, STREAM, HALF, ANYBL, NFA, PIPE, FAST, PQP>), grid, block, 0,
+                  PIPE ? ",PIPE" : "", FAST ? ",FAST" : "", PQP == 4 ? ",R16" : "", SPLIT ? ",SPLIT" : "");
+    hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, STREAM, HALF, ANYBL, NFA, PIPE, FAST, PQP, SPLIT>), grid, block, 0,
                        stream, args);
 }
 

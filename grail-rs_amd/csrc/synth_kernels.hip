@@ -97,6 +97,11 @@ hipError_t launch_synth(const SynthArgs &args, int L, hipStream_t stream)
         else launch_pipe8(args, stream);
         return hipGetLastError();
     }
+    if (args.split_chunks) {
+        if (!args.fast || args.state || L != 1 || args.split_chunks > (uint32_t)SPLIT_MAX_CHUNKS) return hipErrorInvalidValue;
+        launch_split(args, stream);
+        return hipGetLastError();
+    }
     switch (L) {
     case 1: args.fast ? launch_fast_l1(args, stream) : launch_exact_l1(args, stream); break;
     case 2: args.fast ? launch_fast_l2(args, stream) : launch_exact_l2(args, stream); break;

@@ -59,22 +59,34 @@ void launch_one_fast(const SynthArgs &args, hipStream_t stream)
             start<L, T, WAVES, MINW, true, false, false, 4, false, true>(args, grid, block, stream);
             return;
         }
-        if (!args.state && !args.any_blend && args.live4) {
+        if (!args.state && args.live4) {
+            // four live formants (any blend length: the host sets live4 for those too in fast mode).  L = 4
+            // parks 4 floats per sample instead of 8: room for the 64-step tiles of L = 8
             constexpr int T4 = L == 4 ? 64 : T;
-            start<L, (L == 1 ? TF : T4), WAVES, MINW, false, false, false, 4, false, true>(args, grid, block, stream);
+            constexpr int TT = L == 1 ? TF : T4;
+            if (args.any_blend) start<L, TT, WAVES, MINW, false, false, true, 4, false, true>(args, grid, block, stream);
+            else start<L, TT, WAVES, MINW, false, false, false, 4, false, true>(args, grid, block, stream);
             return;
         }
     }
     if (!args.state) {
-        // tolerance mode: the same kernels with the fast calm tile; HALF only where the exact policy uses it
-        if (L == 1 && args.half_capable) start<L, TF, WAVES, MINW, false, true, true, NF, false, true>(args, grid, block, stream);
-        else if (args.any_blend) start<L, TF, WAVES, MINW, false, false, true, NF, false, true>(args, grid, block, stream);
+        // (no half-live loops in tolerance mode: which formants a wave skips would be a decision of the wave,
+        // and a lane's samples may not depend on its wave-mates)
+        if (args.any_blend) start<L, TF, WAVES, MINW, false, false, true, NF, false, true>(args, grid, block, stream);
         else start<L, TF, WAVES, MINW, false, false, false, NF, false, true>(args, grid, block, stream);
         return;
     }
     // resumable streams in tolerance mode (chunks concatenate to the one-shot rendering within the
     // tolerance, not bit for bit: the interpolation ends restart with every call)
     start<L, T, WAVES, MINW, true, false, true, NF, false, true>(args, grid, block, stream);
+}
+
+// time-split fast kernels: one lane per (utterance, chunk), 64-thread workgroups, chunk-major
+template <int NFA_, bool ANYBL_>
+void launch_one_split(const SynthArgs &args, hipStream_t stream)
+{
+    const dim3 grid(((args.n_utt + 63u) / 64u) * args.split_chunks), block(64);
+    start<1, 64, 1, 1, false, false, ANYBL_, NFA_, false, true, 2, true>(args, grid, block, stream);
 }
 
 }  // namespace

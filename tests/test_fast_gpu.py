@@ -384,3 +384,190 @@ def test_fast_mode_streams(gpu_ctx, lanes):
     k = _worst(got, ref, ref_len)
     print(f"fast streams, lanes={lanes}: {k:.1f} * 2^-23")
     assert 0.0 < k * ULP <= TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# Time-split fast kernels (synth_kernel<..., SPLIT>): one lane per (utterance, chunk of its time axis).
+# A chunk's lane fast-forwards the exact chain, warms its filters up from zero state and renders its chunk.
+
+def _split(ctx, chunks, span=0):
+    ctx.set_option("time_split_chunks", chunks)
+    ctx.set_option("time_split_span_samples", span)
+
+
+@pytest.mark.parametrize("n_voices", [1, 8])
+@pytest.mark.parametrize("chunks", [2, 5, 16])
+def test_time_split_within_tolerance_of_the_oracle(gpu_ctx, n_voices, chunks):
+    """Full 2 s utterances cut into 2 / 5 / 16 chunks: lengths are the oracle's, every sample within the
+    tolerance — chunk seams included (the warm-up residual is part of the measured distance)."""
+    voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    n_utt = 80
+    segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=n_voices)
+    stride = W.max_samples()
+    try:
+        _split(gpu_ctx, chunks)
+        out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
+        assert "SPLIT" in gpu_ctx.last_kernel_name(), gpu_ctx.last_kernel_name()
+        assert gpu_ctx.get_option("last_launch_chunks") == chunks
+    finally:
+        _split(gpu_ctx, 0)
+    ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, stride)
+    assert np.array_equal(out_len, ref_len)
+    k = _worst(out, ref, ref_len)
+    print(f"time split, {chunks} chunks, voices={n_voices}: max |d| = {k:.1f} * 2^-23")
+    assert 0.0 < k * ULP <= TOL
+
+
+def test_time_split_ragged_lengths_short_and_empty_utterances(gpu_ctx):
+    """Utterances that end before, inside and exactly around chunk boundaries, empty ones, one-sample segments,
+    non-2^k blends and a blend kink: each length is written by exactly one lane and equals the oracle's."""
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
+    A, E, S = G.PH_A, G.PH_E, G.PH_SILENCE
+    f = 120.0 / 48000.0
+    rng = np.random.default_rng(11)
+    utts = [[], [(A, 1.0 / 48000.0, 0.5, f)], [(S, 0.01, 0.01, f)]]
+    for i in range(61):
+        n_seg = int(rng.integers(1, 6))
+        utts.append([(int(rng.choice([A, E, S])), float(rng.uniform(0.02, 0.25)),
+                      float(rng.choice([0.5, 0.25, 0.03, 0.1, 0.0625])), f * float(rng.uniform(0.8, 1.9)))
+                     for _ in range(n_seg)])
+    # lengths that put the end of the utterance on / next to the uniform 4-chunk grid of a 36 864-sample span
+    for target in (9216, 9216 + 1, 9216 - 1, 18432, 27648 + 63, 27648 - 64):
+        utts.append([(A, (target + 0.5) / 48000.0, 0.25, f)])
+    segs = G.segments([s for u in utts for s in u])
+    offs = np.cumsum([0] + [len(u) for u in utts]).astype(np.uint32)
+    seeds = np.arange(len(utts), dtype=np.uint32) * 31 + 5
+    stride = 65536
+    ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, None, seeds, stride)
+    try:
+        for chunks, span in ((4, 36864), (7, 0), (2, 12800)):
+            _split(gpu_ctx, chunks, span)
+            gpu_ctx.set_option("time_split_ff_cost_permille", 0 if span else 140)   # 0: a uniform grid
+            out, out_len = _render(gpu_ctx, True, segs, offs, None, seeds, stride)
+            assert "SPLIT" in gpu_ctx.last_kernel_name()
+            assert np.array_equal(out_len, ref_len), (chunks, np.nonzero(out_len != ref_len)[0][:8])
+            k = _worst(out, ref, ref_len)
+            print(f"time split edge cases, {chunks} chunks over {span or 'auto'}: {k:.1f} * 2^-23")
+            assert k * ULP <= TOL
+    finally:
+        _split(gpu_ctx, 0)
+        gpu_ctx.set_option("time_split_ff_cost_permille", 140)
+
+
+def test_time_split_truncation_and_pcm16(gpu_ctx):
+    """A row capacity below the utterance length: the last chunk's lane reports the cut; i16 rows are the
+    conversion of the f32 rows."""
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
+    segs, offs, vids, seeds = W.make_batch(70, length=0.25, blend_length=0.25)
+    stride = W.max_samples(length=0.25)
+    try:
+        _split(gpu_ctx, 4)
+        gpu_ctx.set_option("arithmetic", 1)
+        full, full_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+        with pytest.raises(G.GrailError):
+            gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=30016)
+        pcm, pcm_len = gpu_ctx.synthesize_pcm16(segs, offs, vids, seeds, out_stride=stride)
+        assert "SPLIT" in gpu_ctx.last_kernel_name()
+        assert np.array_equal(pcm_len, full_len)
+        want = np.clip(np.trunc(full.astype(np.float32) * np.float32(32767.0)), -32768, 32767).astype(np.int16)
+        for u in range(70):
+            n = int(full_len[u])
+            assert np.array_equal(pcm[u, :n], want[u, :n]), u
+    finally:
+        _split(gpu_ctx, 0)
+        gpu_ctx.set_option("arithmetic", 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# Batch invariance of the tolerance mode, within a kernel family (SURVEY §8b; src/lib.rs:594, :786-797: the
+# chain is a pure function of (segments, voice, seed)).  A lane decides calm / general, its sub-tile length and
+# its smoothness flavour from its own state only, so an utterance's samples do not depend on its wave-mates.
+
+def _ragged_corpus(n_utt, first=0, n_voices=8):
+    """Utterances whose events (segment ends, blend kinks, silent pairs) fall at different samples, so the lanes
+    of a wave disagree about which tiles are calm.  Utterance u depends on u only."""
+    segs, offs, vids, seeds = W.make_batch(n_utt, first_utt=first, n_voices=n_voices, length=0.05, blend_length=0.03125)
+    u = (np.arange(n_utt, dtype=np.uint64) + first).repeat(W.SEGMENTS_PER_UTT)
+    i = np.tile(np.arange(W.SEGMENTS_PER_UTT, dtype=np.uint64), n_utt)
+    h = ((u * 2654435761 + i * 40503) % 1000).astype(np.float32) / 1000.0
+    segs["length"] = (0.02 + 0.06 * h).astype(np.float32)
+    segs["blend_length"] = np.where(h > 0.7, 0.0625, np.where(h > 0.4, 0.03125, 0.015625)).astype(np.float32)
+    return segs, offs, vids, seeds
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8])
+def test_fast_mode_is_batch_invariant_for_a_fixed_lane_mapping(gpu_ctx, lanes):
+    voices = W.preset_voices(8)
+    voices[3].phonemes[0].formant_smooth[2] *= 1.5        # one voice without a shared smoothness: the other flavour
+    gpu_ctx.set_voices(voices)
+    stride = 16384
+    segs, offs, vids, seeds = _ragged_corpus(300)
+    full, full_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride, lanes)
+    assert "FAST" in gpu_ctx.last_kernel_name()
+    ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, stride)
+    assert np.array_equal(full_len, ref_len)
+    assert _worst(full, ref, ref_len) * ULP <= TOL
+    for first, n in [(37, 1), (100, 33), (150, 64), (0, 7), (263, 37)]:
+        s2, o2, v2, j2 = _ragged_corpus(n, first)
+        part, part_len = _render(gpu_ctx, True, s2, o2, v2, j2, stride, lanes)
+        assert np.array_equal(part_len, full_len[first:first + n])
+        for r in range(n):
+            m = int(part_len[r])
+            assert np.array_equal(part[r, :m].view(np.uint32), full[first + r, :m].view(np.uint32)), (first, n, r)
+    # a permutation of the batch: other wave-mates for everybody
+    perm = np.random.default_rng(3).permutation(300)
+    sp = np.concatenate([segs[offs[u]:offs[u + 1]] for u in perm])
+    op = np.cumsum([0] + [int(offs[u + 1] - offs[u]) for u in perm]).astype(np.uint32)
+    out, out_len = _render(gpu_ctx, True, sp, op, vids[perm], seeds[perm], stride, lanes)
+    for r, u in enumerate(perm):
+        m = int(full_len[u])
+        assert out_len[r] == m
+        assert np.array_equal(out[r, :m].view(np.uint32), full[u, :m].view(np.uint32)), (r, u)
+    gpu_ctx.set_voices(W.single_voice())
+
+
+def test_time_split_is_batch_invariant_for_a_fixed_grid(gpu_ctx):
+    voices = W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    stride = 16384
+    segs, offs, vids, seeds = _ragged_corpus(200)
+    try:
+        _split(gpu_ctx, 3, 12800)
+        full, full_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
+        assert "SPLIT" in gpu_ctx.last_kernel_name()
+        for first, n in [(37, 1), (100, 33), (120, 80)]:
+            s2, o2, v2, j2 = _ragged_corpus(n, first)
+            part, part_len = _render(gpu_ctx, True, s2, o2, v2, j2, stride)
+            assert np.array_equal(part_len, full_len[first:first + n])
+            for r in range(n):
+                m = int(part_len[r])
+                assert np.array_equal(part[r, :m].view(np.uint32), full[first + r, :m].view(np.uint32)), (first, n, r)
+    finally:
+        _split(gpu_ctx, 0)
+        gpu_ctx.set_voices(W.single_voice())
+
+
+def test_length_sorted_slot_assignment_is_invisible_in_fast_mode(gpu_ctx):
+    """sort_by_length permutes wave-mates: the fast rows may not notice."""
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
+    segs, offs, vids, seeds = _ragged_corpus(150, n_voices=1)
+    stride = 16384
+    try:
+        rows = {}
+        for sort in (1, 0):
+            gpu_ctx.set_option("sort_by_length", sort)
+            for lanes in (1, 2, 4, 8):
+                rows[sort, lanes] = _render(gpu_ctx, True, segs, offs, vids, seeds, stride, lanes)
+        for lanes in (1, 2, 4, 8):
+            a, al = rows[1, lanes]
+            b, bl = rows[0, lanes]
+            assert np.array_equal(al, bl)
+            for u in range(150):
+                m = int(al[u])
+                assert np.array_equal(a[u, :m].view(np.uint32), b[u, :m].view(np.uint32)), (lanes, u)
+    finally:
+        gpu_ctx.set_option("sort_by_length", 1)
