@@ -133,7 +133,7 @@ struct grail_ctx {
     int split_option = 1;             // fast arithmetic: mid-size batches split every utterance's time axis over lanes
     int64_t split_chunks = 0;         // ... into this many chunks (0: as many as fill the machine)
     int64_t split_span = 0;           // ... laid out over this many samples (0: the batch's longest utterance)
-    int64_t split_ff_permille = 140;  // ... cost of a fast-forwarded sample against a rendered one
+    int64_t split_ff_permille = 165;  // ... cost of a fast-forwarded sample against a rendered one
     int64_t split_min_utts = 1025;    // ... batches smaller than this stay with the scan kernel
     int last_split = 0;               // chunks of the last launch (statistics; 0: not time-split)
     float max_dt = 0.0f;              // largest 1/sample_rate of the table
@@ -330,14 +330,14 @@ bool scan_voice_ok(const grail_voice &v)
     return ok;
 }
 
-// Time-split fast kernels: how many samples until a filter state that started from zero is within 2^-22 of the
+// Time-split fast kernels: how many samples until a filter state that started from zero is within 2^-21 of the
 // state the reference would have (relative to the state's size, which is below full scale)?  The chain of
 // Synthesize::next per formant is a one-pole low-pass with factor exp_approx(smooth) = (1 - smooth)^5 (:535-538)
 // and the trapezoidal state-variable band-pass (:555-571), whose poles are the bilinear images
 // z = (1 + s) / (1 - s) of s = g (-k/2 +- sqrt(k^2/4 - 1)), g = tan_approx(freq), k = bw / freq; for k < 2,
 // |z|^2 = (1 - g k + g^2) / (1 + g k + g^2) ~ exp(-2 pi bw).  The slowest of them over every phoneme (blends
 // move the parameters between phonemes and towards silent()'s 0.25 / 0.25 / 0.25, which decays at once; the
-// formant-frequency jitter hardly moves |z|) with a 10 % margin gives the length.  Formants that are silent in
+// formant-frequency jitter hardly moves |z|) with a 5 % margin gives the length.  Formants that are silent in
 // every phoneme have nothing to converge.  0: the voice does not qualify (a parameter outside the window, or a
 // warm-up longer than 16384 samples).
 uint32_t voice_warmup(const grail_voice &v)
@@ -367,7 +367,7 @@ uint32_t voice_warmup(const grail_voice &v)
         }
     }
     if (slowest >= 1e300) return 64;                        // nothing audible: any state is the right one
-    const double samples = std::log(4194304.0) / (0.9 * slowest);   // 2^-22
+    const double samples = std::log(2097152.0) / (0.95 * slowest);   // 2^-21
     if (!(samples <= 16384.0)) return 0;
     return ((uint32_t)std::ceil(samples) + 63u) / 64u * 64u;
 }
@@ -629,10 +629,12 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         ctx->pipe8_max_groups = value;
         return GRAIL_OK;
     }
-    if (std::strcmp(name, "scan_debug") == 0) {       // development aid: see scan_kernels.hip
+#ifdef GRAIL_SCAN_DEBUG
+    if (std::strcmp(name, "scan_debug") == 0) {       // development builds only (-DGRAIL_SCAN_DEBUG): see scan_kernels.hip
         ctx->scan_debug = (int)value;
         return GRAIL_OK;
     }
+#endif
     if (std::strcmp(name, "time_parallel_scan_split_max_utterances") == 0) {
         if (value < 0) return fail(GRAIL_ERR_INVALID_ARG, "negative limit");
         ctx->scan_split_max = value;
@@ -975,8 +977,10 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
         span = std::fmin(span, (double)out_stride);
         int K = ctx->split_chunks ? (int)ctx->split_chunks : (int)std::min<uint64_t>(65536u / count, SPLIT_MAX_CHUNKS);
         K = (int)std::fmin((double)K, span / 512.0);
-        while (K >= 2 && !split_grid((uint32_t)span, ctx->max_warmup, K, 1e-3 * (double)ctx->split_ff_permille, a.split_bounds))
-            --K;
+        // (a fast-forwarded sample costs the same whatever is rendered afterwards; a rendered sample of eight live
+        // formants costs 1.56 x one of four: 27.0 against 17.3 ms for the headline batch)
+        const double ff_cost = 1e-3 * (double)ctx->split_ff_permille * (batch_live4_any_blend(ctx, batch) ? 1.0 : 0.64);
+        while (K >= 2 && !split_grid((uint32_t)span, ctx->max_warmup, K, ff_cost, a.split_bounds)) --K;
         if (K >= 2) {
             split_k = K;
             a.split_bounds[K] = (uint32_t)out_stride;

@@ -148,7 +148,11 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
     constexpr int NBUF = SPLIT ? 3 : 2;        // super-tiles in flight
     constexpr int W_FILT = SPLIT ? 2 : 1;      // the filter wave; it works W_FILT super-tiles behind the chain
     __shared__ TileIn tin[NBUF];
-    __shared__ ParamBlock par[2];
+    // one block per super-tile in flight: an epoch opens at most once per super-tile, the filter wave is W_FILT
+    // super-tiles behind the chain wave, so epochs e .. e + W_FILT can be live at once (with two blocks the chain
+    // wave of the three-stage flavour overwrote the block the filter wave was still reading whenever three
+    // consecutive super-tiles each opened an epoch: segments of a few milliseconds)
+    __shared__ ParamBlock par[NBUF];
     __shared__ TileMeta meta[4];
     __shared__ int last_tile;                 // index of the utterance's last super-tile, known once the chain ends
 
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
                         }
                         if (params_dirty) {
                             ++epoch;
-                            ParamBlock &pb = par[epoch & 1];
+                            ParamBlock &pb = par[epoch % NBUF];
                             if (lane < ELEM_FLOATS) {
                                 // SynthesisElem::silent() :367-377, copy_silent() :454-459
                                 const float sil = lane == 0 ? 0.25f : (lane < F_BREATH ? 0.25f : 0.0f);
@@ -461,7 +465,11 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
                         const float frequency = f_next;                        // lanes >= n: stale values, unused
                         if (r + TL < S) f_next = ti.saw[r + TL + lane];
                         float saw = 0.0f, nz = 0.0f;
+#ifdef GRAIL_SCAN_DEBUG
                         if (A.resume != 205) carrier(frequency, n, saw, nz);   // 205: development probe, the chain wave alone
+#else
+                        carrier(frequency, n, saw, nz);
+#endif
                         ti.saw[r + lane] = saw;
                         ti.nz[r + lane] = nz;
                     }
@@ -667,6 +675,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
                 const float yp = v1.x + v1.y;
                 y[k] += yp;                                                    // :574, in formant order
             }
+#ifdef GRAIL_SCAN_DEBUG
             if (A.resume && A.resume < 200 && p == 0) {   // development aid ("scan_debug" option): a chain quantity instead of the audio
 #pragma unroll
                 for (int k = 0; k < CK; ++k) {
@@ -676,11 +685,14 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
                     y[k] = 2.0f * dv;
                 }
             }
+#endif
             // the super-tile's end (lanes beyond it carried identities) is the next one's start
             put_lane(st_a, f0, lane63(a_end.x)); put_lane(st_a, f0 + 1, lane63(a_end.y));
             put_lane(st_b, f0, lane63(b.x)); put_lane(st_b, f0 + 1, lane63(b.y));
             put_lane(st_c, f0, lane63(c.x)); put_lane(st_c, f0 + 1, lane63(c.y));
+#ifdef GRAIL_SCAN_DEBUG
             if (A.resume && A.resume < 200) break;
+#endif
         }
         // ---- my eight samples of the row
         const uint64_t at = (uint64_t)u * A.out_stride + m.at + (uint32_t)(CK * lane);
@@ -711,11 +723,16 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
     };
 
     for (int step = 0;; ++step) {
-        if (step >= W_FILT && step - W_FILT <= last_tile && !(A.resume >= 200 && (A.resume & 1))) {
+#ifdef GRAIL_SCAN_DEBUG
+        const bool probe_skip = A.resume >= 200 && (A.resume & 1);    // development probe: the filter wave idle
+#else
+        constexpr bool probe_skip = false;
+#endif
+        if (step >= W_FILT && step - W_FILT <= last_tile && !probe_skip) {
             const TileMeta m = meta[(step - W_FILT) & 3];
             if (m.epoch != have_epoch) {
                 have_epoch = m.epoch;
-                const ParamBlock &pb = par[have_epoch & 1];
+                const ParamBlock &pb = par[have_epoch % NBUF];
                 vX = pb.X[lane < ELEM_FLOATS ? lane : 0];
                 vY = pb.Y[lane < ELEM_FLOATS ? lane : 0];
                 vN = pb.ffc[lane & 31];                  // ffc, ffn, fac, fan: 4 x NF consecutive floats

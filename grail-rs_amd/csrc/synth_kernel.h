@@ -1511,7 +1511,10 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     };
     // ---- the per-utterance chain of samples tc, tc+1: exact (see scalar_packed_steps).  Advances
     // clk, jphase and phase; returns the phases before the two samples and their pitch.
-    auto chain_pair = [&](f2 &PH, f2 &frequency) __attribute__((always_inline)) {
+    // CLAMP = false: the caller has shown that clk / blend_length <= 1 for every sample of the tile (the clock
+    // only falls inside a calm tile), so min(ratio, 1) is the ratio itself.
+    auto chain_pair = [&](auto clamp_tag, f2 &PH, f2 &frequency) __attribute__((always_inline)) {
+        constexpr bool CLAMP = decltype(clamp_tag)::value;
         const f2 one2 = vsplat(1.0f, f2());
         // a both-silent pair emits silent() itself (alpha = 1, :926): its reciprocal blend length is replaced
         // by +inf, the clock is positive in a calm tile, and min(+inf, 1) = 1 — no select per sample
@@ -1529,7 +1532,9 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             ratio = blend_pow2 ? ratio : quot;
         }
         f2 alpha;                                                          // :899/:908/:917
-        if constexpr (ANYBL) {
+        if constexpr (!CLAMP) {
+            alpha = ratio;
+        } else if constexpr (ANYBL) {
             alpha.x = silent_pair ? 1.0f : __builtin_fminf(ratio.x, 1.0f);
             alpha.y = silent_pair ? 1.0f : __builtin_fminf(ratio.y, 1.0f);
         } else {
@@ -1583,7 +1588,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         const f2 one2 = vsplat(1.0f, f2());
         const float nz[2] = {nz0, nz1}, nm[2] = {nm0, nm1_};
         f2 PH, frequency;
-        chain_pair(PH, frequency);
+        chain_pair(std::true_type(), PH, frequency);
         // polyBLEP :503-517 without branches or selects: with d_h = f - p (> 0: the head test
         // p < f) and d_t = p - (1 - f) (> 0: the tail test p > 1 - f; never both), u = max(d_h, d_t, 0) / f
         // is 1 - t for the head (:505) and 1 + t for the tail (:509), and the correction is -u^2 or
@@ -1657,15 +1662,23 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         }
         FTI = FTI + 2.0f;
     };
-    // One whole tile in which every rendering lane is calm with the same flavour and sub-tile length and the
-    // same carrier-noise state: the tight loops.  `noise_of_lane`: lane l holds the noise of the tile's step l.
-    auto fast_tile_uniform = [&](auto su_tag, const int shift, const bool all_fresh,
-                                 const float noise_of_lane) __attribute__((always_inline)) {
-        const int TS = FAST_TS0 >> shift;
+    // One whole tile in which every rendering lane is calm with the same flavour and the same carrier-noise
+    // state: the tight loops.  The lanes may differ in their sub-tile lengths: the wave walks the tile in
+    // sub-tiles of the shortest (32 >> shift_max) and a lane takes new slopes / moves its start on where its OWN
+    // sub-tiles begin and end, so what it computes does not depend on the others' lengths.
+    // `noise_of_lane`: lane l holds the noise of the tile's step l.
+    auto fast_tile_uniform = [&](auto su_tag, const int shift_max, const float noise_of_lane) __attribute__((always_inline)) {
+        const int TS = FAST_TS0 >> shift_max;
+        const int my_mask = (FAST_TS0 >> fast_shift) - 1;
         const float nm1_of_lane = noise_of_lane - 1.0f;
 #pragma unroll 1
         for (int ts = 0; ts < T; ts += TS) {
-            fast_subtile_begin(su_tag, all_fresh && ts == 0);
+            const bool begins = (ts & my_mask) == 0;
+            if (__builtin_amdgcn_ballot_w64(begins & !fast_fresh) != 0) {
+                if (begins) fast_subtile_begin(su_tag, fast_fresh);
+            } else if (begins) {
+                fast_subtile_begin(su_tag, true);
+            }
 #pragma unroll 1
             for (int tc = ts; tc < ts + TS; tc += 2) {
                 const float nz0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc));
@@ -1674,7 +1687,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 const float nm1_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nm1_of_lane), tc + 1));
                 fast_pair(su_tag, tc, nz0, nz1, nm0, nm1_);
             }
-            fast_subtile_end(su_tag);
+            if (((ts + TS) & my_mask) == 0) fast_subtile_end(su_tag);
         }
     };
     // The lane's share of step t of a mixed tile — its wave-mates may be in general steps, in the other
@@ -1795,25 +1808,25 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         // the tight loops: every rendering lane fast, one flavour, one sub-tile length, one carrier-noise state
         const uint64_t rendering = __builtin_amdgcn_ballot_w64(!idle);
         bool uniform = false;
-        int shift_u = 0, flavour_u = 0;
+        int shift_max = 0, flavour_u = 0;
         uint32_t tile_seed = 0u;
-        bool all_fresh = false;
         if (rendering != 0) {
             const int first = __builtin_ctzll(rendering);
             tile_seed = (uint32_t)__builtin_amdgcn_readlane((int)noise_seed, first);
-            shift_u = __builtin_amdgcn_readlane(fast_shift, first);
             flavour_u = __builtin_amdgcn_readlane(flavour, first);
-            const bool fits = idle | (lane_fast & (noise_seed == tile_seed) & (fast_shift == shift_u) & (flavour == flavour_u));
+            const bool fits = idle | (lane_fast & (noise_seed == tile_seed) & (flavour == flavour_u));
             uniform = __builtin_amdgcn_ballot_w64(!fits) == 0;
-            all_fresh = __builtin_amdgcn_ballot_w64(!(idle | fast_fresh)) == 0;
+#pragma unroll
+            for (int s_ = 1; s_ <= 4; ++s_)
+                if (__builtin_amdgcn_ballot_w64(!idle & (fast_shift >= s_)) != 0) shift_max = s_;
         }
         if (uniform) {
             // the carrier noise of the T steps, lane l taking step l (closed-form skip-ahead of the LCG :36-55)
             const uint32_t ahead = (uint32_t)(lane < T ? lane : T - 1) + 1u;
             const uint32_t sk = tile_seed * LCG_SKIP.mul[ahead] + LCG_SKIP.add[ahead];
             const float noise_of_lane = (__uint_as_float((sk >> 9) | 0x3F800000u) - 1.5f) * 2.0f;
-            if (flavour_u) fast_tile_uniform(std::true_type(), shift_u, all_fresh, noise_of_lane);
-            else fast_tile_uniform(std::false_type(), shift_u, all_fresh, noise_of_lane);
+            if (flavour_u) fast_tile_uniform(std::true_type(), shift_max, noise_of_lane);
+            else fast_tile_uniform(std::false_type(), shift_max, noise_of_lane);
             ++fast_tiles;
             n_out += idle ? 0u : (uint32_t)T;
             noise_seed = (uint32_t)__builtin_amdgcn_readlane((int)sk, T - 1);
@@ -1853,10 +1866,20 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             const bool calm = !done & quiet_ok & (dt > 0.0f) & (clk > (float)(T + 8) * dt) &
                               (jphase + (float)(T + 1) * jinc < 0.999f) & (n_out + (uint32_t)T <= base0);
             if (__builtin_amdgcn_ballot_w64(!(calm | done)) == 0) {
+                // (the usual tile: no lane's alpha needs its clamp — the blend is still under way)
+                const bool below_one = !silent_pair & ((clk - dt) * inv_blend_length <= 1.0f) & (ANYBL ? blend_pow2 : true);
+                if (__builtin_amdgcn_ballot_w64(!(below_one | done)) == 0) {
 #pragma unroll 4
-                for (int tc = 0; tc < T; tc += 2) {
-                    f2 PH, frequency;
-                    chain_pair(PH, frequency);
+                    for (int tc = 0; tc < T; tc += 2) {
+                        f2 PH, frequency;
+                        chain_pair(std::false_type(), PH, frequency);
+                    }
+                } else {
+#pragma unroll 4
+                    for (int tc = 0; tc < T; tc += 2) {
+                        f2 PH, frequency;
+                        chain_pair(std::true_type(), PH, frequency);
+                    }
                 }
                 n_out += done ? 0u : (uint32_t)T;
             } else {

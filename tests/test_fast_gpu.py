@@ -444,7 +444,7 @@ def test_time_split_ragged_lengths_short_and_empty_utterances(gpu_ctx):
     try:
         for chunks, span in ((4, 36864), (7, 0), (2, 12800)):
             _split(gpu_ctx, chunks, span)
-            gpu_ctx.set_option("time_split_ff_cost_permille", 0 if span else 140)   # 0: a uniform grid
+            gpu_ctx.set_option("time_split_ff_cost_permille", 0 if span else 165)   # 0: a uniform grid
             out, out_len = _render(gpu_ctx, True, segs, offs, None, seeds, stride)
             assert "SPLIT" in gpu_ctx.last_kernel_name()
             assert np.array_equal(out_len, ref_len), (chunks, np.nonzero(out_len != ref_len)[0][:8])
@@ -453,7 +453,7 @@ def test_time_split_ragged_lengths_short_and_empty_utterances(gpu_ctx):
             assert k * ULP <= TOL
     finally:
         _split(gpu_ctx, 0)
-        gpu_ctx.set_option("time_split_ff_cost_permille", 140)
+        gpu_ctx.set_option("time_split_ff_cost_permille", 165)
 
 
 def test_time_split_truncation_and_pcm16(gpu_ctx):
