@@ -37,7 +37,11 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X
 ALG_BYTES_PER_SAMPLE = 4.01  # 4 B f32 written + <= 0.01 B of segment/voice input
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
 RCCL_TIMEOUT_S = float(os.environ.get("GRAIL_BENCH_RCCL_TIMEOUT", "240"))
-KERNEL_SOURCES = ["synth_kernels.hip", "scan_kernels.hip", "device_common.h", "kernels.h", "pcm16.h"]
+def kernel_sources():
+    """Every device-side source of the library: the kernel template and its instantiation units
+    (csrc/*.hip) and the headers they include (csrc/*.h), sorted by name."""
+    d = os.path.join(ROOT, "grail-rs_amd", "csrc")
+    return sorted(f for f in os.listdir(d) if f.endswith(".hip") or f.endswith(".h"))
 
 
 def kernel_source_sha():
@@ -45,11 +49,9 @@ def kernel_source_sha():
     built from (build() rebuilds whenever they change).  profiles/traffic.json entries carry the
     sha they were measured on; a counter figure from another build is reported as null."""
     h = hashlib.sha256()
-    for name in KERNEL_SOURCES:
-        p = os.path.join(ROOT, "grail-rs_amd", "csrc", name)
-        if os.path.exists(p):
-            with open(p, "rb") as f:
-                h.update(f.read())
+    for name in kernel_sources():
+        with open(os.path.join(ROOT, "grail-rs_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
 
 
@@ -134,8 +136,11 @@ def valu_roofline(entry, kernel_ms):
     return {"bound": "valu-issue", "achieved": rate / 1e9, "peak": peak / 1e9,
             "unit": "G wave-instructions/s", "frac": rate / peak,
             "valu_instructions_per_launch": insts,
-            "note": "SQ_INSTS_VALU (profiles/); a lone wave per SIMD issues at most one "
-                    "instruction per ~5 cycles (measured), i.e. frac <= 0.8"}
+            "note": "SQ_INSTS_VALU (profiles/).  The peak is the PACKED issue rate, one v_pk_*_f32 per 4 "
+                    "cycles per SIMD; plain v_{add,mul,fma}_f32 issue at one per 2.8 cycles with two or more "
+                    "waves per SIMD (profiles/r01_valu_microbench.txt), so this is a fraction of the packed-issue "
+                    "peak, not of the SIMD's best case.  A lone wave per SIMD issues at most one instruction "
+                    "per ~5 cycles whatever it is (measured), i.e. frac <= 0.8 for the headline batch"}
 
 
 class stdout_to_stderr:
@@ -161,6 +166,36 @@ def _free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+def rccl_diagnose():
+    """`bench.py --rccl-diagnose` (started by every rank of a run whose RCCL broadcast failed, just before
+    that run exits 3): meet again over a fresh rendezvous with NCCL_DEBUG=WARN and report what RCCL says
+    on stderr.  A child process, because RCCL reads NCCL_DEBUG once per process."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from grail_hip.rendezvous import FileGroup
+    import grail_hip as G
+    group = FileGroup(rank, world)
+    G.load()
+    device = int(os.environ["GRAIL_BENCH_DEVICE"]) if "GRAIL_BENCH_DEVICE" in os.environ else local_rank
+    tag = f"[rccl-diagnose rank {rank} device {device}]"
+    try:
+        ctx = G.Context(device)
+        print(f"{tag} pci bus id {ctx.pci_bus_id()}", file=sys.stderr, flush=True)
+        uid = G.Context.comm_unique_id() if rank == 0 else None
+        uid = group.broadcast_bytes(uid)
+        with stdout_to_stderr():
+            ctx.comm_init(uid, rank, world)
+            if rank == 0:
+                from grail_hip import workload as W
+                ctx.set_voices(W.single_voice())
+            ctx.broadcast_voices(1, root=0)
+            ctx.sync()
+        print(f"{tag} second attempt succeeded: ncclCommCount={ctx.comm_info()[0]}", file=sys.stderr, flush=True)
+    except Exception as e:                                  # noqa: BLE001 — the point is the message
+        print(f"{tag} second attempt failed: {e}", file=sys.stderr, flush=True)
+    os._exit(0)
 
 
 def launch_ranks(args):
@@ -240,6 +275,7 @@ def main():
     ap.add_argument("--ramp", type=int, default=1, choices=[0, 1],
                     help="0 skips the clock-ramp launches of a small sub-batch before the warm-up "
                          "(counter passes: only the measured kernel should appear)")
+    ap.add_argument("--rccl-diagnose", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-utts", type=int, default=512,
                     help="utterances for the CPU baseline (0 = skip); 512 is ~4-7 s of CPU on one "
                          "thread (samples/s does not depend on it)")
@@ -251,6 +287,8 @@ def main():
     elif args.config == 4:
         args.utts, args.voices = 65536, 8
 
+    if args.rccl_diagnose:
+        return rccl_diagnose()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)
 
@@ -302,6 +340,16 @@ def main():
     n_utt = args.utts
     n_voices = max(args.voices, 1)
     stride = W.max_samples()
+    bus_id = ctx.pci_bus_id()
+    if distributed:
+        # every rank on a GPU of its own: the PCI bus ids must be distinct (the one-GPU test hook aside)
+        bus_ids = [b.decode() for b in group.gather_bytes(bus_id.encode())]
+        print(f"[rank {rank}] device {device} pci bus id {bus_id}", file=sys.stderr, flush=True)
+        if "GRAIL_BENCH_DEVICE" not in os.environ and len(set(bus_ids)) != world:
+            print(f"[rank {rank}] ranks share a GPU: pci bus ids {bus_ids}", file=sys.stderr, flush=True)
+            os._exit(5)
+    else:
+        bus_ids = [bus_id]
 
     # ---- voice table: rank 0 builds it; one RCCL broadcast puts it in every GPU's HBM ----
     voice_path = "local"
@@ -356,6 +404,15 @@ def main():
             why = "timed out" if hung else outcome.get("err", "failed on another rank")
             print(f"[rank {rank}] --require-rccl: the RCCL broadcast over {world} ranks did not "
                   f"happen ({why}; ncclCommCount={comm_ranks})", file=sys.stderr)
+            sys.stderr.flush()
+            # once more, in a child per rank with NCCL_DEBUG=WARN, so that the log says why
+            try:
+                env = dict(os.environ, NCCL_DEBUG="WARN", GRAIL_BENCH_PREBUILT="1",
+                           GRAIL_RDZV_NONCE=os.environ.get("GRAIL_RDZV_NONCE", "") + "-diagnose")
+                subprocess.run([sys.executable, os.path.abspath(__file__), "--rccl-diagnose"], env=env,
+                               stdout=sys.stderr.fileno(), timeout=min(90.0, RCCL_TIMEOUT_S))
+            except Exception as e:                          # noqa: BLE001
+                print(f"[rank {rank}] rccl diagnosis: {e}", file=sys.stderr)
             sys.stderr.flush()
             os._exit(3)              # a thread may still sit inside RCCL: do not wait for it
         if not ok_everywhere:        # keep the job alive: hand the same bytes over through /tmp, on every rank
@@ -454,10 +511,29 @@ def main():
                 mismatches += int(np.count_nonzero(rs != ref_s) + np.count_nonzero(rl != ref_l))
                 checked += n_utt
             # batch invariance: every 61st utterance of rank 0's shard re-rendered as its own small
-            # batch (another batch size, another position, usually another lane mapping); exact mode
-            # must give the same bits, fast mode is compared by the tolerance tests instead
+            # batch (another batch size, another position, other wave-mates; in exact mode usually another
+            # lane mapping too).  Exact mode must give the same bits whatever kernel renders the subset;
+            # fast mode must give the same bits within a kernel family, so the subset is pinned to the
+            # family the batch took (its lane mapping, or its time-split grid)
             rebatched = None
-            if args.mode == "exact":
+            if True:
+                fast_pins = {}
+                if args.mode == "fast":
+                    chunks = ctx.get_option("last_launch_chunks")
+                    if chunks:
+                        fast_pins = {"time_split_chunks": chunks, "time_split_span_samples": stride}
+                        # the batch itself once more on the pinned grid: the digests to compare with
+                        for k_, v_ in fast_pins.items():
+                            ctx.set_option(k_, v_)
+                        batch.synthesize_async(d_out, stride, d_len)
+                        ctx.sync()
+                        sums, _, _ = ctx.digest(d_out, stride, d_len, n_utt)
+                    elif ctx.get_option("last_launch_lanes"):
+                        fast_pins = {"lanes_per_utterance": ctx.get_option("last_launch_lanes")}
+                    else:                                   # the scan kernel: one workgroup per utterance
+                        fast_pins = {"time_parallel_scan_max_utterances": 1 << 30, "time_split": 0}
+                    for k_, v_ in fast_pins.items():
+                        ctx.set_option(k_, v_)
                 pick = np.arange(0, n_utt, 61, dtype=np.int64)
                 _, _, s0, o0, v0, j0 = W.shard_inputs(n_utt, 0, world, len(voices))
                 s0 = s0.reshape(n_utt, -1)[pick].reshape(-1)
@@ -473,6 +549,12 @@ def main():
                 ctx.device_free(d_o3)
                 ctx.device_free(d_l3)
                 b3.free()
+                if fast_pins:
+                    ctx.set_option("time_split_chunks", 0)
+                    ctx.set_option("time_split_span_samples", 0)
+                    ctx.set_option("lanes_per_utterance", args.lanes)
+                    ctx.set_option("time_parallel_scan_max_utterances", 8704)
+                    ctx.set_option("time_split", 1)
             verify = {"utterances_checked": checked, "mismatches": mismatches,
                       "nonfinite_samples": int(bad.sum()), "rebatched_subset_mismatches": rebatched,
                       "method": "per-utterance bit-pattern digests (grail_batch_digest): every rank's rows "
@@ -524,12 +606,18 @@ def main():
             "roofline_valu": valu_roofline(f_entry, fk),
         }
 
+    my_elapsed = elapsed
     if distributed:
-        stats = group.gather_doubles((elapsed, float(samples_per_step)))
-        elapsed = max(e for e, _ in stats)                  # MAX over ranks
-        total_samples_per_step = sum(n for _, n in stats)   # whole-job samples per step
+        stats = group.gather_doubles((elapsed, float(samples_per_step), float(np.mean(kernel_ms)), float(device)))
+        elapsed = max(e for e, _, _, _ in stats)                  # MAX over ranks
+        total_samples_per_step = sum(n for _, n, _, _ in stats)   # whole-job samples per step
     else:
+        stats = [(my_elapsed, float(samples_per_step), float(np.mean(kernel_ms)), float(device))]
         total_samples_per_step = float(samples_per_step)
+    # one row per rank: a straggler or a mis-pinned rank shows here
+    per_rank = [{"rank": r, "device": int(dv), "pci_bus_id": bus_ids[r], "kernel_ms_mean": km,
+                 "ms_per_step": e * 1e3 / args.steps, "samples_per_s": n * args.steps / e}
+                for r, (e, n, km, dv) in enumerate(stats)]
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -571,6 +659,8 @@ def main():
                                           "profiles/ for the config-4 line",
             },
             "rccl": rccl_info,
+            "per_gpu_value": value / world,
+            "per_rank": per_rank,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,

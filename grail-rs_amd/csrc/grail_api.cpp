@@ -506,6 +506,14 @@ int grail_device_count(int *count)
     return GRAIL_OK;
 }
 
+int grail_device_pci_bus_id(grail_ctx *ctx, char *out, size_t cap)
+{
+    if (!ctx || !out || cap < 16) return fail(GRAIL_ERR_INVALID_ARG, "grail_device_pci_bus_id: NULL argument or cap < 16");
+    out[0] = 0;
+    HIP_TRY(hipDeviceGetPCIBusId(out, (int)cap, ctx->device));
+    return GRAIL_OK;
+}
+
 int grail_create(int device, grail_ctx **out)
 {
     if (!out) return fail(GRAIL_ERR_INVALID_ARG, "out is NULL");

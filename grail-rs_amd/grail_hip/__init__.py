@@ -51,7 +51,7 @@ EXPORTS = [
     "grail_abi_version", "grail_status_string", "grail_last_error",
     "grail_elem_silent", "grail_elem_new_phoneme", "grail_elem_new", "grail_elem_resample",
     "grail_elem_blend", "grail_voice_generic", "grail_voice_generic_at", "grail_voice_get",
-    "grail_create", "grail_destroy", "grail_device_count", "grail_set_voices",
+    "grail_create", "grail_destroy", "grail_device_count", "grail_device_pci_bus_id", "grail_set_voices",
     "grail_get_voices", "grail_set_option", "grail_get_option",
     "grail_batch_upload", "grail_batch_upload_elems", "grail_batch_free", "grail_batch_size",
     "grail_batch_lengths", "grail_batch_synthesize_async", "grail_sync",
@@ -178,6 +178,7 @@ def load():
     L.grail_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.grail_destroy.argtypes = [vp]
     L.grail_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.grail_device_pci_bus_id.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.grail_set_voices.argtypes = [vp, vp, C.c_uint32]
     L.grail_get_voices.argtypes = [vp, vp, C.c_uint32, u32p]
     L.grail_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
@@ -446,6 +447,11 @@ class Context:
         arr = (Voice * max(n.value, 1))()
         _check(load().grail_get_voices(self.handle, C.cast(arr, C.c_void_p), n.value, C.byref(n)))
         return [arr[i].copy() for i in range(n.value)]
+
+    def pci_bus_id(self):
+        buf = C.create_string_buffer(32)
+        _check(load().grail_device_pci_bus_id(self.handle, buf, 32))
+        return buf.value.decode()
 
     def set_option(self, name, value):
         _check(load().grail_set_option(self.handle, name.encode(), value))

@@ -42,6 +42,9 @@ class FileGroup:
             key = "_".join([os.environ.get("MASTER_ADDR", "local"),
                             os.environ.get("MASTER_PORT", "0"),
                             os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                            # a restarted attempt of an elastic agent gets a key of its own: its ranks can
+                            # never join the directory of the attempt before (whose rank 0 may be hung but alive)
+                            os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"),
                             os.environ.get("GRAIL_RDZV_NONCE", str(os.getppid()))])
         self.timeout = timeout
         self.seq = 0

@@ -169,6 +169,9 @@ int grail_voice_get(const grail_voice *voice, int32_t phoneme, grail_synthesis_e
 int grail_create(int device, grail_ctx **out);
 int grail_destroy(grail_ctx *ctx);
 int grail_device_count(int *count);
+/* hipDeviceGetPCIBusId of ctx's GPU ("0000:05:00.0", NUL-terminated; cap >= 16).  Lets a launcher prove
+ * that its ranks sit on distinct GPUs. */
+int grail_device_pci_bus_id(grail_ctx *ctx, char *out, size_t cap);
 /* Uploads the voice table (the `voice` argument of .select/.sequence/.jitter,
  * src/lib.rs:1013, 941, 786) to HBM.  Utterances refer to it by voice id. */
 int grail_set_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices);

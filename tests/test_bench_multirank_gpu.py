@@ -33,6 +33,13 @@ def _check_two_ranks(d):
     assert d["rccl"]["broadcast"] in ("ncclBroadcast", "file-fallback")
     assert d["rccl"]["ranks"] == (2 if d["rccl"]["broadcast"] == "ncclBroadcast" else 0)
     assert "cpu_baseline" not in d                      # N=1 only
+    # one row per rank, so that a straggler or a mis-pinned rank is visible in the driver's 8-GPU record
+    assert [r["rank"] for r in d["per_rank"]] == [0, 1]
+    for r in d["per_rank"]:
+        assert r["device"] == 0 and r["pci_bus_id"] and r["kernel_ms_mean"] > 0 and r["ms_per_step"] > 0
+        assert r["samples_per_s"] > 0
+    assert abs(d["per_gpu_value"] * 2 - d["value"]) < 1e-6 * d["value"]
+    assert d["ms_per_step"] >= max(r["ms_per_step"] for r in d["per_rank"]) * (1 - 1e-9)
 
 
 def test_two_ranks_under_torch_distributed_run(built):
@@ -63,6 +70,8 @@ def test_require_rccl_fails_loudly_when_the_ranks_cannot_meet(built):
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode != 0
     assert "require-rccl" in p.stderr
+    assert "pci bus id" in p.stderr                     # every rank says which GPU it sits on
+    assert "rccl-diagnose" in p.stderr                  # ... and the failed step ran once more with NCCL_DEBUG=WARN
     assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{") and "n_gpus" in l]
 
 
@@ -72,6 +81,21 @@ def test_single_gpu_verify_and_fast_leg(built):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     d = _one_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600))
     assert d["n_gpus"] == 1 and d["verify"]["mismatches"] == 0
+    assert d["verify"]["rebatched_subset_mismatches"] == 0
+    assert len(d["per_rank"]) == 1 and d["per_gpu_value"] == d["value"]
     assert d["config"]["arithmetic"] == "exact"
     assert d["fast_mode"]["value"] > 0 and "FAST" in d["fast_mode"]["kernel"]
     assert d["rccl"]["ranks"] == 0
+
+
+@pytest.mark.parametrize("utts", [4096, 65536])
+def test_fast_mode_verify_rerenders_a_subset_within_the_same_kernel_family(built, utts):
+    """--mode fast --verify: the re-batched subset must give the same bits as long as it runs in the kernel
+    family the batch took (its time-split grid at 4096 utterances, one lane per utterance at 65536)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--utts", str(utts),
+           "--mode", "fast", "--verify", "--cpu-utts", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    d = _one_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600))
+    assert d["config"]["arithmetic"] == "fast" and "FAST" in d["roofline"]["kernel"]
+    assert ("SPLIT" in d["roofline"]["kernel"]) == (utts == 4096)
+    assert d["verify"]["mismatches"] == 0 and d["verify"]["rebatched_subset_mismatches"] == 0

@@ -294,6 +294,39 @@ def test_scan_kernel_edge_cases(gpu_ctx):
         assert k * ULP <= TOL
 
 
+@pytest.mark.parametrize("split", [1, 0])
+def test_scan_kernel_runs_of_short_segments(gpu_ctx, split):
+    """Consecutive segments of 2 - 5 ms (96 - 240 samples): every super-tile of 512 samples opens a new
+    parameter epoch, so the three-stage workgroups have three epochs in flight — one parameter block per
+    super-tile in flight (the block ring had two entries once: the chain wave overwrote the block the filter
+    wave was still reading).  Run several times: the fault was a race."""
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
+    rng = np.random.default_rng(5)
+    A, E, S = G.PH_A, G.PH_E, G.PH_SILENCE
+    f = 120.0 / 48000.0
+    utts = [[(int(rng.choice([A, E, E, A, S])), float(rng.uniform(0.002, 0.005)),
+              float(rng.choice([0.00390625, 0.001953125, 0.0078125])), f * float(rng.uniform(0.8, 1.6)))
+             for _ in range(60)] for _ in range(24)]
+    segs = G.segments([s for u in utts for s in u])
+    offs = np.cumsum([0] + [len(u) for u in utts]).astype(np.uint32)
+    seeds = np.arange(len(utts), dtype=np.uint32) * 977 + 3
+    stride = 16384
+    ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, None, seeds, stride)
+    split_default = gpu_ctx.get_option("time_parallel_scan_split_max_utterances")
+    gpu_ctx.set_option("time_parallel_scan_split_max_utterances", split_default if split else 0)
+    try:
+        for attempt in range(4):
+            out, out_len = _render(gpu_ctx, True, segs, offs, None, seeds, stride)
+            assert gpu_ctx.last_kernel_name().startswith("scan_kernel") and ("SPLIT" in gpu_ctx.last_kernel_name()) == bool(split)
+            assert np.array_equal(out_len, ref_len)
+            k = _worst(out, ref, ref_len)
+            assert k * ULP <= TOL, (attempt, k)
+        print(f"scan kernel, runs of short segments, split {split}: {k:.1f} * 2^-23")
+    finally:
+        gpu_ctx.set_option("time_parallel_scan_split_max_utterances", split_default)
+
+
 def test_scan_kernel_gate_sends_unsafe_tables_elsewhere(gpu_ctx):
     """A table outside the safe window (a formant at frequency 0: the reference emits NaN) does not take
     the scan kernel.  Blend lengths that are not powers of two do (the chain wave then takes the IEEE
