@@ -947,12 +947,14 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     // small batches leave SIMDs idle: four-wave workgroups (one wave renders 16 utterances, one carries
     // the per-utterance chain, two prepare the filter coefficients), up to two per CU (tools/pipe4_range.py:
     // 11.5 ms up to 4 096 utterances, 15.7 up to 8 192 where the lane kernels take 18.0; three per CU lose)
-    if (a.live4 && !a.fast && !ctx->lanes_option && ctx->pipeline_option &&
-        ((uint64_t)count + 15) / 16 <= (uint64_t)ctx->pipe4_max_groups) {
+    const bool want_pipe4 = batch_live4(ctx, batch) && !ctx->lanes_option && ctx->pipeline_option &&
+                            ((uint64_t)count + 15) / 16 <= (uint64_t)ctx->pipe4_max_groups;
+    const bool want_pipe8 = !batch_live4(ctx, batch) && !ctx->lanes_option && ctx->pipeline_option && !batch->any_blend &&
+                            ((uint64_t)count + 7) / 8 <= (uint64_t)ctx->pipe8_max_groups;
+    if (want_pipe4 && !a.fast) {
         a.pipe = 1u;
         L = 4;
-    } else if (!a.live4 && !a.fast && !ctx->lanes_option && ctx->pipeline_option && !batch->any_blend &&
-               ((uint64_t)count + 7) / 8 <= (uint64_t)ctx->pipe8_max_groups) {
+    } else if (want_pipe8 && !a.fast) {
         a.pipe = 1u;                                      // eight formants: 8 utterances per workgroup
         L = 8;
     }
@@ -999,6 +1001,16 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
                       batch->phoneme_mode && ctx->voices_scan_ok && batch->plain &&
                       batch->min_length >= 2.0f * ctx->max_dt &&
                       batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f;
+    // fast arithmetic asked for, but the batch takes neither the scan kernel nor the time-split kernels (caller-built
+    // elems, a voice outside their windows, an option switched off) and is small enough for the pipelined exact
+    // workgroups: those are faster than the fast lane kernels there (8.1 - 11.5 against 12.4 ms), and exact bits
+    // satisfy the tolerance trivially
+    if (a.fast && !scan && !split_k && (want_pipe4 || want_pipe8)) {
+        a.fast = 0u;
+        a.live4 = batch_live4(ctx, batch) ? 1u : 0u;
+        a.pipe = 1u;
+        L = want_pipe4 ? 4 : 8;
+    }
     if (split_k) {
         a.split_chunks = (uint32_t)split_k;
         a.live4 = batch_live4_any_blend(ctx, batch) ? 1u : 0u;
@@ -1230,15 +1242,22 @@ int pipe_get(grail_ctx *ctx, size_t block_bytes, bool need_pins, HostPipe **out)
 {
     HostPipe *p = (HostPipe *)ctx->host_pipe;
     if (!p) {
+        // built in a local and published to the context only when every stream and event exists: a
+        // half-built pipe left behind by a failed create would make later calls use null handles
         p = new (std::nothrow) HostPipe();
         if (!p) return fail(GRAIL_ERR_OUT_OF_MEMORY, "host allocation failed");
-        ctx->host_pipe = p;
-        HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) {
-            HIP_TRY(hipEventCreateWithFlags(&p->rendered[i], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&p->drained[i], hipEventDisableTiming));
+        hipError_t e = hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking);
+        for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+            e = hipEventCreateWithFlags(&p->rendered[i], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&p->drained[i], hipEventDisableTiming);
         }
-        for (int i = 0; i < N_PIECES; ++i) HIP_TRY(hipEventCreateWithFlags(&p->landed[i], hipEventDisableTiming));
+        for (int i = 0; i < N_PIECES && e == hipSuccess; ++i)
+            e = hipEventCreateWithFlags(&p->landed[i], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            pipe_destroy(p);
+            return hip_fail(e, "host-output pipe");
+        }
+        ctx->host_pipe = p;
     }
     if (p->dev_bytes < block_bytes) {
         HIP_TRY(hipStreamSynchronize(p->copy_stream));
@@ -1313,6 +1332,8 @@ int render_to_host(grail_ctx *ctx, grail_batch *b, uint32_t n_utt, void *out, si
                    uint32_t *out_len)
 {
     const size_t row_bytes = (size_t)out_stride * elem;
+    // (copier threads memcpy into `out`: a NULL destination must fail here, not fault there)
+    if (!out && n_utt && out_stride) return fail(GRAIL_ERR_INVALID_ARG, "out is NULL");
     uint32_t *d_len = nullptr;
     hipError_t e = hipSuccess;
     if (n_utt) e = hipMalloc((void **)&d_len, (size_t)n_utt * sizeof(uint32_t));

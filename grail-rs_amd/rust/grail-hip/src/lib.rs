@@ -103,34 +103,45 @@ impl<I: IntoIterator<Item = Utterance>> IntoSynthesizeBatch for I {
             r?;
         }
         let stride = (*lens.iter().max().unwrap_or(&0) as u64 + 63) / 64 * 64;
-        // The block lands in PINNED host memory: grail_synthesize_batch renders rows in blocks of up to
-        // 4096 utterances and copies each block out on a second stream while the next one renders; a
-        // pinned destination receives those copies directly (measured 50.9 GB/s end to end = 89 % of a
-        // plain pinned hipMemcpy, profiles/r02_host_output.txt).  A plain Vec works too (staging ring +
-        // copier threads, ~39 GB/s).
+        // Results of up to PINNED_LIMIT bytes land in PINNED host memory: grail_synthesize_batch renders rows in
+        // blocks of up to 4096 utterances and copies each block out on a second stream while the next one
+        // renders; a pinned destination receives those copies directly (measured 50.9 GB/s end to end = 89 %
+        // of a plain pinned hipMemcpy, profiles/r02_host_output.txt; the hipHostMalloc / hipHostFree of the
+        // block itself is not in that figure and costs about a second per 10 GB).  Larger results, and hosts
+        // that refuse the pinned allocation (locked-memory limit, little free RAM), take a plain Vec — the
+        // library then feeds it through its own ring of pinned staging buffers and copier threads (~39 GB/s).
+        const PINNED_LIMIT: usize = 2 << 30;
         let floats = n as usize * stride as usize;
         let mut pinned: *mut std::ffi::c_void = std::ptr::null_mut();
-        check(unsafe { sys::grail_host_alloc(gpu.ctx, floats * 4, &mut pinned) })?;
+        let have_pinned = floats * 4 <= PINNED_LIMIT
+            && unsafe { sys::grail_host_alloc(gpu.ctx, floats * 4, &mut pinned) } == 0
+            && !pinned.is_null();
+        let mut pageable: Vec<f32> = if have_pinned { Vec::new() } else { vec![0f32; floats] };
+        let dst = if have_pinned { pinned as *mut f32 } else { pageable.as_mut_ptr() };
         let r = check(unsafe {
             sys::grail_synthesize_batch(gpu.ctx, segs.as_ptr(), offs.as_ptr(), vids.as_ptr(),
-                                        seeds.as_ptr(), n, pinned as *mut f32, stride,
+                                        seeds.as_ptr(), n, dst, stride,
                                         lens.as_mut_ptr(), sys::GRAIL_OUT_HOST)
         });
         let result = r.map(|_| {
-            let out = unsafe { std::slice::from_raw_parts(pinned as *const f32, floats) };
+            let out = unsafe { std::slice::from_raw_parts(dst as *const f32, floats) };
             lens.iter().enumerate()
                 .map(|(u, &l)| out[u * stride as usize..][..l as usize].to_vec())
                 .collect()
         });
-        unsafe { sys::grail_host_free(gpu.ctx, pinned) };
+        if have_pinned {
+            unsafe { sys::grail_host_free(gpu.ctx, pinned) };
+        }
+        drop(pageable);
         result
     }
 }
 
 /// Arithmetic of the synthesis kernels: `Exact` (default) is bit-identical to the CPU iterator chain;
 /// `Fast` is the stated-tolerance mode (|fast - exact| <= GRAIL_FAST_TOLERANCE = 64 * 2^-23 of full
-/// scale, measured 18 * 2^-23; clock, phases, wraps and noise generators stay exact): 2.4x the
-/// throughput on large batches, 5x on batches of a few hundred utterances (time-parallel scan kernel).
+/// scale, measured 18 * 2^-23; clock, phases, wraps and noise generators stay exact): 2.3x the
+/// throughput on large batches, 2x on batches of a few thousand utterances (time-split kernels), 5x on batches
+/// of a few hundred (time-parallel scan kernel).
 pub enum Arithmetic { Exact, Fast }
 
 impl Gpu {

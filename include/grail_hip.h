@@ -27,8 +27,18 @@
  * (no FMA contraction, correctly rounded division, denormals kept).  That is the
  * default, "arithmetic" = 0.  With grail_set_option(ctx, "arithmetic", 1) the
  * samples are within GRAIL_FAST_TOLERANCE of those bits instead (lengths,
- * segment boundaries, noise wraps and saw edges still exactly the reference's),
- * deterministic for a given batch, 2.4x faster.
+ * segment boundaries, noise wraps and saw edges still exactly the reference's).
+ * Fast-mode samples are a pure function of (the utterance, the kernel family):
+ * every lane decides from its own state, so they do not depend on the batch size,
+ * the position in the batch or the other utterances of the batch AS LONG AS THE
+ * KERNEL FAMILY IS THE SAME.  What still varies is the family the host picks from
+ * the batch size: the time-parallel scan kernel (small batches), the time-split
+ * kernels (their chunk grid follows the batch size and its longest utterance;
+ * "time_split_chunks" / "time_split_span_samples" pin it) or the lane kernels
+ * ("lanes_per_utterance" pins the mapping).  Speed: 2.3x the exact mode for the
+ * headline batch (65536 utterances), 2x for 4096; for batches the fast kernels do
+ * not serve faster than the exact ones the exact kernels run (their bits satisfy
+ * the tolerance trivially).
  *
  * There is no CPU fallback: every compute entry point fails with
  * GRAIL_ERR_NO_DEVICE when no gfx950-capable HIP device is usable.
@@ -187,15 +197,17 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       inside the safe window; no segment shorter than two samples; one-shot phoneme batches),
  *       formants 5-8 are not laid out over the lanes at all.  0 forces the literal evaluation
  *       of all eight.
- *   "small_batch_pipeline": 1 (default) / 0 — batches of at most 4096 utterances that qualify
+ *   "small_batch_pipeline": 1 (default) / 0 — batches of at most 8192 utterances that qualify
  *       for the four-formant layout run four-wave workgroups (render / per-utterance chain /
  *       2 x filter coefficients, handed on through LDS) instead of one wave per 8 utterances.
  *   "arithmetic": 0 (default) = exact, every sample bit-identical to the reference's binary32
  *       arithmetic; 1 = fast, the tolerance mode north_star allows: the discontinuous state
  *       (Sequencer clock, jitter phase, carrier phase and its wrap, both LCGs) stays exact, the
  *       per-formant arithmetic uses fused multiply-adds, one uncorrected reciprocal and filter
- *       coefficients interpolated across 32-sample tiles.  |fast - exact| <= GRAIL_FAST_TOLERANCE
- *       for parameters like voices::generic()'s (DESIGN.md "Fast mode"; tests/test_fast_gpu.py).
+ *       coefficients interpolated across sub-tiles of at most 32 samples whose length an error
+ *       guard picks per utterance (parameters that move too fast for two-sample sub-tiles are
+ *       evaluated directly).  |fast - exact| <= GRAIL_FAST_TOLERANCE (DESIGN.md "Fast mode";
+ *       tests/test_fast_gpu.py: configs 2 / 3 / 4 at full size, edge cases, random voice tables).
  *       This is the ONE knob that changes result bits.
  *   "time_parallel_scan": 1 (default) / 0 — fast arithmetic only: batches of up to
  *       "time_parallel_scan_max_utterances" (default 8704; 4/7 of that when all eight formants are
@@ -207,6 +219,16 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       formants) the workgroups have three pipeline stages (the serial carrier phase on a wave of
  *       its own: lowest time per batch), above it two (more utterances resident per CU: highest
  *       throughput).  Same results either way.
+ *   "time_split": 1 (default) / 0 — fast arithmetic only: batches of "time_split_min_utterances"
+ *       (default 1025) to 32768 utterances of voices whose filters forget their past within 16384
+ *       samples cut every utterance's time axis into chunks with a wavefront lane each, as many as
+ *       fill the machine.  A chunk's lane fast-forwards the exact per-utterance state to its chunk,
+ *       starts the filters from zero a warm-up length earlier (the voice's narrowest bandwidth
+ *       decides: 3968 samples for voices::generic() at 48 kHz, residual < 2^-21 of the state) and
+ *       renders its chunk: 4096 utterances x 2 s in 4.0 ms instead of 6.4 (scan kernel) / 8.2 (exact).
+ *       "time_split_chunks" (0 = auto, 2..64) and "time_split_span_samples" (0 = the batch's longest
+ *       utterance) pin the grid; "time_split_ff_cost_permille" (default 165) is the cost of a
+ *       fast-forwarded sample against a rendered one, which the spacing of the chunks balances.
  *   "sort_by_length": 1 (default) / 0 — batches uploaded afterwards whose utterances differ in
  *       length fill the launch slots in order of decreasing length (lanes of a wave run in lockstep:
  *       a wave lasts as long as its longest utterance).  Rows stay where the caller put them.
@@ -216,7 +238,8 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  * Read-only statistics: "slow_division_wave_steps", "fast_wave_tiles" (wave-tiles rendered in fast
  * arithmetic; scan kernel: 64-sample chain tiles on the closed forms kept from the tile before),
  * "general_wave_steps" (scan kernel: chain tiles whose closed forms were derived afresh),
- * "last_launch_formants" (4 or 8), "last_launch_lanes", "last_launch_pipelined". */
+ * "last_launch_formants" (4 or 8), "last_launch_lanes", "last_launch_pipelined",
+ * "last_launch_chunks" (time-split: chunks per utterance, else 0). */
 int grail_set_option(grail_ctx *ctx, const char *name, int64_t value);
 int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value);
 
