@@ -1383,7 +1383,10 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     f2 FTI = vsplat(0.0f, f2());   // position of the next sample pair inside the lane's sub-tile: (i, i + 1)
     int fast_have = -1;      // the flavour (1: shared smoothness, 0: per formant) of the run FS belongs to; -1: no run
     int fast_shift = 0;      // the lane's sub-tile length is 32 >> fast_shift, chosen when its run starts
-    bool fast_fresh = false; // FD already holds the slopes of the first sub-tile (made when the run started)
+    int fast_sub_left = 0;   // samples of the lane's current sub-tile still to render (0: the next pair begins a
+                             // sub-tile on the lane's grid of 32 >> fast_shift samples)
+    float fast_sub_len = 32.0f;   // length of the lane's current sub-tile (a run that starts between grid points
+                                  // begins with a shorter one, up to the next grid point)
     constexpr int FAST_TS0 = 32;
     static_assert(!FAST || T % FAST_TS0 == 0, "whole sub-tiles");
     // the smooth quantities `after` samples from now (the clock and the jitter phase extrapolated:
@@ -1457,9 +1460,14 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         }
         e.oml = SU ? (SLOPE ? (oml_here - FS.oml) * scale : oml_here) : 1.0f;
     };
-    // A run of calm tiles of this lane starts: the values now, the slopes over 32 samples, the error guard and
-    // with it the lane's sub-tile length.  false: its parameters move faster than TS = 2 can follow.
-    auto fast_begin_run = [&](auto su_tag) __attribute__((always_inline)) -> bool {
+    // A run of this lane starts at step t_at (even) of the tile: the values now, the slopes over 32 samples, the
+    // error guard and with it the lane's sub-tile length; the first sub-tile reaches to the next point of the
+    // lane's grid.  false: its parameters move faster than TS = 2 can follow.
+    // (The slopes aim at values extrapolated along the present segment pair and jitter period.  An event of the
+    // lane before the sub-tile's end — a segment advance, a noise wrap — ends the run there; up to that sample
+    // the extrapolated end is the smooth continuation the interpolation assumes.  Only the kink of
+    // alpha = min(clk / blend_length, 1) is different, and no sub-tile is begun across it: fast_kink_within.)
+    auto fast_begin_run = [&](auto su_tag, const int t_at) __attribute__((always_inline)) -> bool {
         constexpr bool SU = decltype(su_tag)::value;
         constexpr int TS0 = FAST_TS0;
         FastAux xs, xe;
@@ -1505,9 +1513,30 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         }
         if (level > 4) return false;
         fast_shift = level;
-        fast_fresh = level == 0;
+        const int tsl = TS0 >> level;
+        const int n = tsl - (t_at & (tsl - 1));
+        if (n != TS0) {                 // (1 / n by IEEE division: exactly 2^-k for the sub-tiles on the grid)
+            FastAux xn;
+            fast_endpoint(su_tag, std::true_type(), (float)(n + 1), 1.0f / (float)n, FD, xn);
+        }
+        fast_sub_left = n;
+        fast_sub_len = (float)n;
+        FTI.x = 0.0f; FTI.y = 1.0f;
         fast_have = SU ? 1 : 0;
         return true;
+    };
+    // no event of this lane within the next two samples (the margins of the calm tile, written for two steps;
+    // a lane that is calm for a whole tile is pair-calm at every pair of it)
+    auto fast_pair_calm = [&]() __attribute__((always_inline)) -> bool {
+        return !done & quiet_ok & (dt > 0.0f) & (clk > 6.0f * dt) & (jphase + 3.0f * jinc < 0.9995f) &
+               (room_end - n_out >= 2u) & (n_out <= room_end) &
+               (__builtin_fmaxf(X.frequency, Y.frequency) + __builtin_fabsf(d_freq) < 0.5f);
+    };
+    // does the kink of alpha = min(clk / blend_length, 1) lie among the next n samples?
+    auto fast_kink_within = [&](const float n) __attribute__((always_inline)) -> bool {
+        const float r_first = (clk - dt) * inv_blend_length;
+        const float r_last = (clk - (n + 1.0f) * dt) * inv_blend_length;
+        return (r_first > 1.0f) & (r_last < 1.0f);
     };
     // ---- the per-utterance chain of samples tc, tc+1: exact (see scalar_packed_steps).  Advances
     // clk, jphase and phase; returns the phases before the two samples and their pitch.
@@ -1553,22 +1582,22 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         phase = __builtin_amdgcn_fractf(ph1 + frequency.y);
         PH.x = ph0; PH.y = ph1;
     };
-    // the lane's next sub-tile: its slopes (made afresh unless the run has just started), position 0
-    auto fast_subtile_begin = [&](auto su_tag, const bool have_slopes) __attribute__((always_inline)) {
-        const float ts = (float)(FAST_TS0 >> fast_shift);
+    // the lane's next sub-tile, from a point of its grid: the slopes, position 0
+    auto fast_subtile_begin = [&](auto su_tag) __attribute__((always_inline)) {
+        const int tsl = FAST_TS0 >> fast_shift;
         const float inv_ts = __builtin_bit_cast(float, (uint32_t)(127 - 5 + fast_shift) << 23);   // 1 / TS
-        if (!have_slopes) {
-            FastAux xe;
-            fast_endpoint(su_tag, std::true_type(), ts + 1.0f, inv_ts, FD, xe);
-        }
-        fast_fresh = false;
+        FastAux xe;
+        fast_endpoint(su_tag, std::true_type(), (float)(tsl + 1), inv_ts, FD, xe);
+        fast_sub_left = tsl;
+        fast_sub_len = (float)tsl;
         FTI.x = 0.0f; FTI.y = 1.0f;
     };
     // the sub-tile's end is the next one's start: start + TS * slope (the end value the slopes were
     // made from, to within an ulp; every sub-tile's end is evaluated afresh, so nothing accumulates)
     auto fast_subtile_end = [&](auto su_tag) __attribute__((always_inline)) {
         constexpr bool SU = decltype(su_tag)::value;
-        const float fts = (float)(FAST_TS0 >> fast_shift);
+        const float fts = fast_sub_len;
+        fast_sub_left = 0;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             FS.a1[k] = vfma(FD.a1[k], vsplat(fts, V()), FS.a1[k]);
@@ -1673,11 +1702,10 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         const float nm1_of_lane = noise_of_lane - 1.0f;
 #pragma unroll 1
         for (int ts = 0; ts < T; ts += TS) {
-            const bool begins = (ts & my_mask) == 0;
-            if (__builtin_amdgcn_ballot_w64(begins & !fast_fresh) != 0) {
-                if (begins) fast_subtile_begin(su_tag, fast_fresh);
-            } else if (begins) {
-                fast_subtile_begin(su_tag, true);
+            // (a lane whose run started with this tile has its first sub-tile already)
+            const bool begins = ((ts & my_mask) == 0) & !((ts == 0) & (fast_sub_left != 0));
+            if (__builtin_amdgcn_ballot_w64(begins) != 0) {
+                if (begins) fast_subtile_begin(su_tag);
             }
 #pragma unroll 1
             for (int tc = ts; tc < ts + TS; tc += 2) {
@@ -1690,17 +1718,6 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             if (((ts + TS) & my_mask) == 0) fast_subtile_end(su_tag);
         }
     };
-    // The lane's share of step t of a mixed tile — its wave-mates may be in general steps, in the other
-    // flavour or on another sub-tile length: the same functions under the lane's own predicates.
-    auto fast_lane_step = [&](auto su_tag, const int t) __attribute__((always_inline)) {
-        if (t & 1) return;                                   // a pair covers t and t + 1
-        const int ts_mask = (FAST_TS0 >> fast_shift) - 1;
-        if ((t & ts_mask) == 0) fast_subtile_begin(su_tag, fast_fresh);
-        const float nz0 = lcg_f32(noise_seed), nz1 = lcg_f32(noise_seed);   // :528, the lane's own draws
-        fast_pair(su_tag, t, nz0, nz1, nz0 - 1.0f, nz1 - 1.0f);
-        if (((t + 2) & ts_mask) == 0) fast_subtile_end(su_tag);
-    };
-
     // ---- the staged tile's rows to memory: row `slot` holds samples [base_, base_ + T), mine_ of them valid
     // (the general flush; the main loop below has a shortcut for the usual full tile of the lane kernels)
     auto flush_rows = [&](const uint32_t base_, const uint32_t mine_) __attribute__((always_inline)) {
@@ -1787,24 +1804,31 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         {
             const float r_first = (clk - dt) * inv_blend_length;
             const float r_next = (clk - (float)(T + 1) * dt) * inv_blend_length;
-            calm = calm & !((r_first > 1.0f) & (r_next < 1.0f));
+            // (1.0001: whatever fast_kink_within finds later in the tile from the stepped clock, this test found too)
+            calm = calm & !((r_first > 1.0f) & (r_next < 1.0001f));
             calm = calm & (__builtin_fmaxf(X.frequency, Y.frequency) + __builtin_fabsf(d_freq) < 0.5f);
         }
         // shared smoothness: all formants of the utterance, whichever of its L lanes holds them
-        int flavour = smooth_uniform ? 1 : 0;
-        if constexpr (L > 1) {
-            const uint64_t su_mask = __builtin_amdgcn_ballot_w64(smooth_uniform);
-            flavour = ((su_mask >> (lane & ~(L - 1))) & ((1ull << L) - 1ull)) == ((1ull << L) - 1ull) ? 1 : 0;
-        }
+        auto flavour_now = [&]() __attribute__((always_inline)) -> int {
+            if constexpr (L > 1) {
+                const uint64_t su_mask = __builtin_amdgcn_ballot_w64(smooth_uniform);
+                return ((su_mask >> (lane & ~(L - 1))) & ((1ull << L) - 1ull)) == ((1ull << L) - 1ull) ? 1 : 0;
+            } else {
+                return smooth_uniform ? 1 : 0;
+            }
+        };
+        int flavour = flavour_now();
         bool lane_fast = calm;
-        const bool starts = calm && fast_have != flavour;          // a run of calm tiles of this lane starts here
+        int fast_block = 0;      // a run that could not start (parameters too fast for the guard) is not tried again
+                                 // before this step of the tile
+        const bool starts = calm && fast_have != flavour;          // a run of this lane starts with the tile
         if (__builtin_amdgcn_ballot_w64(starts) != 0) {
             if (starts) {
-                const bool ok = flavour ? fast_begin_run(std::true_type()) : fast_begin_run(std::false_type());
+                const bool ok = flavour ? fast_begin_run(std::true_type(), 0) : fast_begin_run(std::false_type(), 0);
                 lane_fast = ok;
+                if (!ok) { fast_have = -1; fast_block = FAST_TS0; }
             }
         }
-        if (!lane_fast) fast_have = -1;                            // general steps end the lane's run
         // the tight loops: every rendering lane fast, one flavour, one sub-tile length, one carrier-noise state
         const uint64_t rendering = __builtin_amdgcn_ballot_w64(!idle);
         bool uniform = false;
@@ -1832,20 +1856,57 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             noise_seed = (uint32_t)__builtin_amdgcn_readlane((int)sk, T - 1);
             return;
         }
-        // the mixed tile: per step, a fast lane runs its share of fast_tile_uniform's work, any other lane the
-        // general step (the reference's control flow; tolerance-mode formants while its pair is inside the
-        // safe window)
-        general_steps += (uint32_t)T;
+        // The mixed tile, pair by pair.  A lane in a run renders the pair with fast_pair as long as no event of
+        // its own is due within the pair; where one is, it takes general steps (the reference's control flow;
+        // tolerance-mode formants while its segment pair is inside the safe window) until the event has passed,
+        // and begins a new run at the next pair — its first sub-tile reaching to the next point of its grid.
+        // The wave pays for a general step only while some lane is that close to an event of its own.  All of
+        // it is decided from the lane's own state: a lane that is calm for the whole tile does here exactly what
+        // it does in the tight loops.
 #pragma unroll 1
-        for (int t = 0; t < T; ++t) {
-            if (lane_fast) {
-                if (flavour) fast_lane_step(std::true_type(), t);
-                else fast_lane_step(std::false_type(), t);
-            } else {
-                general_step(t, std::false_type());
+        for (int t = 0; t < T; t += 2) {
+            flavour = flavour_now();                                // (a segment advance may have changed it)
+            const bool pc = fast_pair_calm();
+            bool run = pc & (fast_have == flavour);
+            // a run at a point of its grid: the next sub-tile — unless the kink of alpha lies inside it
+            const bool at_grid = run & (fast_sub_left == 0);
+            if (__builtin_amdgcn_ballot_w64(at_grid) != 0) {
+                if (at_grid) {
+                    if (fast_kink_within((float)(FAST_TS0 >> fast_shift))) run = false;
+                    else if (flavour) fast_subtile_begin(std::true_type());
+                    else fast_subtile_begin(std::false_type());
+                }
+            }
+            // a lane without a run begins one where it can
+            const bool start = pc & !run & (t >= fast_block) & !fast_kink_within((float)(FAST_TS0 - (t & (FAST_TS0 - 1))));
+            if (__builtin_amdgcn_ballot_w64(start) != 0) {
+                if (start) {
+                    run = flavour ? fast_begin_run(std::true_type(), t) : fast_begin_run(std::false_type(), t);
+                    if (!run) fast_block = (t | (FAST_TS0 - 1)) + 1;
+                }
+            }
+            if (!run) fast_have = -1;
+            if (__builtin_amdgcn_ballot_w64(run) != 0) {
+                if (run) {
+                    const float nz0 = lcg_f32(noise_seed), nz1 = lcg_f32(noise_seed);   // :528, the lane's own draws
+                    if (flavour) fast_pair(std::true_type(), t, nz0, nz1, nz0 - 1.0f, nz1 - 1.0f);
+                    else fast_pair(std::false_type(), t, nz0, nz1, nz0 - 1.0f, nz1 - 1.0f);
+                    fast_sub_left -= 2;
+                    if (fast_sub_left == 0) {
+                        if (flavour) fast_subtile_end(std::true_type());
+                        else fast_subtile_end(std::false_type());
+                    }
+                    n_out += 2u;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(!run & !done) != 0) {
+                general_steps += 2u;
+                if (!run) {
+                    general_step(t, std::false_type());
+                    general_step(t + 1, std::false_type());
+                }
             }
         }
-        n_out += lane_fast ? (uint32_t)T : 0u;
     };
 
     // ---- SPLIT: fast-forward the exact per-utterance chain to where this chunk's filters start

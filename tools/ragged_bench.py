@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Kernel time on a RAGGED corpus: per-segment lengths drawn from [0.3, 0.7] s and (optionally)
 per-voice jitter rates that differ, so segment boundaries and jitter wraps of the 64 utterances of
-a wave do not coincide (the bench corpus has them all aligned).  usage: ragged_bench.py [n_utt]"""
+a wave do not coincide (the bench corpus has them all aligned).
+usage: ragged_bench.py [n_utt [sort_by_length [arithmetic]]]"""
 import os
 import sys
 
@@ -13,9 +14,11 @@ from grail_hip import workload as W
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 sort = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+fast = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 ctx = G.Context(0)
 ctx.set_option("sort_by_length", sort)
-print(f"n = {n} utterances, sort_by_length = {sort}", flush=True)
+ctx.set_option("arithmetic", fast)
+print(f"n = {n} utterances, sort_by_length = {sort}, arithmetic = {'fast' if fast else 'exact'}", flush=True)
 rng = np.random.default_rng(1)
 for label, ragged_len, ragged_jit, n_voices in (("aligned 1 voice", False, False, 1),
                                                  ("ragged lengths, 1 voice", True, False, 1),
