@@ -1466,8 +1466,8 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     // (The slopes aim at values extrapolated along the present segment pair and jitter period.  An event of the
     // lane before the sub-tile's end — a segment advance, a noise wrap — ends the run there; up to that sample
     // the extrapolated end is the smooth continuation the interpolation assumes.  Only the kink of
-    // alpha = min(clk / blend_length, 1) is different, and no sub-tile is begun across it: fast_kink_within.)
-    auto fast_begin_run = [&](auto su_tag, const int t_at) __attribute__((always_inline)) -> bool {
+    // alpha = min(clk / blend_length, 1) is different, and no sub-tile reaches across it: fast_flat_left.)
+    auto fast_begin_run = [&](auto su_tag, const int t_at, const int n_cap) __attribute__((always_inline)) -> bool {
         constexpr bool SU = decltype(su_tag)::value;
         constexpr int TS0 = FAST_TS0;
         FastAux xs, xe;
@@ -1514,7 +1514,8 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         if (level > 4) return false;
         fast_shift = level;
         const int tsl = TS0 >> level;
-        const int n = tsl - (t_at & (tsl - 1));
+        const int n_grid = tsl - (t_at & (tsl - 1));
+        const int n = n_grid < n_cap ? n_grid : n_cap;       // (n_cap: the flat stretch before the kink of alpha)
         if (n != TS0) {                 // (1 / n by IEEE division: exactly 2^-k for the sub-tiles on the grid)
             FastAux xn;
             fast_endpoint(su_tag, std::true_type(), (float)(n + 1), 1.0f / (float)n, FD, xn);
@@ -1525,18 +1526,26 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         fast_have = SU ? 1 : 0;
         return true;
     };
-    // no event of this lane within the next two samples (the margins of the calm tile, written for two steps;
-    // a lane that is calm for a whole tile is pair-calm at every pair of it)
+    // no event of this lane within the next two samples.  clk >= m dt implies RN(clk - dt) >= (m - 1.01) dt, so
+    // clk > 2.5 dt leaves the clock positive after two steps; the noise phase wraps on phase > 1 (:245), and
+    // phase + 2.01 inc < 1 keeps it below after two steps.  A lane that is calm for a whole tile (clk > (T + 8) dt,
+    // phase + (T + 1) inc < 0.999 at its start) satisfies both at every pair of it.
     auto fast_pair_calm = [&]() __attribute__((always_inline)) -> bool {
-        return !done & quiet_ok & (dt > 0.0f) & (clk > 6.0f * dt) & (jphase + 3.0f * jinc < 0.9995f) &
+        return !done & quiet_ok & (dt > 0.0f) & (clk > 2.5f * dt) & (jphase + 2.01f * jinc < 1.0f) &
                (room_end - n_out >= 2u) & (n_out <= room_end) &
                (__builtin_fmaxf(X.frequency, Y.frequency) + __builtin_fabsf(d_freq) < 0.5f);
     };
-    // does the kink of alpha = min(clk / blend_length, 1) lie among the next n samples?
-    auto fast_kink_within = [&](const float n) __attribute__((always_inline)) -> bool {
-        const float r_first = (clk - dt) * inv_blend_length;
-        const float r_last = (clk - (n + 1.0f) * dt) * inv_blend_length;
-        return (r_first > 1.0f) & (r_last < 1.0f);
+    // The kink of alpha = min(clk / blend_length, 1): while the quotient is above one the blended parameters
+    // stand still, below it they move linearly, and no sub-tile may reach across.  How many of the next samples
+    // are certainly still on the flat side (even, two samples of margin; "no limit" when the lane is already on
+    // the slope or its pair is silent on both sides)?  A sub-tile begun on the flat side ends there; the lane
+    // then takes general steps through the kink and begins a new run on the slope.
+    auto fast_flat_left = [&]() __attribute__((always_inline)) -> int {
+        const float c1 = clk - dt;
+        const bool flat = !silent_pair & (c1 * inv_blend_length > 1.0f);
+        const float n = (c1 - blend_length) * __builtin_amdgcn_rcpf(dt) - 2.0f;
+        const int ni = n < 0.0f ? 0 : (n > 1.0e6f ? 1000000 : (int)n);
+        return flat ? (ni & ~1) : 1000000;
     };
     // ---- the per-utterance chain of samples tc, tc+1: exact (see scalar_packed_steps).  Advances
     // clk, jphase and phase; returns the phases before the two samples and their pitch.
@@ -1590,6 +1599,17 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         fast_endpoint(su_tag, std::true_type(), (float)(tsl + 1), inv_ts, FD, xe);
         fast_sub_left = tsl;
         fast_sub_len = (float)tsl;
+        FTI.x = 0.0f; FTI.y = 1.0f;
+    };
+    // ... from step t_at of the tile (anywhere) to the next point of its grid, n_cap samples at most
+    auto fast_subtile_begin_at = [&](auto su_tag, const int t_at, const int n_cap) __attribute__((always_inline)) {
+        const int tsl = FAST_TS0 >> fast_shift;
+        const int n_grid = tsl - (t_at & (tsl - 1));
+        const int n = n_grid < n_cap ? n_grid : n_cap;
+        FastAux xe;
+        fast_endpoint(su_tag, std::true_type(), (float)(n + 1), 1.0f / (float)n, FD, xe);
+        fast_sub_left = n;
+        fast_sub_len = (float)n;
         FTI.x = 0.0f; FTI.y = 1.0f;
     };
     // the sub-tile's end is the next one's start: start + TS * slope (the end value the slopes were
@@ -1803,8 +1823,8 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     (jphase + (float)(T + 1) * jinc < 0.999f) & (room_end - n_out >= (uint32_t)T) & (n_out <= room_end);
         {
             const float r_first = (clk - dt) * inv_blend_length;
-            const float r_next = (clk - (float)(T + 1) * dt) * inv_blend_length;
-            // (1.0001: whatever fast_kink_within finds later in the tile from the stepped clock, this test found too)
+            const float r_next = (clk - (float)(T + 5) * dt) * inv_blend_length;
+            // (T + 5, 1.0001: fast_flat_left, asked anywhere in such a tile from the stepped clock, reaches beyond its end)
             calm = calm & !((r_first > 1.0f) & (r_next < 1.0001f));
             calm = calm & (__builtin_fmaxf(X.frequency, Y.frequency) + __builtin_fabsf(d_freq) < 0.5f);
         }
@@ -1824,7 +1844,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         const bool starts = calm && fast_have != flavour;          // a run of this lane starts with the tile
         if (__builtin_amdgcn_ballot_w64(starts) != 0) {
             if (starts) {
-                const bool ok = flavour ? fast_begin_run(std::true_type(), 0) : fast_begin_run(std::false_type(), 0);
+                const bool ok = flavour ? fast_begin_run(std::true_type(), 0, FAST_TS0) : fast_begin_run(std::false_type(), 0, FAST_TS0);
                 lane_fast = ok;
                 if (!ok) { fast_have = -1; fast_block = FAST_TS0; }
             }
@@ -1863,25 +1883,49 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         // The wave pays for a general step only while some lane is that close to an event of its own.  All of
         // it is decided from the lane's own state: a lane that is calm for the whole tile does here exactly what
         // it does in the tight loops.
+        // The usual pairs even of a mixed tile — every rendering lane inside a sub-tile of its run, events being
+        // rare per pair — go through a tight inner loop of their own (one straight body without lane predicates,
+        // idle lanes riding along; a loop, so that the rarely used code around it does not take its registers).
+        auto plain_pairs = [&](auto su_tag, int &t) __attribute__((always_inline)) {
+            constexpr int FL = decltype(su_tag)::value ? 1 : 0;
+#pragma unroll 1
+            for (; t < T; t += 2) {
+                const bool plain = fast_pair_calm() && fast_have == FL && fast_sub_left != 0 && flavour_now() == FL;
+                if (__builtin_amdgcn_ballot_w64(!idle & !plain) != 0) break;
+                const float nz0 = lcg_f32(noise_seed), nz1 = lcg_f32(noise_seed);   // :528, the lane's own draws
+                fast_pair(su_tag, t, nz0, nz1, nz0 - 1.0f, nz1 - 1.0f);
+                fast_sub_left -= 2;
+                n_out += idle ? 0u : 2u;
+                if (__builtin_amdgcn_ballot_w64(!idle & (fast_sub_left == 0)) != 0) {
+                    if (fast_sub_left == 0) fast_subtile_end(su_tag);
+                }
+            }
+        };
 #pragma unroll 1
         for (int t = 0; t < T; t += 2) {
+            if (__builtin_amdgcn_ballot_w64(!idle) != 0) {
+                plain_pairs(std::true_type(), t);
+                plain_pairs(std::false_type(), t);
+                if (t >= T) break;
+            }
             flavour = flavour_now();                                // (a segment advance may have changed it)
             const bool pc = fast_pair_calm();
             bool run = pc & (fast_have == flavour);
-            // a run at a point of its grid: the next sub-tile — unless the kink of alpha lies inside it
-            const bool at_grid = run & (fast_sub_left == 0);
-            if (__builtin_amdgcn_ballot_w64(at_grid) != 0) {
-                if (at_grid) {
-                    if (fast_kink_within((float)(FAST_TS0 >> fast_shift))) run = false;
-                    else if (flavour) fast_subtile_begin(std::true_type());
-                    else fast_subtile_begin(std::false_type());
+            // a run between sub-tiles: the next one, to the next point of its grid or to the kink of alpha
+            const int flat_left = fast_flat_left();
+            const bool next_sub = run & (fast_sub_left == 0);
+            if (__builtin_amdgcn_ballot_w64(next_sub) != 0) {
+                if (next_sub) {
+                    if (flat_left < 2) run = false;                 // the kink is due: general steps through it
+                    else if (flavour) fast_subtile_begin_at(std::true_type(), t, flat_left);
+                    else fast_subtile_begin_at(std::false_type(), t, flat_left);
                 }
             }
             // a lane without a run begins one where it can
-            const bool start = pc & !run & (t >= fast_block) & !fast_kink_within((float)(FAST_TS0 - (t & (FAST_TS0 - 1))));
+            const bool start = pc & !run & (t >= fast_block) & (flat_left >= 2);
             if (__builtin_amdgcn_ballot_w64(start) != 0) {
                 if (start) {
-                    run = flavour ? fast_begin_run(std::true_type(), t) : fast_begin_run(std::false_type(), t);
+                    run = flavour ? fast_begin_run(std::true_type(), t, flat_left) : fast_begin_run(std::false_type(), t, flat_left);
                     if (!run) fast_block = (t | (FAST_TS0 - 1)) + 1;
                 }
             }

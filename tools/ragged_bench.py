@@ -39,14 +39,17 @@ for label, ragged_len, ragged_jit, n_voices in (("aligned 1 voice", False, False
     d_len = ctx.device_alloc(n * 4)
     ms = []
     for _ in range(3):
+        t0, g0 = ctx.get_option("fast_wave_tiles"), ctx.get_option("general_wave_steps")
         batch.synthesize_async(d_out, stride, d_len)
         ctx.sync()
         ms.append(ctx.last_kernel_ms())
+        stats = (ctx.get_option("fast_wave_tiles") - t0, ctx.get_option("general_wave_steps") - g0)
     lens = np.zeros(n, dtype=np.uint32)
     ctx.d2h(lens, d_len, lens.nbytes)
     total = int(lens.astype(np.uint64).sum())
     print(f"{label:45s} kernel {min(ms):7.2f} ms  {total / (min(ms) * 1e-3):.3e} samples/s  "
-          f"(max row {int(lens.max())} samples, mean {total / n:.0f})  {ctx.last_kernel_name()}", flush=True)
+          f"(max row {int(lens.max())} samples, mean {total / n:.0f})  {ctx.last_kernel_name()}"
+          + (f"  [per wave: {stats[0] * 64 / n:.0f} tight tiles, {stats[1] * 64 / n:.0f} general steps]" if fast else ""), flush=True)
     ctx.device_free(d_out)
     ctx.device_free(d_len)
     batch.free()
