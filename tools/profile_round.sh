@@ -2,7 +2,7 @@
 # The round's evidence, collected on the GPU box: bench lines, rocprofv3 kernel stats of the default
 # bench command, PMC counters for every reported workload (tools/collect_counters.py), tool outputs.
 # usage (through gpurun): tools/profile_round.sh <tag>     -> gpurun_out/<tag>/
-tag=${1:-r02}
+tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/$tag; mkdir -p $out
 python3 tools/collect_counters.py $out/traffic.json > $out/collect_counters.log 2>&1
@@ -22,8 +22,15 @@ cp gpurun_out/prof/stats2/*/*kernel_stats.csv $out/kernel_stats_config2.csv
 python3 tools/small_batch_bench.py > $out/small_batch.txt 2>&1
 python3 tools/stream_latency.py 2>/dev/null | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" > $out/stream_latency.txt
 python3 tools/host_output_bench.py > $out/host_output.txt 2>&1
-python3 tools/ragged_bench.py > $out/ragged.txt 2>&1
-./tools/dpp_check.bin > $out/dpp_check.txt 2>&1
-python3 tools/scan_split_crossover.py > $out/scan_split.txt 2>&1
-./tools/phase_chain_mb.bin > $out/phase_chain.txt 2>&1
+python3 tools/ragged_bench.py 65536 1 0 > $out/ragged.txt 2>&1
+python3 tools/ragged_bench.py 65536 1 1 > $out/ragged_fast.txt 2>&1
+python3 tools/ragged_bench.py 131072 1 0 > $out/ragged_131072.txt 2>&1
+# SQ counters of the final exact headline and config-4 kernels and of the fast headline kernel
+( for cfg in "--config 3" "--config 4" "--config 3 --mode fast"; do
+    bash tools/pmc.sh sq1 "$cfg --steps 1 --warmup 0 --fast-leg 0 --ramp 0" SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY
+    bash tools/pmc.sh sq2 "$cfg --steps 1 --warmup 0 --fast-leg 0 --ramp 0" SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INST_CYCLES_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS
+  done ) > $out/pmc_sq.txt 2>&1
+python3 tools/fast_soak.py > $out/fast_soak.txt 2>&1
+# every utterance of full-size batches against the oracle (exact mode), one size per kernel family
+( for n in 65536 16384 4096; do GRAIL_SOAK=1 GRAIL_SOAK_UTTS=$n python3 -m pytest tests/test_full_parity_soak_gpu.py -m gpu -q -s 2>&1 | grep -E "full parity|passed|failed"; done ) > $out/full_parity.txt 2>&1
 ls -la $out
