@@ -220,7 +220,7 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       its own: lowest time per batch), above it two (more utterances resident per CU: highest
  *       throughput).  Same results either way.
  *   "time_split": 1 (default) / 0 — fast arithmetic only: batches of "time_split_min_utterances"
- *       (default 1025) to 32768 utterances of voices whose filters forget their past within 16384
+ *       (default 2305; 4/7 of that with eight live formants) to 32768 utterances of voices whose filters forget their past within 16384
  *       samples cut every utterance's time axis into chunks with a wavefront lane each, as many as
  *       fill the machine.  A chunk's lane fast-forwards the exact per-utterance state to its chunk,
  *       starts the filters from zero a warm-up length earlier (the voice's narrowest bandwidth
