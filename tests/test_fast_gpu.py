@@ -134,7 +134,7 @@ def test_fast_mode_fuzz_on_random_voice_tables(gpu_ctx):
                 e = G.elem_new_phoneme(centres[_] * rng.uniform(0.65, 1.35, 8), rng.uniform(30, 600, 8),
                                        rng.uniform(200, 4000, 8), rng.uniform(0, 1, 8), rng.uniform(0, 1, 8),
                                        rng.uniform(0.0, 1, 8) * (rng.uniform(0, 1, 8) > 0.3) + 1e-3)
-                v.phonemes[p] = G.elem_resample(e, 1.0, 48000.0)
+                v.phonemes[p] = G.elem_resample(e, 44100.0, 48000.0)
             voices.append(v)
         gpu_ctx.set_voices(voices)
         n_utt = 40
@@ -456,6 +456,54 @@ def test_time_split_within_tolerance_of_the_oracle(gpu_ctx, n_voices, chunks):
     k = _worst(out, ref, ref_len)
     print(f"time split, {chunks} chunks, voices={n_voices}: max |d| = {k:.1f} * 2^-23")
     assert 0.0 < k * ULP <= TOL
+
+
+def test_time_split_fuzz_on_random_voice_tables(gpu_ctx):
+    """Random voice tables (formants anywhere in (150 Hz, 0.35 fs), bandwidths 30 - 600 Hz — i.e. warm-up lengths
+    from a few hundred to ~8 000 samples, different for every voice of the table, so the lanes of a wave reset
+    their filters at different tiles), random segment lists, random chunk grids: lengths are the oracle's and the
+    tolerance holds at every seam (relative to max(1, peak))."""
+    rng = np.random.default_rng(31337)
+    worst = 0.0
+    try:
+        for trial in range(5):
+            voices = []
+            for _ in range(3):
+                centre = np.exp(rng.uniform(np.log(150.0), np.log(12000.0), 8))
+                v = G.voice_generic(48000.0)
+                for p in range(2):
+                    e = G.elem_new_phoneme(centre * rng.uniform(0.65, 1.35, 8), rng.uniform(30, 600, 8),
+                                           rng.uniform(200, 4000, 8), rng.uniform(0, 1, 8), rng.uniform(0, 1, 8),
+                                           rng.uniform(0.0, 1, 8) * (rng.uniform(0, 1, 8) > 0.3) + 1e-3)
+                    v.phonemes[p] = G.elem_resample(e, 44100.0, 48000.0)
+                voices.append(v)
+            gpu_ctx.set_voices(voices)
+            n_utt = 70
+            utts = []
+            for u in range(n_utt):
+                n = int(rng.integers(1, 6))
+                utts.append([(int(rng.choice([G.PH_A, G.PH_E, G.PH_SILENCE])), float(rng.uniform(0.05, 0.3)),
+                              float(rng.choice([0.0625, 0.125, 0.25, 0.5, 0.3, 0.07])),
+                              float(rng.uniform(80, 400) / 48000.0)) for _ in range(n)])
+            segs = G.segments([s for u in utts for s in u])
+            offs = np.cumsum([0] + [len(u) for u in utts]).astype(np.uint32)
+            vids = rng.integers(0, 3, n_utt).astype(np.uint32)
+            seeds = rng.integers(0, 2 ** 32, n_utt, dtype=np.uint64).astype(np.uint32)
+            stride = 81920
+            ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, stride)
+            scale = max(1.0, float(np.max(np.abs(ref))))
+            for chunks, span in ((2, 0), (3, int(rng.integers(20000, 70000))), (6, 0)):
+                _split(gpu_ctx, chunks, span)
+                out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
+                assert "SPLIT" in gpu_ctx.last_kernel_name(), gpu_ctx.last_kernel_name()
+                assert np.array_equal(out_len, ref_len), (trial, chunks)
+                k = _worst(out, ref, ref_len) / scale
+                worst = max(worst, k)
+                assert k * ULP <= TOL, (trial, chunks, span, k)
+        print(f"time-split fuzz: worst {worst:.1f} * 2^-23 (relative to max(1, peak))")
+    finally:
+        _split(gpu_ctx, 0)
+        gpu_ctx.set_voices(W.single_voice())
 
 
 def test_time_split_ragged_lengths_short_and_empty_utterances(gpu_ctx):
