@@ -258,6 +258,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per utterance (0 = auto)")
     ap.add_argument("--pipeline", type=int, default=1, choices=[0, 1],
                     help="0 disables the small-batch producer/consumer kernels (A/B)")
+    ap.add_argument("--round32", type=int, default=-1, choices=[-1, 0, 1], help="pipelined workgroups: rounds of 32 samples (A/B)")
     ap.add_argument("--pcm16", action="store_true",
                     help="i16 PCM rows (the WAV sink's conversion fused into the store), not the "
                          "headline: 2.01 algorithmic bytes per sample")
@@ -436,6 +437,8 @@ def main():
     batch = ctx.upload(segs, offs, vids, seeds)
     ctx.set_option("lanes_per_utterance", args.lanes)
     ctx.set_option("small_batch_pipeline", args.pipeline)
+    if args.round32 >= 0:
+        ctx.set_option("pipeline_round32", args.round32)
     ctx.set_option("arithmetic", 1 if args.mode == "fast" else 0)
     d_out = ctx.device_alloc(n_utt * stride * (2 if args.pcm16 else 4))
     d_len = ctx.device_alloc(n_utt * 4)

@@ -147,6 +147,7 @@ struct grail_ctx {
     int lanes_option = 0;             // 0 = auto
     int skip_silent_option = 1;       // skip band-pass filters of provably silent formants
     int pipeline_option = 1;          // small qualifying batches: producer/consumer workgroups
+    int pipe_round32 = 1;             // ... with rounds of 32 samples while one workgroup per CU suffices (8.20 -> 7.86 ms for config 2)
     uint64_t voices_epoch = 0;        // bumped by every install_voices
     int fast_option = 0;              // "arithmetic": 0 exact (bit-identical), 1 fast (stated tolerance)
     std::string last_kernel = "none"; // instantiation of the last synthesis launch
@@ -639,6 +640,10 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         ctx->pipe8_max_groups = value;
         return GRAIL_OK;
     }
+    if (std::strcmp(name, "pipeline_round32") == 0) {       // tuning (A/B)
+        ctx->pipe_round32 = value ? 1 : 0;
+        return GRAIL_OK;
+    }
 #ifdef GRAIL_SCAN_DEBUG
     if (std::strcmp(name, "scan_debug") == 0) {       // development builds only (-DGRAIL_SCAN_DEBUG): see scan_kernels.hip
         ctx->scan_debug = (int)value;
@@ -953,11 +958,14 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
                             ((uint64_t)count + 15) / 16 <= (uint64_t)ctx->pipe4_max_groups;
     const bool want_pipe8 = !batch_live4(ctx, batch) && !ctx->lanes_option && ctx->pipeline_option && !batch->any_blend &&
                             ((uint64_t)count + 7) / 8 <= (uint64_t)ctx->pipe8_max_groups;
+    // one workgroup per CU suffices: rounds of 32 samples instead of 16 (pipe = 2)
+    const uint32_t pipe4_kind = ctx->pipe_round32 && ((uint64_t)count + 15) / 16 <= 256 ? 2u : 1u;
+    const uint32_t pipe8_kind = ctx->pipe_round32 && ((uint64_t)count + 7) / 8 <= 256 ? 2u : 1u;
     if (want_pipe4 && !a.fast) {
-        a.pipe = 1u;
+        a.pipe = pipe4_kind;
         L = 4;
     } else if (want_pipe8 && !a.fast) {
-        a.pipe = 1u;                                      // eight formants: 8 utterances per workgroup
+        a.pipe = pipe8_kind;                              // eight formants: 8 utterances per workgroup
         L = 8;
     }
     // eight lanes per utterance need eight formants to lay out; for batches that small the
@@ -1011,7 +1019,7 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     if (a.fast && !scan && !split_k && (want_pipe4 || want_pipe8)) {
         a.fast = 0u;
         a.live4 = batch_live4(ctx, batch) ? 1u : 0u;
-        a.pipe = 1u;
+        a.pipe = want_pipe4 ? pipe4_kind : pipe8_kind;
         L = want_pipe4 ? 4 : 8;
     }
     if (split_k) {

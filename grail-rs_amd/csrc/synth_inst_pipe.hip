@@ -7,11 +7,14 @@ namespace grail {
 void launch_pipe4(const SynthArgs &args, hipStream_t stream)
 {
     const dim3 grid((args.n_utt + 15) / 16), block(256);
-    start<4, 64, 4, 1, false, false, false, 4, true, false, 4>(args, grid, block, stream);
+    // args.pipe == 2: rounds of 32 samples (131 KB of LDS: one workgroup per CU, half as many barriers)
+    if (args.pipe == 2) start<4, 64, 4, 1, false, false, false, 4, true, false, 8>(args, grid, block, stream);
+    else start<4, 64, 4, 1, false, false, false, 4, true, false, 4>(args, grid, block, stream);
 }
 void launch_pipe8(const SynthArgs &args, hipStream_t stream)
 {
     const dim3 grid((args.n_utt + 7) / 8), block(256);
-    start<8, 64, 4, 1, false, false, false, NF, true, false, 4>(args, grid, block, stream);
+    if (args.pipe == 2) start<8, 64, 4, 1, false, false, false, NF, true, false, 8>(args, grid, block, stream);
+    else start<8, 64, 4, 1, false, false, false, NF, true, false, 4>(args, grid, block, stream);
 }
 }  // namespace grail

@@ -2085,6 +2085,11 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                         // coefficients (one pair each), wave 0 renders round p; one barrier per phase.
                         constexpr int SPR = 4 * QP;              // samples per round
                         constexpr int ROUNDS = T / SPR;
+                        // who turns the round's 2 QP pairs into coefficients: the two coefficient waves take three
+                        // eighths each, the chain wave — the lightest stage since the quad shares the chain — a quarter
+                        constexpr int CHAIN_PAIRS = QP >= 4 ? QP / 2 : 0;
+                        constexpr int PAIRS_PER_COEF_WAVE = QP >= 4 ? (2 * QP - CHAIN_PAIRS) / 2 : QP;
+                        static_assert(QP < 4 || 2 * PAIRS_PER_COEF_WAVE + CHAIN_PAIRS == 2 * QP, "every pair has a wave");
                         static_assert(T % SPR == 0, "whole rounds");
                         // Consecutive calm tiles (pipe_tiles of them) go through without draining the pipeline:
                         // when the rendering wave has parked a tile all four waves flush it, then carry on.
@@ -2106,19 +2111,20 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 #pragma unroll
                                     for (int g = 0; g < QP / 2; ++g) pipe_chain(chain_all[m & 1][g], noise_chain, SPR * ml + 8 * g);
                                 }
-                                if constexpr (QP == 4) {             // and the last two pairs of the round before
+                                if constexpr (CHAIN_PAIRS > 0) {     // and the last pairs of the round before
                                     const int mc = ph_ + 1;
                                     if (mc >= 0 && mc < all_rounds) {
-                                        pipe_coeffs(chain_all[mc & 1][1], 2, ring_all[mc & 1][6]);
-                                        pipe_coeffs(chain_all[mc & 1][1], 3, ring_all[mc & 1][7]);
+#pragma unroll
+                                        for (int pair = 2 * QP - CHAIN_PAIRS; pair < 2 * QP; ++pair)
+                                            pipe_coeffs(chain_all[mc & 1][pair / 4], pair % 4, ring_all[mc & 1][pair]);
                                     }
                                 }
                             } else if (role >= 2) {
                                 const int m = ph_ + 1;
                                 if (m >= 0 && m < all_rounds) {
 #pragma unroll
-                                    for (int q = 0; q < (QP == 4 ? 3 : QP); ++q) {
-                                        const int pair = QP == 4 ? 3 * (role - 2) + q : 2 * q + (role - 2);
+                                    for (int q = 0; q < PAIRS_PER_COEF_WAVE; ++q) {
+                                        const int pair = QP >= 4 ? PAIRS_PER_COEF_WAVE * (role - 2) + q : 2 * q + (role - 2);
                                         pipe_coeffs(chain_all[m & 1][pair / 4], pair % 4, ring_all[m & 1][pair]);
                                     }
                                 }
@@ -2307,7 +2313,7 @@ void start(const SynthArgs &args, dim3 grid, dim3 block, hipStream_t stream)
 {
     std::snprintf(g_kernel_name, sizeof g_kernel_name, "synth_kernel<L=%d,T=%d,W=%d,%d,%s%s%sNFA=%d%s%s%s%s>", L, T, WAVES,
                   MINW, STREAM ? "STREAM," : "", HALF ? "HALF," : "", ANYBL ? "ANYBL," : "", NFA,
-                  PIPE ? ",PIPE" : "", FAST ? ",FAST" : "", PQP == 4 ? ",R16" : "", SPLIT ? ",SPLIT" : "");
+                  PIPE ? ",PIPE" : "", FAST ? ",FAST" : "", PQP == 4 ? ",R16" : PQP == 8 ? ",R32" : "", SPLIT ? ",SPLIT" : "");
     hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, STREAM, HALF, ANYBL, NFA, PIPE, FAST, PQP, SPLIT>), grid, block, 0,
                        stream, args);
 }

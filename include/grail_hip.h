@@ -232,6 +232,8 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *   "sort_by_length": 1 (default) / 0 — batches uploaded afterwards whose utterances differ in
  *       length fill the launch slots in order of decreasing length (lanes of a wave run in lockstep:
  *       a wave lasts as long as its longest utterance).  Rows stay where the caller put them.
+ *   "pipeline_round32": 1 (default) / 0 — the pipelined workgroups hand their work on in rounds of 32 samples
+ *       instead of 16 (131 KB of LDS) while one workgroup per CU suffices (up to 256 workgroups).
  *   "pipeline4_max_groups" (default 512), "pipeline8_max_groups" (default 512): exact arithmetic, how many
  *       four-wave pipelined workgroups (16 / 8 utterances each, four / eight live formants) a batch may
  *       need to still take them: two per CU.
