@@ -2086,9 +2086,11 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                         // coefficients (one pair each), wave 0 renders round p; one barrier per phase.
                         constexpr int SPR = 4 * QP;              // samples per round
                         constexpr int ROUNDS = T / SPR;
-                        // who turns the round's 2 QP pairs into coefficients: the two coefficient waves take three
-                        // eighths each, the chain wave — the lightest stage since the quad shares the chain — a quarter
-                        constexpr int CHAIN_PAIRS = QP >= 4 ? QP / 2 : 0;
+                        // who turns the round's 2 QP pairs into coefficients: the two coefficient waves and, for a few
+                        // pairs, the chain wave, so that the three stages take about the same time
+                        // (rounds of 32 samples, 16 pairs: with 4 pairs the chain wave was the slowest stage — 7.39 ms for
+                        // config 2 against 6.51 with 2 and 7.26 with none; profiles/r03_pipe_waves.txt)
+                        constexpr int CHAIN_PAIRS = QP == 8 ? 2 : QP >= 4 ? QP / 2 : 0;
                         constexpr int PAIRS_PER_COEF_WAVE = QP >= 4 ? (2 * QP - CHAIN_PAIRS) / 2 : QP;
                         static_assert(QP < 4 || 2 * PAIRS_PER_COEF_WAVE + CHAIN_PAIRS == 2 * QP, "every pair has a wave");
                         static_assert(T % SPR == 0, "whole rounds");
