@@ -2090,7 +2090,10 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                         // pairs, the chain wave, so that the three stages take about the same time
                         // (rounds of 32 samples, 16 pairs: with 4 pairs the chain wave was the slowest stage — 7.39 ms for
                         // config 2 against 6.51 with 2 and 7.26 with none; profiles/r03_pipe_waves.txt)
-                        constexpr int CHAIN_PAIRS = QP == 8 ? 2 : QP >= 4 ? QP / 2 : 0;
+#ifndef PIPE_CP8_L8
+#define PIPE_CP8_L8 4
+#endif
+                        constexpr int CHAIN_PAIRS = QP == 8 ? (L == 4 ? 2 : PIPE_CP8_L8) : QP >= 4 ? QP / 2 : 0;
                         constexpr int PAIRS_PER_COEF_WAVE = QP >= 4 ? (2 * QP - CHAIN_PAIRS) / 2 : QP;
                         static_assert(QP < 4 || 2 * PAIRS_PER_COEF_WAVE + CHAIN_PAIRS == 2 * QP, "every pair has a wave");
                         static_assert(T % SPR == 0, "whole rounds");
