@@ -1693,7 +1693,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 const V w2 = vfma(tg, w1, st_c[k]);                         // :567  c + a2 b + a3 v3
                 st_b[k] = vfma(vsplat(2.0f, V()), w1, -st_b[k]);            // :570
                 st_c[k] = vfma(vsplat(2.0f, V()), w2, -st_c[k]);            // :571
-                acc = acc + w1;
+                acc = k == 0 ? w1 : acc + w1;            // (tree order; the first term needs no 0 +)
             }
             float part = vget(acc, 0);
             if constexpr (W == 2) part = part + vget(acc, 1);
