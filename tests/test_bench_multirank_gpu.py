@@ -99,3 +99,19 @@ def test_fast_mode_verify_rerenders_a_subset_within_the_same_kernel_family(built
     assert d["config"]["arithmetic"] == "fast" and "FAST" in d["roofline"]["kernel"]
     assert ("SPLIT" in d["roofline"]["kernel"]) == (utts == 4096)
     assert d["verify"]["mismatches"] == 0 and d["verify"]["rebatched_subset_mismatches"] == 0
+
+
+def test_eight_ranks_on_one_gpu_take_the_config_5_control_flow(built):
+    """The driver's 8-GPU run (config 5) in miniature: eight rank processes — all pinned to the one GPU of the
+    test box, so the voice table takes the file fallback — shard 8 x 512 utterances, meet at the barriers, and
+    rank 0 prints one line with eight per-rank rows; --verify proves every shard equals rank 0's rendering."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--utts", "512", "--no-require-rccl", "--verify"]
+    env = {k: v for k, v in ENV.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    d = _one_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900))
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak"
+    assert [r["rank"] for r in d["per_rank"]] == list(range(8))
+    assert abs(d["per_gpu_value"] * 8 - d["value"]) < 1e-6 * d["value"]
+    assert d["verify"]["mismatches"] == 0 and d["verify"]["utterances_checked"] == 8 * 512
+    per_rank = d["config"]["samples_per_step_per_gpu"]
+    assert abs(d["value"] - 8 * per_rank * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
