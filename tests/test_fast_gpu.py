@@ -658,3 +658,34 @@ def test_length_sorted_slot_assignment_is_invisible_in_fast_mode(gpu_ctx):
                 assert np.array_equal(a[u, :m].view(np.uint32), b[u, :m].view(np.uint32)), (lanes, u)
     finally:
         gpu_ctx.set_option("sort_by_length", 1)
+
+
+def test_scan_kernel_flavours_and_batches_give_the_same_bits(gpu_ctx):
+    """One workgroup per utterance: the scan kernel's samples cannot depend on the batch, and its three-stage and
+    two-stage workgroups run the same arithmetic (the header promises "same results either way")."""
+    voices = W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    stride = 16384
+    segs, offs, vids, seeds = _ragged_corpus(120)
+    split_default = gpu_ctx.get_option("time_parallel_scan_split_max_utterances")
+    try:
+        gpu_ctx.set_option("time_split", 0)
+        rows = {}
+        for split in (1, 0):
+            gpu_ctx.set_option("time_parallel_scan_split_max_utterances", split_default if split else 0)
+            rows[split] = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
+            assert gpu_ctx.last_kernel_name().startswith("scan_kernel") and ("SPLIT" in gpu_ctx.last_kernel_name()) == bool(split)
+        assert np.array_equal(rows[0][1], rows[1][1])
+        for u in range(120):
+            m = int(rows[0][1][u])
+            assert np.array_equal(rows[0][0][u, :m].view(np.uint32), rows[1][0][u, :m].view(np.uint32)), u
+        s2, o2, v2, j2 = _ragged_corpus(17, 50)
+        part, part_len = _render(gpu_ctx, True, s2, o2, v2, j2, stride)
+        for r in range(17):
+            m = int(part_len[r])
+            assert m == rows[0][1][50 + r]
+            assert np.array_equal(part[r, :m].view(np.uint32), rows[0][0][50 + r, :m].view(np.uint32)), r
+    finally:
+        gpu_ctx.set_option("time_parallel_scan_split_max_utterances", split_default)
+        gpu_ctx.set_option("time_split", 1)
+        gpu_ctx.set_voices(W.single_voice())
