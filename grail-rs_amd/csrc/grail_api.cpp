@@ -999,8 +999,8 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
         int K = ctx->split_chunks ? (int)ctx->split_chunks : (int)std::min<uint64_t>(65536u / count, SPLIT_MAX_CHUNKS);
         K = (int)std::fmin((double)K, span / 512.0);
         // (a fast-forwarded sample costs the same whatever is rendered afterwards; a rendered sample of eight live
-        // formants costs 1.56 x one of four: 27.0 against 17.3 ms for the headline batch)
-        const double ff_cost = 1e-3 * (double)ctx->split_ff_permille * (batch_live4_any_blend(ctx, batch) ? 1.0 : 0.64);
+        // formants costs 1.5 x one of four; 0.8 from a sweep, profiles/r03_small_batch.txt)
+        const double ff_cost = 1e-3 * (double)ctx->split_ff_permille * (batch_live4_any_blend(ctx, batch) ? 1.0 : 0.8);
         while (K >= 2 && !split_grid((uint32_t)span, ctx->max_warmup, K, ff_cost, a.split_bounds)) --K;
         if (K >= 2) {
             split_k = K;

@@ -1989,9 +1989,35 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 }
                 n_out += done ? 0u : (uint32_t)T;
             } else {
+                // A tile in which some lane has an event, pair by pair (as the mixed tile of the rendering loop):
+                // a lane without an event of its own in the pair takes the packed chain step, the others the
+                // reference's control flow; the usual pairs — nobody has one — in a tight loop of their own.  The
+                // lanes of the wave move in lockstep (two samples per pair), so n_out < base0 holds for all of them
+                // until the tile ends.
+                auto pair_calm = [&]() __attribute__((always_inline)) -> bool {
+                    return !done & quiet_ok & (dt > 0.0f) & (clk > 2.5f * dt) & (jphase + 2.01f * jinc < 1.0f);
+                };
+                int t = 0;
 #pragma unroll 1
-                for (int t = 0; t < T; ++t)
-                    if (n_out < base0) general_step(t, std::true_type());
+                while (t < T) {
+#pragma unroll 1
+                    for (; t < T; t += 2) {
+                        if (__builtin_amdgcn_ballot_w64(!(pair_calm() | done)) != 0) break;
+                        f2 PH, frequency;
+                        chain_pair(std::true_type(), PH, frequency);
+                        n_out += done ? 0u : 2u;
+                    }
+                    if (t >= T) break;
+                    if (pair_calm()) {
+                        f2 PH, frequency;
+                        chain_pair(std::true_type(), PH, frequency);
+                        n_out += 2u;
+                    } else {
+                        general_step(t, std::true_type());
+                        general_step(t + 1, std::true_type());
+                    }
+                    t += 2;
+                }
             }
         }
         // the carrier noise state after n_out draws from seed 0 (:594): s -> 16807 s + 1 composed n_out times
