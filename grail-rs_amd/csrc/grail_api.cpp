@@ -134,9 +134,9 @@ struct grail_ctx {
     int64_t split_chunks = 0;         // ... into this many chunks (0: as many as fill the machine)
     int64_t split_span = 0;           // ... laid out over this many samples (0: the batch's longest utterance)
     int64_t split_ff_permille = 165;  // ... cost of a fast-forwarded sample against a rendered one
-    int64_t split_min_utts = 2305;    // ... batches smaller than this (x 4/7 with eight live formants) stay with the scan
-                                      // kernel: 2 048 utterances 3.40 against 3.76 ms, 3 072: 5.13 against 3.82
-                                      // (profiles/r03_small_batch.txt; eight formants: 1 024: 2.9 / 4.5, 1 536: 5.1 / 4.5)
+    int64_t split_min_utts = 1537;    // ... batches smaller than this (x 5/6 with eight live formants) stay with the scan
+                                      // kernel: 1 024 utterances 2.00 against 3.13 ms, 1 536: 3.22 / 3.14, 2 048: 3.33 / 3.13
+                                      // (profiles/r03_small_batch.txt; eight formants: 1 024: 2.98 / 3.94, 1 536: 5.11 / 3.98)
     int last_split = 0;               // chunks of the last launch (statistics; 0: not time-split)
     float max_dt = 0.0f;              // largest 1/sample_rate of the table
     float max_pitch_jitter = 0.0f;    // largest |jitter_delta_frequency| of the table
@@ -992,7 +992,7 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     if (a.fast && ctx->split_option && !ctx->lanes_option && batch->phoneme_mode && ctx->voices_split_ok &&
         batch->plain && out_stride <= 0xFFFFFFFFull &&
         (ctx->split_chunks >= 2 ||
-         (ctx->split_chunks == 0 && (int64_t)count * 7 >= ctx->split_min_utts * (batch_live4_any_blend(ctx, batch) ? 7 : 4)))) {
+         (ctx->split_chunks == 0 && (int64_t)count * 6 >= ctx->split_min_utts * (batch_live4_any_blend(ctx, batch) ? 6 : 5)))) {
         double span = ctx->split_span ? (double)ctx->split_span
                                       : std::ceil((double)batch->max_seconds * ctx->max_rate) + 64.0;
         span = std::fmin(span, (double)out_stride);

@@ -220,12 +220,12 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       its own: lowest time per batch), above it two (more utterances resident per CU: highest
  *       throughput).  Same results either way.
  *   "time_split": 1 (default) / 0 — fast arithmetic only: batches of "time_split_min_utterances"
- *       (default 2305; 4/7 of that with eight live formants) to 32768 utterances of voices whose filters forget their past within 16384
+ *       (default 1537; 5/6 of that with eight live formants) to 32768 utterances of voices whose filters forget their past within 16384
  *       samples cut every utterance's time axis into chunks with a wavefront lane each, as many as
  *       fill the machine.  A chunk's lane fast-forwards the exact per-utterance state to its chunk,
  *       starts the filters from zero a warm-up length earlier (the voice's narrowest bandwidth
  *       decides: 3968 samples for voices::generic() at 48 kHz, residual < 2^-21 of the state) and
- *       renders its chunk: 4096 utterances x 2 s in 4.0 ms instead of 6.4 (scan kernel) / 8.2 (exact).
+ *       renders its chunk: 4096 utterances x 2 s in 3.3 ms instead of 6.4 (scan kernel) / 6.5 (exact).
  *       "time_split_chunks" (0 = auto, 2..64) and "time_split_span_samples" (0 = the batch's longest
  *       utterance) pin the grid; "time_split_ff_cost_permille" (default 165) is the cost of a
  *       fast-forwarded sample against a rendered one, which the spacing of the chunks balances.
