@@ -498,6 +498,22 @@ const char *grail_status_string(int status)
 
 const char *grail_last_error(void) { return g_last_error.c_str(); }
 
+uint32_t grail_time_split_warmup(const grail_voice *voice) { return voice ? voice_warmup(*voice) : 0u; }
+
+int grail_time_split_grid(uint32_t span_samples, uint32_t warmup, uint32_t chunks, uint32_t ff_cost_permille,
+                          uint32_t *bounds)
+{
+    if (!bounds) return fail(GRAIL_ERR_INVALID_ARG, "bounds is NULL");
+    if (chunks < 2u || chunks > (uint32_t)SPLIT_MAX_CHUNKS)
+        return fail(GRAIL_ERR_INVALID_ARG, "chunks must be 2..64");
+    if (ff_cost_permille > 1000u) return fail(GRAIL_ERR_INVALID_ARG, "ff_cost_permille must be 0..1000");
+    uint32_t b[SPLIT_MAX_CHUNKS + 1];
+    if (!split_grid(span_samples, warmup, (int)chunks, 1e-3 * (double)ff_cost_permille, b))
+        return fail(GRAIL_ERR_INVALID_ARG, "so many chunks do not fit the span");
+    std::memcpy(bounds, b, sizeof(uint32_t) * chunks);
+    return GRAIL_OK;
+}
+
 int grail_device_count(int *count)
 {
     if (!count) return fail(GRAIL_ERR_INVALID_ARG, "count is NULL");

@@ -2119,9 +2119,14 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 #ifndef PIPE_CP8_L8
 #define PIPE_CP8_L8 4
 #endif
-                        constexpr int CHAIN_PAIRS = QP == 8 ? (L == 4 ? 2 : PIPE_CP8_L8) : QP >= 4 ? QP / 2 : 0;
-                        constexpr int PAIRS_PER_COEF_WAVE = QP >= 4 ? (2 * QP - CHAIN_PAIRS) / 2 : QP;
-                        static_assert(QP < 4 || 2 * PAIRS_PER_COEF_WAVE + CHAIN_PAIRS == 2 * QP, "every pair has a wave");
+#ifndef PIPE_CP8_L4
+#define PIPE_CP8_L4 2
+#endif
+                        constexpr int CHAIN_PAIRS = QP == 8 ? (L == 4 ? PIPE_CP8_L4 : PIPE_CP8_L8) : QP >= 4 ? QP / 2 : 0;
+                        // the first coefficient wave takes the odd pair, if there is one
+                        constexpr int PAIRS_PER_COEF_WAVE = QP >= 4 ? (2 * QP - CHAIN_PAIRS + 1) / 2 : QP;
+                        constexpr int PAIRS_OF_LAST_WAVE = QP >= 4 ? 2 * QP - CHAIN_PAIRS - PAIRS_PER_COEF_WAVE : QP;
+                        static_assert(QP < 4 || PAIRS_OF_LAST_WAVE >= 1, "every coefficient wave has a pair");
                         static_assert(T % SPR == 0, "whole rounds");
                         // Consecutive calm tiles (pipe_tiles of them) go through without draining the pipeline:
                         // when the rendering wave has parked a tile all four waves flush it, then carry on.
@@ -2157,7 +2162,8 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 #pragma unroll
                                     for (int q = 0; q < PAIRS_PER_COEF_WAVE; ++q) {
                                         const int pair = QP >= 4 ? PAIRS_PER_COEF_WAVE * (role - 2) + q : 2 * q + (role - 2);
-                                        pipe_coeffs(chain_all[m & 1][pair / 4], pair % 4, ring_all[m & 1][pair]);
+                                        if (PAIRS_OF_LAST_WAVE == PAIRS_PER_COEF_WAVE || q < PAIRS_OF_LAST_WAVE || role == 2)
+                                            pipe_coeffs(chain_all[m & 1][pair / 4], pair % 4, ring_all[m & 1][pair]);
                                     }
                                 }
                             } else if (ph_ >= 0) {

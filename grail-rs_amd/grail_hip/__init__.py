@@ -51,7 +51,8 @@ EXPORTS = [
     "grail_abi_version", "grail_status_string", "grail_last_error",
     "grail_elem_silent", "grail_elem_new_phoneme", "grail_elem_new", "grail_elem_resample",
     "grail_elem_blend", "grail_voice_generic", "grail_voice_generic_at", "grail_voice_get",
-    "grail_create", "grail_destroy", "grail_device_count", "grail_device_pci_bus_id", "grail_set_voices",
+    "grail_create", "grail_destroy", "grail_device_count", "grail_device_pci_bus_id", "grail_time_split_warmup",
+    "grail_time_split_grid", "grail_set_voices",
     "grail_get_voices", "grail_set_option", "grail_get_option",
     "grail_batch_upload", "grail_batch_upload_elems", "grail_batch_free", "grail_batch_size",
     "grail_batch_lengths", "grail_batch_synthesize_async", "grail_sync",
@@ -179,6 +180,9 @@ def load():
     L.grail_destroy.argtypes = [vp]
     L.grail_device_count.argtypes = [C.POINTER(C.c_int)]
     L.grail_device_pci_bus_id.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.grail_time_split_warmup.argtypes = [C.POINTER(Voice)]
+    L.grail_time_split_warmup.restype = C.c_uint32
+    L.grail_time_split_grid.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     L.grail_set_voices.argtypes = [vp, vp, C.c_uint32]
     L.grail_get_voices.argtypes = [vp, vp, C.c_uint32, u32p]
     L.grail_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
@@ -358,6 +362,18 @@ def text_to_phoneme_elems(voice, text):
 def wav_write_i16(path, pcm, sample_rate):
     pcm = np.ascontiguousarray(pcm, dtype=np.int16)
     _check(load().grail_wav_write_i16(path.encode(), pcm.ctypes.data, len(pcm), int(sample_rate)))
+
+
+def time_split_warmup(voice):
+    """Warm-up length of `voice` for the time-split fast kernels, in samples (0: does not qualify)."""
+    return int(load().grail_time_split_warmup(C.byref(voice)))
+
+
+def time_split_grid(span_samples, warmup, chunks, ff_cost_permille=165):
+    """Chunk starts of a time-split launch (GrailError when so many chunks do not fit)."""
+    out = (C.c_uint32 * max(int(chunks), 1))()
+    _check(load().grail_time_split_grid(span_samples, warmup, chunks, ff_cost_permille, out))
+    return [int(x) for x in out]
 
 
 def device_count():

@@ -224,7 +224,7 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       samples cut every utterance's time axis into chunks with a wavefront lane each, as many as
  *       fill the machine.  A chunk's lane fast-forwards the exact per-utterance state to its chunk,
  *       starts the filters from zero a warm-up length earlier (the voice's narrowest bandwidth
- *       decides: 3968 samples for voices::generic() at 48 kHz, residual < 2^-21 of the state) and
+ *       decides: 3904 samples for voices::generic() at 48 kHz, residual < 2^-21 of the state) and
  *       renders its chunk: 4096 utterances x 2 s in 3.3 ms instead of 6.4 (scan kernel) / 6.5 (exact).
  *       "time_split_chunks" (0 = auto, 2..64) and "time_split_span_samples" (0 = the batch's longest
  *       utterance) pin the grid; "time_split_ff_cost_permille" (default 165) is the cost of a
@@ -244,6 +244,19 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  * "last_launch_chunks" (time-split: chunks per utterance, else 0). */
 int grail_set_option(grail_ctx *ctx, const char *name, int64_t value);
 int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value);
+/* The planning behind "time_split", as pure host functions (no GPU, no context): what a caller needs to
+ * predict or pin a fast-mode kernel family, and what the CPU tests check.
+ * grail_time_split_warmup: the warm-up length of `voice` in samples, a multiple of 64 — after so many samples a
+ *   filter state started from zero is within 2^-21 of the one Synthesize::next (src/lib.rs:530-575) would hold,
+ *   from the slowest one-pole / band-pass decay over the voice's phonemes with a 5 % margin.  0: the voice does
+ *   not qualify (a formant parameter outside (0, 0.5) / (0, 1), or more than 16384 samples).
+ * grail_time_split_grid: bounds[0 .. chunks) of `chunks` chunks (2..64) over span_samples, multiples of 64 with
+ *   bounds[0] = 0, spaced so that fast-forwarding (ff_cost_permille per sample, a rendered sample = 1000),
+ *   warming up and rendering take every chunk's lane the same time.  GRAIL_ERR_INVALID_ARG when so many chunks
+ *   do not fit (a chunk would render fewer than 64 samples). */
+uint32_t grail_time_split_warmup(const grail_voice *voice);
+int grail_time_split_grid(uint32_t span_samples, uint32_t warmup, uint32_t chunks, uint32_t ff_cost_permille,
+                          uint32_t *bounds);
 
 /* ---- batches ----------------------------------------------------------- */
 /* Uploads the inputs of n_utt utterances: utterance u is

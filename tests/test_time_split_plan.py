@@ -1,0 +1,140 @@
+"""Host logic of the time-split fast kernels (no GPU): the warm-up length of a voice and the chunk grid.
+
+grail_time_split_warmup / grail_time_split_grid are the functions the library itself plans its launches with
+(grail_api.cpp: voice_warmup, split_grid); here they are checked against a numpy restatement of the filter decay of
+Synthesize::next (src/lib.rs:530-575) and against the cost model the grid is meant to balance.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import grail_hip as gh
+
+pytestmark = pytest.mark.skipif(not gh.lib_exists(), reason="libgrail_hip.so not built")
+
+
+def tan_approx(f):
+    # src/lib.rs:595-601
+    return ((1 - f) * f * (5 - 4 * (f + 0.5) * (0.5 - f))) / ((f + 0.5) * (5 - 4 * (1 - f) * f) * (0.5 - f))
+
+
+def slowest_decay(voice):
+    """Smallest per-sample decay rate (-ln |pole|) over the audible formants of every phoneme."""
+    slow = math.inf
+    for i in range(8):
+        if all(voice.phonemes[p].formant_amp[i] == 0.0 for p in range(len(voice.phonemes))):
+            continue
+        for p in range(len(voice.phonemes)):
+            e = voice.phonemes[p]
+            f, w, sm = e.formant_freq[i], e.formant_bw[i], e.formant_smooth[i]
+            g, k = tan_approx(f), w / f
+            # the SVF's transition matrix (trapezoidal, :555-571): spectral radius by numpy
+            a1 = 1.0 / (1.0 + g * (g + k))
+            a2 = g * a1
+            a3 = g * a2
+            m = np.array([[2 * a1 - 1, -2 * a2], [2 * a2, 1 - 2 * a3]])
+            slow = min(slow, -math.log(max(abs(np.linalg.eigvals(m)))))
+            slow = min(slow, -5.0 * math.log1p(-sm))
+    return slow
+
+
+@pytest.mark.parametrize("rate", [16000.0, 22050.0, 44100.0, 48000.0])
+def test_warmup_covers_the_slowest_decay(rate):
+    v = gh.voice_generic(rate)
+    w = gh.time_split_warmup(v)
+    assert w > 0 and w % 64 == 0 and w <= 16384
+    slow = slowest_decay(v)
+    # after w samples the slowest mode has decayed below 2^-21, with the 5 % margin and no more than a tile over
+    assert math.exp(-slow * w) <= 2.0 ** -21
+    need = math.log(2.0 ** 21) / (0.95 * slow)
+    assert need <= w < need + 64
+
+
+def test_warmup_of_the_headline_voice():
+    assert gh.time_split_warmup(gh.voice_generic(48000.0)) == 3904     # include/grail_hip.h, DESIGN.md 4.5
+
+
+def test_warmup_scales_with_the_sample_rate():
+    ws = [gh.time_split_warmup(gh.voice_generic(r)) for r in (16000.0, 32000.0, 48000.0)]
+    assert ws[0] < ws[1] < ws[2]
+
+
+def test_warmup_rejects_unqualified_voices():
+    v = gh.voice_generic(48000.0)
+    v.phonemes[1].formant_bw[1] = 0.0          # a band-pass that never forgets
+    assert gh.time_split_warmup(v) == 0
+    v = gh.voice_generic(48000.0)
+    v.phonemes[0].formant_freq[0] = 0.6        # outside (0, 0.5)
+    assert gh.time_split_warmup(v) == 0
+    v = gh.voice_generic(48000.0)
+    v.phonemes[1].formant_bw[0] = 1e-7         # qualifies in kind, but the warm-up would exceed 16384 samples
+    assert gh.time_split_warmup(v) == 0
+    v = gh.voice_generic(48000.0)
+    v.phonemes[0].formant_smooth[2] = float("nan")
+    assert gh.time_split_warmup(v) == 0
+
+
+def test_warmup_of_a_silent_voice():
+    v = gh.voice_generic(48000.0)
+    for p in range(len(v.phonemes)):
+        for i in range(8):
+            v.phonemes[p].formant_amp[i] = 0.0
+    assert gh.time_split_warmup(v) == 64
+
+
+def lane_cost(bounds, end, warmup, r):
+    out = []
+    for k, b in enumerate(bounds):
+        nxt = bounds[k + 1] if k + 1 < len(bounds) else end
+        before = r * max(b - warmup, 0) + min(warmup, b) if k else 0.0
+        out.append(before + (nxt - b))
+    return out
+
+
+@pytest.mark.parametrize("span,warmup,chunks,permille", [
+    (96064, 3904, 16, 165), (96064, 3904, 8, 165), (96064, 3904, 4, 132), (96064, 3904, 2, 165),
+    (48000, 1344, 8, 165), (400000, 3904, 24, 165), (96064, 0, 16, 0), (1 << 22, 64, 64, 10),
+])
+def test_grid_balances_the_lanes(span, warmup, chunks, permille):
+    b = gh.time_split_grid(span, warmup, chunks, permille)
+    assert len(b) == chunks and b[0] == 0
+    assert all(x % 64 == 0 for x in b)
+    assert all(b[k] < b[k + 1] for k in range(chunks - 1)) and b[-1] < span
+    cost = lane_cost(b, span, warmup, permille * 1e-3)
+    # equal within the rounding of the bounds to tiles of 64 (each bound moves a lane by at most 32 + 32)
+    assert max(cost) - min(cost) <= 2 * 64 + 1
+    # and the chunks shrink along the utterance while fast-forwarding costs anything
+    lens = [y - x for x, y in zip(b, b[1:] + [span])]
+    if permille and chunks > 2:
+        assert lens[1] >= lens[-1]
+
+
+def test_grid_without_costs_is_even():
+    b = gh.time_split_grid(65536, 0, 16, 0)
+    assert b == [4096 * k for k in range(16)]
+
+
+def test_grid_refuses_what_does_not_fit():
+    with pytest.raises(gh.GrailError):
+        gh.time_split_grid(4096, 3904, 16, 165)       # the warm-up alone outweighs a chunk
+    with pytest.raises(gh.GrailError):
+        gh.time_split_grid(8192, 64, 2, 1000)         # fast-forwarding as dear as rendering: nothing to gain
+    with pytest.raises(gh.GrailError):
+        gh.time_split_grid(96064, 3904, 1, 165)
+    with pytest.raises(gh.GrailError):
+        gh.time_split_grid(96064, 3904, 65, 165)
+    with pytest.raises(gh.GrailError):
+        gh.time_split_grid(96064, 3904, 16, 1001)
+
+
+def test_grid_is_what_the_headline_mid_range_launch_uses():
+    # 4096 utterances x 2 s at 48 kHz: 16 chunks (65536 lanes) over 96000 + 64 samples
+    b = gh.time_split_grid(96064, 3904, 16, 165)
+    assert b[1] > 96064 // 16          # the first lane has nothing to fast-forward: the longest chunk
+    # the last lane fast-forwards over 19 of 20 parts and warms up: about a thousand samples are left to render
+    assert 512 <= 96064 - b[-1] <= 2048
+    # more chunks buy little (the fast-forward of the last lane is the floor) and 32 no longer fit
+    assert gh.time_split_grid(96064, 3904, 24, 165)[1] > 0.95 * b[1]
+    with pytest.raises(gh.GrailError):
+        gh.time_split_grid(96064, 3904, 32, 165)
