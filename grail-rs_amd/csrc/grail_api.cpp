@@ -930,17 +930,23 @@ static bool batch_live4(const grail_ctx *ctx, const grail_batch *batch)
 
 // Rows [first, first + count) of the batch (count = 0: all of it).  out_dev / out_len_dev point at the
 // first row RENDERED, i.e. the caller has already applied the row offset to them.
+// family_rows: the number of rows the kernel family is chosen for (0 = count).  A caller that renders a batch in
+// row blocks passes its block size for every block, the short last one included: in fast arithmetic a row's
+// samples depend on the family (lane mapping, chunk grid, scan kernel), and so they depend neither on the row's
+// position nor on n_utt modulo the block size.
 static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_dev,
                            int16_t *out_pcm16_dev, uint64_t out_stride, uint32_t *out_len_dev,
-                           uint32_t first = 0, uint32_t count = 0)
+                           uint32_t first = 0, uint32_t count = 0, uint32_t family_rows = 0)
 {
     int rc = bind(ctx);
     if (rc) return rc;
     if ((rc = check_ready(ctx, batch))) return rc;
     if (batch->n_utt == 0) return GRAIL_OK;
     if (!out_dev && !out_pcm16_dev && out_stride) return fail(GRAIL_ERR_INVALID_ARG, "out_dev is NULL");
-    if (count == 0) count = batch->n_utt - first;
     if (first > batch->n_utt || count > batch->n_utt - first) return fail(GRAIL_ERR_INVALID_ARG, "row range");
+    if (count == 0) count = batch->n_utt - first;
+    if (count == 0) return GRAIL_OK;
+    const uint32_t fam = family_rows > count ? family_rows : count;   // what the kernel family is chosen for
     SynthArgs a{};
     a.out_pcm16 = out_pcm16_dev;
     a.segs = batch->d_segs;
@@ -966,17 +972,17 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     a.fast = ctx->fast_option ? 1u : 0u;
     // (the fast lane kernels have four-formant instantiations for every blend length)
     if (a.fast && batch_live4_any_blend(ctx, batch)) a.live4 = 1u;
-    int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(count);
+    int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(fam);
     // small batches leave SIMDs idle: four-wave workgroups (one wave renders 16 utterances, one carries
     // the per-utterance chain, two prepare the filter coefficients), up to two per CU (tools/pipe4_range.py:
     // 11.5 ms up to 4 096 utterances, 15.7 up to 8 192 where the lane kernels take 18.0; three per CU lose)
     const bool want_pipe4 = batch_live4(ctx, batch) && !ctx->lanes_option && ctx->pipeline_option &&
-                            ((uint64_t)count + 15) / 16 <= (uint64_t)ctx->pipe4_max_groups;
+                            ((uint64_t)fam + 15) / 16 <= (uint64_t)ctx->pipe4_max_groups;
     const bool want_pipe8 = !batch_live4(ctx, batch) && !ctx->lanes_option && ctx->pipeline_option && !batch->any_blend &&
-                            ((uint64_t)count + 7) / 8 <= (uint64_t)ctx->pipe8_max_groups;
+                            ((uint64_t)fam + 7) / 8 <= (uint64_t)ctx->pipe8_max_groups;
     // one workgroup per CU suffices: rounds of 32 samples instead of 16 (pipe = 2)
-    const uint32_t pipe4_kind = ctx->pipe_round32 && ((uint64_t)count + 15) / 16 <= 256 ? 2u : 1u;
-    const uint32_t pipe8_kind = ctx->pipe_round32 && ((uint64_t)count + 7) / 8 <= 256 ? 2u : 1u;
+    const uint32_t pipe4_kind = ctx->pipe_round32 && ((uint64_t)fam + 15) / 16 <= 256 ? 2u : 1u;
+    const uint32_t pipe8_kind = ctx->pipe_round32 && ((uint64_t)fam + 7) / 8 <= 256 ? 2u : 1u;
     if (want_pipe4 && !a.fast) {
         a.pipe = pipe4_kind;
         L = 4;
@@ -989,7 +995,7 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     if (a.live4 && !a.pipe && L == 8) a.live4 = 0u;
     if (a.live4 && !a.pipe && !ctx->lanes_option) {
         // same rule as auto_lanes_per_utt — the widest mapping with one wave per SIMD — over 4 formants
-        L = ((uint64_t)count * 4 + 63) / 64 <= 1024 ? 4 : ((uint64_t)count * 2 + 63) / 64 <= 1024 ? 2 : 1;
+        L = ((uint64_t)fam * 4 + 63) / 64 <= 1024 ? 4 : ((uint64_t)fam * 2 + 63) / 64 <= 1024 ? 2 : 1;
     }
     // voices whose upper formants are never audible but that do not qualify for the 4-formant
     // kernels: one lane per utterance runs the half-live loop and ties two lanes per utterance,
@@ -1008,11 +1014,11 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     if (a.fast && ctx->split_option && !ctx->lanes_option && batch->phoneme_mode && ctx->voices_split_ok &&
         batch->plain && out_stride <= 0xFFFFFFFFull &&
         (ctx->split_chunks >= 2 ||
-         (ctx->split_chunks == 0 && (int64_t)count * 6 >= ctx->split_min_utts * (batch_live4_any_blend(ctx, batch) ? 6 : 5)))) {
+         (ctx->split_chunks == 0 && (int64_t)fam * 6 >= ctx->split_min_utts * (batch_live4_any_blend(ctx, batch) ? 6 : 5)))) {
         double span = ctx->split_span ? (double)ctx->split_span
                                       : std::ceil((double)batch->max_seconds * ctx->max_rate) + 64.0;
         span = std::fmin(span, (double)out_stride);
-        int K = ctx->split_chunks ? (int)ctx->split_chunks : (int)std::min<uint64_t>(65536u / count, SPLIT_MAX_CHUNKS);
+        int K = ctx->split_chunks ? (int)ctx->split_chunks : (int)std::min<uint64_t>(65536u / fam, SPLIT_MAX_CHUNKS);
         K = (int)std::fmin((double)K, span / 512.0);
         // (a fast-forwarded sample costs the same whatever is rendered afterwards; a rendered sample of eight live
         // formants costs 1.5 x one of four; 0.8 from a sweep, profiles/r03_small_batch.txt)
@@ -1024,7 +1030,7 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
         }
     }
     const bool scan = !split_k && a.fast && ctx->scan_option && !ctx->lanes_option &&
-                      (int64_t)count * (batch_live4_any_blend(ctx, batch) ? 4 : 7) <= 4 * ctx->scan_max_utts &&
+                      (int64_t)fam * (batch_live4_any_blend(ctx, batch) ? 4 : 7) <= 4 * ctx->scan_max_utts &&
                       batch->phoneme_mode && ctx->voices_scan_ok && batch->plain &&
                       batch->min_length >= 2.0f * ctx->max_dt &&
                       batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f;
@@ -1056,7 +1062,7 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
         a.resume = (uint32_t)ctx->scan_debug;
         // three-stage workgroups for few utterances (tools/scan_split_crossover.py: up to ~1500 with four
         // live formants, half that with eight, where the filter wave is the slower stage either way)
-        a.pipe = (int64_t)count * (a.live4 ? 1 : 2) <= ctx->scan_split_max ? 1u : 0u;
+        a.pipe = (int64_t)fam * (a.live4 ? 1 : 2) <= ctx->scan_split_max ? 1u : 0u;
         e = launch_scan(a, ctx->stream);
         ctx->last_kernel = a.live4 ? (a.pipe ? "scan_kernel<pairs=2,SPLIT,FAST>" : "scan_kernel<pairs=2,FAST>")
                                    : (a.pipe ? "scan_kernel<pairs=4,SPLIT,FAST>" : "scan_kernel<pairs=4,FAST>");
@@ -1390,7 +1396,7 @@ int render_to_host(grail_ctx *ctx, grail_batch *b, uint32_t n_utt, void *out, si
             if (e != hipSuccess) { rc = hip_fail(e, "block set-up"); break; }
             rc = synthesize_rows(ctx, b, elem == 4 ? (float *)p->dev[slot] : nullptr,
                                  elem == 2 ? (int16_t *)p->dev[slot] : nullptr, out_stride, d_len + first,
-                                 (uint32_t)first, count);
+                                 (uint32_t)first, count, (uint32_t)rows);
             if (rc) break;
             e = hipEventRecord(p->rendered[slot], ctx->stream);
             if (e == hipSuccess) e = hipStreamWaitEvent(p->copy_stream, p->rendered[slot], 0);

@@ -35,7 +35,10 @@
  * the batch size: the time-parallel scan kernel (small batches), the time-split
  * kernels (their chunk grid follows the batch size and its longest utterance;
  * "time_split_chunks" / "time_split_span_samples" pin it) or the lane kernels
- * ("lanes_per_utterance" pins the mapping).  Speed: 2.3x the exact mode for the
+ * ("lanes_per_utterance" pins the mapping).  The host-output calls render a batch
+ * in blocks of up to 4096 rows (2 GB) and choose the family for that block size,
+ * the short last block included: there the "batch size" above is min(n_utt, 4096).
+ * Speed: 2.3x the exact mode for the
  * headline batch (65536 utterances), 2x for 4096; for batches the fast kernels do
  * not serve faster than the exact ones the exact kernels run (their bits satisfy
  * the tolerance trivially).

@@ -689,3 +689,32 @@ def test_scan_kernel_flavours_and_batches_give_the_same_bits(gpu_ctx):
         gpu_ctx.set_option("time_parallel_scan_split_max_utterances", split_default)
         gpu_ctx.set_option("time_split", 1)
         gpu_ctx.set_voices(W.single_voice())
+
+
+def test_host_output_blocks_share_one_kernel_family_in_fast_mode(gpu_ctx):
+    """The host-output calls render in blocks of up to 4096 rows; the short last block takes the kernel family of
+    the full ones (grail_api.cpp synthesize_rows, family_rows), so a row's fast-mode samples depend neither on its
+    position nor on n_utt modulo the block size.  Utterance u depends on u only: rows 4100.. of one batch sit in
+    its short last block, the same utterances sit inside the full first block of a batch that starts 150 later."""
+    voices = W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    stride = 16384
+    n = 4096 + 150
+    try:
+        gpu_ctx.set_option("time_split_span_samples", 15360)     # the grid may not follow each batch's longest row
+        a, a_len = _render(gpu_ctx, True, *_ragged_corpus(n), stride)
+        family = gpu_ctx.last_kernel_name()
+        b, b_len = _render(gpu_ctx, True, *_ragged_corpus(n, first=150), stride)
+        assert gpu_ctx.last_kernel_name() == family
+        assert np.array_equal(a_len[4100:n], b_len[3950:4096])
+        for r in range(4100, n):
+            m = int(a_len[r])
+            assert m > 0
+            assert np.array_equal(a[r, :m].view(np.uint32), b[r - 150, :m].view(np.uint32)), r
+        # and against the oracle, the short block's rows
+        ref, ref_len = O.synthesize_batch(_ovoices(voices), *_ragged_corpus(40, first=4200), stride)
+        assert np.array_equal(a_len[4200:4240], ref_len)
+        assert _worst(a[4200:4240], ref, ref_len) * ULP <= TOL
+    finally:
+        gpu_ctx.set_option("time_split_span_samples", 0)
+        gpu_ctx.set_voices(W.single_voice())

@@ -2,7 +2,7 @@
 """Kernel time on a RAGGED corpus: per-segment lengths drawn from [0.3, 0.7] s and (optionally)
 per-voice jitter rates that differ, so segment boundaries and jitter wraps of the 64 utterances of
 a wave do not coincide (the bench corpus has them all aligned).
-usage: ragged_bench.py [n_utt [sort_by_length [arithmetic]]]"""
+usage: ragged_bench.py [n_utt [sort_by_length [arithmetic [time_split_chunks]]]]"""
 import os
 import sys
 
@@ -18,6 +18,8 @@ fast = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 ctx = G.Context(0)
 ctx.set_option("sort_by_length", sort)
 ctx.set_option("arithmetic", fast)
+if len(sys.argv) > 4:
+    ctx.set_option("time_split_chunks", int(sys.argv[4]))      # 0 = the library's own choice
 print(f"n = {n} utterances, sort_by_length = {sort}, arithmetic = {'fast' if fast else 'exact'}", flush=True)
 rng = np.random.default_rng(1)
 for label, ragged_len, ragged_jit, n_voices in (("aligned 1 voice", False, False, 1),
