@@ -127,6 +127,8 @@ struct grail_ctx {
     int scan_option = 1;              // fast arithmetic: small batches go to the time-parallel scan kernel
     int64_t scan_max_utts = 8704;     // ... up to this many utterances (x 4/7 with eight live formants)
     int64_t scan_split_max = 1536;    // ... and up to this many with the carrier phase on a wave of its own
+    double voices_sharpness = INFINITY;   // the largest predicted fast-mode deviation of the table, units of 2^-23
+    int64_t fast_limit = (int64_t)GRAIL_FAST_SHARPNESS_LIMIT;   // "fast_sharpness_limit": fast kernels up to this
     bool voices_split_ok = false;     // every voice has a warm-up length (voice_warmup): time-split fast kernels
     uint32_t max_warmup = 0;          // ... the longest of them
     float max_rate = 0.0f;            // highest sample rate of the table
@@ -183,6 +185,7 @@ struct grail_batch {
     float max_seconds = 0.0f;  // longest utterance: sum of its segment lengths
     float min_length = 0.0f;   // shortest segment (plain batches)
     float min_pitch = 0.0f;    // lowest frequency.min(0.5) of any segment (plain batches)
+    double elems_sharpness = 0.0;   // elem mode: predicted fast-mode deviation of the caller's elems (elems_sharpness())
 };
 
 namespace {
@@ -375,6 +378,52 @@ uint32_t voice_warmup(const grail_voice &v)
     return ((uint32_t)std::ceil(samples) + 63u) / 64u * 64u;
 }
 
+// Fast arithmetic and sharp resonances.  The fast kernels interpolate the filter coefficients of Synthesize::next
+// (:555-562) between points evaluated with fused and reordered operations; the reference rounds every operation
+// anew at every sample.  A rounding-level difference of a coefficient that lasts for a sub-tile moves the
+// resonance of a band-pass by that much of its centre frequency and its damping by that much of one, i.e. the
+// output by (difference) x Q resp. x (ring time) of the formant's amplitude — the same amplification the
+// reference's own rounding gets (its binary32 rendering is about a third as far from its formulas in double
+// precision).  Measured (tools/q_sweep.py: bandwidth sweeps of the shipped voices; a frequency x bandwidth grid of
+// single formants; tools/sharpness_data.py: 1 400 random tables; profiles/r03_sharpness.txt): the deviation of a
+// single formant that carries all of the amplitude is ~ 2 500 / bandwidth [Hz at 48 kHz] * 2^-23 up to 2.4 kHz
+// and grows with the square of the frequency above that; it is proportional to the formant's share of the
+// amplitudes, and the formants add up in quadrature.  Hence
+//     E_i = share_i * (0.0709 / bw_i) * (1 + (f_i / 0.075)^2)     (f, bw in cycles per sample, as in the elems;
+//     S   = sqrt(sum_i E_i^2)                                       share, bw, f: the worst of the phonemes)
+// which, scaled as it is, lies above 99.5 % of the random tables' measured deviations and within a factor 1.45
+// below the rest; voices::generic() has S = 24 (measured 13 - 20), the bench presets 20 - 22 (11 - 20).
+// GRAIL_FAST_TOLERANCE = 64 * 2^-23 is therefore a promise the fast kernels can keep only up to a sharpness: the
+// host serves fast arithmetic for S <= GRAIL_FAST_SHARPNESS_LIMIT = 32 (worst measured among those: 31) and
+// renders sharper tables with the exact kernels (their bits satisfy the tolerance trivially).
+// Returns S in units of 2^-23 of max(1, peak); +inf for parameters outside the window of the formulas.
+double elems_sharpness(const grail_synthesis_elem *elems, size_t n)
+{
+    double share[NF] = {0}, sens[NF] = {0};
+    for (size_t p = 0; p < n; ++p) {
+        double total = 0.0;
+        for (int i = 0; i < NF; ++i) total += std::fabs((double)elems[p].formant_amp[i]);
+        if (!std::isfinite(total)) return INFINITY;
+        for (int i = 0; i < NF; ++i)
+            if (total > 0.0) share[i] = std::fmax(share[i], std::fabs((double)elems[p].formant_amp[i]) / total);
+    }
+    double sum = 0.0;
+    for (int i = 0; i < NF; ++i) {
+        if (share[i] == 0.0) continue;             // never audible: nothing rings
+        for (size_t p = 0; p < n; ++p) {
+            const double f = elems[p].formant_freq[i], w = elems[p].formant_bw[i];
+            if (!(f > 0.0 && f < 0.5 && w > 0.0) || !std::isfinite(w)) return INFINITY;
+            sens[i] = std::fmax(sens[i], (0.0709 / w) * (1.0 + (f / 0.075) * (f / 0.075)));
+        }
+        sum += (share[i] * sens[i]) * (share[i] * sens[i]);
+    }
+    return std::sqrt(sum);
+}
+bool fast_served(const grail_ctx *ctx, const grail_batch *batch)
+{
+    return (batch && !batch->phoneme_mode ? batch->elems_sharpness : ctx->voices_sharpness) <= (double)ctx->fast_limit;
+}
+
 // The chunk grid of a time-split launch: K chunks over `span` samples.  Chunk k's lane fast-forwards the chain over
 // b[k] - W samples (cost r per sample, in units of a rendered sample), warms up over W and renders b[k+1] - b[k]:
 // the bounds are spaced so that all lanes take the same time (T below, by bisection).  Bounds are multiples
@@ -459,6 +508,9 @@ int install_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices)
     ctx->max_rate = 0.0f;
     ctx->max_warmup = 0;
     ctx->voices_split_ok = true;
+    ctx->voices_sharpness = 0.0;
+    for (uint32_t v = 0; v < n_voices; ++v)
+        ctx->voices_sharpness = std::fmax(ctx->voices_sharpness, elems_sharpness(voices[v].phonemes, NUM_VOICED));
     for (uint32_t v = 0; v < n_voices; ++v) {
         ctx->voices_live4_ok = ctx->voices_live4_ok && live4_ok(voices[v]);
         ctx->voices_split_ok = ctx->voices_split_ok && dv[v].warmup != 0u && voices[v].sample_rate > 0.0f &&
@@ -497,6 +549,11 @@ const char *grail_status_string(int status)
 }
 
 const char *grail_last_error(void) { return g_last_error.c_str(); }
+
+float grail_fast_sharpness(const grail_voice *voice)
+{
+    return voice ? (float)elems_sharpness(voice->phonemes, NUM_VOICED) : INFINITY;
+}
 
 uint32_t grail_time_split_warmup(const grail_voice *voice) { return voice ? voice_warmup(*voice) : 0u; }
 
@@ -648,6 +705,11 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         ctx->split_min_utts = value;
         return GRAIL_OK;
     }
+    if (std::strcmp(name, "fast_sharpness_limit") == 0) {
+        if (value < 0) return fail(GRAIL_ERR_INVALID_ARG, "negative limit");
+        ctx->fast_limit = value;
+        return GRAIL_OK;
+    }
     if (std::strcmp(name, "pipeline4_max_groups") == 0) {   // tuning: four-formant batches, 16 utterances per workgroup
         ctx->pipe4_max_groups = value;
         return GRAIL_OK;
@@ -720,6 +782,14 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
     }
     if (std::strcmp(name, "time_split_min_utterances") == 0) {
         *value = ctx->split_min_utts;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "fast_sharpness_limit") == 0) {
+        *value = ctx->fast_limit;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "fast_arithmetic_served") == 0) {    // read-only: the voice table is below the sharpness limit
+        *value = fast_served(ctx, nullptr) ? 1 : 0;
         return GRAIL_OK;
     }
     if (std::strcmp(name, "last_launch_chunks") == 0) {        // read-only: chunks per utterance (0: not time-split)
@@ -838,6 +908,12 @@ int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
     b->phoneme_mode = false;
     b->any_blend = any_blend;
     b->n_segs = n_segs;
+    {
+        std::vector<grail_synthesis_elem> given;
+        for (uint32_t i = 0; i < n_segs; ++i)
+            if (segs[i].has_elem) given.push_back(segs[i].elem);
+        b->elems_sharpness = given.empty() ? 0.0 : elems_sharpness(given.data(), given.size());
+    }
     std::vector<float> seconds(n_utt, 0.0f);
     for (uint32_t u = 0; u < n_utt; ++u)
         for (uint32_t i = seg_offsets[u]; i < seg_offsets[u + 1]; ++i) seconds[u] += segs[i].length;
@@ -969,7 +1045,8 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     a.half_capable = batch_half_capable(ctx, batch) ? 1u : 0u;
     a.any_blend = batch->any_blend ? 1u : 0u;
     a.live4 = batch_live4(ctx, batch) ? 1u : 0u;
-    a.fast = ctx->fast_option ? 1u : 0u;
+    // fast arithmetic is served up to a sharpness of the resonances (elems_sharpness); beyond it the exact kernels run
+    a.fast = ctx->fast_option && fast_served(ctx, batch) ? 1u : 0u;
     // (the fast lane kernels have four-formant instantiations for every blend length)
     if (a.fast && batch_live4_any_blend(ctx, batch)) a.live4 = 1u;
     int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(fam);
@@ -1153,7 +1230,8 @@ static int stream_next(grail_ctx *ctx, grail_stream *stream, uint32_t max_sample
     a.half_capable = stream->half_capable ? 1u : 0u;
     a.any_blend = stream->any_blend ? 1u : 0u;
     a.live4 = stream->live4 ? 1u : 0u;
-    a.fast = ctx->fast_option ? 1u : 0u;     // may change between calls: both flavours share the state layout
+    // (may change between calls: both flavours share the state layout)
+    a.fast = ctx->fast_option && fast_served(ctx, batch) ? 1u : 0u;
     a.state = stream->d_state;
     a.state_stride = stream->lanes;
     a.resume = stream->started ? 1u : 0u;

@@ -56,6 +56,9 @@
 #ifndef GRAIL_FAST_G_SCALE
 #define GRAIL_FAST_G_SCALE 1048576.0f   // 2^22 / 4: interpolation error of G, H <= 2^-22 (fast_tile's guard)
 #endif
+#ifndef GRAIL_FAST_A_SCALE
+#define GRAIL_FAST_A_SCALE 724.0773439350247f   // 2^9.5: relative change of a1, a2 / a1, 1 - k per sub-tile <= 2^-9.5
+#endif
 #ifndef PIPE_MAX_TILES
 #define PIPE_MAX_TILES 64         // PIPE kernels: consecutive calm tiles rendered without draining the pipeline (8: 7.85 ms for
                                   // config 2, 24: 7.49, 64: 7.41; a run ends at the next event anyway, ~40 tiles)
@@ -1500,7 +1503,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                                                  __builtin_amdgcn_rcpf(vget(FS.om[k], c)));
         }
         // halvings needed: r / 2^s <= 2^-9.5 (error ~ r^2 / 16), |.| / 4 / 4^s <= 2^-22
-        const int la = __builtin_amdgcn_frexp_expf(ra * 724.0773439350247f);      // 2^9.5
+        const int la = __builtin_amdgcn_frexp_expf(ra * GRAIL_FAST_A_SCALE);
         const int lg = (__builtin_amdgcn_frexp_expf(rg * GRAIL_FAST_G_SCALE) + 1) >> 1;
         int level = la > lg ? la : lg;
         level = level < 0 ? 0 : level;

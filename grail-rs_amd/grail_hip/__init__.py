@@ -37,6 +37,7 @@ OUT_DEVICE = 1
 # "arithmetic" = 1 (fast mode): GRAIL_FAST_TOLERANCE of include/grail_hip.h
 FAST_TOLERANCE_ULPS = 64
 FAST_TOLERANCE = FAST_TOLERANCE_ULPS * 2.0 ** -23
+FAST_SHARPNESS_LIMIT = 32.0      # GRAIL_FAST_SHARPNESS_LIMIT
 FAST_TOLERANCE_NOTE = (f"fast mode: max |fast - exact| <= {FAST_TOLERANCE_ULPS} * 2^-23 = {FAST_TOLERANCE:.3g} of "
                        "full scale vs the oracle (tests/test_fast_gpu.py asserts it on configs 2, 3, 4 "
                        "and a fuzz corpus); clock, phases, wraps and LCGs stay exact")
@@ -52,7 +53,7 @@ EXPORTS = [
     "grail_elem_silent", "grail_elem_new_phoneme", "grail_elem_new", "grail_elem_resample",
     "grail_elem_blend", "grail_voice_generic", "grail_voice_generic_at", "grail_voice_get",
     "grail_create", "grail_destroy", "grail_device_count", "grail_device_pci_bus_id", "grail_time_split_warmup",
-    "grail_time_split_grid", "grail_set_voices",
+    "grail_time_split_grid", "grail_fast_sharpness", "grail_set_voices",
     "grail_get_voices", "grail_set_option", "grail_get_option",
     "grail_batch_upload", "grail_batch_upload_elems", "grail_batch_free", "grail_batch_size",
     "grail_batch_lengths", "grail_batch_synthesize_async", "grail_sync",
@@ -182,6 +183,8 @@ def load():
     L.grail_device_pci_bus_id.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.grail_time_split_warmup.argtypes = [C.POINTER(Voice)]
     L.grail_time_split_warmup.restype = C.c_uint32
+    L.grail_fast_sharpness.argtypes = [C.POINTER(Voice)]
+    L.grail_fast_sharpness.restype = C.c_float
     L.grail_time_split_grid.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     L.grail_set_voices.argtypes = [vp, vp, C.c_uint32]
     L.grail_get_voices.argtypes = [vp, vp, C.c_uint32, u32p]
@@ -367,6 +370,11 @@ def wav_write_i16(path, pcm, sample_rate):
 def time_split_warmup(voice):
     """Warm-up length of `voice` for the time-split fast kernels, in samples (0: does not qualify)."""
     return int(load().grail_time_split_warmup(C.byref(voice)))
+
+
+def fast_sharpness(voice):
+    """Predicted bound on |fast - reference| for `voice`, units of 2^-23 (served up to FAST_SHARPNESS_LIMIT)."""
+    return float(load().grail_fast_sharpness(C.byref(voice)))
 
 
 def time_split_grid(span_samples, warmup, chunks, ff_cost_permille=165):

@@ -105,6 +105,7 @@ extern "C" {
     pub fn grail_device_count(count: *mut c_int) -> c_int;
     pub fn grail_device_pci_bus_id(ctx: *mut grail_ctx, out: *mut c_char, cap: usize) -> c_int;
     pub fn grail_time_split_warmup(voice: *const grail_voice) -> u32;
+    pub fn grail_fast_sharpness(voice: *const grail_voice) -> f32;
     pub fn grail_time_split_grid(span_samples: u32, warmup: u32, chunks: u32, ff_cost_permille: u32,
                                  bounds: *mut u32) -> c_int;
     pub fn grail_set_voices(ctx: *mut grail_ctx, voices: *const grail_voice, n: u32) -> c_int;

@@ -60,6 +60,8 @@ extern "C" {
 /* fast mode ("arithmetic" = 1): bound on |fast - exact| per sample, full scale = 1.0; k * 2^-23 */
 #define GRAIL_FAST_TOLERANCE_ULPS 64
 #define GRAIL_FAST_TOLERANCE (GRAIL_FAST_TOLERANCE_ULPS * 1.1920928955078125e-07f)
+/* fast mode is served for voices whose grail_fast_sharpness() is at most this (predicted deviation, units of 2^-23) */
+#define GRAIL_FAST_SHARPNESS_LIMIT 32.0
 
 /* src/lib.rs:24  NUM_FORMANTS, src/lib.rs:21 DEFAULT_SAMPLE_RATE */
 #define GRAIL_NUM_FORMANTS 8
@@ -232,6 +234,12 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       "time_split_chunks" (0 = auto, 2..64) and "time_split_span_samples" (0 = the batch's longest
  *       utterance) pin the grid; "time_split_ff_cost_permille" (default 165) is the cost of a
  *       fast-forwarded sample against a rendered one, which the spacing of the chunks balances.
+ *   "fast_sharpness_limit" (default GRAIL_FAST_SHARPNESS_LIMIT = 32): fast arithmetic is served for voice tables
+ *       (and caller-built elems) whose grail_fast_sharpness() is at most this; sharper resonances amplify
+ *       rounding-level differences of the filter coefficients beyond GRAIL_FAST_TOLERANCE (the reference's own
+ *       binary32 rendering is then that far from its formulas in double precision), so those are rendered by the
+ *       exact kernels.  Raising the limit trades the tolerance for speed: the deviation grows in proportion
+ *       (profiles/r03_sharpness.txt).  Read-only "fast_arithmetic_served": 1 if the current voice table is below it.
  *   "sort_by_length": 1 (default) / 0 — batches uploaded afterwards whose utterances differ in
  *       length fill the launch slots in order of decreasing length (lanes of a wave run in lockstep:
  *       a wave lasts as long as its longest utterance).  Rows stay where the caller put them.
@@ -258,6 +266,16 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value);
  *   warming up and rendering take every chunk's lane the same time.  GRAIL_ERR_INVALID_ARG when so many chunks
  *   do not fit (a chunk would render fewer than 64 samples). */
 uint32_t grail_time_split_warmup(const grail_voice *voice);
+/* The sharpness of a voice's resonances as the fast kernels see it: the predicted |fast - reference| in units of
+ * 2^-23 of max(1, peak).  Per formant E_i = share_i * (0.0709 / bw_i) * (1 + (f_i / 0.075)^2) — share = the
+ * formant's part of the phoneme's amplitudes, f and bw in cycles per sample, each the worst of the voice's
+ * phonemes — and S = sqrt(sum_i E_i^2) (voices::generic(): 24, measured 13 - 20).  A rounding-level difference of a
+ * filter coefficient (src/lib.rs:555-562) is amplified by the quality and the ring time of the band-pass, in the
+ * reference's own arithmetic as well; the formula is a fit to measurements (profiles/r03_sharpness.txt).
+ * Fast arithmetic is served for voice tables up to GRAIL_FAST_SHARPNESS_LIMIT; sharper tables (and caller-built
+ * elems, judged the same way at upload) are rendered by the exact kernels whatever "arithmetic" says — read-only
+ * option "fast_arithmetic_served" tells.  +inf: a formant outside (0, 0.5) or a bandwidth <= 0. */
+float grail_fast_sharpness(const grail_voice *voice);
 int grail_time_split_grid(uint32_t span_samples, uint32_t warmup, uint32_t chunks, uint32_t ff_cost_permille,
                           uint32_t *bounds);
 

@@ -6,6 +6,8 @@ wraps, saw edges) never moves, so the error is rounding-level everywhere, never 
 The yardstick printed beside it is the reference's own rounding noise: the oracle's binary32
 rendering against the same formulas evaluated in double precision on the same parameter track.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -118,25 +120,35 @@ def test_fast_mode_keeps_every_edge_case_structurally_exact(gpu_ctx):
 
 def test_fast_mode_fuzz_on_random_voice_tables(gpu_ctx):
     """Random (sane) voice tables and segment lists: formants anywhere in (60 Hz, 0.4 fs), bandwidths
-    30-600 Hz, every amplitude pattern, blends from 60 ms to 1 s (also longer than the segment, also
-    not powers of two).  The tolerance holds relative to max(1, peak), no structure moves, and the
-    fast tiles really ran (the guard sends too-fast parameter motion to shorter sub-tiles / exact steps)."""
-    rng = np.random.default_rng(20261002)
+    30-600 Hz (two trials of three: at least frequency / 30, the sharpness of speech formants; the third: any,
+    and what is sharper than the fast kernels keep their tolerance for goes to the exact kernels), every amplitude
+    pattern, blends from 60 ms to 1 s (also longer than the segment, also not powers of two).  The tolerance holds
+    relative to max(1, peak), no structure moves, and the fast tiles really ran (the guard sends too-fast
+    parameter motion to shorter sub-tiles / exact steps)."""
+    # GRAIL_FAST_FUZZ_SEED / GRAIL_FAST_FUZZ_TRIALS: soak runs (tools/fuzz_soak.sh); the default suite stays short
+    rng = np.random.default_rng(int(os.environ.get("GRAIL_FAST_FUZZ_SEED", "20261002")))
     worst = 0.0
     tiles0 = gpu_ctx.get_option("fast_wave_tiles")
-    for trial in range(6):
+    for trial in range(int(os.environ.get("GRAIL_FAST_FUZZ_TRIALS", "6"))):
         voices = []
         centres = [np.exp(rng.uniform(np.log(150.0), np.log(12000.0), 8)) for _ in range(3)]
         for _ in range(3):
             v = G.voice_generic(48000.0)
             for p in range(2):
                 # formant k sits within +-35 % of a centre shared by the voice's two phonemes
-                e = G.elem_new_phoneme(centres[_] * rng.uniform(0.65, 1.35, 8), rng.uniform(30, 600, 8),
+                freq, bw = centres[_] * rng.uniform(0.65, 1.35, 8), rng.uniform(30, 600, 8)
+                if trial % 3 != 2:      # two trials of three: resonances as sharp as speech has them (Q <= 30)
+                    bw = np.maximum(bw, freq / 30.0)
+                e = G.elem_new_phoneme(freq, bw,
                                        rng.uniform(200, 4000, 8), rng.uniform(0, 1, 8), rng.uniform(0, 1, 8),
                                        rng.uniform(0.0, 1, 8) * (rng.uniform(0, 1, 8) > 0.3) + 1e-3)
                 v.phonemes[p] = G.elem_resample(e, 44100.0, 48000.0)
-            voices.append(v)
+            voices.append(v if trial % 3 == 2 else W.tame_voice(v))    # (bandwidths widened until served)
         gpu_ctx.set_voices(voices)
+        # sharper tables are rendered by the exact kernels (include/grail_hip.h, grail_fast_sharpness)
+        served = all(G.fast_sharpness(v) <= G.FAST_SHARPNESS_LIMIT for v in voices)
+        assert gpu_ctx.get_option("fast_arithmetic_served") == int(served)
+        assert served or trial % 3 == 2
         n_utt = 40
         utts = []
         for u in range(n_utt):
@@ -463,21 +475,27 @@ def test_time_split_fuzz_on_random_voice_tables(gpu_ctx):
     from a few hundred to ~8 000 samples, different for every voice of the table, so the lanes of a wave reset
     their filters at different tiles), random segment lists, random chunk grids: lengths are the oracle's and the
     tolerance holds at every seam (relative to max(1, peak))."""
-    rng = np.random.default_rng(31337)
+    rng = np.random.default_rng(int(os.environ.get("GRAIL_FAST_FUZZ_SEED", "31337")))
     worst = 0.0
     try:
-        for trial in range(5):
+        for trial in range(int(os.environ.get("GRAIL_FAST_FUZZ_TRIALS", "5"))):
             voices = []
             for _ in range(3):
                 centre = np.exp(rng.uniform(np.log(150.0), np.log(12000.0), 8))
                 v = G.voice_generic(48000.0)
                 for p in range(2):
-                    e = G.elem_new_phoneme(centre * rng.uniform(0.65, 1.35, 8), rng.uniform(30, 600, 8),
+                    freq, bw = centre * rng.uniform(0.65, 1.35, 8), rng.uniform(30, 600, 8)
+                    if trial % 3 != 2:      # (as in the fuzz of the lane kernels: the third trial is any sharpness)
+                        bw = np.maximum(bw, freq / 30.0)
+                    e = G.elem_new_phoneme(freq, bw,
                                            rng.uniform(200, 4000, 8), rng.uniform(0, 1, 8), rng.uniform(0, 1, 8),
                                            rng.uniform(0.0, 1, 8) * (rng.uniform(0, 1, 8) > 0.3) + 1e-3)
                     v.phonemes[p] = G.elem_resample(e, 44100.0, 48000.0)
-                voices.append(v)
+                voices.append(v if trial % 3 == 2 else W.tame_voice(v))
             gpu_ctx.set_voices(voices)
+            served = all(G.fast_sharpness(v) <= G.FAST_SHARPNESS_LIMIT for v in voices)
+            assert gpu_ctx.get_option("fast_arithmetic_served") == int(served)
+            assert served or trial % 3 == 2
             n_utt = 70
             utts = []
             for u in range(n_utt):
@@ -495,7 +513,7 @@ def test_time_split_fuzz_on_random_voice_tables(gpu_ctx):
             for chunks, span in ((2, 0), (3, int(rng.integers(20000, 70000))), (6, 0)):
                 _split(gpu_ctx, chunks, span)
                 out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
-                assert "SPLIT" in gpu_ctx.last_kernel_name(), gpu_ctx.last_kernel_name()
+                assert ("SPLIT" in gpu_ctx.last_kernel_name()) == served, gpu_ctx.last_kernel_name()
                 assert np.array_equal(out_len, ref_len), (trial, chunks)
                 k = _worst(out, ref, ref_len) / scale
                 worst = max(worst, k)
@@ -717,4 +735,38 @@ def test_host_output_blocks_share_one_kernel_family_in_fast_mode(gpu_ctx):
         assert _worst(a[4200:4240], ref, ref_len) * ULP <= TOL
     finally:
         gpu_ctx.set_option("time_split_span_samples", 0)
+        gpu_ctx.set_voices(W.single_voice())
+
+
+def test_sharp_voices_are_rendered_by_the_exact_kernels(gpu_ctx):
+    """grail_fast_sharpness above "fast_sharpness_limit": "arithmetic" = 1 changes nothing — every batch size, the
+    exact kernels, the oracle's bits; with the limit lifted the fast kernels run (and deviate as predicted)."""
+    v = G.voice_generic(48000.0)
+    for p in range(2):
+        for i in range(8):
+            v.phonemes[p].formant_bw[i] /= 6.0           # 10 - 33 Hz: sharpness ~ 90
+    assert G.fast_sharpness(v) > 2 * G.FAST_SHARPNESS_LIMIT
+    gpu_ctx.set_voices([v])
+    try:
+        assert gpu_ctx.get_option("fast_arithmetic_served") == 0
+        stride = 16384
+        for n in (3, 200):
+            segs, offs, vids, seeds = _ragged_corpus(n, n_voices=1)
+            ref, ref_len = O.synthesize_batch(_ovoices([v]), segs, offs, vids, seeds, stride)
+            out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
+            assert "FAST" not in gpu_ctx.last_kernel_name()
+            assert np.array_equal(out_len, ref_len)
+            assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+        st = gpu_ctx.upload(segs, offs, vids, seeds)
+        gpu_ctx.set_option("fast_sharpness_limit", 1000)
+        assert gpu_ctx.get_option("fast_arithmetic_served") == 1
+        out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
+        assert "FAST" in gpu_ctx.last_kernel_name()
+        assert np.array_equal(out_len, ref_len)
+        k = _worst(out, ref, ref_len) / max(1.0, float(np.abs(ref).max()))
+        print(f"sharpness {G.fast_sharpness(v):.0f}, limit lifted: fast vs reference {k:.1f} * 2^-23")
+        assert 0.0 < k <= 4.0 * G.fast_sharpness(v)
+        st.free()
+    finally:
+        gpu_ctx.set_option("fast_sharpness_limit", int(G.FAST_SHARPNESS_LIMIT))
         gpu_ctx.set_voices(W.single_voice())

@@ -1,4 +1,5 @@
-"""Host logic of the time-split fast kernels (no GPU): the warm-up length of a voice and the chunk grid.
+"""Host logic of the fast kernels (no GPU): the warm-up length of a voice and the chunk grid of the time-split
+kernels, and the sharpness up to which fast arithmetic is served at all.
 
 grail_time_split_warmup / grail_time_split_grid are the functions the library itself plans its launches with
 (grail_api.cpp: voice_warmup, split_grid); here they are checked against a numpy restatement of the filter decay of
@@ -138,3 +139,66 @@ def test_grid_is_what_the_headline_mid_range_launch_uses():
     assert gh.time_split_grid(96064, 3904, 24, 165)[1] > 0.95 * b[1]
     with pytest.raises(gh.GrailError):
         gh.time_split_grid(96064, 3904, 32, 165)
+
+
+# ---- grail_fast_sharpness: which voices fast arithmetic is served for
+
+def sharpness(voice):
+    """include/grail_hip.h: E_i = share_i (0.0709 / bw_i) (1 + (f_i / 0.075)^2), S = sqrt(sum E_i^2)."""
+    n = len(voice.phonemes)
+    amps = np.array([[abs(voice.phonemes[p].formant_amp[i]) for i in range(8)] for p in range(n)], dtype=np.float64)
+    share = (amps / amps.sum(axis=1, keepdims=True)).max(axis=0)
+    f = np.array([[voice.phonemes[p].formant_freq[i] for i in range(8)] for p in range(n)], dtype=np.float64)
+    w = np.array([[voice.phonemes[p].formant_bw[i] for i in range(8)] for p in range(n)], dtype=np.float64)
+    sens = ((0.0709 / w) * (1.0 + (f / 0.075) ** 2)).max(axis=0)
+    return float(np.sqrt(((share * sens)[share > 0] ** 2).sum()))
+
+
+def test_sharpness_of_the_shipped_voices_is_below_the_limit():
+    from grail_hip import workload as W
+    assert 23.0 < gh.fast_sharpness(gh.voice_generic(48000.0)) < 26.0
+    assert 21.0 < gh.fast_sharpness(gh.voice_generic()) < 24.0
+    for v in W.preset_voices(8):
+        assert gh.fast_sharpness(v) <= 0.75 * gh.FAST_SHARPNESS_LIMIT
+
+
+def test_sharpness_is_the_formula_of_the_header():
+    from grail_hip import workload as W
+    for v in [gh.voice_generic(48000.0), gh.voice_generic()] + W.preset_voices(8):
+        assert abs(gh.fast_sharpness(v) - sharpness(v)) < 1e-4 * sharpness(v)
+    last = gh.fast_sharpness(gh.voice_generic(48000.0))
+    for div in (2.0, 4.0, 8.0):
+        w = gh.voice_generic(48000.0)
+        for p in range(2):
+            for i in range(8):
+                w.phonemes[p].formant_bw[i] /= div
+        s = gh.fast_sharpness(w)
+        assert abs(s - sharpness(w)) < 1e-4 * s
+        assert 1.9 * last < s < 2.1 * last                          # goes as 1 / bandwidth
+        last = s
+    assert last > gh.FAST_SHARPNESS_LIMIT                           # bandwidths / 8: exact kernels
+    hi = gh.voice_generic(48000.0)
+    for p in range(2):
+        hi.phonemes[p].formant_freq[0] = 0.3                        # the strongest formant at 14.4 kHz
+    assert gh.fast_sharpness(hi) > 10.0 * gh.fast_sharpness(gh.voice_generic(48000.0))
+
+
+def test_sharpness_ignores_formants_that_are_never_audible_and_rejects_bad_parameters():
+    v = gh.voice_generic(48000.0)
+    base = gh.fast_sharpness(v)
+    for p in range(2):
+        v.phonemes[p].formant_bw[7] = 1e-6          # amplitude 0 in both phonemes: nothing rings
+    assert gh.fast_sharpness(v) == base
+    v.phonemes[0].formant_amp[7] = 0.1              # audible in one phoneme: both phonemes' parameters count
+    assert gh.fast_sharpness(v) > 1000.0
+    v = gh.voice_generic(48000.0)
+    v.phonemes[1].formant_freq[0] = 0.5
+    assert math.isinf(gh.fast_sharpness(v))
+    v = gh.voice_generic(48000.0)
+    v.phonemes[1].formant_bw[2] = 0.0
+    assert math.isinf(gh.fast_sharpness(v))
+    v = gh.voice_generic(48000.0)
+    for p in range(2):
+        for i in range(8):
+            v.phonemes[p].formant_amp[i] = 0.0
+    assert gh.fast_sharpness(v) == 0.0              # a silent voice: whatever arithmetic
