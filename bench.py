@@ -603,6 +603,9 @@ def main():
             "value": samples_per_step * args.steps / f_elapsed, "unit": "samples/s",
             "ms_per_step": f_elapsed * 1e3 / args.steps, "kernel_ms": fk, "kernel": f_symbol,
             "tolerance": G.FAST_TOLERANCE_NOTE,
+            # fast arithmetic is served up to a sharpness of the voices' resonances (grail_fast_sharpness)
+            "voice_sharpness": max(G.fast_sharpness(v) for v in voices), "sharpness_limit": G.FAST_SHARPNESS_LIMIT,
+            "fast_kernels_ran": "FAST" in f_symbol,
             "roofline": {"bound": "hbm", "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": f_ach / HBM_PEAK_GBS,
                          "traffic": f_entry.get("hbm_bytes") if f_entry else None},

@@ -149,4 +149,24 @@ impl Gpu {
         let v = match a { Arithmetic::Exact => 0, Arithmetic::Fast => 1 };
         check(unsafe { sys::grail_set_option(self.ctx, b"arithmetic\0".as_ptr() as *const _, v) })
     }
+
+    /// Whether `Arithmetic::Fast` is served for the current voice table (see [`fast_sharpness`]); sharper
+    /// tables are rendered by the exact kernels whatever `set_arithmetic` says.
+    pub fn fast_arithmetic_served(&self) -> Result<bool, Error> {
+        let mut v = 0i64;
+        check(unsafe { sys::grail_get_option(self.ctx, b"fast_arithmetic_served\0".as_ptr() as *const _, &mut v) })?;
+        Ok(v != 0)
+    }
+}
+
+/// Predicted |fast - reference| of `voice` in units of 2^-23 of max(1, peak) (grail_fast_sharpness): narrow and
+/// high formants amplify rounding-level differences of the filter coefficients.  Fast arithmetic is served up to
+/// GRAIL_FAST_SHARPNESS_LIMIT = 32 (`voices::generic()`: 24).  Pure host function, no GPU.
+pub fn fast_sharpness(voice: &Voice) -> f32 {
+    unsafe { sys::grail_fast_sharpness(&voice_to_c(voice)) }
+}
+
+/// Warm-up length of `voice` for the time-split fast kernels in samples (0: the voice does not qualify).
+pub fn time_split_warmup(voice: &Voice) -> u32 {
+    unsafe { sys::grail_time_split_warmup(&voice_to_c(voice)) }
 }

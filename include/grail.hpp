@@ -46,6 +46,8 @@ inline void check(int status)
 
 namespace voices {
 inline Voice generic() { Voice v; grail_voice_generic(&v); return v; }             // generic.rs:5
+// predicted |fast - reference| of a voice, units of 2^-23 of max(1, peak); served up to GRAIL_FAST_SHARPNESS_LIMIT
+inline float fast_sharpness(const Voice &voice) { return grail_fast_sharpness(&voice); }
 inline Voice generic_at(float sample_rate) { Voice v; grail_voice_generic_at(&v, sample_rate); return v; }
 }  // namespace voices
 
@@ -88,6 +90,14 @@ public:
     // mode (|fast - exact| <= GRAIL_FAST_TOLERANCE; clocks, phases, wraps and noise generators stay exact).
     enum class Arithmetic { Exact = 0, Fast = 1 };
     void set_arithmetic(Arithmetic a) const { check(grail_set_option(ctx_, "arithmetic", (int64_t)a)); }
+    // Fast is served for voice tables up to a sharpness of their resonances (grail_fast_sharpness); sharper tables
+    // are rendered by the exact kernels whatever set_arithmetic says.
+    bool fast_arithmetic_served() const
+    {
+        int64_t v = 0;
+        check(grail_get_option(ctx_, "fast_arithmetic_served", &v));
+        return v != 0;
+    }
 
     // utterances.map(|u| u.phonemes.select(v).sequence(v).jitter(seed, v).synthesize().collect())
     std::vector<std::vector<float>> synthesize(const std::vector<Utterance> &utts) const

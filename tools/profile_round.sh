@@ -33,4 +33,7 @@ python3 tools/ragged_bench.py 131072 1 0 > $out/ragged_131072.txt 2>&1
 python3 tools/fast_soak.py > $out/fast_soak.txt 2>&1
 # every utterance of full-size batches against the oracle (exact mode), one size per kernel family
 ( for n in 65536 16384 4096; do GRAIL_SOAK=1 GRAIL_SOAK_UTTS=$n python3 -m pytest tests/test_full_parity_soak_gpu.py -m gpu -q -s 2>&1 | grep -E "full parity|passed|failed"; done ) > $out/full_parity.txt 2>&1
+# fast mode: which voices it is served for (the sweeps behind grail_fast_sharpness) and the fuzz tests with more seeds
+python3 tools/q_sweep.py > $out/q_sweep.txt 2>&1
+bash tools/fuzz_soak.sh 24 32 12 > $out/fuzz_soak.txt 2>&1
 ls -la $out
