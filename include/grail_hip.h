@@ -26,8 +26,10 @@
  * and are bit-identical to the reference's IEEE-754 binary32 arithmetic
  * (no FMA contraction, correctly rounded division, denormals kept).  That is the
  * default, "arithmetic" = 0.  With grail_set_option(ctx, "arithmetic", 1) the
- * samples are within GRAIL_FAST_TOLERANCE of those bits instead (lengths,
- * segment boundaries, noise wraps and saw edges still exactly the reference's).
+ * samples are within GRAIL_FAST_TOLERANCE x max(1, the utterance's largest
+ * |sample|) of those bits instead (lengths, segment boundaries, noise wraps and
+ * saw edges still exactly the reference's) — for voices up to the sharpness fast
+ * arithmetic is served for (grail_fast_sharpness; sharper ones get the exact bits).
  * Fast-mode samples are a pure function of (the utterance, the kernel family):
  * every lane decides from its own state, so they do not depend on the batch size,
  * the position in the batch or the other utterances of the batch AS LONG AS THE
