@@ -779,3 +779,72 @@ def test_sharp_voices_are_rendered_by_the_exact_kernels(gpu_ctx):
     finally:
         gpu_ctx.set_option("fast_sharpness_limit", int(G.FAST_SHARPNESS_LIMIT))
         gpu_ctx.set_voices(W.single_voice())
+
+
+def test_fast_mode_batch_invariance_fuzz(gpu_ctx):
+    """Batch invariance on random material: random served voice tables (one in three voices without a shared
+    smoothness), random segment lists; the full batch against random sub-batches in random order, bit for bit,
+    for each pinned kernel family — lane kernels L = 1, 2, 4, 8, the time-split kernels on a pinned grid, the
+    scan kernel.  GRAIL_FAST_FUZZ_SEED / GRAIL_FAST_FUZZ_TRIALS as in the other fuzz tests."""
+    rng = np.random.default_rng(int(os.environ.get("GRAIL_FAST_FUZZ_SEED", "424242")))
+    stride = 65536
+    families = [("lanes", 1), ("lanes", 2), ("lanes", 4), ("lanes", 8), ("split", 3), ("scan", 0)]
+    try:
+        for trial in range(int(os.environ.get("GRAIL_FAST_FUZZ_TRIALS", "2"))):
+            voices = []
+            for i in range(3):
+                centre = np.exp(rng.uniform(np.log(150.0), np.log(8000.0), 8))
+                v = G.voice_generic(48000.0)
+                smooth = rng.uniform(200, 4000, 8) if i == 2 else np.full(8, rng.uniform(200, 4000))
+                for p in range(2):
+                    e = G.elem_new_phoneme(centre * rng.uniform(0.8, 1.25, 8), rng.uniform(60, 600, 8), smooth,
+                                           rng.uniform(0, 1, 8), rng.uniform(0, 1, 8),
+                                           rng.uniform(0.0, 1, 8) * (rng.uniform(0, 1, 8) > 0.3) + 1e-3)
+                    v.phonemes[p] = G.elem_resample(e, 44100.0, 48000.0)
+                voices.append(W.tame_voice(v))
+            gpu_ctx.set_voices(voices)
+            assert gpu_ctx.get_option("fast_arithmetic_served") == 1
+            n_utt = 96
+            utts = []
+            for u in range(n_utt):
+                n = int(rng.integers(1, 5))
+                utts.append([(int(rng.choice([G.PH_A, G.PH_E, G.PH_SILENCE])), float(rng.uniform(0.02, 0.3)),
+                              float(rng.choice([0.0625, 0.125, 0.25, 0.5, 0.3, 0.07])),
+                              float(rng.uniform(80, 400) / 48000.0)) for _ in range(n)])
+            vids = rng.integers(0, 3, n_utt).astype(np.uint32)
+            seeds = rng.integers(0, 2 ** 32, n_utt, dtype=np.uint64).astype(np.uint32)
+
+            def batch_of(idx):
+                segs = G.segments([s for u in idx for s in utts[u]])
+                offs = np.cumsum([0] + [len(utts[u]) for u in idx]).astype(np.uint32)
+                return segs, offs, vids[idx].copy(), seeds[idx].copy()
+
+            for kind, arg in families:
+                gpu_ctx.set_option("time_split", 1 if kind == "split" else 0)
+                gpu_ctx.set_option("time_parallel_scan", 1 if kind == "scan" else 0)
+                _split(gpu_ctx, arg if kind == "split" else 0, 49152 if kind == "split" else 0)
+                lanes = arg if kind == "lanes" else 0
+                full, full_len = _render(gpu_ctx, True, *batch_of(np.arange(n_utt)), stride, lanes)
+                name = gpu_ctx.last_kernel_name()
+                if kind == "scan" and "scan" not in name:
+                    continue                      # (the scan kernel's own window may reject a table)
+                assert (name.startswith("synth_kernel") and "SPLIT" in name) == (kind == "split"), name
+                assert ("scan" in name) == (kind == "scan"), name
+                for _ in range(3):
+                    idx = rng.permutation(n_utt)[:int(rng.integers(1, 70))]
+                    part, part_len = _render(gpu_ctx, True, *batch_of(idx), stride, lanes)
+                    # (the instantiation may differ — a sub-batch without odd blend lengths takes the kernel without
+                    # their division — the family may not)
+                    sub = gpu_ctx.last_kernel_name()
+                    assert (sub.startswith("synth_kernel") and "SPLIT" in sub) == (kind == "split"), (name, sub)
+                    assert ("scan" in sub) == (kind == "scan") and "FAST" in sub, (name, sub)
+                    assert np.array_equal(part_len, full_len[idx])
+                    for r, u in enumerate(idx):
+                        m = int(part_len[r])
+                        assert np.array_equal(part[r, :m].view(np.uint32), full[u, :m].view(np.uint32)), \
+                            (trial, kind, arg, r, u, name, sub)
+    finally:
+        gpu_ctx.set_option("time_split", 1)
+        gpu_ctx.set_option("time_parallel_scan", 1)
+        _split(gpu_ctx, 0)
+        gpu_ctx.set_voices(W.single_voice())
