@@ -1081,9 +1081,8 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     // fast arithmetic, few utterances: the machine is mostly idle under the lane-per-utterance mapping;
     // one workgroup per utterance with the time axis across the lanes and the filter recurrences solved by
     // parallel scans (scan_kernels.hip).  Needs every parameter inside the safe window (no IEEE fallback).
-    // (measured crossover against the lane-per-utterance fast kernels: ~9000 utterances with four live
-    // formants, ~5000 with eight — the filter wave then has four formant pairs to go through;
-    // profiles/r02_small_batch.txt)
+    // (it is the fastest path up to ~1 500 utterances with four live formants, ~1 300 with eight; above that the
+    // time-split kernels below are: profiles/r03_small_batch.txt)
     // fast arithmetic, mid-size batches: one lane per utterance would leave most of the machine idle, so the time
     // axis of every utterance is cut into chunks with a lane each (synth_kernel<..., SPLIT>): as many chunks as
     // fill 1024 waves, laid out over the batch's longest utterance so that all lanes finish together
