@@ -139,3 +139,75 @@ def test_random_batches_four_formant_path(gpu_ctx, seed):
                                       ref[u, :ref_len[u]].view(np.uint32)), (lanes, u)
     finally:
         gpu_ctx.set_option("lanes_per_utterance", 0)
+
+
+def pow2_blend_batch(rng, n_utt, n_voices):
+    """Random utterances whose blend lengths are powers of two (what the pipelined workgroups take)."""
+    segs, offs, vids, seeds = [], [0], [], []
+    for _ in range(n_utt):
+        for _ in range(int(rng.integers(0, 6))):
+            ph = int(rng.choice([G.PH_SILENCE, G.PH_STOP, G.PH_GLIDE, G.PH_A, G.PH_E], p=[.15, .05, .05, .4, .35]))
+            length = float(rng.choice([rng.uniform(0.0005, 0.03), 2.0 ** -int(rng.integers(5, 9)), 2.0 / 48000.0]))
+            segs.append((ph, length, 2.0 ** -int(rng.integers(4, 11)), np.float32(rng.uniform(60, 400)) / np.float32(48000.0)))
+        offs.append(len(segs))
+        vids.append(int(rng.integers(0, n_voices)))
+        seeds.append(int(rng.integers(0, 2 ** 32)))
+    return (G.segments(segs),) + tuple(np.array(a, dtype=np.uint32) for a in (offs, vids, seeds))
+
+
+@pytest.mark.parametrize("seed", [31, 32] + EXTRA_SEEDS)
+def test_random_batches_eight_formant_pipeline(gpu_ctx, seed):
+    """Random voice tables with all eight formants live and power-of-two blends: the pipelined workgroups with
+    eight utterances each, rounds of 32 and of 16 samples, against the oracle bit for bit."""
+    from test_oracle_crosscheck import random_voice
+    rng = np.random.default_rng(seed)
+    ovoices = [random_voice(rng, 48000.0) for _ in range(4)]
+    for v in ovoices:                     # (random_voice zeroes some amplitudes: keep the eight-formant path)
+        for p in range(2):
+            v.phonemes[p].formant_amp.v[7] = max(float(v.phonemes[p].formant_amp.v[7]), 0.01)
+    voices = [G.Voice.from_buffer_copy(bytes(v)) for v in ovoices]
+    gpu_ctx.set_voices(voices)
+    segs, offs, vids, seeds = pow2_blend_batch(rng, 75, len(voices))
+    stride = 10048
+    ref, ref_len = O.synthesize_batch(ovoices, segs, offs, vids, seeds, stride)
+    assert ref_len.max() < stride
+    try:
+        for round32 in (1, 0):
+            gpu_ctx.set_option("pipeline_round32", round32)
+            out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+            assert gpu_ctx.get_option("last_launch_pipelined") == 1 and gpu_ctx.get_option("last_launch_formants") == 8
+            assert ("R32" if round32 else "R16") in gpu_ctx.last_kernel_name()
+            assert np.array_equal(out_len, ref_len), round32
+            for u in range(len(ref_len)):
+                assert np.array_equal(out[u, :ref_len[u]].view(np.uint32),
+                                      ref[u, :ref_len[u]].view(np.uint32)), (round32, u)
+    finally:
+        gpu_ctx.set_option("pipeline_round32", 1)
+
+
+@pytest.mark.parametrize("seed", [41, 42] + EXTRA_SEEDS)
+def test_random_batches_streamed_in_random_chunks(gpu_ctx, seed):
+    """grail_stream_*: the random batches pulled in chunks of random sizes (1 .. 3000 samples, a new size every
+    call), every lane mapping: the concatenation is the oracle's rendering bit for bit."""
+    from test_stream_gpu import stream_all
+    rng = np.random.default_rng(seed)
+    voices = W.preset_voices(8) if seed % 2 else [G.voice_generic(48000.0), G.voice_generic(44100.0)]
+    gpu_ctx.set_voices(voices)
+    segs, offs, vids, seeds = random_batch(rng, 60, len(voices), 48000.0)
+    ov = [O.Voice.from_buffer_copy(bytes(v)) for v in voices]
+    ref, ref_len = O.synthesize_batch(ov, segs, offs, vids, seeds, 10048)
+    try:
+        for lanes in (0, 1, 2, 4, 8):
+            gpu_ctx.set_option("lanes_per_utterance", lanes)
+            chunks = [int(c) for c in rng.choice([1, 2, 63, 64, 65, 500, 1024, 3000], 24)] + \
+                     [int(c) for c in rng.integers(1, 3001, 24)]
+            b = gpu_ctx.upload(segs, offs, vids, seeds)
+            try:
+                got = stream_all(gpu_ctx, b, len(ref_len), chunks, stride=3008)
+            finally:
+                b.free()
+            for u in range(len(ref_len)):
+                assert len(got[u]) == ref_len[u], (lanes, u)
+                assert np.array_equal(got[u].view(np.uint32), ref[u, :ref_len[u]].view(np.uint32)), (lanes, u)
+    finally:
+        gpu_ctx.set_option("lanes_per_utterance", 0)
