@@ -2,8 +2,9 @@
 samples — against the oracle, through per-utterance checksums (sum of the samples' bit patterns
 mod 2^64, computed on the device for the HIP rows and on the host for the oracle's).  The oracle
 renders the batch in chunks on all host cores; a few minutes of CPU, so it is not part of the
-default suite.  GRAIL_SOAK_UTTS picks another batch size (another kernel family).  Last runs:
-profiles/r02_full_parity.txt."""
+default suite.  GRAIL_SOAK_UTTS picks another batch size (another kernel family), GRAIL_SOAK_FIRST the first
+utterance of the synthetic corpus (k * 65536: shard k of BASELINE config 5, what rank k of an 8-GPU run renders).
+Last runs: profiles/r03_full_parity.txt."""
 import os
 
 import numpy as np
@@ -23,7 +24,8 @@ def test_every_utterance_of_the_full_batch(gpu_ctx, n_voices):
     voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
     ov = [O.Voice.from_buffer_copy(bytes(v)) for v in voices]
     gpu_ctx.set_voices(voices)
-    segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=n_voices)
+    first_utt = int(os.environ.get("GRAIL_SOAK_FIRST", "0"))
+    segs, offs, vids, seeds = W.make_batch(n_utt, first_utt=first_utt, n_voices=n_voices)
     stride = W.max_samples()
     b = gpu_ctx.upload(segs, offs, vids, seeds)
     d_out = gpu_ctx.device_alloc(n_utt * stride * 4)
@@ -55,5 +57,5 @@ def test_every_utterance_of_the_full_batch(gpu_ctx, n_voices):
         bad_rows = np.nonzero(want != sums[first:last])[0]
         assert len(bad_rows) == 0, (first, bad_rows[:8])
         checked += int(ref_len.astype(np.uint64).sum())
-    print(f"\nfull parity: {n_utt} utterances, {checked} samples, {n_voices} voice(s): "
+    print(f"\nfull parity: utterances {first_utt} .. {first_utt + n_utt}, {checked} samples, {n_voices} voice(s): "
           f"every per-utterance checksum equals the oracle's")

@@ -30,7 +30,7 @@ python3 tools/ragged_bench.py 131072 1 0 > $out/ragged_131072.txt 2>&1
     bash tools/pmc.sh sq1 "$cfg --steps 1 --warmup 0 --fast-leg 0 --ramp 0" SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY
     bash tools/pmc.sh sq2 "$cfg --steps 1 --warmup 0 --fast-leg 0 --ramp 0" SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INST_CYCLES_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS
   done ) > $out/pmc_sq.txt 2>&1
-python3 tools/fast_soak.py > $out/fast_soak.txt 2>&1
+python3 tools/fast_soak.py --shards > $out/fast_soak.txt 2>&1
 # every utterance of full-size batches against the oracle (exact mode), one size per kernel family
 ( for n in 65536 16384 4096; do GRAIL_SOAK=1 GRAIL_SOAK_UTTS=$n python3 -m pytest tests/test_full_parity_soak_gpu.py -m gpu -q -s 2>&1 | grep -E "full parity|passed|failed"; done ) > $out/full_parity.txt 2>&1
 # fast mode: which voices it is served for (the sweeps behind grail_fast_sharpness) and the fuzz tests with more seeds
