@@ -794,13 +794,14 @@ def test_fast_mode_batch_invariance_fuzz(gpu_ctx):
             voices = []
             for i in range(3):
                 centre = np.exp(rng.uniform(np.log(150.0), np.log(8000.0), 8))
-                v = G.voice_generic(48000.0)
+                rate = 44100.0 if (i == 1 and trial % 2) else 48000.0      # (odd trials: two sample rates in the table)
+                v = G.voice_generic(rate)
                 smooth = rng.uniform(200, 4000, 8) if i == 2 else np.full(8, rng.uniform(200, 4000))
                 for p in range(2):
                     e = G.elem_new_phoneme(centre * rng.uniform(0.8, 1.25, 8), rng.uniform(60, 600, 8), smooth,
                                            rng.uniform(0, 1, 8), rng.uniform(0, 1, 8),
                                            rng.uniform(0.0, 1, 8) * (rng.uniform(0, 1, 8) > 0.3) + 1e-3)
-                    v.phonemes[p] = G.elem_resample(e, 44100.0, 48000.0)
+                    v.phonemes[p] = G.elem_resample(e, 44100.0, rate)
                 voices.append(W.tame_voice(v))
             gpu_ctx.set_voices(voices)
             assert gpu_ctx.get_option("fast_arithmetic_served") == 1
@@ -813,6 +814,9 @@ def test_fast_mode_batch_invariance_fuzz(gpu_ctx):
                               float(rng.uniform(80, 400) / 48000.0)) for _ in range(n)])
             vids = rng.integers(0, 3, n_utt).astype(np.uint32)
             seeds = rng.integers(0, 2 ** 32, n_utt, dtype=np.uint64).astype(np.uint32)
+            # ... and the rows are the oracle's within the tolerance (both rates, every family below)
+            ref, ref_len = O.synthesize_batch(_ovoices(voices), G.segments([s for u in utts for s in u]),
+                                              np.cumsum([0] + [len(u) for u in utts]).astype(np.uint32), vids, seeds, stride)
 
             def batch_of(idx):
                 segs = G.segments([s for u in idx for s in utts[u]])
@@ -830,6 +834,8 @@ def test_fast_mode_batch_invariance_fuzz(gpu_ctx):
                     continue                      # (the scan kernel's own window may reject a table)
                 assert (name.startswith("synth_kernel") and "SPLIT" in name) == (kind == "split"), name
                 assert ("scan" in name) == (kind == "scan"), name
+                assert np.array_equal(full_len, ref_len), (trial, kind, arg)
+                assert _worst_rel(full, ref, ref_len) * ULP <= TOL, (trial, kind, arg)
                 for _ in range(3):
                     idx = rng.permutation(n_utt)[:int(rng.integers(1, 70))]
                     part, part_len = _render(gpu_ctx, True, *batch_of(idx), stride, lanes)
