@@ -25,6 +25,8 @@ WORKLOADS = [   # key (as bench.py builds it), bench arguments
     ("config2_utts4096", ["--config", "2", "--mode", "exact"]),
     ("config2_utts4096_fast", ["--config", "2", "--mode", "fast"]),
     ("config3_utts65536_pcm16", ["--config", "3", "--mode", "exact", "--pcm16"]),
+    # the regime the time-parallel scan kernel still serves (fast arithmetic, up to 1 536 utterances)
+    ("config3_utts1024_fast", ["--utts", "1024", "--mode", "fast"]),
 ]
 PASSES = [["WRITE_SIZE"], ["FETCH_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_BUSY_CYCLES"]]
 COMMON = ["--fast-leg", "0", "--cpu-utts", "0", "--steps", "2", "--warmup", "0", "--ramp", "0"]
