@@ -274,7 +274,9 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
                     if (uni(cap32 - n_out >= (uint32_t)TL)) {
                         if (uni(c_reg)) {
                             cj = __builtin_fmaf(lane_p1, c_q, clk);
-                            c_ok = __builtin_amdgcn_ballot_w64((__float_as_uint(cj) >> 23) == c_e2) == ~0ull;
+                            // (inside the binade: its lowest value 2^e itself is not — see `extend`)
+                            c_ok = __builtin_amdgcn_ballot_w64((__float_as_uint(cj) >> 23) == c_e2 &&
+                                                               (__float_as_uint(cj) & 0x7FFFFFu) != 0u) == ~0ull;
                         }
                         if (uni(j_reg)) {
                             pj = __builtin_fmaf(lane_p1, j_q, jphase);
@@ -369,7 +371,14 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
                             const float ulp = __uint_as_float(e2 > 23u ? (e2 - 23u) << 23 : 0u);
                             const bool regular = (__builtin_fabsf(step_ - q) != 0.5f * ulp) && e2 > 24u &&
                                                  (!need_same_start || (__float_as_uint(v1) >> 23) == e2);
-                            const bool good = lane < nv || rel <= 1 || (regular && (__float_as_uint(cand) >> 23) == e2);
+                            // A falling sequence that lands exactly on 2^e has left the binade: the exact difference lies
+                            // just below 2^e, where the grid is twice as fine, and rounds to a value there (the quantum was
+                            // rounded to the coarse grid above) — 0x3d000000 instead of 0x3cffffff, one segment in a few
+                            // hundred; the wrong clock moved alpha and with it the pitch of a blend by an ulp, and the
+                            // carrier phase drifted by 1e-6 (found by tools/fuzz_soak.sh, round 3).
+                            const bool inside = (__float_as_uint(cand) >> 23) == e2 &&
+                                                (step_ > 0.0f || (__float_as_uint(cand) & 0x7FFFFFu) != 0u);
+                            const bool good = lane < nv || rel <= 1 || (regular && inside);
                             v = lane >= nv ? cand : v;
                             const uint64_t bad_ = ~__builtin_amdgcn_ballot_w64(good);
                             const int nv_before = nv;
@@ -401,7 +410,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
                         // binades (a tile cut short may end in the binade before) and the phase binade is below one
                         const float c_last = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cj), n - 1));
                         const float j_last = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pj), n - 1));
-                        c_reg = c_reg && (__float_as_uint(c_last) >> 23) == c_e2;
+                        c_reg = c_reg && (__float_as_uint(c_last) >> 23) == c_e2 && (__float_as_uint(c_last) & 0x7FFFFFu) != 0u;
                         j_reg = j_reg && (__float_as_uint(j_last) >> 23) == j_e2 && j_e2 < 127u;
                     }
                     // ---- per lane: alpha, the pitch (exact: :404-414, :254, :763)
@@ -415,7 +424,11 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
                     const float n_freq = fn_cur * jomp + fn_next * pj;
                     frequency = frequency + n_freq * d_freq;
                     // lanes >= n write beyond the tile: the next tile overwrites them, or nobody reads them
+#ifdef GRAIL_SCAN_DEBUG
+                    ti.alpha[S + lane] = A.resume == 9 ? cj : alpha;        // development probe 9: the clock itself
+#else
                     ti.alpha[S + lane] = alpha;
+#endif
                     ti.jp[S + lane] = pj;
                     if constexpr (SPLIT) {
                         ti.saw[S + lane] = frequency;                           // the phase wave turns it into the saw
@@ -679,7 +692,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
             if (A.resume && A.resume < 200 && p == 0) {   // development aid ("scan_debug" option): a chain quantity instead of the audio
 #pragma unroll
                 for (int k = 0; k < CK; ++k) {
-                    const float dv = A.resume == 1 ? ti.alpha[CK * lane + k] : A.resume == 2 ? ti.jp[CK * lane + k] :
+                    const float dv = (A.resume == 1 || A.resume == 9) ? ti.alpha[CK * lane + k] : A.resume == 2 ? ti.jp[CK * lane + k] :
                                      A.resume == 3 ? ti.saw[CK * lane + k] : A.resume == 4 ? ti.nz[CK * lane + k] :
                                      A.resume == 5 ? A1[k].x : A.resume == 6 ? TG[k].x : PW[k].x;
                     y[k] = 2.0f * dv;

@@ -854,3 +854,46 @@ def test_fast_mode_batch_invariance_fuzz(gpu_ctx):
         gpu_ctx.set_option("time_parallel_scan", 1)
         _split(gpu_ctx, 0)
         gpu_ctx.set_voices(W.single_voice())
+
+
+@pytest.mark.parametrize("blend,seed", [(0.02, 79), (0.011, 80)])
+def test_scan_kernel_clock_across_binade_boundaries(gpu_ctx, blend, seed):
+    """The scan kernel's closed-form Sequencer clock (csrc/scan_kernels.hip, `extend`): a falling clock that lands
+    exactly on a power of two has left the binade above it — the exact difference rounds on the finer grid below.
+    Taking it for a member of the upper binade put the clock off by an ulp for the rest of the segment, one
+    segment in a few hundred; alpha, the pitch of a blend and from there the carrier phase followed (a saw 6e-4
+    off at its edges).  1 500 utterances of random segment lengths with short blends between distant pitches,
+    fast (scan kernel) against exact rows on the device: 222 / 235 * 2^-23 before the fix, below 10 after."""
+    rng = np.random.default_rng(seed)
+    n_utt = 1500
+    gpu_ctx.set_voices(W.single_voice())
+    segs, offs, vids, seeds = W.make_batch(n_utt)
+    k = len(segs)
+    segs["length"] = rng.uniform(0.03, 0.3 if blend == 0.02 else 0.2, k).astype(np.float32)
+    segs["blend_length"] = np.float32(blend)
+    segs["frequency"] = (np.where(np.arange(k) % 2 == 0, 70.0, 400.0) / 48000.0).astype(np.float32)
+    segs["phoneme"] = np.where(np.arange(k) % 4 == 0, G.PH_SILENCE, G.PH_A)
+    stride = 4 * 14400 + 64
+    b = gpu_ctx.upload(segs, offs, vids, seeds)
+    d = [gpu_ctx.device_alloc(n_utt * stride * 4) for _ in range(2)]
+    dl = [gpu_ctx.device_alloc(n_utt * 4) for _ in range(2)]
+    try:
+        gpu_ctx.set_option("time_split", 0)
+        gpu_ctx.set_option("arithmetic", 0)
+        b.synthesize_async(d[0], stride, dl[0])
+        gpu_ctx.sync()
+        gpu_ctx.set_option("arithmetic", 1)
+        b.synthesize_async(d[1], stride, dl[1])
+        gpu_ctx.sync()
+        assert "scan" in gpu_ctx.last_kernel_name()
+        md, sq, bad = gpu_ctx.compare(d[0], d[1], stride, dl[0], dl[1], n_utt)
+        assert int(bad.sum()) == 0
+        worst = float(md.max()) / ULP
+        print(f"scan kernel, 1500 utterances with pitch jumps: worst |fast - exact| {worst:.1f} * 2^-23")
+        assert worst <= 32.0
+    finally:
+        gpu_ctx.set_option("arithmetic", 0)
+        gpu_ctx.set_option("time_split", 1)
+        for x in d + dl:
+            gpu_ctx.device_free(x)
+        b.free()
