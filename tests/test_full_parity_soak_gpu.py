@@ -27,12 +27,23 @@ def test_every_utterance_of_the_full_batch(gpu_ctx, n_voices):
     first_utt = int(os.environ.get("GRAIL_SOAK_FIRST", "0"))
     segs, offs, vids, seeds = W.make_batch(n_utt, first_utt=first_utt, n_voices=n_voices)
     stride = W.max_samples()
+    if os.environ.get("GRAIL_SOAK_RANDOM"):
+        # another structure than the bench corpus': random segment lengths, one blend length (GRAIL_SOAK_BLEND, a power
+        # of two keeps the pipelined workgroups in play), pitches jumping between 70 and 400 Hz, Silence / A / E at random
+        rng = np.random.default_rng(int(os.environ["GRAIL_SOAK_RANDOM"]))
+        k = len(segs)
+        segs["length"] = rng.uniform(0.03, 0.3, k).astype(np.float32)
+        segs["blend_length"] = np.float32(float(os.environ.get("GRAIL_SOAK_BLEND", "0.0625")))
+        segs["frequency"] = (rng.choice([70.0, 110.0, 200.0, 400.0], k) / 48000.0).astype(np.float32)
+        segs["phoneme"] = rng.choice([G.PH_SILENCE, G.PH_A, G.PH_E, G.PH_A], k)
+        stride = 4 * 14400 + 64
     b = gpu_ctx.upload(segs, offs, vids, seeds)
     d_out = gpu_ctx.device_alloc(n_utt * stride * 4)
     d_len = gpu_ctx.device_alloc(n_utt * 4)
     try:
         b.synthesize_async(d_out, stride, d_len)
         gpu_ctx.sync()
+        kernel = gpu_ctx.last_kernel_name()
         out_len = np.zeros(n_utt, dtype=np.uint32)
         gpu_ctx.d2h(out_len, d_len, n_utt * 4)
         sums, _, bad = gpu_ctx.digest(d_out, stride, d_len, n_utt)
@@ -58,4 +69,4 @@ def test_every_utterance_of_the_full_batch(gpu_ctx, n_voices):
         assert len(bad_rows) == 0, (first, bad_rows[:8])
         checked += int(ref_len.astype(np.uint64).sum())
     print(f"\nfull parity: utterances {first_utt} .. {first_utt + n_utt}, {checked} samples, {n_voices} voice(s): "
-          f"every per-utterance checksum equals the oracle's")
+          f"every per-utterance checksum equals the oracle's  [{kernel}]")
