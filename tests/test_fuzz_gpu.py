@@ -209,5 +209,86 @@ def test_random_batches_streamed_in_random_chunks(gpu_ctx, seed):
             for u in range(len(ref_len)):
                 assert len(got[u]) == ref_len[u], (lanes, u)
                 assert np.array_equal(got[u].view(np.uint32), ref[u, :ref_len[u]].view(np.uint32)), (lanes, u)
+        # the same in fast arithmetic: the lengths are the oracle's, every sample within the tolerance
+        gpu_ctx.set_option("arithmetic", 1)
+        for lanes in (0, 1, 4):
+            gpu_ctx.set_option("lanes_per_utterance", lanes)
+            chunks = [int(c) for c in rng.integers(1, 3001, 32)]
+            b = gpu_ctx.upload(segs, offs, vids, seeds)
+            try:
+                got = stream_all(gpu_ctx, b, len(ref_len), chunks, stride=3008)
+            finally:
+                b.free()
+            for u in range(len(ref_len)):
+                assert len(got[u]) == ref_len[u], (lanes, u)
+                if ref_len[u]:
+                    want = ref[u, :ref_len[u]]
+                    d = float(np.abs(got[u].astype(np.float64) - want).max())
+                    assert d <= G.FAST_TOLERANCE * max(1.0, float(np.abs(want).max())), (lanes, u, d * 2.0 ** 23)
     finally:
+        gpu_ctx.set_option("arithmetic", 0)
+        gpu_ctx.set_option("lanes_per_utterance", 0)
+
+
+def random_sequence_elems(rng, n_utt, tame):
+    """Caller-built SequenceElems, every segment with an elem of its own (blends between arbitrary parameter sets).
+    tame: resonances fast arithmetic is served for (formants below 0.06 fs, bandwidths of 0.006 fs and more: the
+    sharpness of a batch of elems takes the worst of every formant over all of them)."""
+    gsegs, osegs, offs = [], [], [0]
+    for _ in range(n_utt):
+        for _ in range(int(rng.integers(0, 6))):
+            has = bool(rng.integers(0, 5))
+            e = np.zeros(49, dtype=np.float32)
+            e[0] = rng.uniform(0.0015, 0.009)
+            e[1:9] = rng.uniform(0.004, 0.06 if tame else 0.3, 8)
+            e[9:17] = rng.uniform(0.006, 0.02, 8) if tame else rng.uniform(0.002, 0.012, 8)
+            e[17:25] = rng.uniform(0.01, 0.1) if rng.integers(0, 2) else rng.uniform(0.01, 0.1, 8)
+            e[25:33] = rng.uniform(0, 1, 8)
+            e[33:41] = rng.uniform(0, 1, 8)
+            amp = rng.uniform(0, 1, 8) * (rng.uniform(0, 1, 8) > 0.25)
+            e[41:49] = amp / max(float(amp.sum()), 1e-3)
+            ln = float(rng.choice([rng.uniform(0.002, 0.05), 2.0 ** -int(rng.integers(5, 8))]))
+            bl = float(rng.choice([rng.uniform(0.002, 0.05), 2.0 ** -int(rng.integers(5, 9))]))
+            gsegs.append(G.SequenceElem(int(has), G.SynthesisElem.from_np(e), ln, bl))
+            osegs.append(O.SequenceElem(int(has), O.SynthesisElem.from_buffer_copy(e.tobytes()), ln, bl))
+        offs.append(len(gsegs))
+    return gsegs, osegs, offs
+
+
+@pytest.mark.parametrize("seed", [51, 52] + EXTRA_SEEDS)
+def test_random_sequence_elems_both_arithmetics(gpu_ctx, seed):
+    """grail_synthesize_batch_elems on random caller-built elems: exact arithmetic bit for bit for every lane
+    mapping; fast arithmetic within the tolerance (even seeds: tame elems, the fast kernels run; odd seeds: any,
+    and what is too sharp for them is rendered by the exact kernels)."""
+    rng = np.random.default_rng(seed)
+    tame = seed % 2 == 0
+    v = G.voice_generic(48000.0)
+    gpu_ctx.set_voices([v])
+    ov = O.Voice.from_buffer_copy(bytes(v))
+    n_utt = 60
+    gsegs, osegs, offs = random_sequence_elems(rng, n_utt, tame)
+    seeds = rng.integers(0, 2 ** 32, n_utt, dtype=np.uint64).astype(np.uint32)
+    refs = [O.synthesize_sequence(ov, osegs[offs[u]:offs[u + 1]], int(seeds[u])) for u in range(n_utt)]
+    stride = max(max(len(r) for r in refs) + 64, 64)
+    try:
+        for lanes in (0, 1, 2, 4, 8):
+            gpu_ctx.set_option("lanes_per_utterance", lanes)
+            out, out_len = gpu_ctx.synthesize_elems(gsegs, offs, None, seeds, out_stride=stride)
+            for u in range(n_utt):
+                assert out_len[u] == len(refs[u]), (lanes, u)
+                assert np.array_equal(out[u, :len(refs[u])].view(np.uint32), refs[u].view(np.uint32)), (lanes, u)
+        gpu_ctx.set_option("arithmetic", 1)
+        ran_fast = False
+        for lanes in (0, 1, 4):
+            gpu_ctx.set_option("lanes_per_utterance", lanes)
+            out, out_len = gpu_ctx.synthesize_elems(gsegs, offs, None, seeds, out_stride=stride)
+            ran_fast = ran_fast or "FAST" in gpu_ctx.last_kernel_name()
+            for u in range(n_utt):
+                assert out_len[u] == len(refs[u]), (lanes, u)
+                if len(refs[u]):
+                    d = float(np.abs(out[u, :len(refs[u])].astype(np.float64) - refs[u]).max())
+                    assert d <= G.FAST_TOLERANCE * max(1.0, float(np.abs(refs[u]).max())), (lanes, u, d * 2.0 ** 23)
+        assert ran_fast or not tame
+    finally:
+        gpu_ctx.set_option("arithmetic", 0)
         gpu_ctx.set_option("lanes_per_utterance", 0)
