@@ -292,3 +292,52 @@ def test_random_sequence_elems_both_arithmetics(gpu_ctx, seed):
     finally:
         gpu_ctx.set_option("arithmetic", 0)
         gpu_ctx.set_option("lanes_per_utterance", 0)
+
+
+@pytest.mark.parametrize("seed", [61, 62] + EXTRA_SEEDS)
+def test_random_row_capacities(gpu_ctx, seed):
+    """Rows too short for some utterances, aligned to 64 samples and not: every kernel family reports the cut
+    (GRAIL_ERR_BUFFER_TOO_SMALL), stores min(length, capacity) samples per row and those are the reference's —
+    bit for bit in exact arithmetic, within the tolerance in fast arithmetic (lane kernels, scan kernel, time-split
+    kernels: there the lane of the chunk the capacity falls into ends the row)."""
+    rng = np.random.default_rng(seed)
+    voices = W.preset_voices(8) if seed % 2 else W.single_voice()
+    gpu_ctx.set_voices(voices)
+    n_utt = 90
+    segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=len(voices))
+    k = len(segs)
+    segs["length"] = rng.uniform(0.01, 0.12, k).astype(np.float32)
+    segs["blend_length"] = rng.choice([0.03125, 0.0625, 0.02, 0.05], k).astype(np.float32)
+    ov = [O.Voice.from_buffer_copy(bytes(v)) for v in voices]
+    ref, ref_len = O.synthesize_batch(ov, segs, offs, vids, seeds, 4 * 5760 + 64)
+    assert ref_len.max() > 12000
+    try:
+        for cap in (int(rng.integers(3000, 12000)) // 64 * 64, int(rng.integers(3000, 12000)) | 1, int(rng.integers(40, 900))):
+            want_len = np.minimum(ref_len, cap).astype(np.uint32)
+            cut = bool((ref_len > cap).any())
+            for fast, opts in ((0, {"lanes_per_utterance": 0}), (0, {"lanes_per_utterance": 1}), (0, {"lanes_per_utterance": 4}),
+                               (0, {"lanes_per_utterance": 8}), (1, {"lanes_per_utterance": 1}), (1, {"lanes_per_utterance": 4}),
+                               (1, {"time_split": 0}), (1, {"time_split_chunks": 3})):
+                gpu_ctx.set_option("arithmetic", fast)
+                for name, val in opts.items():
+                    gpu_ctx.set_option(name, val)
+                if cut:
+                    with pytest.raises(G.GrailError) as ei:
+                        gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=cap)
+                    assert ei.value.status == G.ERR_BUFFER_TOO_SMALL, (cap, fast, opts)
+                out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=cap, allow_truncation=True)
+                kernel = gpu_ctx.last_kernel_name()
+                for name in opts:
+                    gpu_ctx.set_option(name, 1 if name == "time_split" else 0)
+                assert np.array_equal(out_len, want_len), (cap, fast, opts, kernel)
+                for u in range(n_utt):
+                    n = int(want_len[u])
+                    if fast == 0:
+                        assert np.array_equal(out[u, :n].view(np.uint32), ref[u, :n].view(np.uint32)), (cap, opts, kernel, u)
+                    elif n:
+                        d = float(np.abs(out[u, :n].astype(np.float64) - ref[u, :n]).max())
+                        assert d <= G.FAST_TOLERANCE * max(1.0, float(np.abs(ref[u, :n]).max())), (cap, opts, kernel, u, d * 2 ** 23)
+    finally:
+        gpu_ctx.set_option("arithmetic", 0)
+        for name, val in (("lanes_per_utterance", 0), ("time_split", 1), ("time_split_chunks", 0)):
+            gpu_ctx.set_option(name, val)
