@@ -394,7 +394,8 @@ uint32_t voice_warmup(const grail_voice &v)
 // which, scaled as it is, lies above 99.5 % of the random tables' measured deviations and within a factor 1.45
 // below the rest; voices::generic() has S = 24 (measured 13 - 20), the bench presets 20 - 22 (11 - 20).
 // GRAIL_FAST_TOLERANCE = 64 * 2^-23 is therefore a promise the fast kernels can keep only up to a sharpness: the
-// host serves fast arithmetic for S <= GRAIL_FAST_SHARPNESS_LIMIT = 32 (worst measured among those: 31) and
+// host serves fast arithmetic for S <= GRAIL_FAST_SHARPNESS_LIMIT = 28 (worst measured among those, 3 000 random tables:
+// 24; at 32 one table in 3 000 reached 56) and
 // renders sharper tables with the exact kernels (their bits satisfy the tolerance trivially).
 // Returns S in units of 2^-23 of max(1, peak); +inf for parameters outside the window of the formulas.
 double elems_sharpness(const grail_synthesis_elem *elems, size_t n)

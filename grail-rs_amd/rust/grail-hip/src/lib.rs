@@ -161,7 +161,7 @@ impl Gpu {
 
 /// Predicted |fast - reference| of `voice` in units of 2^-23 of max(1, peak) (grail_fast_sharpness): narrow and
 /// high formants amplify rounding-level differences of the filter coefficients.  Fast arithmetic is served up to
-/// GRAIL_FAST_SHARPNESS_LIMIT = 32 (`voices::generic()`: 24).  Pure host function, no GPU.
+/// GRAIL_FAST_SHARPNESS_LIMIT = 28 (`voices::generic()`: 24).  Pure host function, no GPU.
 pub fn fast_sharpness(voice: &Voice) -> f32 {
     unsafe { sys::grail_fast_sharpness(&voice_to_c(voice)) }
 }

@@ -63,7 +63,7 @@ extern "C" {
 #define GRAIL_FAST_TOLERANCE_ULPS 64
 #define GRAIL_FAST_TOLERANCE (GRAIL_FAST_TOLERANCE_ULPS * 1.1920928955078125e-07f)
 /* fast mode is served for voices whose grail_fast_sharpness() is at most this (predicted deviation, units of 2^-23) */
-#define GRAIL_FAST_SHARPNESS_LIMIT 32.0
+#define GRAIL_FAST_SHARPNESS_LIMIT 28.0
 
 /* src/lib.rs:24  NUM_FORMANTS, src/lib.rs:21 DEFAULT_SAMPLE_RATE */
 #define GRAIL_NUM_FORMANTS 8
@@ -236,7 +236,7 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       "time_split_chunks" (0 = auto, 2..64) and "time_split_span_samples" (0 = the batch's longest
  *       utterance) pin the grid; "time_split_ff_cost_permille" (default 165) is the cost of a
  *       fast-forwarded sample against a rendered one, which the spacing of the chunks balances.
- *   "fast_sharpness_limit" (default GRAIL_FAST_SHARPNESS_LIMIT = 32): fast arithmetic is served for voice tables
+ *   "fast_sharpness_limit" (default GRAIL_FAST_SHARPNESS_LIMIT = 28): fast arithmetic is served for voice tables
  *       (and caller-built elems) whose grail_fast_sharpness() is at most this; sharper resonances amplify
  *       rounding-level differences of the filter coefficients beyond GRAIL_FAST_TOLERANCE (the reference's own
  *       binary32 rendering is then that far from its formulas in double precision), so those are rendered by the

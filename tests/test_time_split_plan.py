@@ -159,7 +159,7 @@ def test_sharpness_of_the_shipped_voices_is_below_the_limit():
     assert 23.0 < gh.fast_sharpness(gh.voice_generic(48000.0)) < 26.0
     assert 21.0 < gh.fast_sharpness(gh.voice_generic()) < 24.0
     for v in W.preset_voices(8):
-        assert gh.fast_sharpness(v) <= 0.75 * gh.FAST_SHARPNESS_LIMIT
+        assert gh.fast_sharpness(v) <= 0.8 * gh.FAST_SHARPNESS_LIMIT
 
 
 def test_sharpness_is_the_formula_of_the_header():

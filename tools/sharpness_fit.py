@@ -28,13 +28,13 @@ for path in sys.argv[1:]:
         rows += [json.loads(line) for line in fh]
 k = np.array([r["k"] for r in rows])
 s = np.array([predicted(r) for r in rows])
-lib = np.array([r["sharpness"] for r in rows])
+
 print(f"{len(rows)} random one-voice tables; measured deviation (lane kernel, limit lifted): median {np.median(k):.1f}, "
       f"p90 {np.percentile(k, 90):.1f}, p99 {np.percentile(k, 99):.1f}, max {k.max():.1f}  (units of 2^-23 of max(1, peak))")
 ratio = k / s
 print(f"measured / predicted: median {np.median(ratio):.2f}, p99 {np.percentile(ratio, 99):.2f}, p99.5 {np.percentile(ratio, 99.5):.2f}, "
       f"max {ratio.max():.2f}; tables above the prediction: {(ratio > 1).mean() * 100:.2f} %")
-for limit in (24.0, G.FAST_SHARPNESS_LIMIT, 40.0, 48.0):
+for limit in (24.0, G.FAST_SHARPNESS_LIMIT, 32.0, 40.0, 48.0):
     served = s <= limit
     print(f"limit {limit:4.0f}: serves {served.mean() * 100:4.1f} % of the tables; among them worst measured {k[served].max():5.1f}, "
           f"p99 {np.percentile(k[served], 99):5.1f}" + ("   <- GRAIL_FAST_SHARPNESS_LIMIT" if limit == G.FAST_SHARPNESS_LIMIT else ""))
