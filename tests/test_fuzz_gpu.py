@@ -232,7 +232,7 @@ def test_random_batches_streamed_in_random_chunks(gpu_ctx, seed):
 
 def random_sequence_elems(rng, n_utt, tame):
     """Caller-built SequenceElems, every segment with an elem of its own (blends between arbitrary parameter sets).
-    tame: resonances fast arithmetic is served for (formants below 0.06 fs, bandwidths of 0.006 fs and more: the
+    tame: resonances fast arithmetic is served for (formants below 0.05 fs, bandwidths of 0.008 fs and more: the
     sharpness of a batch of elems takes the worst of every formant over all of them)."""
     gsegs, osegs, offs = [], [], [0]
     for _ in range(n_utt):
@@ -240,8 +240,8 @@ def random_sequence_elems(rng, n_utt, tame):
             has = bool(rng.integers(0, 5))
             e = np.zeros(49, dtype=np.float32)
             e[0] = rng.uniform(0.0015, 0.009)
-            e[1:9] = rng.uniform(0.004, 0.06 if tame else 0.3, 8)
-            e[9:17] = rng.uniform(0.006, 0.02, 8) if tame else rng.uniform(0.002, 0.012, 8)
+            e[1:9] = rng.uniform(0.004, 0.05 if tame else 0.3, 8)
+            e[9:17] = rng.uniform(0.008, 0.02, 8) if tame else rng.uniform(0.002, 0.012, 8)
             e[17:25] = rng.uniform(0.01, 0.1) if rng.integers(0, 2) else rng.uniform(0.01, 0.1, 8)
             e[25:33] = rng.uniform(0, 1, 8)
             e[33:41] = rng.uniform(0, 1, 8)
