@@ -4,7 +4,7 @@
 ragged segment counts, Silence / Stop / Glide, blend lengths that are powers of two and not), random settings of
 lanes_per_utterance, small_batch_pipeline, pipeline_round32, pipeline4/8_max_groups, skip_silent_formants,
 sort_by_length, time_parallel_scan (+ its two thresholds), time_split (+ chunks, span, cost, minimum), against the
-oracle.   usage: option_matrix_soak.py [trials [seed]]"""
+oracle.   usage: option_matrix_soak.py [trials [seed [big]]]"""
 import os
 import sys
 
@@ -19,6 +19,7 @@ from test_fuzz_gpu import pow2_blend_batch, random_batch
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"       # also batches of thousands: time-split and scan by themselves
 ctx = G.Context(0)
 DEFAULTS = {"lanes_per_utterance": 0, "small_batch_pipeline": 1, "pipeline_round32": 1, "pipeline4_max_groups": 512,
             "pipeline8_max_groups": 512, "skip_silent_formants": 1, "sort_by_length": 1, "time_parallel_scan": 1,
@@ -36,7 +37,7 @@ for trial in range(trials):
     nv = int(rng.choice([1, 2, 8]))
     voices = W.single_voice() if nv == 1 else ([G.voice_generic(48000.0), G.voice_generic(44100.0)] if nv == 2 else W.preset_voices(8))
     ctx.set_voices(voices)
-    n_utt = int(rng.choice([1, 17, 64, 130, 300]))
+    n_utt = int(rng.choice([1, 17, 64, 130, 300] + ([1700, 2600, 4200] if BIG else [])))
     segs, offs, vids, seeds = (pow2_blend_batch(rng, n_utt, len(voices)) if rng.integers(0, 2)
                                else random_batch(rng, n_utt, len(voices), 48000.0))
     ov = [O.Voice.from_buffer_copy(bytes(v)) for v in voices]
