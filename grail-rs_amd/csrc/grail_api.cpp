@@ -909,12 +909,16 @@ int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
     b->phoneme_mode = false;
     b->any_blend = any_blend;
     b->n_segs = n_segs;
-    {
-        std::vector<grail_synthesis_elem> given;
-        for (uint32_t i = 0; i < n_segs; ++i)
-            if (segs[i].has_elem) given.push_back(segs[i].elem);
-        b->elems_sharpness = given.empty() ? 0.0 : elems_sharpness(given.data(), given.size());
-    }
+    // the sharpness of the batch (elems_sharpness): parameters only ever blend between the elems of two consecutive
+    // segments of an utterance (Sequencer::next :897-921), so every such pair is judged like a voice of two phonemes
+    for (uint32_t u = 0; u < n_utt; ++u)
+        for (uint32_t i = seg_offsets[u]; i < seg_offsets[u + 1]; ++i) {
+            if (!segs[i].has_elem) continue;
+            grail_synthesis_elem pair[2] = {segs[i].elem, segs[i].elem};
+            size_t n_pair = 1;
+            if (i + 1 < seg_offsets[u + 1] && segs[i + 1].has_elem) pair[n_pair++] = segs[i + 1].elem;
+            b->elems_sharpness = std::fmax(b->elems_sharpness, elems_sharpness(pair, n_pair));
+        }
     std::vector<float> seconds(n_utt, 0.0f);
     for (uint32_t u = 0; u < n_utt; ++u)
         for (uint32_t i = seg_offsets[u]; i < seg_offsets[u + 1]; ++i) seconds[u] += segs[i].length;

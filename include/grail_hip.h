@@ -275,7 +275,8 @@ uint32_t grail_time_split_warmup(const grail_voice *voice);
  * filter coefficient (src/lib.rs:555-562) is amplified by the quality and the ring time of the band-pass, in the
  * reference's own arithmetic as well; the formula is a fit to measurements (profiles/r03_sharpness.txt).
  * Fast arithmetic is served for voice tables up to GRAIL_FAST_SHARPNESS_LIMIT; sharper tables (and caller-built
- * elems, judged the same way at upload) are rendered by the exact kernels whatever "arithmetic" says — read-only
+ * elems, judged the same way at upload: every two consecutive elems of an utterance like a voice of two phonemes,
+ * the worst pair of the batch counts) are rendered by the exact kernels whatever "arithmetic" says — read-only
  * option "fast_arithmetic_served" tells.  +inf: a formant outside (0, 0.5) or a bandwidth <= 0. */
 float grail_fast_sharpness(const grail_voice *voice);
 int grail_time_split_grid(uint32_t span_samples, uint32_t warmup, uint32_t chunks, uint32_t ff_cost_permille,
