@@ -111,6 +111,9 @@ int rccl_fail(ncclResult_t r, const char *what)
 
 struct grail_ctx {
     int device = 0;
+    int cus = 256;                    // compute units the launch policy plans for (hipDeviceProp_t::multiProcessorCount;
+                                      // "assume_compute_units" overrides it): every capacity of the policy is a multiple
+    int device_cus = 256;             // ... what the device reported
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool have_timing = false;
@@ -122,11 +125,12 @@ struct grail_ctx {
     bool voices_scan_ok = false;      // every formant of every voice inside the safe window (scan_voice_ok)
     int scan_debug = 0;
     int sort_option = 1;              // ragged batches: fill launch slots in order of decreasing length
-    int64_t pipe8_max_groups = 512;   // eight-formant pipelined workgroups: up to two per CU
-    int64_t pipe4_max_groups = 512;   // four-formant pipelined workgroups (16 utterances each): up to two per CU
+    int64_t pipe8_max_groups = -1;    // eight-formant pipelined workgroups: up to so many (-1: two per CU)
+    int64_t pipe4_max_groups = -1;    // four-formant pipelined workgroups (16 utterances each): up to so many (-1: two per CU)
     int scan_option = 1;              // fast arithmetic: small batches go to the time-parallel scan kernel
-    int64_t scan_max_utts = 8704;     // ... up to this many utterances (x 4/7 with eight live formants)
-    int64_t scan_split_max = 1536;    // ... and up to this many with the carrier phase on a wave of its own
+    int64_t scan_max_utts = -1;       // ... up to this many utterances (x 4/7 with eight live formants; -1: 34 per CU = 8704)
+    int64_t scan_split_max = -1;      // ... and up to this many with the carrier phase on a wave of its own (-1: 6 per CU = 1536)
+    int composite_option = 1;         // a batch may be cut into blocks with a kernel family each (plan_blocks)
     double voices_sharpness = INFINITY;   // the largest predicted fast-mode deviation of the table, units of 2^-23
     int64_t fast_limit = (int64_t)GRAIL_FAST_SHARPNESS_LIMIT;   // "fast_sharpness_limit": fast kernels up to this
     bool voices_split_ok = false;     // every voice has a warm-up length (voice_warmup): time-split fast kernels
@@ -136,10 +140,13 @@ struct grail_ctx {
     int64_t split_chunks = 0;         // ... into this many chunks (0: as many as fill the machine)
     int64_t split_span = 0;           // ... laid out over this many samples (0: the batch's longest utterance)
     int64_t split_ff_permille = 165;  // ... cost of a fast-forwarded sample against a rendered one
-    int64_t split_min_utts = 1537;    // ... batches smaller than this (x 5/6 with eight live formants) stay with the scan
-                                      // kernel: 1 024 utterances 2.00 against 3.13 ms, 1 536: 3.22 / 3.14, 2 048: 3.33 / 3.13
-                                      // (profiles/r03_small_batch.txt; eight formants: 1 024: 2.98 / 3.94, 1 536: 5.11 / 3.98)
+    int64_t split_min_utts = -1;      // ... -1: the cost model picks between the scan kernel, the time-split kernels and the lane
+                                      // kernels (family_cost; 2 s utterances: 1 024 of them 2.00 (scan) against 3.13 ms (split),
+                                      // 1 536: 3.22 / 3.14, 2 048: 3.33 / 3.13, profiles/r03_small_batch.txt); >= 0: batches smaller
+                                      // than this (x 5/6 with eight live formants) stay with the scan kernel, whatever their length
     int last_split = 0;               // chunks of the last launch (statistics; 0: not time-split)
+    int last_fast = 0;                // the last launch ran tolerance arithmetic in some block
+    int last_blocks = 0;              // kernel launches the last synthesis call was cut into
     float max_dt = 0.0f;              // largest 1/sample_rate of the table
     float max_pitch_jitter = 0.0f;    // largest |jitter_delta_frequency| of the table
     int last_formants = 8, last_lanes = 0, last_pipe = 0;   // what the last synthesis launch used (statistics)
@@ -187,6 +194,17 @@ struct grail_batch {
     float min_pitch = 0.0f;    // lowest frequency.min(0.5) of any segment (plain batches)
     double elems_sharpness = 0.0;   // elem mode: predicted fast-mode deviation of the caller's elems (elems_sharpness())
 };
+
+// the SIMDs and lanes the policy plans for: 4 SIMDs per compute unit, 64 lanes per wavefront.  Every family is laid out
+// for ONE resident wave per SIMD (a second wave on a SIMD costs as much as it brings: profiles/r01_lanes_sweep.txt), so
+// all capacities below are multiples of the compute-unit count hipGetDeviceProperties reports (a partitioned MI355X —
+// CPX, 32 CUs — plans for 32, not 256); "assume_compute_units" overrides it for tests.
+static inline uint64_t ctx_simds(const grail_ctx *ctx) { return 4ull * (uint64_t)ctx->cus; }
+static inline uint64_t ctx_lanes(const grail_ctx *ctx) { return 256ull * (uint64_t)ctx->cus; }
+static inline int64_t pipe4_groups(const grail_ctx *ctx) { return ctx->pipe4_max_groups < 0 ? 2 * (int64_t)ctx->cus : ctx->pipe4_max_groups; }
+static inline int64_t pipe8_groups(const grail_ctx *ctx) { return ctx->pipe8_max_groups < 0 ? 2 * (int64_t)ctx->cus : ctx->pipe8_max_groups; }
+static inline int64_t scan_max_utts(const grail_ctx *ctx) { return ctx->scan_max_utts < 0 ? 34 * (int64_t)ctx->cus : ctx->scan_max_utts; }
+static inline int64_t scan_split_max(const grail_ctx *ctx) { return ctx->scan_split_max < 0 ? 6 * (int64_t)ctx->cus : ctx->scan_split_max; }
 
 namespace {
 
@@ -602,9 +620,18 @@ int grail_create(int device, grail_ctx **out)
                     std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count 0"));
     if (device < 0 || device >= n) return fail(GRAIL_ERR_NO_DEVICE, "device index out of range");
     HIP_TRY(hipSetDevice(device));
+    // the kernels in this library are gfx950 code objects only, and the launch policy is laid out for CDNA4's
+    // 4 SIMDs x 64 lanes per compute unit: any other architecture is "no usable device"
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(GRAIL_ERR_NO_DEVICE, std::string("device ") + std::to_string(device) + " is " + prop.gcnArchName +
+                                             ": this library holds gfx950 (MI355X) kernels only");
+    if (prop.multiProcessorCount <= 0) return fail(GRAIL_ERR_NO_DEVICE, "the device reports no compute units");
     grail_ctx *ctx = new (std::nothrow) grail_ctx();
     if (!ctx) return fail(GRAIL_ERR_OUT_OF_MEMORY, "host allocation failed");
     ctx->device = device;
+    ctx->cus = ctx->device_cus = prop.multiProcessorCount;
     hipError_t err;
     if ((err = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (err = hipEventCreate(&ctx->ev_start)) != hipSuccess ||
@@ -701,8 +728,8 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         ctx->split_ff_permille = value;
         return GRAIL_OK;
     }
-    if (std::strcmp(name, "time_split_min_utterances") == 0) {
-        if (value < 0) return fail(GRAIL_ERR_INVALID_ARG, "negative limit");
+    if (std::strcmp(name, "time_split_min_utterances") == 0) {   // -1: the cost model decides
+        if (value < -1) return fail(GRAIL_ERR_INVALID_ARG, "negative limit");
         ctx->split_min_utts = value;
         return GRAIL_OK;
     }
@@ -712,7 +739,16 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         return GRAIL_OK;
     }
     if (std::strcmp(name, "pipeline4_max_groups") == 0) {   // tuning: four-formant batches, 16 utterances per workgroup
-        ctx->pipe4_max_groups = value;
+        ctx->pipe4_max_groups = value;                       // (-1: two per compute unit)
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "assume_compute_units") == 0) {   // plan for so many compute units (0: what the device reports)
+        if (value < 0 || value > 4096) return fail(GRAIL_ERR_INVALID_ARG, "assume_compute_units must be 0 (the device's) .. 4096");
+        ctx->cus = value ? (int)value : ctx->device_cus;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "composite_launches") == 0) {
+        ctx->composite_option = value ? 1 : 0;
         return GRAIL_OK;
     }
     if (std::strcmp(name, "pipeline8_max_groups") == 0) {   // tuning: 0 keeps eight-formant batches off the pipeline
@@ -729,13 +765,13 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         return GRAIL_OK;
     }
 #endif
-    if (std::strcmp(name, "time_parallel_scan_split_max_utterances") == 0) {
-        if (value < 0) return fail(GRAIL_ERR_INVALID_ARG, "negative limit");
+    if (std::strcmp(name, "time_parallel_scan_split_max_utterances") == 0) {   // -1: 6 per compute unit
+        if (value < -1) return fail(GRAIL_ERR_INVALID_ARG, "negative limit");
         ctx->scan_split_max = value;
         return GRAIL_OK;
     }
-    if (std::strcmp(name, "time_parallel_scan_max_utterances") == 0) {
-        if (value < 0) return fail(GRAIL_ERR_INVALID_ARG, "negative limit");
+    if (std::strcmp(name, "time_parallel_scan_max_utterances") == 0) {         // -1: 34 per compute unit
+        if (value < -1) return fail(GRAIL_ERR_INVALID_ARG, "negative limit");
         ctx->scan_max_utts = value;
         return GRAIL_OK;
     }
@@ -761,8 +797,44 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
         *value = ctx->scan_option;
         return GRAIL_OK;
     }
-    if (std::strcmp(name, "time_parallel_scan_max_utterances") == 0) {
-        *value = ctx->scan_max_utts;
+    if (std::strcmp(name, "time_parallel_scan_max_utterances") == 0) {   // the limit in force
+        *value = scan_max_utts(ctx);
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "compute_units") == 0) {             // read-only: what the launch policy plans for
+        *value = ctx->cus;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "assume_compute_units") == 0) {      // 0: the device's own count is in force
+        *value = ctx->cus == ctx->device_cus ? 0 : ctx->cus;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "composite_launches") == 0) {
+        *value = ctx->composite_option;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "pipeline4_max_groups") == 0) {
+        *value = pipe4_groups(ctx);
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "pipeline8_max_groups") == 0) {
+        *value = pipe8_groups(ctx);
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "pipeline_round32") == 0) {
+        *value = ctx->pipe_round32;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "sort_by_length") == 0) {
+        *value = ctx->sort_option;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "last_launch_fast") == 0) {          // read-only: some block of the last launch ran tolerance arithmetic
+        *value = ctx->last_fast;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "last_launch_blocks") == 0) {        // read-only: kernel launches the last synthesis call was cut into
+        *value = ctx->last_blocks;
         return GRAIL_OK;
     }
     if (std::strcmp(name, "time_split") == 0) {
@@ -798,7 +870,7 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
         return GRAIL_OK;
     }
     if (std::strcmp(name, "time_parallel_scan_split_max_utterances") == 0) {
-        *value = ctx->scan_split_max;
+        *value = scan_split_max(ctx);
         return GRAIL_OK;
     }
     if (std::strcmp(name, "slow_division_wave_steps") == 0) {  // read-only statistic
@@ -988,6 +1060,67 @@ int grail_batch_lengths(grail_ctx *ctx, const grail_batch *batch, uint32_t max_l
     return GRAIL_OK;
 }
 
+// ---- which kernel family renders a block of rows, what a block costs, how a batch is cut into blocks --------------
+
+struct Family {
+    int L = 1;                 // lanes per utterance (lane kernels, pipelined workgroups)
+    uint32_t pipe = 0;         // exact pipelined workgroups: 1 = rounds of 16 samples, 2 = rounds of 32
+    uint32_t live4 = 0;        // formants 5-8 not laid out
+    uint32_t fast = 0;         // tolerance arithmetic
+    int split_k = 0;           // time-split kernels: chunks per utterance (0: not time-split)
+    uint32_t split_bounds[SPLIT_MAX_CHUNKS + 1] = {};
+    bool scan = false;         // the time-parallel scan kernel
+    uint32_t scan_pipe = 0;    // ... its three-stage flavour
+};
+
+// the longest utterance of the batch in samples, as far as the host knows it (the f32 clock adds a few per segment)
+static double batch_span(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride)
+{
+    double span = std::ceil((double)batch->max_seconds * ctx->max_rate) + 64.0;
+    if (!(span >= 64.0)) span = 64.0;                         // NaN / negative lengths
+    return std::fmin(span, (double)(out_stride ? out_stride : 1));
+}
+
+// Cost model of the planner, in milliseconds per SAMPLE OF THE LONGEST UTTERANCE for one round of a family (a round:
+// as many rows as give every SIMD one wave).  Calibrated on 2 s utterances at 48 kHz, one MI355X
+// (profiles/r03_small_batch.txt, profiles/r04_duration_sweep.txt); only the ratios matter.  Indexed [L = 1, 2, 4, 8].
+static double lane_ms_per_sample(bool fast, bool live4, int L)
+{
+    static const double exact4[4] = {40.6, 26.9, 16.3, 18.2}, exact8[4] = {77.1, 43.5, 25.8, 15.7};
+    static const double fast4[4] = {15.6, 13.0, 12.1, 11.7}, fast8[4] = {23.2, 19.9, 13.3, 11.7};
+    const int i = L == 1 ? 0 : L == 2 ? 1 : L == 4 ? 2 : 3;
+    return (fast ? (live4 ? fast4 : fast8) : (live4 ? exact4 : exact8))[i] / 96006.0;
+}
+
+// what launching `rows` rows with family f costs (model milliseconds)
+static double family_cost(const grail_ctx *ctx, const Family &f, uint32_t rows, double span)
+{
+    const double cus = (double)ctx->cus, lanes = (double)ctx_lanes(ctx);
+    if (f.scan) {
+        // one workgroup per utterance; g = workgroups per compute unit.  Three-stage flavour: the latency of one
+        // utterance's chain up to ~2 per CU, then ~0.53 ms per workgroup and CU (2 s); two-stage: 0.41 (four live
+        // formants) / 0.65 (eight)
+        const double g = std::ceil((double)rows / cus);
+        const double ms2s = f.scan_pipe ? (f.live4 ? std::fmax(1.14, 0.53 * g) : std::fmax(1.67, 0.75 * g))
+                                        : (f.live4 ? 0.41 * g + 0.1 : 0.65 * g + 0.2);
+        return ms2s * span / 96006.0;
+    }
+    if (f.split_k) {
+        // every lane takes as long as the first chunk's, which renders split_bounds[1] samples and nothing else
+        const double rounds = std::ceil((double)rows * f.split_k / lanes);
+        return rounds * (double)f.split_bounds[1] * (f.live4 ? 15.9 : 23.6) / 96006.0;
+    }
+    if (f.pipe) {
+        const double groups = std::ceil((double)rows / (f.live4 ? 16.0 : 8.0));
+        const double per_cu = std::ceil(groups / cus);
+        // rounds of 32: one workgroup per CU; rounds of 16: two per CU are resident together, further ones queue
+        const double ms2s = f.pipe == 2 ? (f.live4 ? 6.5 : 7.3) * per_cu : 11.2 * std::ceil(per_cu / 2.0);
+        return ms2s * span / 96006.0;
+    }
+    const double rounds = std::ceil((double)rows * f.L / lanes);
+    return rounds * span * lane_ms_per_sample(f.fast != 0, f.live4 != 0, f.L);
+}
+
 static bool batch_half_capable(const grail_ctx *ctx, const grail_batch *batch)
 {
     return ctx->skip_silent_option && batch->phoneme_mode && ctx->voices_upper_silent;
@@ -1009,6 +1142,233 @@ static bool batch_live4(const grail_ctx *ctx, const grail_batch *batch)
     return batch_live4_any_blend(ctx, batch) && !batch->any_blend;
 }
 
+// The family a block of `fam` rows of this batch takes.  Exact arithmetic: the widest mapping that still gives every
+// SIMD at most one wave (pipelined workgroups, then 8 / 4 / 2 / 1 lanes per utterance).  Fast arithmetic: the cheapest
+// of the scan kernel, the time-split kernels and the fast lane kernels by the cost model above (which follows the
+// utterances' length: a time-split pays a warm-up per chunk, the scan kernel the latency of one utterance's chain),
+// unless an option pins the choice.
+static void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t fam, Family &f)
+{
+    const uint64_t simds = ctx_simds(ctx), lanes = ctx_lanes(ctx), cus = (uint64_t)ctx->cus;
+    f = Family();
+    f.live4 = batch_live4(ctx, batch) ? 1u : 0u;
+    // fast arithmetic is served up to a sharpness of the resonances (elems_sharpness); beyond it the exact kernels run
+    f.fast = ctx->fast_option && fast_served(ctx, batch) ? 1u : 0u;
+    // (the fast lane kernels have four-formant instantiations for every blend length)
+    if (f.fast && batch_live4_any_blend(ctx, batch)) f.live4 = 1u;
+    int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(fam, simds);
+    // small batches leave SIMDs idle: four-wave workgroups (one wave renders 16 utterances, one carries
+    // the per-utterance chain, two prepare the filter coefficients), up to two per CU (tools/pipe4_range.py:
+    // 11.5 ms up to 4 096 utterances, 15.7 up to 8 192 where the lane kernels take 18.0; three per CU lose)
+    const bool want_pipe4 = batch_live4(ctx, batch) && !ctx->lanes_option && ctx->pipeline_option &&
+                            (int64_t)(((uint64_t)fam + 15) / 16) <= pipe4_groups(ctx);
+    const bool want_pipe8 = !batch_live4(ctx, batch) && !ctx->lanes_option && ctx->pipeline_option && !batch->any_blend &&
+                            (int64_t)(((uint64_t)fam + 7) / 8) <= pipe8_groups(ctx);
+    // one workgroup per CU suffices: rounds of 32 samples instead of 16 (pipe = 2)
+    const uint32_t pipe4_kind = ctx->pipe_round32 && ((uint64_t)fam + 15) / 16 <= cus ? 2u : 1u;
+    const uint32_t pipe8_kind = ctx->pipe_round32 && ((uint64_t)fam + 7) / 8 <= cus ? 2u : 1u;
+    if (want_pipe4 && !f.fast) {
+        f.pipe = pipe4_kind;
+        L = 4;
+    } else if (want_pipe8 && !f.fast) {
+        f.pipe = pipe8_kind;                              // eight formants: 8 utterances per workgroup
+        L = 8;
+    }
+    // eight lanes per utterance need eight formants to lay out; for batches that small the
+    // 8-lane kernel is also the fastest (18.2 against 18.8 ms: half the rows to flush per wave)
+    if (f.live4 && !f.pipe && L == 8) f.live4 = 0u;
+    if (f.live4 && !f.pipe && !ctx->lanes_option) {
+        // same rule as auto_lanes_per_utt — the widest mapping with one wave per SIMD — over 4 formants
+        L = ((uint64_t)fam * 4 + 63) / 64 <= simds ? 4 : ((uint64_t)fam * 2 + 63) / 64 <= simds ? 2 : 1;
+    }
+    // voices whose upper formants are never audible but that do not qualify for the 4-formant
+    // kernels: one lane per utterance runs the half-live loop and ties two lanes per utterance,
+    // whose second lane would only hold silent formants
+    if (!ctx->lanes_option && !f.live4 && L == 2 && batch_half_capable(ctx, batch)) L = 1;
+    f.L = L;
+    if (!f.fast) return;
+
+    const double span = batch_span(ctx, batch, out_stride);
+    const bool l4ab = batch_live4_any_blend(ctx, batch);
+    // fast arithmetic, mid-size batches: one lane per utterance would leave most of the machine idle, so the time
+    // axis of every utterance is cut into chunks with a lane each (synth_kernel<..., SPLIT>): as many chunks as
+    // fill the machine, laid out over the batch's longest utterance so that all lanes finish together
+    Family split = f;
+    if (ctx->split_option && !ctx->lanes_option && batch->phoneme_mode && ctx->voices_split_ok && batch->plain &&
+        out_stride <= 0xFFFFFFFFull && (ctx->split_chunks >= 2 || ctx->split_chunks == 0)) {
+        const double sp = ctx->split_span ? std::fmin((double)ctx->split_span, (double)out_stride) : span;
+        int K = ctx->split_chunks ? (int)ctx->split_chunks : (int)std::min<uint64_t>(lanes / fam, SPLIT_MAX_CHUNKS);
+        K = (int)std::fmin((double)K, sp / 512.0);
+        // (a fast-forwarded sample costs the same whatever is rendered afterwards; a rendered sample of eight live
+        // formants costs 1.5 x one of four; 0.8 from a sweep, profiles/r03_small_batch.txt)
+        const double ff_cost = 1e-3 * (double)ctx->split_ff_permille * (l4ab ? 1.0 : 0.8);
+        while (K >= 2 && !split_grid((uint32_t)sp, ctx->max_warmup, K, ff_cost, split.split_bounds)) --K;
+        if (K >= 2) {
+            split.split_k = K;
+            split.split_bounds[K] = (uint32_t)out_stride;
+            split.live4 = l4ab ? 1u : 0u;
+            split.pipe = 0u;
+            split.L = 1;
+        }
+    }
+    // fast arithmetic, few utterances: one workgroup per utterance with the time axis across the lanes and the
+    // filter recurrences solved by parallel scans (scan_kernels.hip).  Needs every parameter inside the safe window
+    // (no IEEE fallback).
+    Family scan = f;
+    if (ctx->scan_option && !ctx->lanes_option && (int64_t)fam * (l4ab ? 4 : 7) <= 4 * scan_max_utts(ctx) &&
+        batch->phoneme_mode && ctx->voices_scan_ok && batch->plain && batch->min_length >= 2.0f * ctx->max_dt &&
+        batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f) {
+        scan.scan = true;
+        scan.live4 = l4ab ? 1u : 0u;                          // (the scan kernel takes any blend length)
+        // three-stage workgroups for few utterances (tools/scan_split_crossover.py: up to ~1500 with four
+        // live formants, half that with eight, where the filter wave is the slower stage either way)
+        scan.scan_pipe = (int64_t)fam * (scan.live4 ? 1 : 2) <= scan_split_max(ctx) ? 1u : 0u;
+        scan.pipe = 0u;
+    }
+    // which of them: a pinned grid or an explicit "time_split_min_utterances" decide as they always did; otherwise
+    // the cost model does (2 s utterances: the scan kernel up to ~1 500 of them, the time-split kernels up to half the
+    // machine's lanes, the lane kernels beyond; shorter utterances move the first crossover up — a chunk's warm-up
+    // does not shrink with the utterance)
+    bool take_split = false, take_scan = false;
+    if (split.split_k && ctx->split_chunks >= 2) {
+        take_split = true;
+    } else if (ctx->split_min_utts >= 0) {
+        take_split = split.split_k && (int64_t)fam * 6 >= ctx->split_min_utts * (l4ab ? 6 : 5);
+        take_scan = !take_split && scan.scan;
+    } else {
+        const double c_lane = family_cost(ctx, f, fam, span);
+        const double c_split = split.split_k ? family_cost(ctx, split, fam, span) : INFINITY;
+        const double c_scan = scan.scan ? family_cost(ctx, scan, fam, span) : INFINITY;
+        take_split = c_split <= c_scan && c_split < c_lane;
+        take_scan = !take_split && c_scan < c_lane;
+    }
+    if (take_split) {
+        f = split;
+        return;
+    }
+    if (take_scan) {
+        f = scan;
+        return;
+    }
+    // fast arithmetic asked for, but the batch takes neither the scan kernel nor the time-split kernels (caller-built
+    // elems, a voice outside their windows, an option switched off) and is small enough for the pipelined exact
+    // workgroups: those are faster than the fast lane kernels there (8.1 - 11.5 against 12.4 ms), and exact bits
+    // satisfy the tolerance trivially
+    if (want_pipe4 || want_pipe8) {
+        f.fast = 0u;
+        f.live4 = batch_live4(ctx, batch) ? 1u : 0u;
+        f.pipe = want_pipe4 ? pipe4_kind : pipe8_kind;
+        f.L = want_pipe4 ? 4 : 8;
+    }
+}
+
+// One launch: `count` launch slots from slot `slot0` of the rows [first, first + n_rows) the caller renders, with
+// family f.  out_dev / out_len_dev point at row `first`.  use_perm: the batch's length-sorted slot order applies
+// (whole-batch calls): slot s renders utterance perm[s], and every per-utterance array is indexed by the utterance.
+static int launch_block(grail_ctx *ctx, const grail_batch *batch, const Family &f, float *out_dev, int16_t *out_pcm16_dev,
+                        uint64_t out_stride, uint32_t *out_len_dev, uint32_t first, uint32_t slot0, uint32_t count,
+                        bool use_perm)
+{
+    SynthArgs a{};
+    const uint32_t row0 = use_perm ? 0u : first + slot0;      // the utterance that index 0 of the launch's arrays is
+    const uint64_t out_shift = use_perm ? 0ull : (uint64_t)slot0 * out_stride;
+    a.out_pcm16 = out_pcm16_dev ? out_pcm16_dev + out_shift : nullptr;
+    a.segs = batch->d_segs;
+    a.seg_offsets = batch->d_offsets + row0;       // the offsets themselves are absolute into segs
+    a.voice_ids = batch->d_voice_ids ? batch->d_voice_ids + row0 : nullptr;
+    a.seeds = batch->d_seeds ? batch->d_seeds + row0 : nullptr;
+    a.perm = use_perm ? batch->d_perm + slot0 : nullptr;
+    a.elems = batch->phoneme_mode ? ctx->d_voice_elems : batch->d_elems;
+    a.voices = ctx->d_voices;
+    a.out = out_dev ? out_dev + out_shift : nullptr;
+    a.out_len = out_len_dev ? out_len_dev + (use_perm ? 0u : slot0) : nullptr;
+    a.truncated = ctx->d_truncated;
+    a.out_stride = out_stride;
+    a.cap = out_stride;
+    a.n_utt = count;
+    a.n_voices = (uint32_t)ctx->voices.size();
+    a.phoneme_mode = batch->phoneme_mode ? 1u : 0u;
+    a.skip_silent = ctx->skip_silent_option ? 1u : 0u;
+    a.half_capable = batch_half_capable(ctx, batch) ? 1u : 0u;
+    a.any_blend = batch->any_blend ? 1u : 0u;
+    a.live4 = f.live4;
+    a.fast = f.fast;
+    a.pipe = f.pipe;
+    hipError_t e;
+    if (f.scan) {
+        a.resume = (uint32_t)ctx->scan_debug;
+        a.pipe = f.scan_pipe;
+        e = launch_scan(a, ctx->stream);
+        ctx->last_kernel = a.live4 ? (a.pipe ? "scan_kernel<pairs=2,SPLIT,FAST>" : "scan_kernel<pairs=2,FAST>")
+                                   : (a.pipe ? "scan_kernel<pairs=4,SPLIT,FAST>" : "scan_kernel<pairs=4,FAST>");
+    } else {
+        if (f.split_k) {
+            a.split_chunks = (uint32_t)f.split_k;
+            std::memcpy(a.split_bounds, f.split_bounds, sizeof a.split_bounds);
+        }
+        e = launch_synth(a, f.L, ctx->stream);
+        ctx->last_kernel = last_kernel_name();
+    }
+    if (e != hipSuccess) return hip_fail(e, "synth kernel launch");
+    return GRAIL_OK;
+}
+
+struct Block {
+    uint32_t rows;
+    Family f;
+};
+
+// Cut `rows` rows into blocks, each rendered by the family that suits ITS size, so that the time of a batch is not a
+// step function of its size: a family fills the machine with a fixed number of rows (one wave per SIMD), one row more
+// costs a whole further round of it — 65 537 utterances took two rounds of the one-lane kernel (81 ms) where one
+// round and a pipelined workgroup launch (40.6 + 6.5 ms) do.  Candidates: the whole of it in one launch; or a full
+// block of one of the families' capacities (as many rounds as fit for the one-lane kernels) followed by the best
+// plan for the rest.  Exact arithmetic is mapping-invariant, so the cut never changes a bit; in fast arithmetic a row's
+// samples follow the family of ITS block (include/grail_hip.h, "Determinism contract").
+static double plan_blocks(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t rows, double span,
+                          std::vector<Block> &out, int depth)
+{
+    constexpr double LAUNCH_MS = 0.05;         // what a further launch costs by itself (measured: 0.02 - 0.06 ms)
+    Family whole;
+    choose_family(ctx, batch, out_stride, rows, whole);
+    double best = family_cost(ctx, whole, rows, span);
+    std::vector<Block> best_plan{Block{rows, whole}};
+    if (depth < 6) {
+        const uint64_t lanes = ctx_lanes(ctx), cus = (uint64_t)ctx->cus;
+        // the capacities at which some family is exactly full
+        // (largest first: of two plans of equal cost the one with the larger head wins)
+        const uint64_t caps[] = {lanes, lanes / 2, lanes / 4, lanes / 8, 32 * cus, 16 * cus, 8 * cus};
+        uint64_t seen = 0;
+        for (const uint64_t c : caps) {
+            if (c == 0 || c >= rows || c == seen) continue;
+            seen = c;
+            const uint32_t m = c == lanes ? (uint32_t)(rows / c) : 1u;
+            const uint32_t head = (uint32_t)(m * c);
+            Family fc;
+            choose_family(ctx, batch, out_stride, head, fc);
+            const double c_head = family_cost(ctx, fc, head, span);
+            if (c_head + LAUNCH_MS >= best) continue;
+            std::vector<Block> rest;
+            const double c_rest = plan_blocks(ctx, batch, out_stride, rows - head, span, rest, depth + 1);
+            if (c_head + LAUNCH_MS + c_rest < best) {
+                best = c_head + LAUNCH_MS + c_rest;
+                best_plan.assign(1, Block{head, fc});
+                best_plan.insert(best_plan.end(), rest.begin(), rest.end());
+            }
+        }
+    }
+    out = best_plan;
+    if (depth == 0 && out.size() > 1) {
+        // launch order: the family that is cheapest per sample first.  Length-sorted (ragged) batches hand out their
+        // slots longest first, and a block lasts as long as its longest utterance: the long ones go where a sample
+        // costs least.  (Aligned batches: any order costs the same.)
+        std::stable_sort(out.begin(), out.end(), [&](const Block &x, const Block &y) {
+            return family_cost(ctx, x.f, x.rows, span) < family_cost(ctx, y.f, y.rows, span);
+        });
+    }
+    return best;
+}
+
 // Rows [first, first + count) of the batch (count = 0: all of it).  out_dev / out_len_dev point at the
 // first row RENDERED, i.e. the caller has already applied the row offset to them.
 // family_rows: the number of rows the kernel family is chosen for (0 = count).  A caller that renders a batch in
@@ -1027,133 +1387,88 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     if (first > batch->n_utt || count > batch->n_utt - first) return fail(GRAIL_ERR_INVALID_ARG, "row range");
     if (count == 0) count = batch->n_utt - first;
     if (count == 0) return GRAIL_OK;
-    const uint32_t fam = family_rows > count ? family_rows : count;   // what the kernel family is chosen for
-    SynthArgs a{};
-    a.out_pcm16 = out_pcm16_dev;
-    a.segs = batch->d_segs;
-    a.seg_offsets = batch->d_offsets + first;      // the offsets themselves are absolute into segs
-    a.voice_ids = batch->d_voice_ids ? batch->d_voice_ids + first : nullptr;
-    a.seeds = batch->d_seeds ? batch->d_seeds + first : nullptr;
     // the length-sorted slot assignment covers the whole batch: row-block launches keep launch order
-    a.perm = (first == 0 && count == batch->n_utt) ? batch->d_perm : nullptr;
-    a.elems = batch->phoneme_mode ? ctx->d_voice_elems : batch->d_elems;
-    a.voices = ctx->d_voices;
-    a.out = out_dev;
-    a.out_len = out_len_dev;
-    a.truncated = ctx->d_truncated;
-    a.out_stride = out_stride;
-    a.cap = out_stride;
-    a.n_utt = count;
-    a.n_voices = (uint32_t)ctx->voices.size();
-    a.phoneme_mode = batch->phoneme_mode ? 1u : 0u;
-    a.skip_silent = ctx->skip_silent_option ? 1u : 0u;
-    a.half_capable = batch_half_capable(ctx, batch) ? 1u : 0u;
-    a.any_blend = batch->any_blend ? 1u : 0u;
-    a.live4 = batch_live4(ctx, batch) ? 1u : 0u;
-    // fast arithmetic is served up to a sharpness of the resonances (elems_sharpness); beyond it the exact kernels run
-    a.fast = ctx->fast_option && fast_served(ctx, batch) ? 1u : 0u;
-    // (the fast lane kernels have four-formant instantiations for every blend length)
-    if (a.fast && batch_live4_any_blend(ctx, batch)) a.live4 = 1u;
-    int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(fam);
-    // small batches leave SIMDs idle: four-wave workgroups (one wave renders 16 utterances, one carries
-    // the per-utterance chain, two prepare the filter coefficients), up to two per CU (tools/pipe4_range.py:
-    // 11.5 ms up to 4 096 utterances, 15.7 up to 8 192 where the lane kernels take 18.0; three per CU lose)
-    const bool want_pipe4 = batch_live4(ctx, batch) && !ctx->lanes_option && ctx->pipeline_option &&
-                            ((uint64_t)fam + 15) / 16 <= (uint64_t)ctx->pipe4_max_groups;
-    const bool want_pipe8 = !batch_live4(ctx, batch) && !ctx->lanes_option && ctx->pipeline_option && !batch->any_blend &&
-                            ((uint64_t)fam + 7) / 8 <= (uint64_t)ctx->pipe8_max_groups;
-    // one workgroup per CU suffices: rounds of 32 samples instead of 16 (pipe = 2)
-    const uint32_t pipe4_kind = ctx->pipe_round32 && ((uint64_t)fam + 15) / 16 <= 256 ? 2u : 1u;
-    const uint32_t pipe8_kind = ctx->pipe_round32 && ((uint64_t)fam + 7) / 8 <= 256 ? 2u : 1u;
-    if (want_pipe4 && !a.fast) {
-        a.pipe = pipe4_kind;
-        L = 4;
-    } else if (want_pipe8 && !a.fast) {
-        a.pipe = pipe8_kind;                              // eight formants: 8 utterances per workgroup
-        L = 8;
-    }
-    // eight lanes per utterance need eight formants to lay out; for batches that small the
-    // 8-lane kernel is also the fastest (18.2 against 18.8 ms: half the rows to flush per wave)
-    if (a.live4 && !a.pipe && L == 8) a.live4 = 0u;
-    if (a.live4 && !a.pipe && !ctx->lanes_option) {
-        // same rule as auto_lanes_per_utt — the widest mapping with one wave per SIMD — over 4 formants
-        L = ((uint64_t)fam * 4 + 63) / 64 <= 1024 ? 4 : ((uint64_t)fam * 2 + 63) / 64 <= 1024 ? 2 : 1;
-    }
-    // voices whose upper formants are never audible but that do not qualify for the 4-formant
-    // kernels: one lane per utterance runs the half-live loop and ties two lanes per utterance,
-    // whose second lane would only hold silent formants
-    if (!ctx->lanes_option && !a.live4 && L == 2 && a.half_capable) L = 1;
-    // fast arithmetic, few utterances: the machine is mostly idle under the lane-per-utterance mapping;
-    // one workgroup per utterance with the time axis across the lanes and the filter recurrences solved by
-    // parallel scans (scan_kernels.hip).  Needs every parameter inside the safe window (no IEEE fallback).
-    // (it is the fastest path up to ~1 500 utterances with four live formants, ~1 300 with eight; above that the
-    // time-split kernels below are: profiles/r03_small_batch.txt)
-    // fast arithmetic, mid-size batches: one lane per utterance would leave most of the machine idle, so the time
-    // axis of every utterance is cut into chunks with a lane each (synth_kernel<..., SPLIT>): as many chunks as
-    // fill 1024 waves, laid out over the batch's longest utterance so that all lanes finish together
-    int split_k = 0;
-    if (a.fast && ctx->split_option && !ctx->lanes_option && batch->phoneme_mode && ctx->voices_split_ok &&
-        batch->plain && out_stride <= 0xFFFFFFFFull &&
-        (ctx->split_chunks >= 2 ||
-         (ctx->split_chunks == 0 && (int64_t)fam * 6 >= ctx->split_min_utts * (batch_live4_any_blend(ctx, batch) ? 6 : 5)))) {
-        double span = ctx->split_span ? (double)ctx->split_span
-                                      : std::ceil((double)batch->max_seconds * ctx->max_rate) + 64.0;
-        span = std::fmin(span, (double)out_stride);
-        int K = ctx->split_chunks ? (int)ctx->split_chunks : (int)std::min<uint64_t>(65536u / fam, SPLIT_MAX_CHUNKS);
-        K = (int)std::fmin((double)K, span / 512.0);
-        // (a fast-forwarded sample costs the same whatever is rendered afterwards; a rendered sample of eight live
-        // formants costs 1.5 x one of four; 0.8 from a sweep, profiles/r03_small_batch.txt)
-        const double ff_cost = 1e-3 * (double)ctx->split_ff_permille * (batch_live4_any_blend(ctx, batch) ? 1.0 : 0.8);
-        while (K >= 2 && !split_grid((uint32_t)span, ctx->max_warmup, K, ff_cost, a.split_bounds)) --K;
-        if (K >= 2) {
-            split_k = K;
-            a.split_bounds[K] = (uint32_t)out_stride;
-        }
-    }
-    const bool scan = !split_k && a.fast && ctx->scan_option && !ctx->lanes_option &&
-                      (int64_t)fam * (batch_live4_any_blend(ctx, batch) ? 4 : 7) <= 4 * ctx->scan_max_utts &&
-                      batch->phoneme_mode && ctx->voices_scan_ok && batch->plain &&
-                      batch->min_length >= 2.0f * ctx->max_dt &&
-                      batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f;
-    // fast arithmetic asked for, but the batch takes neither the scan kernel nor the time-split kernels (caller-built
-    // elems, a voice outside their windows, an option switched off) and is small enough for the pipelined exact
-    // workgroups: those are faster than the fast lane kernels there (8.1 - 11.5 against 12.4 ms), and exact bits
-    // satisfy the tolerance trivially
-    if (a.fast && !scan && !split_k && (want_pipe4 || want_pipe8)) {
-        a.fast = 0u;
-        a.live4 = batch_live4(ctx, batch) ? 1u : 0u;
-        a.pipe = want_pipe4 ? pipe4_kind : pipe8_kind;
-        L = want_pipe4 ? 4 : 8;
-    }
-    if (split_k) {
-        a.split_chunks = (uint32_t)split_k;
-        a.live4 = batch_live4_any_blend(ctx, batch) ? 1u : 0u;
-        a.pipe = 0u;
-        L = 1;
-    }
-    ctx->last_split = split_k;
-    ctx->last_formants = a.live4 ? 4 : 8;
-    ctx->last_lanes = scan ? 0 : L;
-    ctx->last_pipe = a.pipe && !scan ? 1 : 0;
-    HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
-    hipError_t e;
-    if (scan) {
-        a.live4 = batch_live4_any_blend(ctx, batch) ? 1u : 0u;   // (the scan kernel takes any blend length)
-        ctx->last_formants = a.live4 ? 4 : 8;
-        a.resume = (uint32_t)ctx->scan_debug;
-        // three-stage workgroups for few utterances (tools/scan_split_crossover.py: up to ~1500 with four
-        // live formants, half that with eight, where the filter wave is the slower stage either way)
-        a.pipe = (int64_t)fam * (a.live4 ? 1 : 2) <= ctx->scan_split_max ? 1u : 0u;
-        e = launch_scan(a, ctx->stream);
-        ctx->last_kernel = a.live4 ? (a.pipe ? "scan_kernel<pairs=2,SPLIT,FAST>" : "scan_kernel<pairs=2,FAST>")
-                                   : (a.pipe ? "scan_kernel<pairs=4,SPLIT,FAST>" : "scan_kernel<pairs=4,FAST>");
+    const bool use_perm = first == 0 && count == batch->n_utt && batch->d_perm;
+    std::vector<Block> plan;
+    // one launch when the caller fixes the family (row blocks, a pinned lane mapping or chunk grid) or asks for it
+    const bool single = family_rows != 0 || !ctx->composite_option || ctx->lanes_option || ctx->split_chunks >= 2;
+    if (single) {
+        Family f;
+        choose_family(ctx, batch, out_stride, family_rows > count ? family_rows : count, f);
+        plan.push_back(Block{count, f});
     } else {
-        e = launch_synth(a, L, ctx->stream);
-        ctx->last_kernel = last_kernel_name();
+        plan_blocks(ctx, batch, out_stride, count, batch_span(ctx, batch, out_stride), plan, 0);
     }
-    if (e != hipSuccess) return hip_fail(e, "synth kernel launch");
+    size_t main_block = 0;                     // the block with the most rows: the one the statistics describe
+    for (size_t i = 1; i < plan.size(); ++i)
+        if (plan[i].rows > plan[main_block].rows) main_block = i;
+    const Family f0 = plan[main_block].f;
+    ctx->last_split = f0.split_k;
+    ctx->last_formants = f0.live4 ? 4 : 8;
+    ctx->last_lanes = f0.scan ? 0 : f0.L;
+    ctx->last_pipe = f0.pipe && !f0.scan ? 1 : 0;
+    ctx->last_fast = 0;
+    ctx->last_blocks = (int)plan.size();
+    HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    uint32_t slot0 = 0;
+    std::string first_kernel;
+    for (size_t i = 0; i < plan.size(); ++i) {
+        const Block &b = plan[i];
+        rc = launch_block(ctx, batch, b.f, out_dev, out_pcm16_dev, out_stride, out_len_dev, first, slot0, b.rows, use_perm);
+        if (rc) return rc;
+        if (i == main_block) first_kernel = ctx->last_kernel;
+        if (b.f.fast) ctx->last_fast = 1;
+        slot0 += b.rows;
+    }
+    ctx->last_kernel = first_kernel;            // the largest block's instantiation names the launch
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->have_timing = true;
+    return GRAIL_OK;
+}
+
+int grail_plan_blocks(uint32_t compute_units, int arithmetic, int live_formants, uint32_t warmup, uint32_t rows,
+                      uint32_t span_samples, grail_plan_block *blocks, uint32_t cap, uint32_t *n_blocks)
+{
+    if (!n_blocks) return fail(GRAIL_ERR_INVALID_ARG, "n_blocks is NULL");
+    *n_blocks = 0;
+    if (compute_units == 0 || compute_units > 4096) return fail(GRAIL_ERR_INVALID_ARG, "compute_units must be 1 .. 4096");
+    if (live_formants != 4 && live_formants != 8) return fail(GRAIL_ERR_INVALID_ARG, "live_formants must be 4 or 8");
+    if (arithmetic != 0 && arithmetic != 1) return fail(GRAIL_ERR_INVALID_ARG, "arithmetic must be 0 or 1");
+    if (rows == 0) return GRAIL_OK;
+    // a context and a batch as choose_family sees them: default options, a voice table that qualifies for every
+    // family (four or eight live formants), a plain phoneme batch with power-of-two blend lengths
+    grail_ctx ctx;
+    ctx.cus = ctx.device_cus = (int)compute_units;
+    ctx.fast_option = arithmetic;
+    ctx.voices_sharpness = 0.0;
+    ctx.voices_upper_silent = ctx.voices_live4_ok = live_formants == 4;
+    ctx.voices_scan_ok = true;
+    ctx.voices_split_ok = warmup != 0u;
+    ctx.max_warmup = warmup;
+    ctx.max_rate = 1.0f;                  // max_seconds below is in samples
+    ctx.max_dt = 1.0f;
+    grail_batch batch;
+    batch.n_utt = rows;
+    batch.phoneme_mode = true;
+    batch.plain = true;
+    batch.max_seconds = (float)span_samples;
+    batch.min_length = 1e9f;
+    batch.min_pitch = 0.25f;
+    const uint64_t stride = ((uint64_t)span_samples + 64u + 63u) / 64u * 64u;
+    std::vector<Block> plan;
+    plan_blocks(&ctx, &batch, stride, rows, batch_span(&ctx, &batch, stride), plan, 0);
+    *n_blocks = (uint32_t)plan.size();
+    for (uint32_t i = 0; i < plan.size() && i < cap && blocks; ++i) {
+        const Family &f = plan[i].f;
+        blocks[i].rows = plan[i].rows;
+        blocks[i].lanes_per_utterance = f.scan ? 0u : (uint32_t)f.L;
+        blocks[i].pipelined = f.scan ? 0u : f.pipe;
+        blocks[i].chunks = (uint32_t)f.split_k;
+        blocks[i].scan = f.scan ? (f.scan_pipe ? 2u : 1u) : 0u;
+        blocks[i].fast = f.fast;
+        blocks[i].formants = f.live4 ? 4u : 8u;
+        blocks[i].model_ms = (float)family_cost(&ctx, f, plan[i].rows, batch_span(&ctx, &batch, stride));
+    }
     return GRAIL_OK;
 }
 
@@ -1183,11 +1498,11 @@ int grail_stream_open(grail_ctx *ctx, const grail_batch *batch, grail_stream **o
     s->any_blend = batch->any_blend;
     s->live4 = batch_live4(ctx, batch);
     s->voices_epoch = ctx->voices_epoch;
-    s->L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(batch->n_utt);
+    s->L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(batch->n_utt, ctx_simds(ctx));
     if (s->live4) {
         if (s->L == 8) s->live4 = false;     // eight lanes per utterance need eight formants to lay out
         else if (!ctx->lanes_option)         // same rule over four formants: the widest one-wave-per-SIMD mapping
-            s->L = ((uint64_t)batch->n_utt * 4 + 63) / 64 <= 1024 ? 4 : ((uint64_t)batch->n_utt * 2 + 63) / 64 <= 1024 ? 2 : 1;
+            s->L = ((uint64_t)batch->n_utt * 4 + 63) / 64 <= ctx_simds(ctx) ? 4 : ((uint64_t)batch->n_utt * 2 + 63) / 64 <= ctx_simds(ctx) ? 2 : 1;
     }
     s->lanes = state_lanes(batch->n_utt, s->L);
     const size_t bytes = (size_t)state_words(s->L) * s->lanes * sizeof(uint32_t);
@@ -1478,7 +1793,7 @@ int render_to_host(grail_ctx *ctx, grail_batch *b, uint32_t n_utt, void *out, si
             if (e != hipSuccess) { rc = hip_fail(e, "block set-up"); break; }
             rc = synthesize_rows(ctx, b, elem == 4 ? (float *)p->dev[slot] : nullptr,
                                  elem == 2 ? (int16_t *)p->dev[slot] : nullptr, out_stride, d_len + first,
-                                 (uint32_t)first, count, (uint32_t)rows);
+                                 (uint32_t)first, count, rows < n_utt ? (uint32_t)rows : 0u);   // (one block: plan freely)
             if (rc) break;
             e = hipEventRecord(p->rendered[slot], ctx->stream);
             if (e == hipSuccess) e = hipStreamWaitEvent(p->copy_stream, p->rendered[slot], 0);

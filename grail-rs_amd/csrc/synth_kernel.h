@@ -420,7 +420,9 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                               : PIPE ? blockIdx.x * S : (blockIdx.x * WAVES + wave) * S;
     // which utterance this slot renders: its position in the launch, or — ragged batches — the host's
     // length-sorted assignment (A.perm), so that the lanes of a wave end together; rows, lengths and
-    // per-utterance inputs always belong to utterance `u`
+    // per-utterance inputs always belong to utterance `u`.  (A launch may cover a range of the slots only —
+    // A.perm then points at the range's first slot and `u` may well exceed A.n_utt: `slot_used` says whether
+    // the slot renders, never a comparison of `u`.)
     const bool slot_used = u0 + slot < A.n_utt;
     const uint32_t u = !slot_used ? A.n_utt : (A.perm ? A.perm[u0 + slot] : u0 + slot);
     bool done = !slot_used;
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             io(st_a[k]); io(st_b[k]); io(st_c[k]);
         }
     };
-    if (streaming && A.state && A.resume && u < A.n_utt) {
+    if (streaming && A.state && A.resume && slot_used) {
         StateIO<true> io{A.state, A.state_stride, state_lane};
         visit_state(io);
         done = finished;
@@ -2331,15 +2333,15 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         // the utterance's length comes from the lane that saw it end — the chain returned None, or the row was
         // full — inside its own chunk: a lane that stopped at the next chunk's first sample has only paused, and
         // an utterance that ended before this lane's chunk began belongs to an earlier lane
-        if (u < A.n_utt && done && !paused && n_out >= chunk_lo) {
+        if (slot_used && done && !paused && n_out >= chunk_lo) {
             if (A.out_len) A.out_len[u] = n_out;
             if (truncated) atomicOr(A.truncated, 1u);
         }
-    } else if (emit && j == L - 1 && u < A.n_utt) {
+    } else if (emit && j == L - 1 && slot_used) {
         if (A.out_len) A.out_len[u] = n_out;
         if (truncated) atomicOr(A.truncated, 1u);
     }
-    if (streaming && A.state && u < A.n_utt) {
+    if (streaming && A.state && slot_used) {
         StateIO<false> io{A.state, A.state_stride, state_lane};
         visit_state(io);
     }

@@ -42,6 +42,7 @@ FAST_TOLERANCE_NOTE = (f"fast mode: max |fast - exact| <= {FAST_TOLERANCE_ULPS} 
                        "full scale vs the oracle (tests/test_fast_gpu.py asserts it on configs 2, 3, 4 "
                        "and a fuzz corpus); clock, phases, wraps and LCGs stay exact")
 UNIQUE_ID_BYTES = 128
+ABI_VERSION = 2                  # GRAIL_ABI_VERSION of the header this binding mirrors
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRAIL_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib",
@@ -53,7 +54,7 @@ EXPORTS = [
     "grail_elem_silent", "grail_elem_new_phoneme", "grail_elem_new", "grail_elem_resample",
     "grail_elem_blend", "grail_voice_generic", "grail_voice_generic_at", "grail_voice_get",
     "grail_create", "grail_destroy", "grail_device_count", "grail_device_pci_bus_id", "grail_time_split_warmup",
-    "grail_time_split_grid", "grail_fast_sharpness", "grail_set_voices",
+    "grail_time_split_grid", "grail_fast_sharpness", "grail_plan_blocks", "grail_set_voices",
     "grail_get_voices", "grail_set_option", "grail_get_option",
     "grail_batch_upload", "grail_batch_upload_elems", "grail_batch_free", "grail_batch_size",
     "grail_batch_lengths", "grail_batch_synthesize_async", "grail_sync",
@@ -127,6 +128,29 @@ class SequenceElem(C.Structure):
     ]
 
 
+class PlanBlock(C.Structure):
+    """grail_plan_block: one kernel launch of a batch's plan (grail_plan_blocks)."""
+    _fields_ = [
+        ("rows", C.c_uint32),
+        ("lanes_per_utterance", C.c_uint32),
+        ("pipelined", C.c_uint32),
+        ("chunks", C.c_uint32),
+        ("scan", C.c_uint32),
+        ("fast", C.c_uint32),
+        ("formants", C.c_uint32),
+        ("model_ms", C.c_float),
+    ]
+
+    def family(self):
+        if self.scan:
+            return f"scan{self.scan + 1}"
+        if self.chunks:
+            return f"split{self.chunks}"
+        if self.pipelined:
+            return f"pipe{self.formants}r{16 * self.pipelined}"
+        return ("fast" if self.fast else "exact") + f"L{self.lanes_per_utterance}"
+
+
 class Rule(C.Structure):
     _fields_ = [
         ("string", C.POINTER(C.c_uint32)),
@@ -158,6 +182,9 @@ def load():
     L = C.CDLL(LIB_PATH)
     vp, u32p, u64 = C.c_void_p, C.POINTER(C.c_uint32), C.c_uint64
     L.grail_abi_version.restype = C.c_int
+    if L.grail_abi_version() != ABI_VERSION:     # before any other symbol is touched
+        raise GrailError(ERR_INVALID_ARG, f"{LIB_PATH} has ABI version {L.grail_abi_version()}, this binding "
+                                          f"mirrors version {ABI_VERSION} of include/grail_hip.h: rebuild the library")
     L.grail_status_string.restype = C.c_char_p
     L.grail_status_string.argtypes = [C.c_int]
     L.grail_last_error.restype = C.c_char_p
@@ -186,6 +213,8 @@ def load():
     L.grail_fast_sharpness.argtypes = [C.POINTER(Voice)]
     L.grail_fast_sharpness.restype = C.c_float
     L.grail_time_split_grid.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.grail_plan_blocks.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.POINTER(PlanBlock), C.c_uint32, u32p]
     L.grail_set_voices.argtypes = [vp, vp, C.c_uint32]
     L.grail_get_voices.argtypes = [vp, vp, C.c_uint32, u32p]
     L.grail_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
@@ -382,6 +411,15 @@ def time_split_grid(span_samples, warmup, chunks, ff_cost_permille=165):
     out = (C.c_uint32 * max(int(chunks), 1))()
     _check(load().grail_time_split_grid(span_samples, warmup, chunks, ff_cost_permille, out))
     return [int(x) for x in out]
+
+
+def plan_blocks(rows, span_samples, arithmetic=0, live_formants=4, warmup=3904, compute_units=256):
+    """How a batch of `rows` utterances (longest: span_samples) is cut into kernel launches: [PlanBlock]."""
+    arr = (PlanBlock * 16)()
+    n = C.c_uint32()
+    _check(load().grail_plan_blocks(compute_units, arithmetic, live_formants, warmup, rows, span_samples, arr, 16,
+                                    C.byref(n)))
+    return [PlanBlock.from_buffer_copy(bytes(arr[i])) for i in range(min(n.value, 16))]
 
 
 def device_count():

@@ -1,4 +1,5 @@
-//! Raw mirror of `include/grail_hip.h` (ABI version 1).  Field orders follow grail-rs:
+//! Raw mirror of `include/grail_hip.h` (ABI version 2: `GRAIL_ABI_VERSION`; compare it with
+//! `grail_abi_version()` before the first call, as `grail_hip::Context::new` does).  Field orders follow grail-rs:
 //! `SynthesisElem` src/lib.rs:316-337, `Voice` :696-717, `PhonemeElem` :961-973,
 //! `SequenceElem` :814-824, `Phoneme` :632-649.
 #![allow(non_camel_case_types)]
@@ -7,6 +8,8 @@ use std::os::raw::{c_char, c_int};
 pub const GRAIL_NUM_FORMANTS: usize = 8;
 pub const GRAIL_NUM_VOICED: usize = 2;
 pub const GRAIL_UNIQUE_ID_BYTES: usize = 128;
+
+pub const GRAIL_ABI_VERSION: c_int = 2;
 
 pub const GRAIL_OK: c_int = 0;
 pub const GRAIL_ERR_INVALID_ARG: c_int = -1;
@@ -69,6 +72,20 @@ pub struct grail_rule {
     pub n_phonemes: u32,
 }
 
+/// One kernel launch of a batch's plan (`grail_plan_blocks`).
+#[repr(C)]
+#[derive(Copy, Clone, Debug, Default, PartialEq)]
+pub struct grail_plan_block {
+    pub rows: u32,
+    pub lanes_per_utterance: u32,
+    pub pipelined: u32,
+    pub chunks: u32,
+    pub scan: u32,
+    pub fast: u32,
+    pub formants: u32,
+    pub model_ms: f32,
+}
+
 #[repr(C)]
 pub struct grail_ctx {
     _private: [u8; 0],
@@ -108,6 +125,8 @@ extern "C" {
     pub fn grail_fast_sharpness(voice: *const grail_voice) -> f32;
     pub fn grail_time_split_grid(span_samples: u32, warmup: u32, chunks: u32, ff_cost_permille: u32,
                                  bounds: *mut u32) -> c_int;
+    pub fn grail_plan_blocks(compute_units: u32, arithmetic: c_int, live_formants: c_int, warmup: u32, rows: u32,
+                             span_samples: u32, blocks: *mut grail_plan_block, cap: u32, n_blocks: *mut u32) -> c_int;
     pub fn grail_set_voices(ctx: *mut grail_ctx, voices: *const grail_voice, n: u32) -> c_int;
     pub fn grail_get_voices(ctx: *mut grail_ctx, voices: *mut grail_voice, cap: u32, n: *mut u32) -> c_int;
     pub fn grail_set_option(ctx: *mut grail_ctx, name: *const c_char, value: i64) -> c_int;

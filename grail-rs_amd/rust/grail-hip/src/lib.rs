@@ -53,6 +53,12 @@ fn voice_to_c(v: &Voice) -> sys::grail_voice {
 
 impl Gpu {
     pub fn new(device: i32, voices: &[Voice]) -> Result<Self, Error> {
+        // the library on the loader's path may be older or newer than the header this crate mirrors
+        let have = unsafe { sys::grail_abi_version() };
+        if have != sys::GRAIL_ABI_VERSION {
+            return Err(Error { status: sys::GRAIL_ERR_INVALID_ARG,
+                               message: format!("libgrail_hip.so has ABI version {have}, grail-hip-sys mirrors {}", sys::GRAIL_ABI_VERSION) });
+        }
         let mut ctx = std::ptr::null_mut();
         check(unsafe { sys::grail_create(device, &mut ctx) })?;
         let gpu = Gpu { ctx };

@@ -58,7 +58,12 @@
 extern "C" {
 #endif
 
-#define GRAIL_ABI_VERSION 1
+/* Bumped whenever an entry point, an option name or the meaning of an option changes; a binding compares it with
+ * grail_abi_version() of the library it loaded BEFORE its first call (the Python and Rust bindings do).
+ *   1: rounds 1-2.   2: round 3-4 — grail_device_pci_bus_id, grail_time_split_warmup / _grid, grail_fast_sharpness,
+ *   grail_plan_blocks, grail_stream_open_live / _append / _finish; option "kernel_variant" removed, "scan_debug" in
+ *   development builds only; "arithmetic" = 1 is served up to a sharpness of the voice table. */
+#define GRAIL_ABI_VERSION 2
 /* fast mode ("arithmetic" = 1): bound on |fast - exact| per sample, full scale = 1.0; k * 2^-23 */
 #define GRAIL_FAST_TOLERANCE_ULPS 64
 #define GRAIL_FAST_TOLERANCE (GRAIL_FAST_TOLERANCE_ULPS * 1.1920928955078125e-07f)
@@ -281,6 +286,32 @@ uint32_t grail_time_split_warmup(const grail_voice *voice);
 float grail_fast_sharpness(const grail_voice *voice);
 int grail_time_split_grid(uint32_t span_samples, uint32_t warmup, uint32_t chunks, uint32_t ff_cost_permille,
                           uint32_t *bounds);
+/* The launch plan, as a pure host function (no GPU, no context).  A kernel family fills the machine with a fixed
+ * number of utterances (one wavefront per SIMD: 16 / 32 per compute unit for the pipelined workgroups, 256 / L for L
+ * lanes per utterance), and one utterance more costs it a whole further round.  A batch is therefore cut into BLOCKS,
+ * each rendered by the family that suits the block's size: whole rounds of the one-lane kernels first, the rest with
+ * wider mappings (65537 utterances: 65536 on one lane each + 1 on a pipelined workgroup, 47 ms instead of 81).  The
+ * cut minimises a cost model calibrated on the device (profiles/r04_duration_sweep.txt) that follows the compute-unit
+ * count and the utterances' length.  Exact arithmetic is mapping-invariant: the cut never changes a bit.  In fast
+ * arithmetic a row's samples follow the family of ITS block, which this function predicts: rows keep batch order
+ * (length-sorted batches: slot order), block i covers the next blocks[i].rows of them.
+ *   compute_units: hipDeviceProp_t::multiProcessorCount (256 for a whole MI355X; option "compute_units" tells)
+ *   arithmetic: 0 exact / 1 fast;  live_formants: 4 (formants 5-8 silent in every phoneme, as voices::generic()) or 8
+ *   warmup: grail_time_split_warmup() of the voice table's slowest voice (0: no time-split kernels)
+ *   rows, span_samples: the batch size and its longest utterance
+ * *n_blocks receives the number of blocks even when it exceeds cap. */
+typedef struct grail_plan_block {
+    uint32_t rows;
+    uint32_t lanes_per_utterance; /* lane kernels and pipelined workgroups: 1 / 2 / 4 / 8; scan kernel: 0 */
+    uint32_t pipelined;           /* exact pipelined workgroups: 1 rounds of 16 samples, 2 rounds of 32; else 0 */
+    uint32_t chunks;              /* time-split kernels: chunks per utterance; else 0 */
+    uint32_t scan;                /* scan kernel: 1 two-stage, 2 three-stage workgroups; else 0 */
+    uint32_t fast;                /* the block runs tolerance arithmetic */
+    uint32_t formants;            /* formants laid out: 4 or 8 */
+    float    model_ms;            /* the cost model's estimate for the block */
+} grail_plan_block;
+int grail_plan_blocks(uint32_t compute_units, int arithmetic, int live_formants, uint32_t warmup, uint32_t rows,
+                      uint32_t span_samples, grail_plan_block *blocks, uint32_t cap, uint32_t *n_blocks);
 
 /* ---- batches ----------------------------------------------------------- */
 /* Uploads the inputs of n_utt utterances: utterance u is

@@ -31,7 +31,11 @@ def test_library_exports_every_declared_symbol(built):
 
 def test_abi_version_and_status_strings(built):
     lib = G.load()
-    assert lib.grail_abi_version() == 1
+    assert lib.grail_abi_version() == G.ABI_VERSION == 2
+    hdr = open(os.path.join(ROOT, "include", "grail_hip.h")).read()
+    assert re.search(r"#define GRAIL_ABI_VERSION (\d+)", hdr).group(1) == "2"
+    sys_rs = open(os.path.join(ROOT, "grail-rs_amd", "rust", "grail-hip-sys", "src", "lib.rs")).read()
+    assert "pub const GRAIL_ABI_VERSION: c_int = 2;" in sys_rs
     for st in range(0, -8, -1):
         assert lib.grail_status_string(st)
     assert b"CPU fallback" in lib.grail_status_string(G.ERR_NO_DEVICE)

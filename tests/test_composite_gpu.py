@@ -1,0 +1,255 @@
+"""Composite launches: a batch is cut into blocks with a kernel family each (grail_api.cpp plan_blocks), so that one
+utterance more than a family holds does not cost a whole further round of it.  Exact arithmetic is mapping-invariant:
+whatever the cut, every sample must equal the oracle's bit pattern.  The machine is made small with
+"assume_compute_units" (1 CU = 256 lanes), so that batches of a few hundred short utterances are cut the way batches
+of 70 000 are on the whole device."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import grail_hip as G
+import oracle_lib as O
+from grail_hip import workload as W
+
+pytestmark = pytest.mark.gpu
+ULP = 2.0 ** -23
+
+
+def _ovoices(voices):
+    return [O.Voice.from_buffer_copy(bytes(v)) for v in voices]
+
+
+def _ragged(n_utt, n_voices, seed=5):
+    """Utterances of 1 - 6 segments of 8 - 40 ms with random blend lengths of 2^-k s: lengths differ by 10 x."""
+    rng = np.random.default_rng(seed)
+    segs, offs, _, _ = W.make_batch(n_utt, n_voices=n_voices, segments=6, length=0.02, blend_length=2.0 ** -6)
+    segs = segs.reshape(n_utt, 6)
+    keep = rng.integers(1, 7, size=n_utt)
+    segs["length"] = rng.uniform(0.008, 0.04, size=segs.shape).astype(np.float32)
+    segs["blend_length"] = (2.0 ** -rng.integers(5, 8, size=segs.shape)).astype(np.float32)
+    flat, o = [], [0]
+    for u in range(n_utt):
+        flat.append(segs[u, :keep[u]])
+        o.append(o[-1] + int(keep[u]))
+    ids = np.arange(n_utt, dtype=np.uint32)
+    return np.concatenate(flat), np.array(o, dtype=np.uint32), ids % np.uint32(n_voices), ids * np.uint32(31) + np.uint32(7)
+
+
+def _device_render(ctx, segs, offs, vids, seeds, stride, pcm16=False):
+    """Through the asynchronous entry points (device buffers): what bench.py and a Rust caller use."""
+    n = len(offs) - 1
+    batch = ctx.upload(segs, offs, vids, seeds)
+    item = 2 if pcm16 else 4
+    d_out = ctx.device_alloc(n * stride * item)
+    d_len = ctx.device_alloc(n * 4)
+    try:
+        ctx.memset(d_out, 0, n * stride * item)
+        if pcm16:
+            batch.synthesize_pcm16_async(d_out, stride, d_len)
+        else:
+            batch.synthesize_async(d_out, stride, d_len)
+        status = G.OK
+        try:
+            ctx.sync()
+        except G.GrailError as e:
+            status = e.status
+        out = np.zeros((n, stride), dtype=np.int16 if pcm16 else np.float32)
+        lens = np.zeros(n, dtype=np.uint32)
+        ctx.d2h(out, d_out, out.nbytes)
+        ctx.d2h(lens, d_len, lens.nbytes)
+        return out, lens, status
+    finally:
+        ctx.device_free(d_out)
+        ctx.device_free(d_len)
+        batch.free()
+
+
+def _bit_identical(out, lens, ref, ref_len, what):
+    assert np.array_equal(lens, ref_len), f"{what}: lengths differ at {np.flatnonzero(lens != ref_len)[:8]}"
+    for u in range(len(lens)):
+        n = int(lens[u])
+        a, b = out[u, :n].view(np.uint32), ref[u, :n].view(np.uint32)
+        assert np.array_equal(a, b), f"{what}: utterance {u} first differs at sample {int(np.argmax(a != b))}"
+
+
+@pytest.fixture
+def small_machine(gpu_ctx):
+    def set_cus(c):
+        gpu_ctx.set_option("assume_compute_units", c)
+    yield set_cus
+    gpu_ctx.set_option("assume_compute_units", 0)
+    gpu_ctx.set_option("composite_launches", 1)
+    gpu_ctx.set_option("sort_by_length", 1)
+    gpu_ctx.set_option("arithmetic", 0)
+    gpu_ctx.set_voices(W.single_voice())
+
+
+@pytest.mark.parametrize("n_voices", [1, 8])
+@pytest.mark.parametrize("cus,n_utt", [(1, 257), (1, 300), (1, 341), (1, 600), (2, 700), (1, 1100)])
+def test_composite_exact_is_bit_identical_to_the_oracle(gpu_ctx, small_machine, cus, n_utt, n_voices):
+    """1 CU holds 256 utterances on one lane each, 128 / 64 on two / four, 32 / 16 in pipelined workgroups: 257, 300,
+    341 ... are one round of the one-lane kernel plus a rest on a wider mapping."""
+    voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    small_machine(cus)
+    segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=n_voices, length=0.03, blend_length=2.0 ** -5)
+    stride = W.max_samples(length=0.03)
+    out, lens, status = _device_render(gpu_ctx, segs, offs, vids, seeds, stride)
+    blocks = gpu_ctx.get_option("last_launch_blocks")
+    assert status == G.OK and blocks >= 2, blocks
+    ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, stride)
+    _bit_identical(out, lens, ref, ref_len, f"cus={cus} n={n_utt} blocks={blocks}")
+    # the cut is the one the pure planner predicts (aligned batch, default options)
+    span = int(np.ceil(4 * np.float32(0.03) * 48000.0)) + 0
+    plan = G.plan_blocks(n_utt, span, 0, 4 if n_voices == 1 else 8, compute_units=cus)
+    assert len(plan) == blocks
+    # and switching the composite launches off gives the same bits in one launch
+    gpu_ctx.set_option("composite_launches", 0)
+    one, one_len, _ = _device_render(gpu_ctx, segs, offs, vids, seeds, stride)
+    assert gpu_ctx.get_option("last_launch_blocks") == 1
+    _bit_identical(one, one_len, ref, ref_len, "single launch")
+
+
+@pytest.mark.parametrize("sort", [1, 0])
+def test_composite_ragged_batch_with_the_length_sorted_slot_order(gpu_ctx, small_machine, sort):
+    """Ragged utterances: the host hands out launch slots longest first (sort_by_length) and the blocks are ranges of
+    SLOTS; rows, lengths and seeds stay the utterance's own."""
+    voices = W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    small_machine(1)
+    gpu_ctx.set_option("sort_by_length", sort)
+    n_utt = 431
+    segs, offs, vids, seeds = _ragged(n_utt, 8)
+    stride = 12288
+    out, lens, status = _device_render(gpu_ctx, segs, offs, vids, seeds, stride)
+    assert status == G.OK and gpu_ctx.get_option("last_launch_blocks") >= 2
+    ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, stride)
+    assert ref_len.max() > 5 * max(int(ref_len.min()), 1)
+    _bit_identical(out, lens, ref, ref_len, f"ragged sort={sort}")
+    # the one-call host form (a single row block) takes the same path
+    host, host_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+    assert gpu_ctx.get_option("last_launch_blocks") >= 2
+    _bit_identical(host, host_len, ref, ref_len, "host form")
+
+
+def test_composite_lengths_and_truncation_are_reported_across_blocks(gpu_ctx, small_machine):
+    """Rows that do not fit out_stride are cut and reported whichever block they sit in; untouched tails stay."""
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
+    small_machine(1)
+    gpu_ctx.set_option("sort_by_length", 0)            # blocks in batch order: rows 0..255 | 256..
+    n_utt = 300
+    segs, offs, vids, seeds = _ragged(n_utt, 1, seed=11)
+    full_ref, full_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, 12288)
+    stride = int(np.sort(full_len)[n_utt // 2]) // 64 * 64          # about half of the rows do not fit
+    out, lens, status = _device_render(gpu_ctx, segs, offs, vids, seeds, stride)
+    assert gpu_ctx.get_option("last_launch_blocks") >= 2
+    assert status == G.ERR_BUFFER_TOO_SMALL
+    want = np.minimum(full_len, stride)
+    assert np.array_equal(lens, want)
+    cut = np.flatnonzero(full_len > stride)
+    assert (cut < 256).any() and (cut >= 256).any()          # truncated rows in both blocks
+    for u in range(n_utt):
+        m = int(want[u])
+        assert np.array_equal(out[u, :m].view(np.uint32), full_ref[u, :m].view(np.uint32)), u
+        assert not out[u, m:].any()                           # nothing written past a row's end
+    # a batch that fits reports OK again (the flag does not stick)
+    out, lens, status = _device_render(gpu_ctx, segs, offs, vids, seeds, 12288)
+    assert status == G.OK and np.array_equal(lens, full_len)
+
+
+def test_composite_is_batch_invariant(gpu_ctx, small_machine):
+    """utterance u's samples do not depend on N or on its position — here: on the block it lands in."""
+    voices = W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    small_machine(1)
+    stride = 12288
+    segs, offs, vids, seeds = _ragged(700, 8, seed=3)
+    big, big_len, _ = _device_render(gpu_ctx, segs, offs, vids, seeds, stride)
+    assert gpu_ctx.get_option("last_launch_blocks") >= 2
+    for first, n in ((0, 40), (250, 20), (500, 200), (699, 1)):
+        lo, hi = int(offs[first]), int(offs[first + n])
+        osub = (offs[first:first + n + 1] - offs[first]).astype(np.uint32)
+        part, part_len, _ = _device_render(gpu_ctx, segs[lo:hi], osub, vids[first:first + n], seeds[first:first + n], stride)
+        assert np.array_equal(part_len, big_len[first:first + n])
+        for r in range(n):
+            m = int(part_len[r])
+            assert np.array_equal(part[r, :m].view(np.uint32), big[first + r, :m].view(np.uint32)), (first, r)
+
+
+def test_composite_pcm16_rows(gpu_ctx, small_machine):
+    """i16 rows (examples/cli.rs:49 fused into the flush) through a composite launch: the conversion of the oracle's rows."""
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
+    small_machine(1)
+    n_utt = 333
+    segs, offs, vids, seeds = _ragged(n_utt, 1, seed=21)
+    stride = 12288
+    pcm, lens, status = _device_render(gpu_ctx, segs, offs, vids, seeds, stride, pcm16=True)
+    assert status == G.OK and gpu_ctx.get_option("last_launch_blocks") >= 2
+    ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, stride)
+    assert np.array_equal(lens, ref_len)
+    L = O.lib()
+    conv = np.vectorize(lambda x: L.orc_pcm16(C.c_float(x)), otypes=[np.int16])
+    for u in range(0, n_utt, 7):
+        m = int(lens[u])
+        assert np.array_equal(pcm[u, :m], conv(ref[u, :m])), u
+        assert not pcm[u, m:].any()
+
+
+@pytest.mark.parametrize("n_voices", [1, 8])
+def test_composite_fast_mode_stays_within_the_tolerance(gpu_ctx, small_machine, n_voices):
+    """Fast arithmetic: a head on the fast one-lane kernels and a rest on whatever suits its size (time-split chunks,
+    the scan kernel); every row within GRAIL_FAST_TOLERANCE of the oracle, lengths identical."""
+    voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    small_machine(1)
+    gpu_ctx.set_option("arithmetic", 1)
+    n_utt = 300
+    segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=n_voices, length=0.25, blend_length=0.25)
+    stride = W.max_samples(length=0.25)
+    out, lens, status = _device_render(gpu_ctx, segs, offs, vids, seeds, stride)
+    assert status == G.OK
+    assert gpu_ctx.get_option("last_launch_blocks") >= 2 and gpu_ctx.get_option("last_launch_fast") == 1
+    ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, stride)
+    assert np.array_equal(lens, ref_len)
+    worst = 0.0
+    for u in range(n_utt):
+        m = int(lens[u])
+        d = float(np.max(np.abs(out[u, :m].astype(np.float64) - ref[u, :m].astype(np.float64))))
+        worst = max(worst, d / max(1.0, float(np.max(np.abs(ref[u, :m])))))
+    print(f"composite fast vs oracle, voices={n_voices}: {worst / ULP:.1f} * 2^-23")
+    assert 0.0 < worst <= G.FAST_TOLERANCE
+
+
+def test_policy_follows_the_compute_unit_count_and_parity_stays(gpu_ctx, small_machine):
+    """the L / family choice scales with the CU count (a CPX partition has 32), bits do not move."""
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
+    n_utt = 2048
+    segs, offs, vids, seeds = W.make_batch(n_utt, length=0.01, blend_length=2.0 ** -7)
+    stride = W.max_samples(length=0.01)
+    ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, stride)
+    assert gpu_ctx.get_option("compute_units") >= 32
+    seen = {}
+    for cus in (0, 64, 32, 16, 8, 2):
+        small_machine(cus)
+        out, lens, status = _device_render(gpu_ctx, segs, offs, vids, seeds, stride)
+        assert status == G.OK
+        _bit_identical(out, lens, ref, ref_len, f"cus={cus}")
+        seen[cus] = (gpu_ctx.get_option("last_launch_pipelined"), gpu_ctx.get_option("last_launch_lanes"),
+                     gpu_ctx.get_option("last_launch_blocks"))
+    print(seen)
+    assert seen[0][0] == 1                       # the whole device: pipelined workgroups (2048 <= 16 per CU)
+    assert seen[64] == (1, 4, 1)                 # 64 CUs: 32 per CU, still pipelined (rounds of 16)
+    assert seen[32] == (0, 4, 1)                 # 32 CUs: four lanes per utterance fill 128 SIMDs exactly
+    assert seen[16] == (0, 2, 1)                 # 16 CUs: two lanes
+    assert seen[8] == (0, 1, 1)                  # 8 CUs: one lane each, one round
+    assert seen[2][1] == 1 and seen[2][2] == 1   # 2 CUs: four whole rounds of the one-lane kernel, nothing left over
+
+
+def test_create_reports_the_device_and_refuses_nothing_on_gfx950(gpu_ctx):
+    cus = gpu_ctx.get_option("compute_units")
+    assert cus in (32, 64, 128, 256) or cus > 0
+    assert gpu_ctx.get_option("assume_compute_units") == 0

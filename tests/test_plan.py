@@ -1,0 +1,94 @@
+"""The launch plan (grail_plan_blocks, include/grail_hip.h) as a pure host function: how a batch is cut into blocks
+with a kernel family each, so that the time of a batch is not a step function of its size.  No GPU needed."""
+import numpy as np
+import pytest
+
+import grail_hip as G
+
+SPAN = 96006          # 2 s at 48 kHz as the f32 Sequencer clock counts them
+
+
+def _cost(plan):
+    return sum(b.model_ms for b in plan) + 0.05 * (len(plan) - 1)
+
+
+def _one(n, fast, formants=4, cus=256, span=SPAN):
+    return G.plan_blocks(n, span, fast, formants, compute_units=cus)
+
+
+@pytest.mark.parametrize("fast", [0, 1])
+@pytest.mark.parametrize("formants", [4, 8])
+def test_blocks_cover_the_batch_and_no_row_twice(fast, formants):
+    for n in (1, 15, 16, 17, 4096, 4097, 65535, 65536, 65537, 70000, 98304, 131073, 200000, 524288):
+        plan = _one(n, fast, formants)
+        assert sum(b.rows for b in plan) == n
+        assert all(b.rows > 0 for b in plan)
+        assert len(plan) <= 8
+
+
+@pytest.mark.parametrize("fast", [0, 1])
+@pytest.mark.parametrize("formants", [4, 8])
+def test_cost_is_not_a_step_function_above_one_round(fast, formants):
+    """T(n) <= floor(n / 65536) T(65536) + T_best(n mod 65536) + a launch."""
+    full = _cost(_one(65536, fast, formants))
+    assert len(_one(65536, fast, formants)) == 1
+    for n in (65537, 70000, 81920, 98304, 131073, 200000):
+        rest = n % 65536
+        single_rest = G.plan_blocks(rest, SPAN, fast, formants)          # (itself possibly composite: at most as dear)
+        bound = (n // 65536) * full + _cost(single_rest) + 0.3
+        assert _cost(_one(n, fast, formants)) <= bound, n
+        # and far below what one more full round costs when the rest is small
+        if rest <= 8192:
+            assert _cost(_one(n, fast, formants)) <= (n // 65536) * full + 0.3 * full, n
+
+
+def test_exact_headline_sizes_keep_their_single_launch():
+    for n, fam in ((4096, "pipe4r32"), (8192, "pipe4r16"), (16384, "exactL4"), (32768, "exactL2"), (65536, "exactL1"),
+                   (131072, "exactL1")):
+        plan = _one(n, 0)
+        assert [(b.rows, b.family()) for b in plan] == [(n, fam)]
+    for n, fam in ((2048, "pipe8r32"), (4096, "pipe8r16"), (8192, "exactL8"), (65536, "exactL1")):
+        assert [(b.rows, b.family()) for b in _one(n, 0, 8)] == [(n, fam)]
+
+
+def test_fast_families_by_size_at_two_seconds():
+    assert _one(256, 1)[0].family() == "scan3"
+    assert _one(1024, 1)[0].family() == "scan3"
+    assert _one(4096, 1)[0].family() == "split16"
+    assert _one(32768, 1)[0].family() == "split2"
+    assert _one(65536, 1)[0].family() == "fastL1"
+    # the gap between half a machine and a whole one: a time-split head and a time-split rest
+    plan = _one(40000, 1)
+    assert sorted(b.rows for b in plan) == [7232, 32768] and all(b.chunks for b in plan)
+    assert _cost(plan) < _cost(_one(65536, 1)) - 1.0
+
+
+def test_capacities_follow_the_compute_unit_count():
+    """A partitioned MI355X (CPX: 32 CUs) is planned for 32 CUs: every capacity is 1/8 of the whole device's."""
+    for n256, n32 in ((4096, 512), (8192, 1024), (16384, 2048), (32768, 4096), (65536, 8192), (70000, 8750 - 6)):
+        a = [(b.family()) for b in _one(n256, 0, 4, 256)]
+        b = [(b.family()) for b in _one(n32, 0, 4, 32)]
+        assert a == b, (n256, n32, a, b)
+    assert _one(8192, 0, 4, 32)[0].family() == "exactL1"
+    assert _one(8192, 1, 4, 32)[0].family() == "fastL1"
+    assert [b.rows for b in sorted(_one(8193, 0, 4, 32), key=lambda b: -b.rows)] == [8192, 1]
+
+
+def test_short_utterances_move_the_scan_split_crossover_up():
+    """A chunk's warm-up (3904 samples for voices::generic() at 48 kHz) does not shrink with the utterance: at 0.25 s
+    the time-split kernels pay a third of the utterance per chunk and the scan kernel keeps batches that would be
+    time-split at 2 s."""
+    assert _one(2048, 1, span=SPAN)[0].chunks > 0
+    assert _one(2048, 1, span=12000)[0].scan > 0
+    # long utterances: the same crossover as at 2 s, or lower
+    assert _one(2048, 1, span=30 * 48000)[0].chunks > 0
+
+
+def test_bad_arguments():
+    with pytest.raises(G.GrailError):
+        G.plan_blocks(10, SPAN, 0, 5)
+    with pytest.raises(G.GrailError):
+        G.plan_blocks(10, SPAN, 2, 4)
+    with pytest.raises(G.GrailError):
+        G.plan_blocks(10, SPAN, 0, 4, compute_units=0)
+    assert G.plan_blocks(0, SPAN) == []
