@@ -11,6 +11,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <cstdlib>
@@ -1325,48 +1326,75 @@ struct Block {
 // block of one of the families' capacities (as many rounds as fit for the one-lane kernels) followed by the best
 // plan for the rest.  Exact arithmetic is mapping-invariant, so the cut never changes a bit; in fast arithmetic a row's
 // samples follow the family of ITS block (include/grail_hip.h, "Determinism contract").
-static double plan_blocks(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t rows, double span,
-                          std::vector<Block> &out, int depth)
-{
-    constexpr double LAUNCH_MS = 0.05;         // what a further launch costs by itself (measured: 0.02 - 0.06 ms)
-    Family whole;
-    choose_family(ctx, batch, out_stride, rows, whole);
-    double best = family_cost(ctx, whole, rows, span);
-    std::vector<Block> best_plan{Block{rows, whole}};
-    if (depth < 6) {
-        const uint64_t lanes = ctx_lanes(ctx), cus = (uint64_t)ctx->cus;
-        // the capacities at which some family is exactly full
-        // (largest first: of two plans of equal cost the one with the larger head wins)
-        const uint64_t caps[] = {lanes, lanes / 2, lanes / 4, lanes / 8, 32 * cus, 16 * cus, 8 * cus};
-        uint64_t seen = 0;
-        for (const uint64_t c : caps) {
-            if (c == 0 || c >= rows || c == seen) continue;
-            seen = c;
-            const uint32_t m = c == lanes ? (uint32_t)(rows / c) : 1u;
-            const uint32_t head = (uint32_t)(m * c);
-            Family fc;
-            choose_family(ctx, batch, out_stride, head, fc);
-            const double c_head = family_cost(ctx, fc, head, span);
-            if (c_head + LAUNCH_MS >= best) continue;
-            std::vector<Block> rest;
-            const double c_rest = plan_blocks(ctx, batch, out_stride, rows - head, span, rest, depth + 1);
-            if (c_head + LAUNCH_MS + c_rest < best) {
-                best = c_head + LAUNCH_MS + c_rest;
-                best_plan.assign(1, Block{head, fc});
-                best_plan.insert(best_plan.end(), rest.begin(), rest.end());
+struct Planner {
+    const grail_ctx *ctx;
+    const grail_batch *batch;
+    uint64_t out_stride;
+    double span;
+    static constexpr double LAUNCH_MS = 0.05;  // what a further launch costs by itself (measured: 0.02 - 0.06 ms)
+    // (choose_family lays out time-split grids by bisection: every size is looked at once)
+    std::map<uint32_t, std::pair<Family, double>> families;
+    std::map<uint32_t, std::pair<double, std::vector<Block>>> plans;
+
+    const std::pair<Family, double> &family(uint32_t rows)
+    {
+        auto it = families.find(rows);
+        if (it != families.end()) return it->second;
+        std::pair<Family, double> e;
+        choose_family(ctx, batch, out_stride, rows, e.first);
+        e.second = family_cost(ctx, e.first, rows, span);
+        return families.emplace(rows, e).first->second;
+    }
+    const std::pair<double, std::vector<Block>> &plan(uint32_t rows, int depth)
+    {
+        auto it = plans.find(rows);
+        if (it != plans.end()) return it->second;
+        const std::pair<Family, double> &whole = family(rows);
+        double best = whole.second;
+        std::vector<Block> best_plan{Block{rows, whole.first}};
+        if (depth < 4) {
+            const uint64_t lanes = ctx_lanes(ctx), cus = (uint64_t)ctx->cus;
+            // the capacities at which some family is exactly full (largest first: of two plans of equal cost the
+            // one with the larger head wins)
+            const uint64_t caps[] = {lanes, lanes / 2, lanes / 4, lanes / 8, 32 * cus, 16 * cus, 8 * cus};
+            uint64_t seen = 0;
+            for (const uint64_t c : caps) {
+                if (c == 0 || c >= rows || c == seen) continue;
+                seen = c;
+                const uint32_t m = c == lanes ? (uint32_t)(rows / c) : 1u;
+                const uint32_t head = (uint32_t)(m * c);
+                const std::pair<Family, double> &fc = family(head);
+                if (fc.second + LAUNCH_MS >= best) continue;
+                const std::pair<double, std::vector<Block>> &rest = plan(rows - head, depth + 1);
+                if (fc.second + LAUNCH_MS + rest.first < best) {
+                    best = fc.second + LAUNCH_MS + rest.first;
+                    best_plan.assign(1, Block{head, fc.first});
+                    best_plan.insert(best_plan.end(), rest.second.begin(), rest.second.end());
+                }
             }
         }
+        return plans.emplace(rows, std::make_pair(best, best_plan)).first->second;
     }
-    out = best_plan;
-    if (depth == 0 && out.size() > 1) {
-        // launch order: the family that is cheapest per sample first.  Length-sorted (ragged) batches hand out their
-        // slots longest first, and a block lasts as long as its longest utterance: the long ones go where a sample
-        // costs least.  (Aligned batches: any order costs the same.)
+};
+
+static double plan_blocks(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t rows, double span,
+                          std::vector<Block> &out)
+{
+    Planner p{ctx, batch, out_stride, span, {}, {}};
+    const std::pair<double, std::vector<Block>> &best = p.plan(rows, 0);
+    out = best.second;
+    if (out.size() > 1) {
+        // launch order: the block that is cheapest PER ROW first (in practice: the largest).  Two reasons.  Length-
+        // sorted (ragged) batches hand out their slots longest first and a block lasts as long as its longest
+        // utterance: with lengths falling by g per slot, moving a block of r rows and per-sample cost c behind one of
+        // r', c' saves g (c r' - c' r) — the long utterances belong where a ROW costs least.  And a small block leaves
+        // most of the machine idle for milliseconds: the large kernel behind it then starts on lowered clocks and
+        // loses 2.5 - 3 ms (65 537 utterances: 50.3 ms with the single utterance first, profiles/r04_tail.txt).
         std::stable_sort(out.begin(), out.end(), [&](const Block &x, const Block &y) {
-            return family_cost(ctx, x.f, x.rows, span) < family_cost(ctx, y.f, y.rows, span);
+            return family_cost(ctx, x.f, x.rows, span) * (double)y.rows < family_cost(ctx, y.f, y.rows, span) * (double)x.rows;
         });
     }
-    return best;
+    return best.first;
 }
 
 // Rows [first, first + count) of the batch (count = 0: all of it).  out_dev / out_len_dev point at the
@@ -1397,7 +1425,7 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
         choose_family(ctx, batch, out_stride, family_rows > count ? family_rows : count, f);
         plan.push_back(Block{count, f});
     } else {
-        plan_blocks(ctx, batch, out_stride, count, batch_span(ctx, batch, out_stride), plan, 0);
+        plan_blocks(ctx, batch, out_stride, count, batch_span(ctx, batch, out_stride), plan);
     }
     size_t main_block = 0;                     // the block with the most rows: the one the statistics describe
     for (size_t i = 1; i < plan.size(); ++i)
@@ -1456,7 +1484,7 @@ int grail_plan_blocks(uint32_t compute_units, int arithmetic, int live_formants,
     batch.min_pitch = 0.25f;
     const uint64_t stride = ((uint64_t)span_samples + 64u + 63u) / 64u * 64u;
     std::vector<Block> plan;
-    plan_blocks(&ctx, &batch, stride, rows, batch_span(&ctx, &batch, stride), plan, 0);
+    plan_blocks(&ctx, &batch, stride, rows, batch_span(&ctx, &batch, stride), plan);
     *n_blocks = (uint32_t)plan.size();
     for (uint32_t i = 0; i < plan.size() && i < cap && blocks; ++i) {
         const Family &f = plan[i].f;

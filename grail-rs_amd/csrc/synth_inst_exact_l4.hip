@@ -4,5 +4,5 @@
 #include "synth_launch_impl.h"
 
 namespace grail {
-void launch_exact_l4(const SynthArgs &args, hipStream_t stream) { launch_one_exact<4, 32, 4, 2>(args, stream); }
+void launch_exact_l4(const SynthArgs &args, hipStream_t stream) { launch_one_exact<4, 32, 4, 1>(args, stream); }
 }  // namespace grail

@@ -4,5 +4,5 @@
 #include "synth_launch_impl.h"
 
 namespace grail {
-void launch_fast_l2(const SynthArgs &args, hipStream_t stream) { launch_one_fast<2, 64, 1, 2>(args, stream); }
+void launch_fast_l2(const SynthArgs &args, hipStream_t stream) { launch_one_fast<2, 64, 1, 1>(args, stream); }
 }  // namespace grail

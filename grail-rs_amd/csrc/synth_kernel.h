@@ -392,6 +392,15 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     constexpr int S = 64 / L;            // utterances per wave
     constexpr int SP = S + 1;            // padded row of the staging tile
     static_assert(T % 4 == 0 && (64 % (T / 4)) == 0, "T");
+    // ONE WAVE PER SIMD, by construction.  Every family is laid out for one resident wave per SIMD (a second wave on
+    // a SIMD costs as much as it brings), and the host sizes its launches accordingly — but where the waves of a
+    // launch LAND is the dispatcher's business: with kernels that fit a SIMD twice (<= 256 registers) it put two
+    // waves on some SIMDs and none on others whenever the launch before had left its round-robin state "odd"
+    // (a two-lane launch of 1024 waves: 27 ms after another 1024-wave launch, 48 ms after one of 1536 waves or as
+    // the first launch of a process; profiles/r04_dispatch.txt).  A wave that owns more than half of the SIMD's 512
+    // registers cannot share it: the one-lane kernels do anyway (256 VGPRs + AGPRs); the others claim accumulation
+    // registers they never touch.  (PIPE workgroups are placed by their LDS footprint instead.)
+    if constexpr (L > 1 && !PIPE) asm volatile("" ::: "a127");
 
     // every wave of the block works alone on its own S utterances and its own
     // slice of LDS: there is no inter-wave communication and no block barrier

@@ -22,7 +22,7 @@ stride = W.max_samples()
 warm = max(G.time_split_warmup(v) for v in voices)
 cus = ctx.get_option("compute_units")
 print(f"# tail_bench: {'8 presets (eight live formants)' if presets else 'voices::generic() (four live formants)'}, "
-      f"2 s utterances, compute_units={cus}; kernel ms = min of 3 (hipEvents around all launches of the call)")
+      f"2 s utterances, compute_units={cus}; kernel ms = min of 5 after a warm-up, composite and single launches alternating (hipEvents around all launches of the call)")
 T = {}
 for n in sizes:
     segs, offs, vids, seeds = W.make_batch(n, n_voices=len(voices))
@@ -32,15 +32,16 @@ for n in sizes:
     row = [f"n={n:6d}"]
     for fast in (0, 1):
         ctx.set_option("arithmetic", fast)
-        res = {}
-        for comp in (1, 0):
-            ctx.set_option("composite_launches", comp)
-            ms = []
-            for _ in range(3):
+        # warm up both variants, then alternate them: min over 5 (a box drifts by a few per cent within seconds)
+        res = {1: [float("inf"), 0], 0: [float("inf"), 0]}
+        for rep in range(6):
+            for comp in (1, 0):
+                ctx.set_option("composite_launches", comp)
                 batch.synthesize_async(d_out, stride, d_len)
                 ctx.sync()
-                ms.append(ctx.last_kernel_ms())
-            res[comp] = (min(ms), ctx.get_option("last_launch_blocks"))
+                if rep:
+                    res[comp][0] = min(res[comp][0], ctx.last_kernel_ms())
+                res[comp][1] = ctx.get_option("last_launch_blocks")
         plan = G.plan_blocks(n, 96006, fast, 8 if presets else 4, warmup=warm, compute_units=cus)
         T[(n, fast)] = res[1][0]
         row.append(f"{'fast ' if fast else 'exact'} {res[1][0]:7.2f} ms in {res[1][1]} launch(es) "
