@@ -266,19 +266,26 @@ def test_scan_kernel_small_batch_within_tolerance(gpu_ctx, n_voices, split):
     k = _worst(out, ref, ref_len)
     print(f"scan kernel, voices={n_voices}: max |d| = {k:.1f} * 2^-23")
     assert 0.0 < k * ULP <= TOL
-    # the option switches it off (A/B).  A batch this small is then served by the pipelined EXACT workgroups —
-    # faster than the fast lane kernels there, and exact bits satisfy the tolerance; with the lane mapping
-    # pinned the fast lane kernels run
+    # the option switches it off (A/B).  The cost model then takes the next best family for a batch this small: the
+    # time-split kernels (3.1 ms where the pipelined exact workgroups take 6.5); with those switched off as well the
+    # pipelined EXACT workgroups — faster than the fast lane kernels there, and exact bits satisfy the tolerance; with
+    # the lane mapping pinned the fast lane kernels run
     gpu_ctx.set_option("time_parallel_scan", 0)
     try:
+        out1, len1 = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
+        assert "SPLIT" in gpu_ctx.last_kernel_name() and np.array_equal(len1, ref_len)
+        assert 0.0 < _worst(out1, ref, ref_len) * ULP <= TOL
+        gpu_ctx.set_option("time_split", 0)
         out2, len2 = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
         assert "PIPE" in gpu_ctx.last_kernel_name() and np.array_equal(len2, ref_len)
+        assert gpu_ctx.get_option("last_launch_fast") == 0      # (what ran, not what was asked for)
         assert _worst(out2, ref, ref_len) == 0.0
         out3, len3 = _render(gpu_ctx, True, segs, offs, vids, seeds, stride, lanes=8)
         assert "FAST" in gpu_ctx.last_kernel_name() and np.array_equal(len3, ref_len)
         assert 0.0 < _worst(out3, ref, ref_len) * ULP <= TOL
     finally:
         gpu_ctx.set_option("time_parallel_scan", 1)
+        gpu_ctx.set_option("time_split", 1)
     gpu_ctx.set_voices(W.single_voice())
 
 
