@@ -1109,7 +1109,8 @@ static double family_cost(const grail_ctx *ctx, const Family &f, uint32_t rows, 
     if (f.split_k) {
         // every lane takes as long as the first chunk's, which renders split_bounds[1] samples and nothing else
         const double rounds = std::ceil((double)rows * f.split_k / lanes);
-        return rounds * (double)f.split_bounds[1] * (f.live4 ? 15.9 : 23.6) / 96006.0;
+        // (+ 0.12 ms: what a launch of chunk lanes costs before any of them renders — short utterances see it)
+        return rounds * ((double)f.split_bounds[1] * (f.live4 ? 15.7 : 23.3) / 96006.0 + 0.12);
     }
     if (f.pipe) {
         const double groups = std::ceil((double)rows / (f.live4 ? 16.0 : 8.0));
