@@ -123,12 +123,15 @@ struct Seg {
 // iter.next() of the Sequencer's source.  Phoneme mode folds in Selector::next
 // (src/lib.rs:990-1005): VoiceStorage::get (:664-671) and
 // copy_with_frequency (:445-450: frequency.min(0.5)).
+// Live streams keep an utterance's segments in a ring: segment `pos` sits at ring_base + (pos & ring_mask); every
+// other launch passes ring_base = 0, ring_mask = ~0 (pos indexes segs directly).
 __device__ __forceinline__ void fetch_seg(Seg &s, const DevSeg *__restrict__ segs,
                                           uint32_t &pos, uint32_t end, bool phoneme_mode,
-                                          uint32_t elem_base)
+                                          uint32_t elem_base, uint32_t ring_base = 0u, uint32_t ring_mask = 0xFFFFFFFFu)
 {
     if (pos < end) {
-        const DevSeg d = segs[pos++];
+        const DevSeg d = segs[ring_base + (pos & ring_mask)];
+        ++pos;
         s.some = true;
         s.length = d.length;
         s.blend_length = d.blend_length;

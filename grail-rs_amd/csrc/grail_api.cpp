@@ -175,6 +175,17 @@ struct grail_stream {
     // the kernel flavour, fixed when the stream is opened (the state layout follows it)
     bool live4 = false, half_capable = false, any_blend = false;
     uint64_t voices_epoch = 0;
+    // live streams (grail_stream_open_live): the stream owns its batch, whose segments sit in per-utterance rings
+    grail_batch *own = nullptr;
+    uint32_t ring_cap = 0;            // segments per utterance ring (a power of two); 0: not a live stream
+    uint32_t *d_counts = nullptr;     // [n_utt] segments appended so far
+    uint32_t *d_open = nullptr;       // [n_utt] 1 while the utterance's source may deliver more
+    uint32_t *d_consumed = nullptr;   // [n_utt] segments the Sequencer has pulled (written by the kernels)
+    std::vector<uint32_t> appended;   // host copy of d_counts
+    std::vector<uint32_t> consumed;   // what the host last read of d_consumed (a lower bound)
+    std::vector<uint8_t> open;        // host copy of d_open
+    std::vector<grail_synthesis_elem> last_elem;   // elem mode: the last elem appended per utterance (sharpness of the next pair)
+    std::vector<uint8_t> last_has;
 };
 
 struct grail_batch {
@@ -1558,6 +1569,10 @@ static int stream_next(grail_ctx *ctx, grail_stream *stream, uint32_t max_sample
     SynthArgs a{};
     a.segs = batch->d_segs;
     a.seg_offsets = batch->d_offsets;
+    a.ring_cap = stream->ring_cap;
+    a.seg_counts = stream->d_counts;
+    a.seg_open = stream->d_open;
+    a.seg_consumed = stream->d_consumed;
     a.voice_ids = batch->d_voice_ids;
     a.seeds = batch->d_seeds;
     a.perm = batch->d_perm;
@@ -1615,7 +1630,239 @@ int grail_stream_close(grail_ctx *ctx, grail_stream *stream)
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (stream->d_state) (void)hipFree(stream->d_state);
+    if (stream->d_counts) (void)hipFree(stream->d_counts);
+    if (stream->d_open) (void)hipFree(stream->d_open);
+    if (stream->d_consumed) (void)hipFree(stream->d_consumed);
+    if (stream->own) {
+        free_batch_buffers(stream->own);
+        delete stream->own;
+    }
     delete stream;
+    return GRAIL_OK;
+}
+
+// ---- live streams: the lazy source of examples/interactive.rs:31-38 -------------------------------------------------
+int grail_stream_open_live(grail_ctx *ctx, uint32_t n_utt, const uint32_t *voice_ids, const uint32_t *jitter_seeds,
+                           uint32_t ring_segments, int caller_built_elems, grail_stream **out)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!out) return fail(GRAIL_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (n_utt == 0) return fail(GRAIL_ERR_INVALID_ARG, "a live stream needs at least one utterance");
+    if (ring_segments == 0) ring_segments = 64;
+    if (ring_segments < 4 || (ring_segments & (ring_segments - 1)) != 0 || ring_segments > 65536)
+        return fail(GRAIL_ERR_INVALID_ARG, "ring_segments must be a power of two, 4 .. 65536 (0: 64)");
+    if ((uint64_t)n_utt * ring_segments > 0x7FFFFFFFull) return fail(GRAIL_ERR_INVALID_ARG, "n_utt x ring_segments exceeds 2^31");
+    if (ctx->voices.empty() || !ctx->d_voices) return fail(GRAIL_ERR_NO_VOICES, "call grail_set_voices first");
+    grail_batch *b = new (std::nothrow) grail_batch();
+    grail_stream *s = new (std::nothrow) grail_stream();
+    if (!b || !s) {
+        delete b;
+        delete s;
+        return fail(GRAIL_ERR_OUT_OF_MEMORY, "host allocation failed");
+    }
+    s->own = b;
+    s->batch = b;
+    s->ring_cap = ring_segments;
+    b->phoneme_mode = !caller_built_elems;
+    b->any_blend = true;          // what will be appended is not known: the general instantiations
+    b->plain = false;
+    b->n_utt = n_utt;
+    b->max_voice_id = 0;
+    if (voice_ids)
+        for (uint32_t u = 0; u < n_utt; ++u) b->max_voice_id = std::max(b->max_voice_id, voice_ids[u]);
+    const size_t ring_rows = (size_t)n_utt * ring_segments;
+    hipError_t e = hipSuccess;
+    auto zeroed = [&](void **p, size_t bytes) {
+        if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 4);
+        if (e == hipSuccess) e = hipMemsetAsync(*p, 0, bytes ? bytes : 4, ctx->stream);
+    };
+    zeroed((void **)&b->d_segs, ring_rows * sizeof(DevSeg));
+    if (caller_built_elems) zeroed((void **)&b->d_elems, ring_rows * ELEM_FLOATS * sizeof(float));
+    zeroed((void **)&s->d_counts, (size_t)n_utt * 4);
+    zeroed((void **)&s->d_consumed, (size_t)n_utt * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_open, (size_t)n_utt * 4);
+    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)s->d_open, 1, n_utt, ctx->stream);
+    if (e == hipSuccess && voice_ids) {
+        e = hipMalloc((void **)&b->d_voice_ids, (size_t)n_utt * 4);
+        if (e == hipSuccess) e = hipMemcpyAsync(b->d_voice_ids, voice_ids, (size_t)n_utt * 4, hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (e == hipSuccess && jitter_seeds) {
+        e = hipMalloc((void **)&b->d_seeds, (size_t)n_utt * 4);
+        if (e == hipSuccess) e = hipMemcpyAsync(b->d_seeds, jitter_seeds, (size_t)n_utt * 4, hipMemcpyHostToDevice, ctx->stream);
+    }
+    s->half_capable = batch_half_capable(ctx, b);
+    s->any_blend = true;
+    s->live4 = false;
+    s->voices_epoch = ctx->voices_epoch;
+    s->L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(n_utt, ctx_simds(ctx));
+    s->lanes = state_lanes(n_utt, s->L);
+    const size_t bytes = (size_t)state_words(s->L) * s->lanes * sizeof(uint32_t);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_state, bytes ? bytes : 4);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);      // voice_ids / jitter_seeds are the caller's
+    if (e != hipSuccess) {
+        const int st = hip_fail(e, "live stream allocation");
+        const std::string keep = g_last_error;
+        grail_stream_close(ctx, s);
+        g_last_error = keep;
+        return st;
+    }
+    s->appended.assign(n_utt, 0u);
+    s->consumed.assign(n_utt, 0u);
+    s->open.assign(n_utt, 1);
+    if (caller_built_elems) {
+        s->last_elem.resize(n_utt);
+        s->last_has.assign(n_utt, 0);
+    }
+    *out = s;
+    return GRAIL_OK;
+}
+
+// common part of the two append calls: room in the rings, upload, scatter on the device
+static int live_append(grail_ctx *ctx, grail_stream *s, const std::vector<DevSeg> &segs, const float *elems,
+                       const uint32_t *seg_offsets)
+{
+    const uint32_t n_utt = s->own->n_utt, cap = s->ring_cap;
+    const uint32_t n_new = seg_offsets[n_utt];
+    if (n_new == 0) return GRAIL_OK;
+    // The Sequencer holds on to its current and next segment (and their elems in the ring are re-read when a call
+    // resumes): a ring keeps the last two segments pulled besides everything pending.
+    auto fits = [&]() {
+        for (uint32_t u = 0; u < n_utt; ++u) {
+            const uint32_t add = seg_offsets[u + 1] - seg_offsets[u];
+            if (add && (uint64_t)s->appended[u] - s->consumed[u] + add + 2u > cap) return false;
+        }
+        return true;
+    };
+    if (!fits()) {
+        // what the host knows of the Sequencers' progress is a lower bound: ask the device
+        HIP_TRY(hipMemcpyAsync(s->consumed.data(), s->d_consumed, (size_t)n_utt * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (!fits())
+            return fail(GRAIL_ERR_BUFFER_TOO_SMALL, "a segment ring of the live stream is full: pull samples first (or open the "
+                                                    "stream with a larger ring_segments)");
+    }
+    for (uint32_t u = 0; u < n_utt; ++u)
+        if (seg_offsets[u + 1] > seg_offsets[u] && !s->open[u])
+            return fail(GRAIL_ERR_INVALID_ARG, "an utterance of the live stream has been finished: nothing can be appended to it");
+    DevSeg *d_new = nullptr;
+    float *d_new_elems = nullptr;
+    uint32_t *d_offs = nullptr;
+    hipError_t e = hipMalloc((void **)&d_new, (size_t)n_new * sizeof(DevSeg));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_offs, ((size_t)n_utt + 1) * 4);
+    if (e == hipSuccess && elems) e = hipMalloc((void **)&d_new_elems, (size_t)n_new * ELEM_FLOATS * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_new, segs.data(), (size_t)n_new * sizeof(DevSeg), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_offs, seg_offsets, ((size_t)n_utt + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && elems)
+        e = hipMemcpyAsync(d_new_elems, elems, (size_t)n_new * ELEM_FLOATS * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    // (stream order: behind every kernel that still reads the rings, ahead of every kernel that will)
+    if (e == hipSuccess)
+        e = launch_ring_append(s->own->d_segs, s->own->d_elems, s->d_counts, cap, d_new, d_new_elems, d_offs, n_utt, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);      // the host buffers are the caller's / locals
+    if (d_new) (void)hipFree(d_new);
+    if (d_offs) (void)hipFree(d_offs);
+    if (d_new_elems) (void)hipFree(d_new_elems);
+    if (e != hipSuccess) return hip_fail(e, "grail_stream_append");
+    for (uint32_t u = 0; u < n_utt; ++u) s->appended[u] += seg_offsets[u + 1] - seg_offsets[u];
+    return GRAIL_OK;
+}
+
+static int live_check(grail_ctx *ctx, grail_stream *stream, const uint32_t *seg_offsets, bool elems)
+{
+    if (!stream || !stream->own) return fail(GRAIL_ERR_INVALID_ARG, "not a live stream (grail_stream_open_live)");
+    if (stream->own->phoneme_mode == elems)
+        return fail(GRAIL_ERR_INVALID_ARG, elems ? "the live stream takes PhonemeElems (grail_stream_append)"
+                                                 : "the live stream takes SequenceElems (grail_stream_append_elems)");
+    if (stream->voices_epoch != ctx->voices_epoch)
+        return fail(GRAIL_ERR_INVALID_ARG, "the voice table changed since the stream was opened");
+    uint32_t n = 0;
+    return check_offsets(seg_offsets, stream->own->n_utt, &n);
+}
+
+int grail_stream_append(grail_ctx *ctx, grail_stream *stream, const grail_phoneme_elem *segs, const uint32_t *seg_offsets)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if ((rc = live_check(ctx, stream, seg_offsets, false))) return rc;
+    const uint32_t n_new = seg_offsets[stream->own->n_utt];
+    if (n_new && !segs) return fail(GRAIL_ERR_INVALID_ARG, "segs is NULL");
+    std::vector<DevSeg> ds(n_new);
+    for (uint32_t i = 0; i < n_new; ++i) {
+        if (segs[i].phoneme < 0 || segs[i].phoneme >= GRAIL_PH_COUNT)
+            return fail(GRAIL_ERR_INVALID_ARG, "phoneme discriminant out of range");
+        std::memcpy(&ds[i], &segs[i], sizeof(DevSeg));
+    }
+    return live_append(ctx, stream, ds, nullptr, seg_offsets);
+}
+
+int grail_stream_append_elems(grail_ctx *ctx, grail_stream *stream, const grail_sequence_elem *segs,
+                              const uint32_t *seg_offsets)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if ((rc = live_check(ctx, stream, seg_offsets, true))) return rc;
+    const uint32_t n_utt = stream->own->n_utt, n_new = seg_offsets[n_utt];
+    if (n_new && !segs) return fail(GRAIL_ERR_INVALID_ARG, "segs is NULL");
+    std::vector<DevSeg> ds(n_new);
+    std::vector<float> elems((size_t)(n_new ? n_new : 1) * ELEM_FLOATS);
+    for (uint32_t i = 0; i < n_new; ++i) {
+        ds[i].elem = segs[i].has_elem ? 0 : -1;        // (the device writes the ring row)
+        ds[i].length = segs[i].length;
+        ds[i].blend_length = segs[i].blend_length;
+        ds[i].frequency = segs[i].elem.frequency;
+        std::memcpy(&elems[(size_t)i * ELEM_FLOATS], &segs[i].elem, sizeof(grail_synthesis_elem));
+    }
+    // the sharpness fast arithmetic is served up to: every two consecutive elems of an utterance, the seam to what was
+    // appended before included (grail_batch_upload_elems does the same over a closed list)
+    double sharp = stream->own->elems_sharpness;
+    std::vector<grail_synthesis_elem> last = stream->last_elem;
+    std::vector<uint8_t> has = stream->last_has;
+    for (uint32_t u = 0; u < n_utt; ++u)
+        for (uint32_t i = seg_offsets[u]; i < seg_offsets[u + 1]; ++i) {
+            if (segs[i].has_elem) {
+                grail_synthesis_elem pair[2] = {segs[i].elem, segs[i].elem};
+                size_t n_pair = 1;
+                if (has[u]) pair[n_pair++] = last[u];
+                sharp = std::fmax(sharp, elems_sharpness(pair, n_pair));
+                last[u] = segs[i].elem;
+            }
+            has[u] = segs[i].has_elem ? 1 : 0;
+        }
+    rc = live_append(ctx, stream, ds, elems.data(), seg_offsets);
+    if (rc) return rc;
+    stream->own->elems_sharpness = sharp;
+    stream->last_elem.swap(last);
+    stream->last_has.swap(has);
+    return GRAIL_OK;
+}
+
+int grail_stream_finish(grail_ctx *ctx, grail_stream *stream, const uint8_t *which)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!stream || !stream->own) return fail(GRAIL_ERR_INVALID_ARG, "not a live stream (grail_stream_open_live)");
+    const uint32_t n_utt = stream->own->n_utt;
+    std::vector<uint32_t> open(n_utt);
+    for (uint32_t u = 0; u < n_utt; ++u) {
+        if (!which || which[u]) stream->open[u] = 0;
+        open[u] = stream->open[u];
+    }
+    HIP_TRY(hipMemcpyAsync(stream->d_open, open.data(), (size_t)n_utt * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GRAIL_OK;
+}
+
+int grail_stream_pending(grail_ctx *ctx, grail_stream *stream, uint32_t *pending)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!stream || !stream->own) return fail(GRAIL_ERR_INVALID_ARG, "not a live stream (grail_stream_open_live)");
+    if (!pending) return fail(GRAIL_ERR_INVALID_ARG, "pending is NULL");
+    const uint32_t n_utt = stream->own->n_utt;
+    HIP_TRY(hipMemcpyAsync(stream->consumed.data(), stream->d_consumed, (size_t)n_utt * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (uint32_t u = 0; u < n_utt; ++u) pending[u] = stream->appended[u] - stream->consumed[u];
     return GRAIL_OK;
 }
 

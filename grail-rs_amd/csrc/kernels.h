@@ -76,6 +76,15 @@ struct SynthArgs {
     uint32_t *state;              // resumable synthesis: state[word][lane] or nullptr (one-shot)
     uint64_t state_stride;        // lanes of the launch (= state_lanes())
     uint32_t resume;              // 1: load the state first (not the first call of a stream)
+    // live streams (grail_stream_open_live: the lazy source of examples/interactive.rs:31-38): the segments of
+    // utterance u sit in a ring, segs[u * ring_cap + (i & (ring_cap - 1))] for its i-th segment ever appended;
+    // seg_counts[u] of them have been appended so far, and while seg_open[u] != 0 more may follow: a Sequencer that
+    // needs a segment which is not there yet PAUSES (src/lib.rs:866-888 pulls iter.next() on demand) instead of
+    // ending the utterance.  seg_offsets is unused then.
+    uint32_t ring_cap;            // 0: not a live stream
+    const uint32_t *seg_counts;   // [n_utt]
+    const uint32_t *seg_open;     // [n_utt]
+    uint32_t *seg_consumed;       // [n_utt] out: segments the Sequencer has pulled so far
     // time-split fast kernels (synth_kernel<..., SPLIT>): chunk k of every utterance is the samples
     // [split_bounds[k], split_bounds[k + 1]) (multiples of 64; the last bound is `cap`), one lane each
     uint32_t split_chunks;        // K, 0: not a time-split launch
@@ -98,6 +107,11 @@ const char *last_kernel_name();
 // lanes_per_utt in {1, 2, 4, 8}; returns hipSuccess or the launch error.
 hipError_t launch_synth(const SynthArgs &args, int lanes_per_utt, hipStream_t stream);
 hipError_t launch_lengths(const LenArgs &args, hipStream_t stream);
+// live streams: utterance u's new segments new_segs[new_offsets[u] .. new_offsets[u + 1]) go to the next slots of its
+// ring and counts[u] grows by their number; elem mode (new_elems != nullptr): new_elems[i] is new_segs[i]'s elem (49
+// floats) and the segment's `elem` field is rewritten to the ring slot's row of ring_elems (or stays -1 for None)
+hipError_t launch_ring_append(DevSeg *ring, float *ring_elems, uint32_t *counts, uint32_t ring_cap, const DevSeg *new_segs,
+                              const float *new_elems, const uint32_t *new_offsets, uint32_t n_utt, hipStream_t stream);
 // small batches, fast arithmetic: one workgroup per utterance, lanes = time, recurrences by parallel scan
 // (scan_kernels.hip).  args.live4 selects two formant-pair waves instead of four.
 hipError_t launch_scan(const SynthArgs &args, hipStream_t stream);

@@ -60,6 +60,7 @@ EXPORTS = [
     "grail_batch_lengths", "grail_batch_synthesize_async", "grail_sync",
     "grail_last_kernel_ms", "grail_last_kernel_name", "grail_synthesize_batch", "grail_synthesize_batch_elems",
     "grail_stream_open", "grail_stream_next_async", "grail_stream_close",
+    "grail_stream_open_live", "grail_stream_append", "grail_stream_append_elems", "grail_stream_finish", "grail_stream_pending",
     "grail_language_generic", "grail_transcribe", "grail_intonate", "grail_text_to_phoneme_elems",
     "grail_synthesize_batch_pcm16", "grail_batch_synthesize_pcm16_async", "grail_stream_next_pcm16_async", "grail_say_batch", "grail_pcm16_async", "grail_batch_digest", "grail_batch_compare", "grail_wav_write_i16",
     "grail_device_alloc", "grail_device_free", "grail_host_alloc", "grail_host_free", "grail_memcpy_d2h", "grail_memcpy_h2d",
@@ -237,6 +238,11 @@ def load():
     L.grail_stream_next_async.argtypes = [vp, vp, C.c_uint32, vp, u64, vp]
     L.grail_stream_next_pcm16_async.argtypes = [vp, vp, C.c_uint32, vp, u64, vp]
     L.grail_stream_close.argtypes = [vp, vp]
+    L.grail_stream_open_live.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint32, C.c_int, C.POINTER(vp)]
+    L.grail_stream_append.argtypes = [vp, vp, vp, vp]
+    L.grail_stream_append_elems.argtypes = [vp, vp, vp, vp]
+    L.grail_stream_finish.argtypes = [vp, vp, vp]
+    L.grail_stream_pending.argtypes = [vp, vp, vp]
     L.grail_language_generic.restype = C.c_uint32
     L.grail_language_generic.argtypes = [C.POINTER(C.POINTER(Rule)), C.POINTER(C.c_int)]
     L.grail_transcribe.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(Rule), C.c_uint32,
@@ -477,6 +483,46 @@ class Stream:
         if self.handle:
             load().grail_stream_close(self.ctx.handle, self.handle)
             self.handle = None
+
+
+class LiveStream(Stream):
+    """grail_stream_open_live: n_utt chains whose sources deliver while they run (examples/interactive.rs:31-48)."""
+
+    def __init__(self, ctx, n_utt, voice_ids=None, jitter_seeds=None, ring_segments=0, elems=False):
+        self.ctx, self.n_utt, self.elems, self.batch = ctx, n_utt, elems, None
+        if voice_ids is not None:
+            voice_ids = np.ascontiguousarray(voice_ids, dtype=np.uint32)
+            assert len(voice_ids) == n_utt
+        if jitter_seeds is not None:
+            jitter_seeds = np.ascontiguousarray(jitter_seeds, dtype=np.uint32)
+            assert len(jitter_seeds) == n_utt
+        h = C.c_void_p()
+        _check(load().grail_stream_open_live(ctx.handle, n_utt, _ptr(voice_ids), _ptr(jitter_seeds), ring_segments,
+                                             1 if elems else 0, C.byref(h)))
+        self.handle = h
+
+    def append(self, segs, seg_offsets):
+        """Utterance u receives segs[seg_offsets[u]:seg_offsets[u + 1]] behind what it already has."""
+        seg_offsets = np.ascontiguousarray(seg_offsets, dtype=np.uint32)
+        assert len(seg_offsets) == self.n_utt + 1
+        if self.elems:
+            arr = (SequenceElem * max(len(segs), 1))(*segs)
+            _check(load().grail_stream_append_elems(self.ctx.handle, self.handle, C.cast(arr, C.c_void_p),
+                                                    seg_offsets.ctypes.data))
+        else:
+            segs = np.ascontiguousarray(segs, dtype=PHONEME_DTYPE)
+            _check(load().grail_stream_append(self.ctx.handle, self.handle, segs.ctypes.data, seg_offsets.ctypes.data))
+
+    def finish(self, which=None):
+        if which is not None:
+            which = np.ascontiguousarray(which, dtype=np.uint8)
+            assert len(which) == self.n_utt
+        _check(load().grail_stream_finish(self.ctx.handle, self.handle, _ptr(which)))
+
+    def pending(self):
+        out = np.zeros(self.n_utt, dtype=np.uint32)
+        _check(load().grail_stream_pending(self.ctx.handle, self.handle, out.ctypes.data))
+        return out
 
 
 class Context:

@@ -151,6 +151,14 @@ extern "C" {
     pub fn grail_stream_next_pcm16_async(ctx: *mut grail_ctx, stream: *mut grail_stream,
         max_samples: u32, out_dev: *mut i16, out_stride: u64, out_len_dev: *mut u32) -> c_int;
     pub fn grail_stream_close(ctx: *mut grail_ctx, stream: *mut grail_stream) -> c_int;
+    pub fn grail_stream_open_live(ctx: *mut grail_ctx, n_utt: u32, voice_ids: *const u32, jitter_seeds: *const u32,
+        ring_segments: u32, caller_built_elems: c_int, out: *mut *mut grail_stream) -> c_int;
+    pub fn grail_stream_append(ctx: *mut grail_ctx, stream: *mut grail_stream, segs: *const grail_phoneme_elem,
+        seg_offsets: *const u32) -> c_int;
+    pub fn grail_stream_append_elems(ctx: *mut grail_ctx, stream: *mut grail_stream, segs: *const grail_sequence_elem,
+        seg_offsets: *const u32) -> c_int;
+    pub fn grail_stream_finish(ctx: *mut grail_ctx, stream: *mut grail_stream, which: *const u8) -> c_int;
+    pub fn grail_stream_pending(ctx: *mut grail_ctx, stream: *mut grail_stream, pending: *mut u32) -> c_int;
     pub fn grail_sync(ctx: *mut grail_ctx) -> c_int;
     pub fn grail_last_kernel_ms(ctx: *mut grail_ctx, ms: *mut f32) -> c_int;
     pub fn grail_last_kernel_name(ctx: *mut grail_ctx) -> *const c_char;

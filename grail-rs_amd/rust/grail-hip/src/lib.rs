@@ -176,3 +176,81 @@ pub fn fast_sharpness(voice: &Voice) -> f32 {
 pub fn time_split_warmup(voice: &Voice) -> u32 {
     unsafe { sys::grail_time_split_warmup(&voice_to_c(voice)) }
 }
+
+/// The lazy source of `examples/interactive.rs:31-48` on the GPU: ONE chain for a whole session.  Segments are
+/// appended while samples are pulled; a Sequencer that needs a segment which has not been appended yet pauses
+/// (`src/lib.rs:866-888` pulls `iter.next()` on demand) and `next` comes back short — the front end then feeds it, a
+/// `Phoneme::Silence` when no text is waiting, as the reference's `repeat_with(|| receiver.try_recv().unwrap_or(' '))`
+/// does.  Carrier phase, noise seed, jitter and filter state carry across everything appended: the samples are those
+/// of the CPU iterator chain over the concatenated list, bit for bit.
+pub struct LiveStream<'a> {
+    gpu: &'a Gpu,
+    stream: *mut sys::grail_stream,
+    d_out: *mut std::ffi::c_void,
+    d_len: *mut std::ffi::c_void,
+    chunk: u32,
+    stride: u64,
+}
+
+impl<'a> LiveStream<'a> {
+    /// `.sequence(voice).jitter(jitter_seed, voice).synthesize()` over a source that is still being written.
+    pub fn new(gpu: &'a Gpu, chunk: u32, voice: u32, jitter_seed: u32) -> Result<Self, Error> {
+        let stride = (chunk as u64 + 63) / 64 * 64;
+        let mut s = LiveStream { gpu, stream: std::ptr::null_mut(), d_out: std::ptr::null_mut(),
+                                 d_len: std::ptr::null_mut(), chunk, stride };
+        unsafe {
+            check(sys::grail_stream_open_live(gpu.ctx, 1, &voice, &jitter_seed, 0, 0, &mut s.stream))?;
+            check(sys::grail_device_alloc(gpu.ctx, stride as usize * 4, &mut s.d_out))?;
+            check(sys::grail_device_alloc(gpu.ctx, 4, &mut s.d_len))?;
+        }
+        Ok(s)
+    }
+
+    /// The source delivers: these segments follow what the chain already has.
+    pub fn append(&mut self, phonemes: &[PhonemeElem]) -> Result<(), Error> {
+        let segs: Vec<_> = phonemes.iter().map(|p| sys::grail_phoneme_elem {
+            phoneme: p.phoneme as i32, length: p.length, blend_length: p.blend_length, frequency: p.frequency,
+        }).collect();
+        let offs = [0u32, segs.len() as u32];
+        check(unsafe { sys::grail_stream_append(self.gpu.ctx, self.stream, segs.as_ptr(), offs.as_ptr()) })
+    }
+
+    /// The source has ended: what is pending is spoken, the last segment fades out, `next` then returns nothing.
+    pub fn finish(&mut self) -> Result<(), Error> {
+        check(unsafe { sys::grail_stream_finish(self.gpu.ctx, self.stream, std::ptr::null()) })
+    }
+
+    /// Segments appended that the Sequencer has not pulled yet.
+    pub fn pending(&mut self) -> Result<u32, Error> {
+        let mut n = 0u32;
+        check(unsafe { sys::grail_stream_pending(self.gpu.ctx, self.stream, &mut n) })?;
+        Ok(n)
+    }
+
+    /// `Iterator::next`, up to `chunk` samples at a time: fewer when the Sequencer waits for its source (or the
+    /// chain has ended).
+    pub fn next(&mut self) -> Result<Vec<f32>, Error> {
+        let mut n = 0u32;
+        unsafe {
+            check(sys::grail_stream_next_async(self.gpu.ctx, self.stream, self.chunk, self.d_out as *mut f32,
+                                               self.stride, self.d_len as *mut u32))?;
+            check(sys::grail_sync(self.gpu.ctx))?;
+            check(sys::grail_memcpy_d2h(self.gpu.ctx, &mut n as *mut u32 as *mut _, self.d_len, 4))?;
+            let mut out = vec![0f32; n as usize];
+            if n > 0 {
+                check(sys::grail_memcpy_d2h(self.gpu.ctx, out.as_mut_ptr() as *mut _, self.d_out, n as usize * 4))?;
+            }
+            Ok(out)
+        }
+    }
+}
+
+impl Drop for LiveStream<'_> {
+    fn drop(&mut self) {
+        unsafe {
+            if !self.stream.is_null() { sys::grail_stream_close(self.gpu.ctx, self.stream); }
+            if !self.d_out.is_null() { sys::grail_device_free(self.gpu.ctx, self.d_out); }
+            if !self.d_len.is_null() { sys::grail_device_free(self.gpu.ctx, self.d_len); }
+        }
+    }
+}

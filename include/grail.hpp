@@ -8,6 +8,8 @@
 //   voices::generic()                                 -> grail::voices::generic()
 //   pulling the iterator a buffer at a time             -> grail::Stream(gpu, utterances, chunk).next(...)
 //       (examples/interactive.rs:31-48)
+//   a chain whose source delivers while it runs         -> grail::LiveStream(gpu, chunk).append(...) / .next()
+//       (repeat_with(|| receiver.try_recv()...), interactive.rs:31)
 //
 // No arithmetic lives here; everything forwards to libgrail_hip.so.
 #pragma once
@@ -230,6 +232,71 @@ private:
     void *d_out_ = nullptr, *d_len_ = nullptr;
     std::vector<float> host_;
     std::vector<uint32_t> lens_;
+};
+
+// The live use of the chain (examples/interactive.rs:31-48): ONE chain runs for the whole session, its source delivers
+// while the audio callback is pulling, and carrier phase, noise seed, jitter and filter state carry across everything that
+// is ever said.  Segments are appended whenever they are known; next() yields the next `chunk` samples, or fewer when
+// the Sequencer is waiting for a segment that has not been appended yet (src/lib.rs:866-888 pulls iter.next() on demand)
+// — the front end then feeds it, a Silence when no text is waiting, exactly as the reference's source hands over ' '.
+class LiveStream {
+public:
+    LiveStream(const Gpu &gpu, uint32_t chunk, uint32_t voice = 0, uint32_t jitter_seed = 0, uint32_t ring_segments = 0)
+        : ctx_(gpu.ctx()), chunk_(chunk), stride_(((uint64_t)chunk + 63) / 64 * 64)
+    {
+        check(grail_stream_open_live(ctx_, 1, &voice, &jitter_seed, ring_segments, 0, &stream_));
+        int rc = grail_device_alloc(ctx_, (size_t)stride_ * sizeof(float), &d_out_);
+        if (!rc) rc = grail_device_alloc(ctx_, sizeof(uint32_t), &d_len_);
+        if (rc) {
+            release();
+            check(rc);
+        }
+    }
+    ~LiveStream() { release(); }
+    LiveStream(const LiveStream &) = delete;
+    LiveStream &operator=(const LiveStream &) = delete;
+
+    // the source delivers: these segments follow what the chain already has
+    void append(const std::vector<PhonemeElem> &segs)
+    {
+        const uint32_t offs[2] = {0u, (uint32_t)segs.size()};
+        check(grail_stream_append(ctx_, stream_, segs.data(), offs));
+    }
+    // the source has ended: what is pending is spoken, the last segment fades out, next() then returns nothing
+    void finish() { check(grail_stream_finish(ctx_, stream_, nullptr)); }
+    // segments appended that the Sequencer has not pulled yet
+    uint32_t pending()
+    {
+        uint32_t n = 0;
+        check(grail_stream_pending(ctx_, stream_, &n));
+        return n;
+    }
+    // Iterator::next, up to `chunk` samples: fewer when the Sequencer waits for the source (or the chain has ended)
+    std::vector<float> next()
+    {
+        uint32_t n = 0;
+        check(grail_stream_next_async(ctx_, stream_, chunk_, (float *)d_out_, stride_, (uint32_t *)d_len_));
+        check(grail_sync(ctx_));
+        check(grail_memcpy_d2h(ctx_, &n, d_len_, sizeof n));
+        std::vector<float> out(n);
+        if (n) check(grail_memcpy_d2h(ctx_, out.data(), d_out_, (size_t)n * sizeof(float)));
+        return out;
+    }
+    uint32_t chunk() const { return chunk_; }
+
+private:
+    void release()
+    {
+        if (stream_) grail_stream_close(ctx_, stream_);
+        if (d_out_) grail_device_free(ctx_, d_out_);
+        if (d_len_) grail_device_free(ctx_, d_len_);
+        stream_ = nullptr; d_out_ = nullptr; d_len_ = nullptr;
+    }
+    grail_ctx *ctx_;
+    uint32_t chunk_;
+    uint64_t stride_;
+    grail_stream *stream_ = nullptr;
+    void *d_out_ = nullptr, *d_len_ = nullptr;
 };
 
 }  // namespace grail

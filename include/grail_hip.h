@@ -61,7 +61,7 @@ extern "C" {
 /* Bumped whenever an entry point, an option name or the meaning of an option changes; a binding compares it with
  * grail_abi_version() of the library it loaded BEFORE its first call (the Python and Rust bindings do).
  *   1: rounds 1-2.   2: round 3-4 — grail_device_pci_bus_id, grail_time_split_warmup / _grid, grail_fast_sharpness,
- *   grail_plan_blocks, grail_stream_open_live / _append / _finish; option "kernel_variant" removed, "scan_debug" in
+ *   grail_plan_blocks, grail_stream_open_live / _append / _append_elems / _finish / _pending; option "kernel_variant" removed, "scan_debug" in
  *   development builds only; "arithmetic" = 1 is served up to a sharpness of the voice table. */
 #define GRAIL_ABI_VERSION 2
 /* fast mode ("arithmetic" = 1): bound on |fast - exact| per sample, full scale = 1.0; k * 2^-23 */
@@ -369,6 +369,37 @@ int grail_stream_next_async(grail_ctx *ctx, grail_stream *stream, uint32_t max_s
 int grail_stream_next_pcm16_async(grail_ctx *ctx, grail_stream *stream, uint32_t max_samples,
                                   int16_t *out_dev, uint64_t out_stride, uint32_t *out_len_dev);
 int grail_stream_close(grail_ctx *ctx, grail_stream *stream);
+/* LIVE streams — the lazy source of examples/interactive.rs:31-48.  There ONE chain runs for the whole session and its
+ * source never ends: text arrives while the audio callback is pulling samples, Sequencer::next fetches the next
+ * SequenceElem only when a segment runs out (src/lib.rs:866-888), and carrier phase, noise seed, jitter and filter
+ * state carry across everything that is ever said.  A live stream is that: it is opened EMPTY for n_utt utterances
+ * (each one chain: voice_ids / jitter_seeds as in grail_batch_upload, NULL = voice 0 / seed 0), segments are appended
+ * while it runs, and samples are pulled with grail_stream_next_async / _pcm16_async as from any stream.
+ *   grail_stream_append: utterance u receives segs[seg_offsets[u] .. seg_offsets[u + 1]) behind what it already has
+ *     (seg_offsets as in grail_batch_upload: n_utt + 1 non-decreasing entries; an empty range appends nothing).
+ *   grail_stream_append_elems: the same for streams opened with caller_built_elems != 0 (SequenceElems, no Selector).
+ *   A Sequencer that needs a segment which has not been appended yet PAUSES: the call returns fewer than max_samples
+ *     for that row (possibly 0) and the next call after an append carries on from exactly the same state — so the
+ *     samples are those of the one-shot rendering of everything appended, bit for bit ("arithmetic" = 0), whatever
+ *     the interleaving of appends and pulls.  (The reference starts by pulling TWO segments, :877-878: a fresh stream
+ *     renders nothing until two are there or it is finished.)
+ *   grail_stream_finish: the source of the utterances marked in `which` (n_utt bytes; NULL = all) has ended: what is
+ *     pending is rendered, the last segment fades out (:906-912) and the row ends, as with a closed batch.
+ *   grail_stream_pending: segments appended but not yet pulled by the Sequencer, per utterance (host memory [n_utt]);
+ *     synchronises.  What an interactive front end needs to feed its chain just in time — the reference's source
+ *     hands over ' ' (a Silence phoneme, src/lib.rs:1201 and the transcriber's no-rule case :1158-1163) whenever the
+ *     Sequencer asks and no text is waiting.
+ * Every ring holds ring_segments segments per utterance (a power of two, 4 .. 65536; 0 = 64): two the Sequencer is
+ * working on and ring_segments - 2 pending; an append that does not fit fails with GRAIL_ERR_BUFFER_TOO_SMALL and
+ * changes nothing.  Live streams run the general kernel instantiations (nothing is known about segments to come). */
+int grail_stream_open_live(grail_ctx *ctx, uint32_t n_utt, const uint32_t *voice_ids, const uint32_t *jitter_seeds,
+                           uint32_t ring_segments, int caller_built_elems, grail_stream **out);
+int grail_stream_append(grail_ctx *ctx, grail_stream *stream, const grail_phoneme_elem *segs,
+                        const uint32_t *seg_offsets);
+int grail_stream_append_elems(grail_ctx *ctx, grail_stream *stream, const grail_sequence_elem *segs,
+                              const uint32_t *seg_offsets);
+int grail_stream_finish(grail_ctx *ctx, grail_stream *stream, const uint8_t *which);
+int grail_stream_pending(grail_ctx *ctx, grail_stream *stream, uint32_t *pending);
 
 /* One-call forms: upload, synthesize, copy back (GRAIL_OUT_HOST) or leave in
  * place (GRAIL_OUT_DEVICE), wait.  With GRAIL_OUT_HOST the rows are rendered in blocks of up to
