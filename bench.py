@@ -519,18 +519,24 @@ def main():
             # fast mode must give the same bits within a kernel family, so the subset is pinned to the
             # family the batch took (its lane mapping, or its time-split grid)
             rebatched = None
-            if True:
+            pin_names = ("time_split_chunks", "time_split_span_samples", "lanes_per_utterance",
+                         "time_parallel_scan_max_utterances", "time_split")
+            saved = {k_: ctx.get_option(k_) for k_ in pin_names}     # what is in force now: restored below, whatever happens
+            sums_family = sums                                       # the digests the subset is compared with
+            d_o3 = d_l3 = b3 = None
+            try:
                 fast_pins = {}
                 if args.mode == "fast":
                     chunks = ctx.get_option("last_launch_chunks")
                     if chunks:
                         fast_pins = {"time_split_chunks": chunks, "time_split_span_samples": stride}
-                        # the batch itself once more on the pinned grid: the digests to compare with
+                        # the batch itself once more on the pinned grid: the digests to compare with (the timed
+                        # rendering's own digests, `sums`, stay what the cross-rank comparison above used)
                         for k_, v_ in fast_pins.items():
                             ctx.set_option(k_, v_)
                         batch.synthesize_async(d_out, stride, d_len)
                         ctx.sync()
-                        sums, _, _ = ctx.digest(d_out, stride, d_len, n_utt)
+                        sums_family, _, _ = ctx.digest(d_out, stride, d_len, n_utt)
                     elif ctx.get_option("last_launch_lanes"):
                         fast_pins = {"lanes_per_utterance": ctx.get_option("last_launch_lanes")}
                     else:                                   # the scan kernel: one workgroup per utterance
@@ -547,17 +553,17 @@ def main():
                 b3.synthesize_async(d_o3, stride, d_l3)
                 ctx.sync()
                 s3, _, _ = ctx.digest(d_o3, stride, d_l3, len(pick))
-                rebatched = int(np.count_nonzero(s3 != sums[pick]))
+                rebatched = int(np.count_nonzero(s3 != sums_family[pick]))
                 mismatches += rebatched
-                ctx.device_free(d_o3)
-                ctx.device_free(d_l3)
-                b3.free()
-                if fast_pins:
-                    ctx.set_option("time_split_chunks", 0)
-                    ctx.set_option("time_split_span_samples", 0)
-                    ctx.set_option("lanes_per_utterance", args.lanes)
-                    ctx.set_option("time_parallel_scan_max_utterances", 8704)
-                    ctx.set_option("time_split", 1)
+            finally:
+                if d_o3 is not None:
+                    ctx.device_free(d_o3)
+                if d_l3 is not None:
+                    ctx.device_free(d_l3)
+                if b3 is not None:
+                    b3.free()
+                for k_, v_ in saved.items():
+                    ctx.set_option(k_, v_)
             verify = {"utterances_checked": checked, "mismatches": mismatches,
                       "nonfinite_samples": int(bad.sum()), "rebatched_subset_mismatches": rebatched,
                       "method": "per-utterance bit-pattern digests (grail_batch_digest): every rank's rows "

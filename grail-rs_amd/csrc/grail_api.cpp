@@ -372,40 +372,64 @@ bool scan_voice_ok(const grail_voice &v)
 // and the trapezoidal state-variable band-pass (:555-571), whose poles are the bilinear images
 // z = (1 + s) / (1 - s) of s = g (-k/2 +- sqrt(k^2/4 - 1)), g = tan_approx(freq), k = bw / freq; for k < 2,
 // |z|^2 = (1 - g k + g^2) / (1 + g k + g^2) ~ exp(-2 pi bw).  The slowest of them over every phoneme (blends
-// move the parameters between phonemes and towards silent()'s 0.25 / 0.25 / 0.25, which decays at once; the
-// formant-frequency jitter hardly moves |z|) with a 5 % margin gives the length.  Formants that are silent in
+// move the parameters between phonemes and towards silent()'s 0.25 / 0.25 / 0.25, which decays at once) over the range
+// the formant-frequency jitter moves the band-pass through, with a 5 % margin, gives the length; where the low-pass and
+// the band-pass decay at nearly the same rate the cascade's n rho^n is solved for instead of rho^n.  Formants that are silent in
 // every phoneme have nothing to converge.  0: the voice does not qualify (a parameter outside the window, or a
 // warm-up longer than 16384 samples).
 uint32_t voice_warmup(const grail_voice &v)
 {
-    double slowest = 1e300;   // smallest decay rate, per sample
+    // per-sample decay rate of the band-pass envelope at formant frequency f, bandwidth w (0: not a decaying filter)
+    auto svf_rate = [](double f, double w) -> double {
+        if (!(f > 0.0 && f < 0.5)) return 0.0;
+        const double g = ((1 - f) * f * (5 - 4 * (f + 0.5) * (0.5 - f))) / ((f + 0.5) * (5 - 4 * (1 - f) * f) * (0.5 - f));
+        const double k = w / f;
+        double z;
+        if (k < 2.0) {
+            z = std::sqrt((1 - g * k + g * g) / (1 + g * k + g * g));
+        } else {
+            const double root = std::sqrt(k * k / 4 - 1);
+            const double s1 = g * (-k / 2 + root), s2 = g * (-k / 2 - root);
+            z = std::fmax(std::fabs((1 + s1) / (1 - s1)), std::fabs((1 + s2) / (1 - s2)));
+        }
+        return (z > 0.0 && z < 1.0) ? -std::log(z) : 0.0;
+    };
+    const double eps = 1.0 / 2097152.0;                     // 2^-21
+    const double jd = std::fabs((double)v.jitter_delta_formant_frequency);
+    if (!std::isfinite(jd)) return 0;
+    double longest = 0.0;                                   // samples
+    bool any = false;
     for (int i = 0; i < NF; ++i) {
         bool audible = false;
         for (int p = 0; p < NUM_VOICED; ++p) audible = audible || !(v.phonemes[p].formant_amp[i] == 0.0f);
         if (!audible) continue;
+        any = true;
         for (int p = 0; p < NUM_VOICED; ++p) {
             const grail_synthesis_elem &e = v.phonemes[p];
             const double f = e.formant_freq[i], w = e.formant_bw[i], sm = e.formant_smooth[i];
             if (!(f > 0.0 && f < 0.5 && w > 0.0 && sm > 0.0 && sm < 1.0) || !std::isfinite(w)) return 0;
-            const double g = ((1 - f) * f * (5 - 4 * (f + 0.5) * (0.5 - f))) / ((f + 0.5) * (5 - 4 * (1 - f) * f) * (0.5 - f));
-            const double k = w / f;
-            double z;
-            if (k < 2.0) {
-                z = std::sqrt((1 - g * k + g * g) / (1 + g * k + g * g));
-            } else {
-                const double root = std::sqrt(k * k / 4 - 1);
-                const double s1 = g * (-k / 2 + root), s2 = g * (-k / 2 - root);
-                z = std::fmax(std::fabs((1 + s1) / (1 - s1)), std::fabs((1 + s2) / (1 - s2)));
-            }
-            if (!(z > 0.0 && z < 1.0)) return 0;
-            slowest = std::fmin(slowest, -std::log(z));
-            slowest = std::fmin(slowest, -5.0 * std::log1p(-sm));
+            // the formant-frequency jitter moves the band-pass by up to +-jitter_delta_formant_frequency (Jitter::next
+            // :764 adds noise in [-1, 1] times it): the slowest decay over that range
+            double l_bp = svf_rate(f, w);
+            for (const double ff : {f - jd, f + jd})
+                if (ff > 0.0 && ff < 0.5) l_bp = std::fmin(l_bp, svf_rate(ff, w));
+            const double l_lp = -5.0 * std::log1p(-sm);                          // (1 - smooth)^5 per sample
+            if (!(l_bp > 0.0) || !(l_lp > 0.0)) return 0;
+            const double slow = std::fmin(l_bp, l_lp), gap = std::fabs(l_bp - l_lp);
+            // The low-pass feeds the band-pass: what is left of a wrong start after n samples is bounded by
+            // rho^n + sum_j rho_bp^(n-1-j) rho_lp^j, i.e. by (1 + m) rho^n with m = min(n, 1 / |rate difference|).  Far
+            // apart (every shipped voice: 0.17 against 0.004 per sample) m is a few samples' worth and the 5 % margin
+            // covers it; when the two rates are within a fifth of each other the residual decays like n rho^n and the
+            // length is solved for that.
+            double n = std::log(1.0 / eps) / (0.95 * slow);
+            if (gap <= 0.2 * std::fmax(l_bp, l_lp))
+                for (int it = 0; it < 4; ++it) n = std::log((1.0 + std::fmin(n, 1.0 / std::fmax(gap, 1e-12))) / eps) / (0.95 * slow);
+            longest = std::fmax(longest, n);
         }
     }
-    if (slowest >= 1e300) return 64;                        // nothing audible: any state is the right one
-    const double samples = std::log(2097152.0) / (0.95 * slowest);   // 2^-21
-    if (!(samples <= 16384.0)) return 0;
-    return ((uint32_t)std::ceil(samples) + 63u) / 64u * 64u;
+    if (!any) return 64;                                    // nothing audible: any state is the right one
+    if (!(longest <= 16384.0)) return 0;
+    return ((uint32_t)std::ceil(longest) + 63u) / 64u * 64u;
 }
 
 // Fast arithmetic and sharp resonances.  The fast kernels interpolate the filter coefficients of Synthesize::next
@@ -809,8 +833,8 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
         *value = ctx->scan_option;
         return GRAIL_OK;
     }
-    if (std::strcmp(name, "time_parallel_scan_max_utterances") == 0) {   // the limit in force
-        *value = scan_max_utts(ctx);
+    if (std::strcmp(name, "time_parallel_scan_max_utterances") == 0) {   // as set (-1: 34 per compute unit), so that
+        *value = ctx->scan_max_utts;                                       // get / set restores exactly
         return GRAIL_OK;
     }
     if (std::strcmp(name, "compute_units") == 0) {             // read-only: what the launch policy plans for
@@ -826,11 +850,11 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
         return GRAIL_OK;
     }
     if (std::strcmp(name, "pipeline4_max_groups") == 0) {
-        *value = pipe4_groups(ctx);
+        *value = ctx->pipe4_max_groups;
         return GRAIL_OK;
     }
     if (std::strcmp(name, "pipeline8_max_groups") == 0) {
-        *value = pipe8_groups(ctx);
+        *value = ctx->pipe8_max_groups;
         return GRAIL_OK;
     }
     if (std::strcmp(name, "pipeline_round32") == 0) {
@@ -882,7 +906,7 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
         return GRAIL_OK;
     }
     if (std::strcmp(name, "time_parallel_scan_split_max_utterances") == 0) {
-        *value = scan_split_max(ctx);
+        *value = ctx->scan_split_max;
         return GRAIL_OK;
     }
     if (std::strcmp(name, "slow_division_wave_steps") == 0) {  // read-only statistic

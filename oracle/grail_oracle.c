@@ -448,6 +448,11 @@ typedef struct {
  * double precision on the SAME f32 parameter track, saw and noise.  The distance between this and
  * the binary32 rendering is the rounding noise of the reference itself — the yardstick the fast
  * (tolerance) mode of the product is measured against.  Never the parity target. */
+/* on = 2, 3 (round 4, VERDICT r3 item 4 — "a middle arithmetic tier"): what would a tolerance arithmetic deviate by
+ * that rounds the band-pass coefficients g, k, a1, a2 = g a1, a3 = g a2 (src/lib.rs:555-562) EXACTLY as the reference does
+ * at every sample and is free everywhere else?  2: everything else in double precision (the best any such tier can do);
+ * 3: everything else in binary32 with fused multiply-adds and the factored state update, as a kernel would do it.
+ * tools/middle_tier_experiment.py runs both over the random voice tables of profiles/r03_sharpness.txt. */
 static int g_precise = 0;
 void orc_set_precise(int on) { g_precise = on; }
 
@@ -487,6 +492,58 @@ static float synthesize_step(synthesize *s, const orc_synthesis_elem *elem)
     /* :528 */
     float noise = orc_random_f32(&s->seed);
 
+    if (g_precise == 2) {
+        double sum = 0.0;
+        for (int i = 0; i < NF; ++i) {
+            double breath = elem->formant_breath.v[i], turb = elem->formant_turb.v[i];
+            double nw = (double)saw * (1.0 - breath) + (double)noise * breath;
+            double o = 1.0 - (double)elem->formant_smooth.v[i];
+            double lp = (o * o) * (o * o) * o;
+            s->pa[i] = s->pa[i] + (1.0 - lp) * (nw - s->pa[i]);
+            double v0 = s->pa[i] * ((1.0 - turb) + (double)noise * turb) * (double)elem->formant_amp.v[i];
+            /* the reference's own binary32 coefficients :555-562 */
+            float g = orc_tan_approx(elem->formant_freq.v[i]);
+            float k = elem->formant_bw.v[i] / elem->formant_freq.v[i];
+            float a1 = 1.0f / (1.0f + g * (g + k));
+            float a2 = g * a1;
+            float a3 = g * a2;
+            double b = s->pb[i], c = s->pc[i];
+            double v3 = v0 - c;
+            double v1i = (double)a1 * b + (double)a2 * v3;
+            double v2 = c + (double)a2 * b + (double)a3 * v3;
+            s->pb[i] = 2.0 * v1i - b;
+            s->pc[i] = 2.0 * v2 - c;
+            sum += v1i;
+        }
+        return (float)(sum * 0.5);
+    }
+    if (g_precise == 3) {
+        float sum = 0.0f;
+        for (int i = 0; i < NF; ++i) {
+            float breath = elem->formant_breath.v[i], turb = elem->formant_turb.v[i];
+            float nw = fmaf(breath, noise - saw, saw);
+            float o = 1.0f - elem->formant_smooth.v[i];
+            float o2 = o * o;
+            float oml = 1.0f - (o2 * o2) * o;
+            float a = s->filter_state_a.v[i];
+            a = fmaf(oml, nw - a, a);
+            s->filter_state_a.v[i] = a;
+            float v0 = a * (elem->formant_amp.v[i] * fmaf(turb, noise - 1.0f, 1.0f));
+            float g = orc_tan_approx(elem->formant_freq.v[i]);
+            float k = elem->formant_bw.v[i] / elem->formant_freq.v[i];
+            float a1 = 1.0f / (1.0f + g * (g + k));
+            float a2 = g * a1;
+            float a3 = g * a2;
+            float b = s->filter_state_b.v[i], c = s->filter_state_c.v[i];
+            float v3 = v0 - c;
+            float v1i = fmaf(a2, v3, a1 * b);
+            float v2 = fmaf(a3, v3, fmaf(a2, b, c));
+            s->filter_state_b.v[i] = fmaf(2.0f, v1i, -b);
+            s->filter_state_c.v[i] = fmaf(2.0f, v2, -c);
+            sum += v1i;
+        }
+        return sum * 0.5f;
+    }
     if (g_precise) {
         double sum = 0.0;
         for (int i = 0; i < NF; ++i) {

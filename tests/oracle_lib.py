@@ -292,4 +292,4 @@ def set_precise(on):
     L = lib()
     L.orc_set_precise.argtypes = [C.c_int]
     L.orc_set_precise.restype = None
-    L.orc_set_precise(1 if on else 0)
+    L.orc_set_precise(int(on))       # (True -> 1; 2 / 3: the middle-tier experiment's modes, oracle/grail_oracle.c)

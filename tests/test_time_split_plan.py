@@ -202,3 +202,81 @@ def test_sharpness_ignores_formants_that_are_never_audible_and_rejects_bad_param
         for i in range(8):
             v.phonemes[p].formant_amp[i] = 0.0
     assert gh.fast_sharpness(v) == 0.0              # a silent voice: whatever arithmetic
+
+
+def _residual_after(f, w, sm, n, drive_seed=1):
+    """float64 model of one formant of Synthesize::next (:531-571): the one-pole low-pass feeding the trapezoidal
+    band-pass, run twice on the same input — from its true (long-running) state and from zero state — and the largest
+    difference of any state after n samples, relative to the largest state seen (what the warm-up has to undo)."""
+    rng = np.random.default_rng(drive_seed)
+    g, k = tan_approx(f), w / f
+    a1 = 1.0 / (1.0 + g * (g + k))
+    a2, a3 = g * a1, g * g * a1
+    lp = (1.0 - sm) ** 5
+
+    def step(state, x):
+        a, b, c = state
+        a = a + (1.0 - lp) * (x - a)
+        v3 = a - c
+        v1 = a1 * b + a2 * v3
+        v2 = c + a2 * b + a3 * v3
+        return (a, 2.0 * v1 - b, 2.0 * v2 - c)
+
+    true = (0.0, 0.0, 0.0)
+    pre = int(12.0 / min(-math.log(math.sqrt((1 - g * k + g * g) / (1 + g * k + g * g))) if k < 2 else 1.0, -5.0 * math.log1p(-sm))) + 2000
+    xs = rng.uniform(-1.0, 1.0, pre + n)
+    peak = 0.0
+    for x in xs[:pre]:
+        true = step(true, x)
+        peak = max(peak, abs(true[1]), abs(true[2]), abs(true[0]))
+    zero = (0.0, 0.0, 0.0)
+    for x in xs[pre:]:
+        true, zero = step(true, x), step(zero, x)
+        peak = max(peak, abs(true[1]), abs(true[2]))
+    return max(abs(true[i] - zero[i]) for i in range(3)) / peak
+
+
+def _one_formant_voice(f, w, sm, jitter=0.0):
+    v = gh.voice_generic(48000.0)
+    for p in range(2):
+        e = v.phonemes[p]
+        for i in range(8):
+            e.formant_amp[i] = 1.0 if i == 0 else 0.0
+        e.formant_freq[0], e.formant_bw[0], e.formant_smooth[0] = f, w, sm
+    v.jitter_delta_formant_frequency = jitter
+    return v
+
+
+def test_warmup_residual_by_simulation_including_the_cascade_case():
+    """where the low-pass and the band-pass decay at nearly the same rate the residual of a wrong start
+    decays like n r^n, not r^n.  A float64 model of the chain, started from zero, must be within 2^-21 of the true
+    state after grail_time_split_warmup samples — far-apart rates (the shipped voices) and equal ones."""
+    cases = []
+    for f, bw_hz in ((910.0 / 48000.0, 60.0), (0.05, 120.0), (0.2, 300.0), (0.01, 40.0)):
+        w = bw_hz / 48000.0
+        g, k = tan_approx(f), w / f
+        l_bp = -0.5 * math.log((1 - g * k + g * g) / (1 + g * k + g * g))
+        sm_equal = 1.0 - math.exp(-l_bp / 5.0)            # the low-pass decaying exactly as fast as the band-pass
+        cases += [(f, w, 1600.0 / 48000.0), (f, w, sm_equal), (f, w, sm_equal * 1.1), (f, w, sm_equal * 0.9)]
+    for f, w, sm in cases:
+        n = gh.time_split_warmup(_one_formant_voice(f, w, sm))
+        assert 0 < n <= 16384, (f, w, sm)
+        res = _residual_after(f, w, sm, n)
+        assert res <= 2.0 ** -21, (f, w, sm, n, res * 2 ** 21)
+    # where the two rates meet the length is that of n r^n: longer than the plain r^n length by more than a tile
+    f, w = 0.05, 120.0 / 48000.0
+    g, k = tan_approx(f), w / f
+    l_bp = -0.5 * math.log((1 - g * k + g * g) / (1 + g * k + g * g))
+    sm = 1.0 - math.exp(-l_bp / 5.0)
+    plain = int(math.ceil(math.log(2.0 ** 21) / (0.95 * l_bp)))
+    assert gh.time_split_warmup(_one_formant_voice(f, w, sm)) > plain + 64
+
+
+def test_warmup_covers_the_range_of_the_formant_frequency_jitter():
+    """The band-pass decays most slowly at one end of the range the jitter moves its frequency through (:764)."""
+    f, w, sm = 0.02, 30.0 / 48000.0, 0.2
+    quiet = gh.time_split_warmup(_one_formant_voice(f, w, sm, 0.0))
+    jittered = gh.time_split_warmup(_one_formant_voice(f, w, sm, 0.015))
+    assert jittered >= quiet
+    for ff in (f - 0.015, f, f + 0.015):
+        assert _residual_after(ff, w, sm, jittered) <= 2.0 ** -21
