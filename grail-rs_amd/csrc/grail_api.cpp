@@ -133,7 +133,10 @@ struct grail_ctx {
     int64_t scan_split_max = -1;      // ... and up to this many with the carrier phase on a wave of its own (-1: 6 per CU = 1536)
     int composite_option = 1;         // a batch may be cut into blocks with a kernel family each (plan_blocks)
     double voices_sharpness = INFINITY;   // the largest predicted fast-mode deviation of the table, units of 2^-23
+    std::vector<double> voice_sharpness;  // ... per voice (a batch is judged by the voices it uses)
     int64_t fast_limit = (int64_t)GRAIL_FAST_SHARPNESS_LIMIT;   // "fast_sharpness_limit": fast kernels up to this
+    int mid_option = 1;               // "fast_exact_coefficients": sharper voices get the second tolerance tier (MID)
+    int64_t mid_limit = (int64_t)GRAIL_FAST_SHARPNESS_LIMIT_EXACT_COEFFICIENTS;   // ... up to this sharpness
     bool voices_split_ok = false;     // every voice has a warm-up length (voice_warmup): time-split fast kernels
     uint32_t max_warmup = 0;          // ... the longest of them
     float max_rate = 0.0f;            // highest sample rate of the table
@@ -159,7 +162,8 @@ struct grail_ctx {
     int pipeline_option = 1;          // small qualifying batches: producer/consumer workgroups
     int pipe_round32 = 1;             // ... with rounds of 32 samples while one workgroup per CU suffices (8.20 -> 7.86 ms for config 2)
     uint64_t voices_epoch = 0;        // bumped by every install_voices
-    int fast_option = 0;              // "arithmetic": 0 exact (bit-identical), 1 fast (stated tolerance)
+    int fast_option = 0;              // "arithmetic": 0 exact (bit-identical), 1 fast (stated tolerance: the tier the voices'
+                                      // sharpness allows), 2 fast with the reference's own coefficients (MID) whatever the voices
     std::string last_kernel = "none"; // instantiation of the last synthesis launch
     ncclComm_t comm = nullptr;
     uint32_t comm_rank = 0, comm_world = 1;
@@ -205,6 +209,7 @@ struct grail_batch {
     float min_length = 0.0f;   // shortest segment (plain batches)
     float min_pitch = 0.0f;    // lowest frequency.min(0.5) of any segment (plain batches)
     double elems_sharpness = 0.0;   // elem mode: predicted fast-mode deviation of the caller's elems (elems_sharpness())
+    std::vector<uint32_t> used_voices;   // the distinct voice ids of the batch, ascending
 };
 
 // the SIMDs and lanes the policy plans for: 4 SIMDs per compute unit, 64 lanes per wavefront.  Every family is laid out
@@ -296,9 +301,15 @@ int upload_common(grail_ctx *ctx, grail_batch *b, const uint32_t *seg_offsets,
     int rc;
     if ((rc = upload(&b->d_offsets, seg_offsets, (size_t)n_utt + 1, ctx->stream))) return rc;
     b->max_voice_id = 0;
+    b->used_voices.assign(1, 0u);                     // no ids: voice 0 for all
     if (voice_ids) {
         for (uint32_t u = 0; u < n_utt; ++u)
             if (voice_ids[u] > b->max_voice_id) b->max_voice_id = voice_ids[u];
+        if (n_utt) {
+            b->used_voices.assign(voice_ids, voice_ids + n_utt);
+            std::sort(b->used_voices.begin(), b->used_voices.end());
+            b->used_voices.erase(std::unique(b->used_voices.begin(), b->used_voices.end()), b->used_voices.end());
+        }
         if ((rc = upload(&b->d_voice_ids, voice_ids, n_utt, ctx->stream))) return rc;
     }
     if (jitter_seeds)
@@ -474,11 +485,29 @@ double elems_sharpness(const grail_synthesis_elem *elems, size_t n)
     }
     return std::sqrt(sum);
 }
-bool fast_served(const grail_ctx *ctx, const grail_batch *batch)
+// Is fast arithmetic served for this batch?  Caller-built elems are judged themselves; a phoneme batch by the sharpest of
+// the voices IT USES (one sharp voice in the table does not take fast arithmetic away from batches that never name it);
+// without a batch: by the whole table.
+double batch_sharpness(const grail_ctx *ctx, const grail_batch *batch)
 {
-    return (batch && !batch->phoneme_mode ? batch->elems_sharpness : ctx->voices_sharpness) <= (double)ctx->fast_limit;
+    if (!batch) return ctx->voices_sharpness;
+    if (!batch->phoneme_mode) return batch->elems_sharpness;
+    double s = 0.0;
+    for (const uint32_t v : batch->used_voices) s = std::fmax(s, v < ctx->voice_sharpness.size() ? ctx->voice_sharpness[v] : INFINITY);
+    return s;
 }
-
+// Which arithmetic a batch is rendered in when "arithmetic" asks for a tolerance mode: 1 = the interpolating tier (up
+// to "fast_sharpness_limit"), 2 = the reference's own band-pass coefficients at every sample (MID; sharper voices, up to
+// "fast_sharpness_limit_exact_coefficients"), 0 = the exact kernels (sharper still, or the tier switched off).
+int fast_tier_for(const grail_ctx *ctx, const grail_batch *batch, int arithmetic)
+{
+    if (!arithmetic) return 0;
+    const double s = batch_sharpness(ctx, batch);
+    if (arithmetic == 1 && s <= (double)ctx->fast_limit) return 1;
+    if ((ctx->mid_option || arithmetic == 2) && s <= (double)ctx->mid_limit) return 2;
+    return 0;
+}
+int fast_tier(const grail_ctx *ctx, const grail_batch *batch) { return fast_tier_for(ctx, batch, ctx->fast_option); }
 // The chunk grid of a time-split launch: K chunks over `span` samples.  Chunk k's lane fast-forwards the chain over
 // b[k] - W samples (cost r per sample, in units of a rendered sample), warms up over W and renders b[k+1] - b[k]:
 // the bounds are spaced so that all lanes take the same time (T below, by bisection).  Bounds are multiples
@@ -564,8 +593,11 @@ int install_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices)
     ctx->max_warmup = 0;
     ctx->voices_split_ok = true;
     ctx->voices_sharpness = 0.0;
-    for (uint32_t v = 0; v < n_voices; ++v)
-        ctx->voices_sharpness = std::fmax(ctx->voices_sharpness, elems_sharpness(voices[v].phonemes, NUM_VOICED));
+    ctx->voice_sharpness.assign(n_voices, 0.0);
+    for (uint32_t v = 0; v < n_voices; ++v) {
+        ctx->voice_sharpness[v] = elems_sharpness(voices[v].phonemes, NUM_VOICED);
+        ctx->voices_sharpness = std::fmax(ctx->voices_sharpness, ctx->voice_sharpness[v]);
+    }
     for (uint32_t v = 0; v < n_voices; ++v) {
         ctx->voices_live4_ok = ctx->voices_live4_ok && live4_ok(voices[v]);
         ctx->voices_split_ok = ctx->voices_split_ok && dv[v].warmup != 0u && voices[v].sample_rate > 0.0f &&
@@ -733,8 +765,18 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         return GRAIL_OK;
     }
     if (std::strcmp(name, "arithmetic") == 0) {
-        if (value != 0 && value != 1) return fail(GRAIL_ERR_INVALID_ARG, "arithmetic must be 0 (exact) or 1 (fast)");
+        if (value != 0 && value != 1 && value != 2)
+            return fail(GRAIL_ERR_INVALID_ARG, "arithmetic must be 0 (exact), 1 (fast) or 2 (fast, exact coefficients)");
         ctx->fast_option = (int)value;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "fast_exact_coefficients") == 0) {
+        ctx->mid_option = value ? 1 : 0;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "fast_sharpness_limit_exact_coefficients") == 0) {
+        if (value < 0) return fail(GRAIL_ERR_INVALID_ARG, "negative limit");
+        ctx->mid_limit = value;
         return GRAIL_OK;
     }
     if (std::strcmp(name, "time_parallel_scan") == 0) {
@@ -897,8 +939,16 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
         *value = ctx->fast_limit;
         return GRAIL_OK;
     }
-    if (std::strcmp(name, "fast_arithmetic_served") == 0) {    // read-only: the voice table is below the sharpness limit
-        *value = fast_served(ctx, nullptr) ? 1 : 0;
+    if (std::strcmp(name, "fast_arithmetic_served") == 0) {    // read-only: the tier "arithmetic" = 1 gets for the voice table
+        *value = fast_tier_for(ctx, nullptr, 1);                // as a whole: 1 interpolating, 2 exact coefficients, 0 exact kernels
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "fast_exact_coefficients") == 0) {
+        *value = ctx->mid_option;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "fast_sharpness_limit_exact_coefficients") == 0) {
+        *value = ctx->mid_limit;
         return GRAIL_OK;
     }
     if (std::strcmp(name, "last_launch_chunks") == 0) {        // read-only: chunks per utterance (0: not time-split)
@@ -1120,6 +1170,7 @@ static double batch_span(const grail_ctx *ctx, const grail_batch *batch, uint64_
 // Cost model of the planner, in milliseconds per SAMPLE OF THE LONGEST UTTERANCE for one round of a family (a round:
 // as many rows as give every SIMD one wave).  Calibrated on 2 s utterances at 48 kHz, one MI355X
 // (profiles/r03_small_batch.txt, profiles/r04_duration_sweep.txt); only the ratios matter.  Indexed [L = 1, 2, 4, 8].
+constexpr double MID_MS_4 = 32.6, MID_MS_8 = 57.2;     // 65 536 x 2 s, the MID kernels (profiles/r04_middle_tier.txt)
 static double lane_ms_per_sample(bool fast, bool live4, int L)
 {
     static const double exact4[4] = {40.6, 26.9, 16.3, 18.2}, exact8[4] = {77.1, 43.5, 25.8, 15.7};
@@ -1127,6 +1178,8 @@ static double lane_ms_per_sample(bool fast, bool live4, int L)
     const int i = L == 1 ? 0 : L == 2 ? 1 : L == 4 ? 2 : 3;
     return (fast ? (live4 ? fast4 : fast8) : (live4 ? exact4 : exact8))[i] / 96006.0;
 }
+// ... of the second tolerance tier (MID, one lane per utterance)
+static double mid_ms_per_sample(bool live4) { return (live4 ? MID_MS_4 : MID_MS_8) / 96006.0; }
 
 // what launching `rows` rows with family f costs (model milliseconds)
 static double family_cost(const grail_ctx *ctx, const Family &f, uint32_t rows, double span)
@@ -1145,6 +1198,7 @@ static double family_cost(const grail_ctx *ctx, const Family &f, uint32_t rows, 
         // every lane takes as long as the first chunk's, which renders split_bounds[1] samples and nothing else
         const double rounds = std::ceil((double)rows * f.split_k / lanes);
         // (+ 0.12 ms: what a launch of chunk lanes costs before any of them renders — short utterances see it)
+        if (f.fast == 2u) return rounds * ((double)f.split_bounds[1] * mid_ms_per_sample(f.live4 != 0) + 0.12);
         return rounds * ((double)f.split_bounds[1] * (f.live4 ? 15.7 : 23.3) / 96006.0 + 0.12);
     }
     if (f.pipe) {
@@ -1155,6 +1209,7 @@ static double family_cost(const grail_ctx *ctx, const Family &f, uint32_t rows, 
         return ms2s * span / 96006.0;
     }
     const double rounds = std::ceil((double)rows * f.L / lanes);
+    if (f.fast == 2u) return rounds * span * mid_ms_per_sample(f.live4 != 0);
     return rounds * span * lane_ms_per_sample(f.fast != 0, f.live4 != 0, f.L);
 }
 
@@ -1184,13 +1239,17 @@ static bool batch_live4(const grail_ctx *ctx, const grail_batch *batch)
 // of the scan kernel, the time-split kernels and the fast lane kernels by the cost model above (which follows the
 // utterances' length: a time-split pays a warm-up per chunk, the scan kernel the latency of one utterance's chain),
 // unless an option pins the choice.
-static void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t fam, Family &f)
+static void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t fam, Family &f,
+                          bool exact_only = false)
 {
     const uint64_t simds = ctx_simds(ctx), lanes = ctx_lanes(ctx), cus = (uint64_t)ctx->cus;
     f = Family();
     f.live4 = batch_live4(ctx, batch) ? 1u : 0u;
     // fast arithmetic is served up to a sharpness of the resonances (elems_sharpness); beyond it the exact kernels run
-    f.fast = ctx->fast_option && fast_served(ctx, batch) ? 1u : 0u;
+    // ... in the tier the sharpness allows: 1 = coefficients interpolated, 2 = the reference's own coefficients (MID)
+    f.fast = exact_only ? 0u : (uint32_t)fast_tier(ctx, batch);
+    // (MID kernels exist one-shot with one lane per utterance, and time-split: a pinned wider mapping gets the exact kernels)
+    if (f.fast == 2u && ctx->lanes_option > 1) f.fast = 0u;
     // (the fast lane kernels have four-formant instantiations for every blend length)
     if (f.fast && batch_live4_any_blend(ctx, batch)) f.live4 = 1u;
     int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(fam, simds);
@@ -1222,6 +1281,7 @@ static void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64
     // kernels: one lane per utterance runs the half-live loop and ties two lanes per utterance,
     // whose second lane would only hold silent formants
     if (!ctx->lanes_option && !f.live4 && L == 2 && batch_half_capable(ctx, batch)) L = 1;
+    if (f.fast == 2u) L = 1;
     f.L = L;
     if (!f.fast) return;
 
@@ -1238,7 +1298,7 @@ static void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64
         K = (int)std::fmin((double)K, sp / 512.0);
         // (a fast-forwarded sample costs the same whatever is rendered afterwards; a rendered sample of eight live
         // formants costs 1.5 x one of four; 0.8 from a sweep, profiles/r03_small_batch.txt)
-        const double ff_cost = 1e-3 * (double)ctx->split_ff_permille * (l4ab ? 1.0 : 0.8);
+        const double ff_cost = 1e-3 * (double)ctx->split_ff_permille * (l4ab ? 1.0 : 0.8) * (f.fast == 2u ? 0.6 : 1.0);
         while (K >= 2 && !split_grid((uint32_t)sp, ctx->max_warmup, K, ff_cost, split.split_bounds)) --K;
         if (K >= 2) {
             split.split_k = K;
@@ -1252,7 +1312,7 @@ static void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64
     // filter recurrences solved by parallel scans (scan_kernels.hip).  Needs every parameter inside the safe window
     // (no IEEE fallback).
     Family scan = f;
-    if (ctx->scan_option && !ctx->lanes_option && (int64_t)fam * (l4ab ? 4 : 7) <= 4 * scan_max_utts(ctx) &&
+    if (f.fast == 1u && ctx->scan_option && !ctx->lanes_option && (int64_t)fam * (l4ab ? 4 : 7) <= 4 * scan_max_utts(ctx) &&
         batch->phoneme_mode && ctx->voices_scan_ok && batch->plain && batch->min_length >= 2.0f * ctx->max_dt &&
         batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f) {
         scan.scan = true;
@@ -1279,14 +1339,18 @@ static void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64
         take_split = c_split <= c_scan && c_split < c_lane;
         take_scan = !take_split && c_scan < c_lane;
     }
-    if (take_split) {
-        f = split;
+    if (take_split) f = split;
+    else if (take_scan) f = scan;
+    if (f.fast == 2u && !ctx->lanes_option && ctx->split_chunks < 2) {
+        // The second tier costs 0.8 of the exact one-lane kernel (0.64 - 0.8 time-split): where the exact kernels have a
+        // wider mapping to fill the machine with — mid-size batches of voices that do not qualify for time-splitting —
+        // they are the faster way to the same tolerance (their bits satisfy it trivially).
+        Family exact;
+        choose_family(ctx, batch, out_stride, fam, exact, true);
+        if (family_cost(ctx, exact, fam, span) <= family_cost(ctx, f, fam, span)) f = exact;
         return;
     }
-    if (take_scan) {
-        f = scan;
-        return;
-    }
+    if (take_split || take_scan) return;
     // fast arithmetic asked for, but the batch takes neither the scan kernel nor the time-split kernels (caller-built
     // elems, a voice outside their windows, an option switched off) and is small enough for the pipelined exact
     // workgroups: those are faster than the fast lane kernels there (8.1 - 11.5 against 12.4 ms), and exact bits
@@ -1481,7 +1545,7 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
         rc = launch_block(ctx, batch, b.f, out_dev, out_pcm16_dev, out_stride, out_len_dev, first, slot0, b.rows, use_perm);
         if (rc) return rc;
         if (i == main_block) first_kernel = ctx->last_kernel;
-        if (b.f.fast) ctx->last_fast = 1;
+        if ((int)b.f.fast > ctx->last_fast) ctx->last_fast = (int)b.f.fast;
         slot0 += b.rows;
     }
     ctx->last_kernel = first_kernel;            // the largest block's instantiation names the launch
@@ -1618,7 +1682,7 @@ static int stream_next(grail_ctx *ctx, grail_stream *stream, uint32_t max_sample
     a.any_blend = stream->any_blend ? 1u : 0u;
     a.live4 = stream->live4 ? 1u : 0u;
     // (may change between calls: both flavours share the state layout)
-    a.fast = ctx->fast_option && fast_served(ctx, batch) ? 1u : 0u;
+    a.fast = fast_tier(ctx, batch) == 1 ? 1u : 0u;      // (no resumable MID kernels: sharper voices stream exactly)
     a.state = stream->d_state;
     a.state_stride = stream->lanes;
     a.resume = stream->started ? 1u : 0u;
@@ -1694,8 +1758,13 @@ int grail_stream_open_live(grail_ctx *ctx, uint32_t n_utt, const uint32_t *voice
     b->plain = false;
     b->n_utt = n_utt;
     b->max_voice_id = 0;
-    if (voice_ids)
+    b->used_voices.assign(1, 0u);
+    if (voice_ids) {
         for (uint32_t u = 0; u < n_utt; ++u) b->max_voice_id = std::max(b->max_voice_id, voice_ids[u]);
+        b->used_voices.assign(voice_ids, voice_ids + n_utt);
+        std::sort(b->used_voices.begin(), b->used_voices.end());
+        b->used_voices.erase(std::unique(b->used_voices.begin(), b->used_voices.end()), b->used_voices.end());
+    }
     const size_t ring_rows = (size_t)n_utt * ring_segments;
     hipError_t e = hipSuccess;
     auto zeroed = [&](void **p, size_t bytes) {

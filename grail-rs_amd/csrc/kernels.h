@@ -71,7 +71,8 @@ struct SynthArgs {
                                   // batch (see grail_api.cpp live4_ok); selects the NFA = 4 kernels
     uint32_t pipe;                // live4 batches small enough to leave SIMDs idle: the four-wave
                                   // pipelined workgroups (synth_kernel<..., PIPE>)
-    uint32_t fast;                // tolerance-mode arithmetic in calm tiles (option "arithmetic" = 1)
+    uint32_t fast;                // tolerance-mode arithmetic in calm tiles (option "arithmetic" = 1): 1 = coefficients
+                                  // interpolated, 2 = the reference's own coefficients at every sample (MID)
     uint32_t any_blend;           // host hint: some segment has a blend length that is not +-2^k
     uint32_t *state;              // resumable synthesis: state[word][lane] or nullptr (one-shot)
     uint64_t state_stride;        // lanes of the launch (= state_lanes())

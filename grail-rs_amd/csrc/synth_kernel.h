@@ -241,6 +241,46 @@ __device__ __forceinline__ void formant_filters(const float saw, const float noi
 #undef FOR_L
 #undef FOR_K
 
+// MID kernels: the band-pass coefficients of one sample for the NV formant vectors of a lane — the reference's own
+// operation sequence on its own operands (blend :404-414, jitter :305 / :764, tan_approx :555, bw / freq :558,
+// a1, a2, a3 :560-562), i.e. the bits the exact kernels compute — written breadth-first across the vectors like
+// formant_filters above: the independent chains hide each other's latency and no v_rcp result is consumed by the next
+// instruction (each such pair costs a wait state, and a lone wave pays for every issue slot).
+template <int NV, typename V>
+__device__ __forceinline__ void exact_band_pass_coeffs(const V (&xf)[NV], const V (&yf)[NV], const V (&xb)[NV], const V (&yb)[NV],
+                                                       const V (&ffc)[NV], const V (&ffn)[NV], const float alpha, const float oma,
+                                                       const float jp, const float jomp, const float d_ffreq,
+                                                       V (&a1)[NV], V (&a2)[NV], V (&a3)[NV])
+{
+#define FOR_K _Pragma("unroll") for (int k = 0; k < NV; ++k)
+    V ef[NV], eb[NV], nff[NV], num[NV], den[NV], g[NV], kq[NV], y[NV], e[NV], q[NV], r[NV], d3[NV], y2[NV], e2[NV], q2[NV], r2[NV];
+    const V one = vsplat(1.0f, xf[0]), five = vsplat(5.0f, xf[0]), m4 = vsplat(-4.0f, xf[0]);
+    FOR_K ef[k] = xf[k] * oma + yf[k] * alpha;                        // :404-414
+    FOR_K eb[k] = xb[k] * oma + yb[k] * alpha;
+    FOR_K nff[k] = ffc[k] * jomp + ffn[k] * jp;                       // :305
+    FOR_K ef[k] = ef[k] + nff[k] * d_ffreq;                           // :764
+    FOR_K {
+        const V x = ef[k];
+        const V omx = 1.0f - x, xph = x + 0.5f, hmx = 0.5f - x;
+        const V ox = omx * x, ph = xph * hmx;
+        num[k] = ox * vfma(m4, ph, five);                             // see formant_filters: one rounding of the same number
+        den[k] = (xph * vfma(m4, ox, five)) * hmx;
+    }
+    FOR_K { y[k] = vrcp(den[k]); y2[k] = vrcp(ef[k]); }
+    FOR_K { e[k] = vfma(-den[k], y[k], one); e2[k] = vfma(-ef[k], y2[k], one); }
+    FOR_K { y[k] = vfma(e[k], y[k], y[k]); y2[k] = vfma(e2[k], y2[k], y2[k]); }
+    FOR_K { q[k] = num[k] * y[k]; q2[k] = eb[k] * y2[k]; }
+    FOR_K { r[k] = vfma(-den[k], q[k], num[k]); r2[k] = vfma(-ef[k], q2[k], eb[k]); }
+    FOR_K { g[k] = vfma(r[k], y[k], q[k]); kq[k] = vfma(r2[k], y2[k], q2[k]); }   // :555, :558
+    FOR_K d3[k] = 1.0f + g[k] * (g[k] + kq[k]);                                   // :560
+    FOR_K y[k] = vrcp(d3[k]);
+    FOR_K e[k] = vfma(-d3[k], y[k], one);
+    FOR_K a1[k] = vfma(e[k], y[k], y[k]);
+    FOR_K a2[k] = g[k] * a1[k];                                                   // :561
+    FOR_K a3[k] = g[k] * a2[k];                                                   // :562
+#undef FOR_K
+}
+
 // Can every division of the coming segment pair take the SAFE path?  Bounds every
 // divisor/dividend over the pair: alpha in [0,1] (clk >= 0 for the whole pair once it
 // is >= 0 at its first sample, blend_length > 0), the jitter noises in [-1,1] (0 <=
@@ -377,11 +417,22 @@ struct StateIO {
 // full scale (DevVoice::warmup, from the narrowest bandwidth of the voice) — and then renders like any fast
 // kernel, storing from the chunk's first sample on.  All 64 lanes of a wave work on the same chunk index, so
 // they sit at the same sample position and share the carrier noise of a tile as everywhere else.
+// MID (FAST kernels): the second tolerance tier, for voices whose resonances are too sharp for interpolated
+// coefficients.  What makes a sharp band-pass drift away from the reference is not the size of a coefficient error but
+// its PERSISTENCE: a1, a2 = g a1, a3 = g a2 (:560-562) that differ from the reference's rounded values in the same
+// direction for the length of a sub-tile move the resonance for that long, and its ring time integrates it
+// (profiles/r03_sharpness.txt).  MID evaluates exactly those — the blended and jittered formant frequency and
+// bandwidth, g = tan_approx, k = bw / freq, a1, a2, a3 — at every sample with the reference's own operation sequence
+// (the same bits as the exact kernels) and keeps the fast arithmetic for everything else: amplitudes, turbulence,
+// breath and the low-pass factor interpolated, fused multiply-adds in the filter updates, v_rcp in the polyBLEP, the
+// sum in tree order.  Measured on 3 000 random voice tables (oracle model, profiles/r04_middle_tier.txt): at most
+// 16 * 2^-23 from the reference at ANY sharpness, where the interpolating tier reaches 95 and plain double precision 150.
 template <int L, int T, int WAVES, int MIN_WAVES_PER_SIMD, bool STREAM, bool HALF, bool ANYBL, int NFA = NF,
-          bool PIPE = false, bool FAST = false, int PQP = 2, bool SPLIT = false>
+          bool PIPE = false, bool FAST = false, int PQP = 2, bool SPLIT = false, bool MID = false>
 __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(const SynthArgs A)
 {
     static_assert(!FAST || (!PIPE && !HALF), "FAST");
+    static_assert(!MID || FAST, "MID is a flavour of the tolerance kernels");
     static_assert(!SPLIT || (FAST && !STREAM && L == 1 && WAVES == 1 && T == 64), "SPLIT");
     static_assert(NFA == NF || (NFA == 4 && !HALF), "NFA");
     static_assert(!PIPE || (WAVES == 4 && NFA / L == 1 && L >= 4 && !STREAM && !HALF && !ANYBL && T % 4 == 0), "PIPE");
@@ -796,26 +847,38 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             const V nms = vsplat(noise - saw, V()), nm1 = vsplat(noise - 1.0f, V()), sawv = vsplat(saw, V());
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
-                const V x = e_freq[k];
-                const V omx = 1.0f - x, xph = x + 0.5f, hmx = 0.5f - x;
-                const V ox = omx * x, ph_ = xph * hmx;
-                const V num = ox * vfma(m4, ph_, five);
-                const V den = (xph * vfma(m4, ox, five)) * hmx;
-                V rd = vrcp(den), rx = vrcp(x);
-                rd = vfma(vfma(-den, rd, one), rd, rd);
-                rx = vfma(vfma(-x, rx, one), rx, rx);
-                const V tg = num * rd;                                              // :555
-                const V kq = e_bw[k] * rx;                                          // :558
-                const V d3 = vfma(tg, tg + kq, one);
-                V a1 = vrcp(d3);
-                a1 = vfma(vfma(-d3, a1, one), a1, a1);                              // :560
                 const V oml = 1.0f - exp_approx(e_smooth[k]);                       // :535
                 const V nw = vfma(e_breath[k], nms, sawv);                          // :531
                 st_a[k] = vfma(oml, nw - st_a[k], st_a[k]);                         // :538
                 const V v0 = st_a[k] * (e_amp[k] * vfma(e_turb[k], nm1, one));      // :544-550
                 const V v3 = v0 - st_c[k];                                          // :565
-                const V w1 = a1 * vfma(tg, v3, st_b[k]);                            // :566
-                const V w2 = vfma(tg, w1, st_c[k]);                                 // :567
+                V w1, w2;
+                if constexpr (MID) {
+                    // the reference's own coefficients (e_freq, e_bw above ARE its blend and jitter), fused updates
+                    const V g = tan_approx<true>(e_freq[k]);                        // :555
+                    const V kq = div_exact<true>(e_bw[k], e_freq[k]);               // :558
+                    const V a1 = rcp_exact<true>(1.0f + g * (g + kq));              // :560
+                    const V a2 = g * a1;                                            // :561
+                    const V a3 = g * a2;                                            // :562
+                    w1 = vfma(a2, v3, a1 * st_b[k]);                                // :566
+                    w2 = vfma(a3, v3, vfma(a2, st_b[k], st_c[k]));                  // :567
+                } else {
+                    const V x = e_freq[k];
+                    const V omx = 1.0f - x, xph = x + 0.5f, hmx = 0.5f - x;
+                    const V ox = omx * x, ph_ = xph * hmx;
+                    const V num = ox * vfma(m4, ph_, five);
+                    const V den = (xph * vfma(m4, ox, five)) * hmx;
+                    V rd = vrcp(den), rx = vrcp(x);
+                    rd = vfma(vfma(-den, rd, one), rd, rd);
+                    rx = vfma(vfma(-x, rx, one), rx, rx);
+                    const V tg = num * rd;                                          // :555
+                    const V kq = e_bw[k] * rx;                                      // :558
+                    const V d3 = vfma(tg, tg + kq, one);
+                    V a1 = vrcp(d3);
+                    a1 = vfma(vfma(-d3, a1, one), a1, a1);                          // :560
+                    w1 = a1 * vfma(tg, v3, st_b[k]);                                // :566
+                    w2 = vfma(tg, w1, st_c[k]);                                     // :567
+                }
                 st_b[k] = vfma(vsplat(2.0f, V()), w1, -st_b[k]);                    // :570
                 st_c[k] = vfma(vsplat(2.0f, V()), w2, -st_c[k]);                    // :571
                 v1[k] = w1;
@@ -1450,23 +1513,30 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             const V nfa = vfma(fa_next[k], vsplat(jp, V()), fa_cur[k] * jomp);
             ef = vfma(nff, vsplat(d_ffreq, V()), ef);
             const V mul = vfma(nfa + 1.0f, vsplat(-amp_scale, V()), one);
-            const V omx = 1.0f - ef, xph = ef + 0.5f, hmx = 0.5f - ef;
-            const V ox = omx * ef, ph = xph * hmx;
-            const V num = ox * vfma(m4, ph, five);
-            const V den = (xph * vfma(m4, ox, five)) * hmx;
-            // g = num / den (:555), k = bw / x (:558), a1 = 1 / (1 + g (g + k)) (:560): v_rcp + one
-            // Newton step each (correctly rounded reciprocals; the quotients are within an ulp)
-            V rd = vrcp(den), rx = vrcp(ef);
-            rd = vfma(vfma(-den, rd, one), rd, rd);
-            rx = vfma(vfma(-ef, rx, one), rx, rx);
-            const V tg = num * rd;
-            const V kq = eb * rx;
-            const V d3 = vfma(tg, tg + kq, one);
-            V r3 = vrcp(d3);
-            r3 = vfma(vfma(-d3, r3, one), r3, r3);
             const V gg = ea * mul;
-            put(e.a1[k], FS.a1[k], r3);
-            put(e.tg[k], FS.tg[k], tg);
+            if constexpr (!MID) {
+                const V omx = 1.0f - ef, xph = ef + 0.5f, hmx = 0.5f - ef;
+                const V ox = omx * ef, ph = xph * hmx;
+                const V num = ox * vfma(m4, ph, five);
+                const V den = (xph * vfma(m4, ox, five)) * hmx;
+                // g = num / den (:555), k = bw / x (:558), a1 = 1 / (1 + g (g + k)) (:560): v_rcp + one
+                // Newton step each (correctly rounded reciprocals; the quotients are within an ulp)
+                V rd = vrcp(den), rx = vrcp(ef);
+                rd = vfma(vfma(-den, rd, one), rd, rd);
+                rx = vfma(vfma(-ef, rx, one), rx, rx);
+                const V tg = num * rd;
+                const V kq = eb * rx;
+                const V d3 = vfma(tg, tg + kq, one);
+                V r3 = vrcp(d3);
+                r3 = vfma(vfma(-d3, r3, one), r3, r3);
+                put(e.a1[k], FS.a1[k], r3);
+                put(e.tg[k], FS.tg[k], tg);
+            } else {
+                // (MID: a1, a2, a3 come from the reference's own sequence at every sample — nothing to interpolate)
+                e.a1[k] = one;
+                e.tg[k] = one;
+                (void)eb; (void)five; (void)m4;
+            }
             put(e.g[k], FS.g[k], gg);
             put(e.h[k], FS.h[k], et * gg);
             x.ap[k] = ea;
@@ -1513,10 +1583,12 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 #pragma unroll
             for (int c = 0; c < W; ++c) {
                 // relative change of a1 and g over 32 samples; 32^2 x the products of slopes behind G and H
-                ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(FD.a1[k], c)) * (float)TS0 *
-                                             __builtin_amdgcn_rcpf(vget(FS.a1[k], c)));
-                ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(FD.tg[k], c)) * (float)TS0 *
-                                             __builtin_amdgcn_rcpf(vget(FS.tg[k], c)));
+                if constexpr (!MID) {
+                    ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(FD.a1[k], c)) * (float)TS0 *
+                                                 __builtin_amdgcn_rcpf(vget(FS.a1[k], c)));
+                    ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(FD.tg[k], c)) * (float)TS0 *
+                                                 __builtin_amdgcn_rcpf(vget(FS.tg[k], c)));
+                }
                 rg = __builtin_fmaxf(rg, __builtin_fabsf((vget(xe.ap[k], c) - vget(xs.ap[k], c)) *
                                                          (vget(xe.mu[k], c) - vget(xs.mu[k], c))));
                 rg = __builtin_fmaxf(rg, __builtin_fabsf((vget(xe.tb[k], c) - vget(xs.tb[k], c)) *
@@ -1585,6 +1657,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     // clk, jphase and phase; returns the phases before the two samples and their pitch.
     // CLAMP = false: the caller has shown that clk / blend_length <= 1 for every sample of the tile (the clock
     // only falls inside a calm tile), so min(ratio, 1) is the ratio itself.
+    f2 chain_alpha = vsplat(0.0f, f2()), chain_jp = vsplat(0.0f, f2());   // MID: alpha and jitter phase of the pair just stepped
     auto chain_pair = [&](auto clamp_tag, f2 &PH, f2 &frequency) __attribute__((always_inline)) {
         constexpr bool CLAMP = decltype(clamp_tag)::value;
         const f2 one2 = vsplat(1.0f, f2());
@@ -1615,6 +1688,10 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         }
         const f2 oma = 1.0f - alpha;
         const f2 jomp = 1.0f - JP;
+        if constexpr (MID) {
+            chain_alpha = alpha;
+            chain_jp = JP;
+        }
         frequency = X.frequency * oma + Y.frequency * alpha;               // :404-414
         const f2 n_freq = fn_cur * jomp + fn_next * JP;                    // :254
         frequency = frequency + n_freq * d_freq;                           // :763
@@ -1714,16 +1791,29 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     st_a[k] = vfma(oml_v, nw - st_a[k], st_a[k]);           // :538
                 }
             }
+            // MID: this sample's coefficients as the reference has them, from its own blend weights (:899-903, :242)
+            V a1x[NV], a2x[NV], a3x[NV];
+            if constexpr (MID) {
+                const float al_h = vget(chain_alpha, h), jp_h = vget(chain_jp, h);
+                exact_band_pass_coeffs<NV, V>(X.freq, Y.freq, X.bw, Y.bw, ff_cur, ff_next, al_h, 1.0f - al_h, jp_h, 1.0f - jp_h,
+                                              d_ffreq, a1x, a2x, a3x);
+            }
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
-                const V a1 = vfma(FD.a1[k], tiv, FS.a1[k]);
-                const V tg = vfma(FD.tg[k], tiv, FS.tg[k]);
                 const V g_ = vfma(FD.g[k], tiv, FS.g[k]);
                 const V h_ = vfma(FD.h[k], tiv, FS.h[k]);
                 const V v0 = st_a[k] * vfma(h_, nm1, g_);                   // :544-550
                 const V v3 = v0 - st_c[k];                                  // :565
-                const V w1 = a1 * vfma(tg, v3, st_b[k]);                    // :566  a1 b + a2 v3
-                const V w2 = vfma(tg, w1, st_c[k]);                         // :567  c + a2 b + a3 v3
+                V w1, w2;
+                if constexpr (MID) {
+                    w1 = vfma(a2x[k], v3, a1x[k] * st_b[k]);                // :566
+                    w2 = vfma(a3x[k], v3, vfma(a2x[k], st_b[k], st_c[k]));  // :567
+                } else {
+                    const V a1 = vfma(FD.a1[k], tiv, FS.a1[k]);
+                    const V tg = vfma(FD.tg[k], tiv, FS.tg[k]);
+                    w1 = a1 * vfma(tg, v3, st_b[k]);                        // :566  a1 b + a2 v3
+                    w2 = vfma(tg, w1, st_c[k]);                             // :567  c + a2 b + a3 v3
+                }
                 st_b[k] = vfma(vsplat(2.0f, V()), w1, -st_b[k]);            // :570
                 st_c[k] = vfma(vsplat(2.0f, V()), w2, -st_c[k]);            // :571
                 acc = k == 0 ? w1 : acc + w1;            // (tree order; the first term needs no 0 +)
@@ -2380,13 +2470,14 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 }
 
 template <int L, int T, int WAVES, int MINW, bool STREAM, bool HALF, bool ANYBL, int NFA = NF, bool PIPE = false,
-          bool FAST = false, int PQP = 2, bool SPLIT = false>
+          bool FAST = false, int PQP = 2, bool SPLIT = false, bool MID = false>
 void start(const SynthArgs &args, dim3 grid, dim3 block, hipStream_t stream)
 {
-    std::snprintf(g_kernel_name, sizeof g_kernel_name, "synth_kernel<L=%d,T=%d,W=%d,%d,%s%s%sNFA=%d%s%s%s%s>", L, T, WAVES,
+    std::snprintf(g_kernel_name, sizeof g_kernel_name, "synth_kernel<L=%d,T=%d,W=%d,%d,%s%s%sNFA=%d%s%s%s%s%s>", L, T, WAVES,
                   MINW, STREAM ? "STREAM," : "", HALF ? "HALF," : "", ANYBL ? "ANYBL," : "", NFA,
-                  PIPE ? ",PIPE" : "", FAST ? ",FAST" : "", PQP == 4 ? ",R16" : PQP == 8 ? ",R32" : "", SPLIT ? ",SPLIT" : "");
-    hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, STREAM, HALF, ANYBL, NFA, PIPE, FAST, PQP, SPLIT>), grid, block, 0,
+                  PIPE ? ",PIPE" : "", FAST ? ",FAST" : "", PQP == 4 ? ",R16" : PQP == 8 ? ",R32" : "", SPLIT ? ",SPLIT" : "",
+                  MID ? ",MID" : "");
+    hipLaunchKernelGGL((synth_kernel<L, T, WAVES, MINW, STREAM, HALF, ANYBL, NFA, PIPE, FAST, PQP, SPLIT, MID>), grid, block, 0,
                        stream, args);
 }
 

@@ -99,11 +99,13 @@ hipError_t launch_synth(const SynthArgs &args, int L, hipStream_t stream)
     }
     if (args.split_chunks) {
         if (!args.fast || args.state || L != 1 || args.split_chunks > (uint32_t)SPLIT_MAX_CHUNKS) return hipErrorInvalidValue;
-        launch_split(args, stream);
+        if (args.fast == 2u) launch_split_mid(args, stream);
+        else launch_split(args, stream);
         return hipGetLastError();
     }
+    if (args.fast == 2u && (L != 1 || args.state)) return hipErrorInvalidValue;   // MID: one-shot, one lane per utterance
     switch (L) {
-    case 1: args.fast ? launch_fast_l1(args, stream) : launch_exact_l1(args, stream); break;
+    case 1: args.fast == 2u ? launch_mid_l1(args, stream) : args.fast ? launch_fast_l1(args, stream) : launch_exact_l1(args, stream); break;
     case 2: args.fast ? launch_fast_l2(args, stream) : launch_exact_l2(args, stream); break;
     case 4: args.fast ? launch_fast_l4(args, stream) : launch_exact_l4(args, stream); break;
     case 8: args.fast ? launch_fast_l8(args, stream) : launch_exact_l8(args, stream); break;

@@ -89,5 +89,19 @@ void launch_one_split(const SynthArgs &args, hipStream_t stream)
     start<1, 64, 1, 1, false, false, ANYBL_, NFA_, false, true, 2, true>(args, grid, block, stream);
 }
 
+// the second tolerance tier (MID: the reference's own filter coefficients at every sample), one lane per utterance
+template <int NFA_, bool ANYBL_>
+void launch_one_mid(const SynthArgs &args, hipStream_t stream)
+{
+    const dim3 grid = lane_grid<1, 1>(args), block(64);
+    start<1, 64, 1, 1, false, false, ANYBL_, NFA_, false, true, 2, false, true>(args, grid, block, stream);
+}
+template <int NFA_, bool ANYBL_>
+void launch_one_split_mid(const SynthArgs &args, hipStream_t stream)
+{
+    const dim3 grid(((args.n_utt + 63u) / 64u) * args.split_chunks), block(64);
+    start<1, 64, 1, 1, false, false, ANYBL_, NFA_, false, true, 2, true, true>(args, grid, block, stream);
+}
+
 }  // namespace
 }  // namespace grail

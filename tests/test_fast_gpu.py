@@ -156,9 +156,10 @@ def test_fast_mode_fuzz_on_random_voice_tables(gpu_ctx):
                 v.phonemes[p] = G.elem_resample(e, 44100.0, 48000.0)
             voices.append(v if trial % 3 == 2 else W.tame_voice(v))    # (bandwidths widened until served)
         gpu_ctx.set_voices(voices)
-        # sharper tables are rendered by the exact kernels (include/grail_hip.h, grail_fast_sharpness)
+        # sharper tables are rendered by the second tier — the reference's own filter coefficients at every sample
+        # (include/grail_hip.h, grail_fast_sharpness): the tolerance is the same
         served = all(G.fast_sharpness(v) <= G.FAST_SHARPNESS_LIMIT for v in voices)
-        assert gpu_ctx.get_option("fast_arithmetic_served") == int(served)
+        assert gpu_ctx.get_option("fast_arithmetic_served") == (1 if served else 2)
         assert served or trial % 3 == 2
         n_utt = 40
         utts = []
@@ -176,6 +177,12 @@ def test_fast_mode_fuzz_on_random_voice_tables(gpu_ctx):
         for lanes in (0, 1, 4):
             out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride, lanes)
             assert np.array_equal(out_len, ref_len)
+            # (a batch is judged by the voices it uses; the second tier has one-lane and time-split kernels only: a pinned
+            # wider mapping gets the exact kernels, and left to itself the library takes whichever is faster — the exact
+            # kernels' bits satisfy any tolerance)
+            used = all(G.fast_sharpness(voices[int(i)]) <= G.FAST_SHARPNESS_LIMIT for i in set(vids.tolist()))
+            ran = gpu_ctx.get_option("last_launch_fast")
+            assert ran == 1 if used else (ran == 2 if lanes == 1 else ran == 0 if lanes == 4 else ran in (0, 2)), (trial, lanes, ran)
             k = _worst_rel(out, ref, ref_len)
             worst = max(worst, k)
             assert k * ULP <= TOL, (trial, lanes, k)
@@ -511,7 +518,7 @@ def test_time_split_fuzz_on_random_voice_tables(gpu_ctx):
                 voices.append(v if trial % 3 == 2 else W.tame_voice(v))
             gpu_ctx.set_voices(voices)
             served = all(G.fast_sharpness(v) <= G.FAST_SHARPNESS_LIMIT for v in voices)
-            assert gpu_ctx.get_option("fast_arithmetic_served") == int(served)
+            assert gpu_ctx.get_option("fast_arithmetic_served") == (1 if served else 2)
             assert served or trial % 3 == 2
             n_utt = 70
             utts = []
@@ -529,7 +536,10 @@ def test_time_split_fuzz_on_random_voice_tables(gpu_ctx):
             for chunks, span in ((2, 0), (3, int(rng.integers(20000, 70000))), (6, 0)):
                 _split(gpu_ctx, chunks, span)
                 out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
-                assert ("SPLIT" in gpu_ctx.last_kernel_name()) == served, gpu_ctx.last_kernel_name()
+                # (sharper tables: the time-split kernels of the second tier)
+                used = all(G.fast_sharpness(voices[int(i)]) <= G.FAST_SHARPNESS_LIMIT for i in set(vids.tolist()))
+                assert "SPLIT" in gpu_ctx.last_kernel_name() and ("MID" in gpu_ctx.last_kernel_name()) == (not used), \
+                    gpu_ctx.last_kernel_name()
                 assert np.array_equal(out_len, ref_len), (trial, chunks)
                 k = _worst_rel(out, ref, ref_len)
                 worst = max(worst, k)
@@ -754,9 +764,11 @@ def test_host_output_blocks_share_one_kernel_family_in_fast_mode(gpu_ctx):
         gpu_ctx.set_voices(W.single_voice())
 
 
-def test_sharp_voices_are_rendered_by_the_exact_kernels(gpu_ctx):
-    """grail_fast_sharpness above "fast_sharpness_limit": "arithmetic" = 1 changes nothing — every batch size, the
-    exact kernels, the oracle's bits; with the limit lifted the fast kernels run (and deviate as predicted)."""
+def test_sharp_voices_get_the_reference_coefficients_or_the_exact_kernels(gpu_ctx):
+    """grail_fast_sharpness above "fast_sharpness_limit": "arithmetic" = 1 is served by the second tier — the reference's
+    own band-pass coefficients at every sample, fast arithmetic elsewhere — which stays far inside the tolerance where
+    the interpolating tier does not; with "fast_exact_coefficients" = 0 by the exact kernels (the oracle's bits); with
+    the limit lifted by the interpolating kernels (which deviate as predicted)."""
     v = G.voice_generic(48000.0)
     for p in range(2):
         for i in range(8):
@@ -764,26 +776,55 @@ def test_sharp_voices_are_rendered_by_the_exact_kernels(gpu_ctx):
     assert G.fast_sharpness(v) > 2 * G.FAST_SHARPNESS_LIMIT
     gpu_ctx.set_voices([v])
     try:
-        assert gpu_ctx.get_option("fast_arithmetic_served") == 0
+        assert gpu_ctx.get_option("fast_arithmetic_served") == 2
         stride = 16384
-        for n in (3, 200):
+        k_mid = 0.0
+        for n, lanes in ((3, 1), (200, 1), (3000, 1), (200, 0)):
             segs, offs, vids, seeds = _ragged_corpus(n, n_voices=1)
             ref, ref_len = O.synthesize_batch(_ovoices([v]), segs, offs, vids, seeds, stride)
-            out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
-            assert "FAST" not in gpu_ctx.last_kernel_name()
+            out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride, lanes)
             assert np.array_equal(out_len, ref_len)
-            assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
-        st = gpu_ctx.upload(segs, offs, vids, seeds)
+            if lanes == 1:     # one lane per utterance pinned: the second tier's lane kernel
+                assert "MID" in gpu_ctx.last_kernel_name() and gpu_ctx.get_option("last_launch_fast") == 2, gpu_ctx.last_kernel_name()
+                k_mid = max(k_mid, _worst_rel(out, ref, ref_len))
+            else:              # left to the library: a batch this small is rendered faster by the exact pipelined workgroups
+                assert "PIPE" in gpu_ctx.last_kernel_name() and gpu_ctx.get_option("last_launch_fast") == 0
+                assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+        # (oracle model of the tier over 3 000 random tables: at most 16; here a sharpness of ~195, and the kernel also
+        # interpolates amplitudes and the low-pass factor: 22.5 measured)
+        assert 0.0 < k_mid <= 32.0, k_mid
+        segs, offs, vids, seeds = _ragged_corpus(200, n_voices=1)
+        ref, ref_len = O.synthesize_batch(_ovoices([v]), segs, offs, vids, seeds, stride)
+        # the second tier switched off: the exact kernels, the oracle's bits
+        gpu_ctx.set_option("fast_exact_coefficients", 0)
+        assert gpu_ctx.get_option("fast_arithmetic_served") == 0
+        out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
+        assert "FAST" not in gpu_ctx.last_kernel_name() and gpu_ctx.get_option("last_launch_fast") == 0
+        assert np.array_equal(out_len, ref_len) and np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+        gpu_ctx.set_option("fast_exact_coefficients", 1)
+        # the limit lifted: the interpolating tier, off by about what the sharpness predicts
         gpu_ctx.set_option("fast_sharpness_limit", 1000)
         assert gpu_ctx.get_option("fast_arithmetic_served") == 1
         out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
-        assert "FAST" in gpu_ctx.last_kernel_name()
+        assert "FAST" in gpu_ctx.last_kernel_name() and "MID" not in gpu_ctx.last_kernel_name()
         assert np.array_equal(out_len, ref_len)
         k = _worst(out, ref, ref_len) / max(1.0, float(np.abs(ref).max()))
-        print(f"sharpness {G.fast_sharpness(v):.0f}, limit lifted: fast vs reference {k:.1f} * 2^-23")
-        assert 0.0 < k <= 4.0 * G.fast_sharpness(v)
-        st.free()
+        print(f"sharpness {G.fast_sharpness(v):.0f}: second tier {k_mid:.1f}, interpolating tier (limit lifted) {k:.1f} * 2^-23")
+        assert k_mid < k <= 4.0 * G.fast_sharpness(v)
+        # "arithmetic" = 2 asks for the second tier whatever the voices
+        gpu_ctx.set_option("fast_sharpness_limit", int(G.FAST_SHARPNESS_LIMIT))
+        gpu_ctx.set_voices(W.single_voice())
+        gpu_ctx.set_option("arithmetic", 2)
+        gpu_ctx.set_option("lanes_per_utterance", 1)
+        segs, offs, vids, seeds = W.make_batch(64, length=0.125, blend_length=0.125)
+        out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=W.max_samples(length=0.125))
+        assert "MID" in gpu_ctx.last_kernel_name()
+        ref, ref_len = O.synthesize_batch(_ovoices(W.single_voice()), segs, offs, vids, seeds, W.max_samples(length=0.125))
+        assert np.array_equal(out_len, ref_len) and 0.0 < _worst_rel(out, ref, ref_len) <= 20.0
     finally:
+        gpu_ctx.set_option("arithmetic", 0)
+        gpu_ctx.set_option("lanes_per_utterance", 0)
+        gpu_ctx.set_option("fast_exact_coefficients", 1)
         gpu_ctx.set_option("fast_sharpness_limit", int(G.FAST_SHARPNESS_LIMIT))
         gpu_ctx.set_voices(W.single_voice())
 
@@ -904,3 +945,42 @@ def test_scan_kernel_clock_across_binade_boundaries(gpu_ctx, blend, seed):
         for x in d + dl:
             gpu_ctx.device_free(x)
         b.free()
+
+
+def test_a_sharp_voice_takes_fast_arithmetic_only_from_the_batches_that_use_it(gpu_ctx):
+    """the sharpness is judged over the voices a batch references, not over the whole table; what a launch
+    actually ran is readable afterwards ("last_launch_fast")."""
+    mild = G.voice_generic(48000.0)
+    sharp = G.voice_generic(48000.0)
+    for p in range(2):
+        for i in range(8):
+            sharp.phonemes[p].formant_bw[i] /= 6.0
+    assert G.fast_sharpness(mild) <= G.FAST_SHARPNESS_LIMIT < G.fast_sharpness(sharp)
+    gpu_ctx.set_voices([mild, sharp])
+    assert gpu_ctx.get_option("fast_arithmetic_served") == 2          # the table as a whole: the second tier
+    n_utt = 40
+    segs, offs, _, seeds = W.make_batch(n_utt, length=0.125, blend_length=0.125)
+    stride = W.max_samples(length=0.125)
+    ov = _ovoices([mild, sharp])
+    try:
+        for vids, want_fast in ((np.zeros(n_utt, dtype=np.uint32), 1), (None, 1), (np.ones(n_utt, dtype=np.uint32), 2),
+                                ((np.arange(n_utt) % 2).astype(np.uint32), 2)):
+            # (one lane per utterance pinned: left to itself the library renders a batch this small of the sharp voice
+            # with the exact kernels on a wider mapping — faster, and exact bits satisfy any tolerance)
+            out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride, lanes=1)
+            assert gpu_ctx.get_option("last_launch_fast") == want_fast, vids
+            ref, ref_len = O.synthesize_batch(ov, segs, offs, vids, seeds, stride)
+            assert np.array_equal(out_len, ref_len)
+            k = _worst_rel(out, ref, ref_len)
+            assert 0.0 < k * ULP <= TOL
+            out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
+            assert gpu_ctx.get_option("last_launch_fast") in ((1,) if want_fast == 1 else (0, 2))
+            assert np.array_equal(out_len, ref_len) and _worst_rel(out, ref, ref_len) * ULP <= TOL
+        gpu_ctx.set_option("fast_exact_coefficients", 0)              # without the second tier: the exact kernels
+        out, out_len = _render(gpu_ctx, True, segs, offs, np.ones(n_utt, dtype=np.uint32), seeds, stride)
+        assert gpu_ctx.get_option("last_launch_fast") == 0
+        ref, ref_len = O.synthesize_batch(ov, segs, offs, np.ones(n_utt, dtype=np.uint32), seeds, stride)
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+    finally:
+        gpu_ctx.set_option("fast_exact_coefficients", 1)
+        gpu_ctx.set_voices(W.single_voice())

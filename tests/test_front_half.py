@@ -206,19 +206,5 @@ def test_fused_pcm16_store_every_lane_mapping(gpu_ctx, lanes):
         batch.free()
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("chunk", [441, 1000])
-def test_cpp_interactive_example_streams_the_oracle_samples(gpu_ctx, chunk):
-    """examples/grail_interactive.cpp (grail::Stream in include/grail.hpp): each stdin line is pulled
-    a buffer at a time, as examples/interactive.rs:31-48 pulls the crate's iterator; the buffers
-    concatenate to the oracle's rendering of the same lines, bit for bit."""
-    import subprocess
-    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                       "grail-rs_amd", "lib", "grail_interactive")
-    r = subprocess.run([exe, str(chunk)], input=b"ae\n\na\n", capture_output=True, timeout=120)
-    assert r.returncode == 0, r.stderr.decode()
-    got = np.frombuffer(r.stdout, dtype="<f4")
-    want = np.concatenate([O.say(O.voice_generic(), "ae"), O.say(O.voice_generic(), "a")])
-    assert len(got) == len(want)
-    assert np.array_equal(got.view(np.uint32), want.astype("<f4").view(np.uint32))
-    assert b"buffers of %d" % chunk in r.stderr
+# (examples/grail_interactive.cpp — ONE chain per session on a live stream — is checked against the oracle in
+# tests/test_live_stream_gpu.py::test_interactive_example_is_one_chain_for_the_whole_session)

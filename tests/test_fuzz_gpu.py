@@ -259,7 +259,7 @@ def random_sequence_elems(rng, n_utt, tame):
 def test_random_sequence_elems_both_arithmetics(gpu_ctx, seed):
     """grail_synthesize_batch_elems on random caller-built elems: exact arithmetic bit for bit for every lane
     mapping; fast arithmetic within the tolerance (even seeds: tame elems, the fast kernels run; odd seeds: any,
-    and what is too sharp for them is rendered by the exact kernels)."""
+    and what is too sharp for them goes to the second tier: the reference's own filter coefficients)."""
     rng = np.random.default_rng(seed)
     tame = seed % 2 == 0
     v = G.voice_generic(48000.0)

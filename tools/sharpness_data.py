@@ -2,7 +2,8 @@
 """Data behind grail_fast_sharpness(): random one-voice tables (the fuzz tests' generator), each rendered in exact
 and in fast arithmetic (sharpness limit lifted) on a corpus of random segment lists; one line per table with the
 measured deviation (units of 2^-23 of max(1, peak)) and, per formant of both phonemes, frequency, bandwidth,
-amplitude.   usage: sharpness_data.py <n_tables> <seed> > table.jsonl"""
+amplitude.   usage: sharpness_data.py <n_tables> <seed> [arithmetic] > table.jsonl
+(arithmetic 1, the default: the interpolating tier; 2: the reference's own coefficients at every sample, MID)"""
 import json
 import os
 import sys
@@ -13,6 +14,7 @@ import numpy as np
 import grail_hip as G
 
 n_tables, seed = int(sys.argv[1]), int(sys.argv[2])
+arithmetic = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 rng = np.random.default_rng(seed)
 ctx = G.Context(0)
 ctx.set_option("fast_sharpness_limit", 1 << 30)
@@ -41,9 +43,10 @@ for t in range(n_tables):
     seeds = rng.integers(0, 2 ** 32, n_utt, dtype=np.uint64).astype(np.uint32)
     ctx.set_option("arithmetic", 0)
     ref, ref_len = ctx.synthesize(segs, offs, None, seeds, out_stride=stride)
-    ctx.set_option("arithmetic", 1)
+    ctx.set_option("arithmetic", arithmetic)
     ctx.set_option("lanes_per_utterance", 1)
     out, out_len = ctx.synthesize(segs, offs, None, seeds, out_stride=stride)
+    assert ("MID" in ctx.last_kernel_name()) == (arithmetic == 2), ctx.last_kernel_name()
     ctx.set_option("lanes_per_utterance", 0)
     assert np.array_equal(out_len, ref_len)
     scale = max(1.0, float(np.abs(ref).max()))
