@@ -249,7 +249,7 @@ def main():
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4],
                     help="BASELINE.json config: 2 = 4096 utterances, 3 = the headline (default), "
                          "4 = 8 voice presets; shorthand for --utts / --voices")
-    ap.add_argument("--mode", choices=["exact", "fast"], default="exact",
+    ap.add_argument("--mode", choices=["exact", "fast", "mid"], default="exact",
                     help="arithmetic of the timed region: exact (bit-identical to the reference, the "
                          "headline) or fast (stated tolerance, DESIGN.md §Fast mode)")
     ap.add_argument("--fast-leg", type=int, default=-1, choices=[-1, 0, 1],
@@ -439,7 +439,8 @@ def main():
     ctx.set_option("small_batch_pipeline", args.pipeline)
     if args.round32 >= 0:
         ctx.set_option("pipeline_round32", args.round32)
-    ctx.set_option("arithmetic", 1 if args.mode == "fast" else 0)
+    # ("mid": the second tolerance tier — the reference's own filter coefficients at every sample — whatever the voices)
+    ctx.set_option("arithmetic", {"exact": 0, "fast": 1, "mid": 2}[args.mode])
     d_out = ctx.device_alloc(n_utt * stride * (2 if args.pcm16 else 4))
     d_len = ctx.device_alloc(n_utt * 4)
     # first touch of the 25 GB of rows outside every measurement: a kernel that also has to fault its
@@ -487,7 +488,11 @@ def main():
     kernel_symbol = ctx.last_kernel_name()
     launch_info = {"formants_laid_out": ctx.get_option("last_launch_formants"),
                    "lanes_per_utterance_used": ctx.get_option("last_launch_lanes"),
-                   "pipelined": ctx.get_option("last_launch_pipelined")}
+                   "pipelined": ctx.get_option("last_launch_pipelined"),
+                   # what the library made of the call: kernel launches it was cut into (grail_plan_blocks), the tier that ran
+                   "launch_blocks": ctx.get_option("last_launch_blocks"), "compute_units": ctx.get_option("compute_units"),
+                   "arithmetic_ran": ("exact", "fast (coefficients interpolated)", "fast (reference coefficients)")[
+                       ctx.get_option("last_launch_fast")]}
 
     # ---- --verify: GPU-count invariance and batch invariance, on the device ----------------
     verify = None
@@ -526,7 +531,7 @@ def main():
             d_o3 = d_l3 = b3 = None
             try:
                 fast_pins = {}
-                if args.mode == "fast":
+                if args.mode in ("fast", "mid"):
                     chunks = ctx.get_option("last_launch_chunks")
                     if chunks:
                         fast_pins = {"time_split_chunks": chunks, "time_split_span_samples": stride}
@@ -639,7 +644,7 @@ def main():
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         cfg = "4" if len(voices) > 1 else ("2" if n_utt == 4096 else "3")
         wl_key = f"config{cfg}_utts{n_utt}" + ("_pcm16" if args.pcm16 else "") + \
-                 ("_fast" if args.mode == "fast" else "")
+                 ("_fast" if args.mode == "fast" else "_mid" if args.mode == "mid" else "")
         entry = committed_counters(wl_key, kernel_symbol)
         line = {
             "metric": "audio samples/sec (whole node) at 48 kHz, batch=65536 utterances",

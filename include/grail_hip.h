@@ -28,25 +28,36 @@
  * default, "arithmetic" = 0.  With grail_set_option(ctx, "arithmetic", 1) the
  * samples are within GRAIL_FAST_TOLERANCE x max(1, the utterance's largest
  * |sample|) of those bits instead (lengths, segment boundaries, noise wraps and
- * saw edges still exactly the reference's) — for voices up to the sharpness fast
- * arithmetic is served for (grail_fast_sharpness; sharper ones get the exact bits).
+ * saw edges still exactly the reference's).  Two tolerance tiers serve it, chosen from
+ * the sharpness of the resonances of the voices a batch uses (grail_fast_sharpness):
+ * up to GRAIL_FAST_SHARPNESS_LIMIT the filter coefficients are interpolated across
+ * sub-tiles (2.6x the exact mode on the headline batch); sharper voices get the
+ * reference's own band-pass coefficients at every sample and fast arithmetic for
+ * the rest (1.25x - 1.55x; at most 17.3 * 2^-23 off on 1000 random voice tables of
+ * any sharpness, profiles/r04_middle_tier.txt); beyond
+ * GRAIL_FAST_SHARPNESS_LIMIT_EXACT_COEFFICIENTS, and wherever an exact kernel is the
+ * faster way to render a block, the exact bits (they satisfy any tolerance).
  * Fast-mode samples are a pure function of (the utterance, the kernel family):
  * every lane decides from its own state, so they do not depend on the batch size,
  * the position in the batch or the other utterances of the batch AS LONG AS THE
- * KERNEL FAMILY IS THE SAME.  What still varies is the family the host picks from
- * the batch size: the time-parallel scan kernel (small batches), the time-split
- * kernels (their chunk grid follows the batch size and its longest utterance;
- * "time_split_chunks" / "time_split_span_samples" pin it) or the lane kernels
- * ("lanes_per_utterance" pins the mapping).  The host-output calls render a batch
- * in blocks of up to 4096 rows (2 GB) and choose the family for that block size,
- * the short last block included: there the "batch size" above is min(n_utt, 4096).
- * Speed: 2.3x the exact mode for the
- * headline batch (65536 utterances), 2x for 4096; for batches the fast kernels do
- * not serve faster than the exact ones the exact kernels run (their bits satisfy
- * the tolerance trivially).
+ * KERNEL FAMILY IS THE SAME.  The family is what the host picks for the BLOCK of rows
+ * an utterance is rendered in: a batch is cut into blocks by size (grail_plan_blocks
+ * predicts the cut: whole rounds of the one-lane kernels, then the rest on whatever
+ * suits its size) and each block takes the time-parallel scan kernel (few rows),
+ * the time-split kernels (their chunk grid follows the block's size and the batch's
+ * longest utterance; "time_split_chunks" / "time_split_span_samples" pin it) or the
+ * lane kernels ("lanes_per_utterance" pins the mapping; a pinned option also keeps
+ * the batch in ONE block).  The host-output calls render a batch in blocks of up to
+ * 4096 rows (2 GB) and choose the family for that block size, the short last block
+ * included: there the "batch size" is min(n_utt, 4096).
  *
  * There is no CPU fallback: every compute entry point fails with
- * GRAIL_ERR_NO_DEVICE when no gfx950-capable HIP device is usable.
+ * GRAIL_ERR_NO_DEVICE when no HIP device is usable, and grail_create() refuses a
+ * device whose architecture is not gfx950 (the library holds gfx950 code objects
+ * only).  The launch policy is derived from the device: every capacity is a multiple
+ * of hipDeviceProp_t::multiProcessorCount (256 on a whole MI355X, 32 on a CPX
+ * partition), every crossover follows the utterances' length
+ * (profiles/r04_duration_sweep.txt).
  */
 #ifndef GRAIL_HIP_H
 #define GRAIL_HIP_H
@@ -191,7 +202,7 @@ int grail_voice_get(const grail_voice *voice, int32_t phoneme, grail_synthesis_e
 
 /* ---- context ----------------------------------------------------------- */
 /* Binds to HIP device `device` (>= 0) and creates a stream.
- * GRAIL_ERR_NO_DEVICE when HIP reports no such device. */
+ * GRAIL_ERR_NO_DEVICE when HIP reports no such device or its architecture is not gfx950. */
 int grail_create(int device, grail_ctx **out);
 int grail_destroy(grail_ctx *ctx);
 int grail_device_count(int *count);
@@ -213,57 +224,76 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       inside the safe window; no segment shorter than two samples; one-shot phoneme batches),
  *       formants 5-8 are not laid out over the lanes at all.  0 forces the literal evaluation
  *       of all eight.
- *   "small_batch_pipeline": 1 (default) / 0 — batches of at most 8192 utterances that qualify
- *       for the four-formant layout run four-wave workgroups (render / per-utterance chain /
- *       2 x filter coefficients, handed on through LDS) instead of one wave per 8 utterances.
+ *   "small_batch_pipeline": 1 (default) / 0 — blocks of at most 32 utterances per compute unit (8192 on
+ *       a whole MI355X; 16 per compute unit with eight live formants) run four-wave workgroups (render /
+ *       per-utterance chain / 2 x filter coefficients, handed on through LDS) instead of one wave per 8
+ *       utterances: 4096 utterances x 2 s in 6.5 ms.
  *   "arithmetic": 0 (default) = exact, every sample bit-identical to the reference's binary32
  *       arithmetic; 1 = fast, the tolerance mode north_star allows: the discontinuous state
- *       (Sequencer clock, jitter phase, carrier phase and its wrap, both LCGs) stays exact, the
- *       per-formant arithmetic uses fused multiply-adds, one uncorrected reciprocal and filter
- *       coefficients interpolated across sub-tiles of at most 32 samples whose length an error
- *       guard picks per utterance (parameters that move too fast for two-sample sub-tiles are
- *       evaluated directly).  |fast - exact| <= GRAIL_FAST_TOLERANCE (DESIGN.md "Fast mode";
- *       tests/test_fast_gpu.py: configs 2 / 3 / 4 at full size, edge cases, random voice tables).
- *       This is the ONE knob that changes result bits.
- *   "time_parallel_scan": 1 (default) / 0 — fast arithmetic only: batches of up to
- *       "time_parallel_scan_max_utterances" (default 8704; 4/7 of that when all eight formants are
- *       live) whose every parameter is inside the safe window run one workgroup per utterance with
- *       the time axis across the lanes and the filter recurrences solved by parallel scans
- *       (csrc/scan_kernels.hip): 256 utterances x 2 s in 1.2 ms instead of 8.1 ms (exact arithmetic),
- *       4096 in 6.3 ms instead of 8.2 ms.
- *       Up to "time_parallel_scan_split_max_utterances" (default 1536; half with eight live
+ *       (Sequencer clock, jitter phase, carrier phase and its wrap, both LCGs) stays exact; the
+ *       per-formant arithmetic uses fused multiply-adds and — first tier — filter coefficients
+ *       interpolated across sub-tiles of at most 32 samples whose length an error guard picks per
+ *       utterance (parameters that move too fast for two-sample sub-tiles are evaluated directly), or —
+ *       second tier, voices sharper than "fast_sharpness_limit" — the reference's own coefficient
+ *       sequence at every sample (src/lib.rs:555-562: same bits as the exact kernels).  |fast - exact| <=
+ *       GRAIL_FAST_TOLERANCE (DESIGN.md "Fast mode"; tests/test_fast_gpu.py: configs 2 / 3 / 4 at full size,
+ *       edge cases, random voice tables of any sharpness).  2 = the second tier whatever the voices.  This is
+ *       the ONE knob that changes result bits.
+ *   "time_parallel_scan": 1 (default) / 0 — fast arithmetic, first tier: blocks of few utterances whose
+ *       every parameter is inside the safe window run one workgroup per utterance with the time axis across
+ *       the lanes and the filter recurrences solved by parallel scans (csrc/scan_kernels.hip): 256 utterances
+ *       x 2 s in 1.15 ms instead of 6.5 ms (exact arithmetic).  A cost model picks between it, the time-split
+ *       kernels and the lane kernels: ~1500 utterances of 2 s, ~6000 of 0.25 s (a time-split chunk pays a
+ *       warm-up that does not shrink with the utterance); "time_parallel_scan_max_utterances" (-1 = 34 per
+ *       compute unit = 8704; 4/7 of that when all eight formants are live) is a hard upper limit.
+ *       Up to "time_parallel_scan_split_max_utterances" (-1 = 6 per compute unit = 1536; half with eight live
  *       formants) the workgroups have three pipeline stages (the serial carrier phase on a wave of
  *       its own: lowest time per batch), above it two (more utterances resident per CU: highest
  *       throughput).  Same results either way.
- *   "time_split": 1 (default) / 0 — fast arithmetic only: batches of "time_split_min_utterances"
- *       (default 1537; 5/6 of that with eight live formants) to 32768 utterances of voices whose filters forget their past within 16384
- *       samples cut every utterance's time axis into chunks with a wavefront lane each, as many as
- *       fill the machine.  A chunk's lane fast-forwards the exact per-utterance state to its chunk,
- *       starts the filters from zero a warm-up length earlier (the voice's narrowest bandwidth
- *       decides: 3904 samples for voices::generic() at 48 kHz, residual < 2^-21 of the state) and
- *       renders its chunk: 4096 utterances x 2 s in 3.3 ms instead of 6.4 (scan kernel) / 6.5 (exact).
- *       "time_split_chunks" (0 = auto, 2..64) and "time_split_span_samples" (0 = the batch's longest
- *       utterance) pin the grid; "time_split_ff_cost_permille" (default 165) is the cost of a
- *       fast-forwarded sample against a rendered one, which the spacing of the chunks balances.
- *   "fast_sharpness_limit" (default GRAIL_FAST_SHARPNESS_LIMIT = 28): fast arithmetic is served for voice tables
- *       (and caller-built elems) whose grail_fast_sharpness() is at most this; sharper resonances amplify
+ *   "time_split": 1 (default) / 0 — fast arithmetic, both tiers: blocks of up to half as many utterances as
+ *       the device has lanes (32768), of voices whose filters forget their past within 16384 samples, cut every
+ *       utterance's time axis into chunks with a wavefront lane each, as many as fill the machine.  A chunk's
+ *       lane fast-forwards the exact per-utterance state to its chunk, starts the filters from zero a warm-up
+ *       length earlier (the voice's slowest filter decides: 3904 samples for voices::generic() at 48 kHz,
+ *       residual < 2^-21 of the state) and renders its chunk: 4096 utterances x 2 s in 3.3 ms instead of 6.5
+ *       (exact).  "time_split_min_utterances" (-1 = the cost model decides; >= 0: smaller batches stay with
+ *       the scan kernel whatever their length); "time_split_chunks" (0 = auto, 2..64) and
+ *       "time_split_span_samples" (0 = the batch's longest utterance) pin the grid;
+ *       "time_split_ff_cost_permille" (default 165) is the cost of a fast-forwarded sample against a rendered
+ *       one, which the spacing of the chunks balances.
+ *   "fast_sharpness_limit" (default GRAIL_FAST_SHARPNESS_LIMIT = 28): the first tier is served for batches whose
+ *       voices (or caller-built elems) have a grail_fast_sharpness() of at most this; sharper resonances amplify
  *       rounding-level differences of the filter coefficients beyond GRAIL_FAST_TOLERANCE (the reference's own
- *       binary32 rendering is then that far from its formulas in double precision), so those are rendered by the
- *       exact kernels.  Raising the limit trades the tolerance for speed: the deviation grows in proportion
- *       (profiles/r03_sharpness.txt).  Read-only "fast_arithmetic_served": 1 if the current voice table is below it.
+ *       binary32 rendering is then that far from its formulas in double precision).  Raising the limit trades
+ *       the tolerance for speed: the deviation grows in proportion (profiles/r03_sharpness.txt).
+ *   "fast_exact_coefficients": 1 (default) / 0 — sharper batches, up to
+ *       "fast_sharpness_limit_exact_coefficients" (default GRAIL_FAST_SHARPNESS_LIMIT_EXACT_COEFFICIENTS = 1024),
+ *       get the second tier (one lane per utterance, or time-split); 0: the exact kernels.  Streams
+ *       (grail_stream_*) of such voices always run the exact kernels.
+ *       Read-only "fast_arithmetic_served": what "arithmetic" = 1 gets for the current voice table as a whole —
+ *       1 first tier, 2 second tier, 0 exact kernels (a batch is judged by the voices IT names);
+ *       "last_launch_fast": what the last launch actually ran, same values (0 also when an exact family was the
+ *       faster way to render the block).
+ *   "composite_launches": 1 (default) / 0 — a batch is cut into blocks with a kernel family each
+ *       (grail_plan_blocks): 65537 utterances take one round of the one-lane kernel and one pipelined
+ *       workgroup (50 ms) instead of two rounds (81 ms).  0: one launch per call, whatever it costs.  Read-only
+ *       "last_launch_blocks".
+ *   "assume_compute_units": plan for so many compute units instead of what the device reports (0 = the
+ *       device's own count; read-only "compute_units" tells what is in force): tests, and callers that share a
+ *       device.
  *   "sort_by_length": 1 (default) / 0 — batches uploaded afterwards whose utterances differ in
  *       length fill the launch slots in order of decreasing length (lanes of a wave run in lockstep:
  *       a wave lasts as long as its longest utterance).  Rows stay where the caller put them.
  *   "pipeline_round32": 1 (default) / 0 — the pipelined workgroups hand their work on in rounds of 32 samples
- *       instead of 16 (131 KB of LDS) while one workgroup per CU suffices (up to 256 workgroups).
- *   "pipeline4_max_groups" (default 512), "pipeline8_max_groups" (default 512): exact arithmetic, how many
- *       four-wave pipelined workgroups (16 / 8 utterances each, four / eight live formants) a batch may
- *       need to still take them: two per CU.
+ *       instead of 16 (131 KB of LDS) while one workgroup per CU suffices.
+ *   "pipeline4_max_groups", "pipeline8_max_groups" (default -1 = two per compute unit): exact arithmetic, how
+ *       many four-wave pipelined workgroups (16 / 8 utterances each, four / eight live formants) a block may
+ *       need to still take them.
  * Read-only statistics: "slow_division_wave_steps", "fast_wave_tiles" (wave-tiles rendered in fast
  * arithmetic; scan kernel: 64-sample chain tiles on the closed forms kept from the tile before),
  * "general_wave_steps" (scan kernel: chain tiles whose closed forms were derived afresh),
  * "last_launch_formants" (4 or 8), "last_launch_lanes", "last_launch_pipelined",
- * "last_launch_chunks" (time-split: chunks per utterance, else 0). */
+ * "last_launch_chunks" (time-split: chunks per utterance, else 0) — of the largest block of the launch. */
 int grail_set_option(grail_ctx *ctx, const char *name, int64_t value);
 int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value);
 /* The planning behind "time_split", as pure host functions (no GPU, no context): what a caller needs to
@@ -283,10 +313,11 @@ uint32_t grail_time_split_warmup(const grail_voice *voice);
  * phonemes — and S = sqrt(sum_i E_i^2) (voices::generic(): 24, measured 13 - 20).  A rounding-level difference of a
  * filter coefficient (src/lib.rs:555-562) is amplified by the quality and the ring time of the band-pass, in the
  * reference's own arithmetic as well; the formula is a fit to measurements (profiles/r03_sharpness.txt).
- * Fast arithmetic is served for voice tables up to GRAIL_FAST_SHARPNESS_LIMIT; sharper tables (and caller-built
- * elems, judged the same way at upload: every two consecutive elems of an utterance like a voice of two phonemes,
- * the worst pair of the batch counts) are rendered by the exact kernels whatever "arithmetic" says — read-only
- * option "fast_arithmetic_served" tells.  +inf: a formant outside (0, 0.5) or a bandwidth <= 0. */
+ * The interpolating tier of fast arithmetic is served up to GRAIL_FAST_SHARPNESS_LIMIT; sharper voices (and
+ * caller-built elems, judged the same way at upload: every two consecutive elems of an utterance like a voice of two
+ * phonemes, the worst pair of the batch counts) get the tier that evaluates the reference's own coefficients, or the
+ * exact kernels — read-only options "fast_arithmetic_served" / "last_launch_fast" tell.  A batch is judged by the
+ * voices it names, not by the whole table.  +inf: a formant outside (0, 0.5) or a bandwidth <= 0. */
 float grail_fast_sharpness(const grail_voice *voice);
 int grail_time_split_grid(uint32_t span_samples, uint32_t warmup, uint32_t chunks, uint32_t ff_cost_permille,
                           uint32_t *bounds);

@@ -22,6 +22,7 @@ WORKLOADS = [   # key (as bench.py builds it), bench arguments
     ("config3_utts65536_fast", ["--config", "3", "--mode", "fast"]),
     ("config4_utts65536", ["--config", "4", "--mode", "exact"]),
     ("config4_utts65536_fast", ["--config", "4", "--mode", "fast"]),
+    ("config3_utts65536_mid", ["--config", "3", "--mode", "mid"]),
     ("config2_utts4096", ["--config", "2", "--mode", "exact"]),
     ("config2_utts4096_fast", ["--config", "2", "--mode", "fast"]),
     ("config3_utts65536_pcm16", ["--config", "3", "--mode", "exact", "--pcm16"]),

@@ -2,7 +2,7 @@
 # The round's evidence, collected on the GPU box: bench lines, rocprofv3 kernel stats of the default
 # bench command, PMC counters for every reported workload (tools/collect_counters.py), tool outputs.
 # usage (through gpurun): tools/profile_round.sh <tag>     -> gpurun_out/<tag>/
-tag=${1:-r03}
+tag=${1:-r04}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/$tag; mkdir -p $out
 python3 tools/collect_counters.py $out/traffic.json > $out/collect_counters.log 2>&1
@@ -19,6 +19,17 @@ cp gpurun_out/prof/stats/*/*kernel_stats.csv $out/kernel_stats.csv
 rm -rf gpurun_out/prof/stats2
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats2 -- python3 bench.py --config 2 --cpu-utts 0 > $out/stats2.log 2>&1
 cp gpurun_out/prof/stats2/*/*kernel_stats.csv $out/kernel_stats_config2.csv
+# config 4 (all eight formants live), exact (with the fast leg of the default line) and the second tolerance tier
+rm -rf gpurun_out/prof/stats4
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats4 -- python3 bench.py --config 4 --cpu-utts 0 > $out/stats4.log 2>&1
+cp gpurun_out/prof/stats4/*/*kernel_stats.csv $out/kernel_stats_config4.csv
+rm -rf gpurun_out/prof/stats5
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats5 -- python3 bench.py --mode mid --cpu-utts 0 --fast-leg 0 > $out/stats5.log 2>&1
+cp gpurun_out/prof/stats5/*/*kernel_stats.csv $out/kernel_stats_mid.csv
+python3 bench.py --mode mid --cpu-utts 0 > $out/bench_n1_mid.json 2>/dev/null
+python3 tools/tail_bench.py > $out/tail.txt 2>&1
+python3 tools/tail_bench.py --presets 65536 65537 70000 98304 131073 > $out/tail_presets.txt 2>&1
+python3 tools/mid_bench.py > $out/mid_bench.txt 2>&1
 python3 tools/small_batch_bench.py > $out/small_batch.txt 2>&1
 python3 tools/stream_latency.py 2>/dev/null | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" > $out/stream_latency.txt
 python3 tools/host_output_bench.py > $out/host_output.txt 2>&1
@@ -30,10 +41,7 @@ python3 tools/ragged_bench.py 131072 1 0 > $out/ragged_131072.txt 2>&1
     bash tools/pmc.sh sq1 "$cfg --steps 1 --warmup 0 --fast-leg 0 --ramp 0" SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY
     bash tools/pmc.sh sq2 "$cfg --steps 1 --warmup 0 --fast-leg 0 --ramp 0" SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INST_CYCLES_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS
   done ) > $out/pmc_sq.txt 2>&1
-python3 tools/fast_soak.py --shards > $out/fast_soak.txt 2>&1
-# every utterance of full-size batches against the oracle (exact mode), one size per kernel family
-( for n in 65536 16384 4096; do GRAIL_SOAK=1 GRAIL_SOAK_UTTS=$n python3 -m pytest tests/test_full_parity_soak_gpu.py -m gpu -q -s 2>&1 | grep -E "full parity|passed|failed"; done ) > $out/full_parity.txt 2>&1
-# fast mode: which voices it is served for (the sweeps behind grail_fast_sharpness) and the fuzz tests with more seeds
-python3 tools/q_sweep.py > $out/q_sweep.txt 2>&1
-bash tools/fuzz_soak.sh 24 32 12 > $out/fuzz_soak.txt 2>&1
+# every utterance of full-size batches against the oracle (exact mode), one size per kernel family — the 2 / 4 / 8-lane
+# kernels were rebuilt this round (one wave per SIMD by construction), 70 000 is a composite launch
+( for n in 70000 32768 16384 8192 4096; do GRAIL_SOAK=1 GRAIL_SOAK_UTTS=$n python3 -m pytest tests/test_full_parity_soak_gpu.py -m gpu -q -s 2>&1 | grep -E "full parity|passed|failed"; done ) > $out/full_parity.txt 2>&1
 ls -la $out
