@@ -1561,7 +1561,7 @@ int grail_plan_blocks(uint32_t compute_units, int arithmetic, int live_formants,
     *n_blocks = 0;
     if (compute_units == 0 || compute_units > 4096) return fail(GRAIL_ERR_INVALID_ARG, "compute_units must be 1 .. 4096");
     if (live_formants != 4 && live_formants != 8) return fail(GRAIL_ERR_INVALID_ARG, "live_formants must be 4 or 8");
-    if (arithmetic != 0 && arithmetic != 1) return fail(GRAIL_ERR_INVALID_ARG, "arithmetic must be 0 or 1");
+    if (arithmetic != 0 && arithmetic != 1 && arithmetic != 2) return fail(GRAIL_ERR_INVALID_ARG, "arithmetic must be 0, 1 or 2");
     if (rows == 0) return GRAIL_OK;
     // a context and a batch as choose_family sees them: default options, a voice table that qualifies for every
     // family (four or eight live formants), a plain phoneme batch with power-of-two blend lengths

@@ -1513,30 +1513,36 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             const V nfa = vfma(fa_next[k], vsplat(jp, V()), fa_cur[k] * jomp);
             ef = vfma(nff, vsplat(d_ffreq, V()), ef);
             const V mul = vfma(nfa + 1.0f, vsplat(-amp_scale, V()), one);
-            const V gg = ea * mul;
-            if constexpr (!MID) {
-                const V omx = 1.0f - ef, xph = ef + 0.5f, hmx = 0.5f - ef;
-                const V ox = omx * ef, ph = xph * hmx;
-                const V num = ox * vfma(m4, ph, five);
-                const V den = (xph * vfma(m4, ox, five)) * hmx;
-                // g = num / den (:555), k = bw / x (:558), a1 = 1 / (1 + g (g + k)) (:560): v_rcp + one
-                // Newton step each (correctly rounded reciprocals; the quotients are within an ulp)
-                V rd = vrcp(den), rx = vrcp(ef);
-                rd = vfma(vfma(-den, rd, one), rd, rd);
-                rx = vfma(vfma(-ef, rx, one), rx, rx);
-                const V tg = num * rd;
-                const V kq = eb * rx;
-                const V d3 = vfma(tg, tg + kq, one);
-                V r3 = vrcp(d3);
-                r3 = vfma(vfma(-d3, r3, one), r3, r3);
-                put(e.a1[k], FS.a1[k], r3);
-                put(e.tg[k], FS.tg[k], tg);
-            } else {
-                // (MID: a1, a2, a3 come from the reference's own sequence at every sample — nothing to interpolate)
+            if constexpr (MID) {
+                // (a1, a2, a3 come from the reference's own sequence at every sample — nothing to interpolate)
+                const V gg = ea * mul;
                 e.a1[k] = one;
                 e.tg[k] = one;
                 (void)eb; (void)five; (void)m4;
+                put(e.g[k], FS.g[k], gg);
+                put(e.h[k], FS.h[k], et * gg);
+                x.ap[k] = ea;
+                x.mu[k] = mul;
+                x.tb[k] = et;
+                continue;
             }
+            const V omx = 1.0f - ef, xph = ef + 0.5f, hmx = 0.5f - ef;
+            const V ox = omx * ef, ph = xph * hmx;
+            const V num = ox * vfma(m4, ph, five);
+            const V den = (xph * vfma(m4, ox, five)) * hmx;
+            // g = num / den (:555), k = bw / x (:558), a1 = 1 / (1 + g (g + k)) (:560): v_rcp + one
+            // Newton step each (correctly rounded reciprocals; the quotients are within an ulp)
+            V rd = vrcp(den), rx = vrcp(ef);
+            rd = vfma(vfma(-den, rd, one), rd, rd);
+            rx = vfma(vfma(-ef, rx, one), rx, rx);
+            const V tg = num * rd;
+            const V kq = eb * rx;
+            const V d3 = vfma(tg, tg + kq, one);
+            V r3 = vrcp(d3);
+            r3 = vfma(vfma(-d3, r3, one), r3, r3);
+            const V gg = ea * mul;
+            put(e.a1[k], FS.a1[k], r3);
+            put(e.tg[k], FS.tg[k], tg);
             put(e.g[k], FS.g[k], gg);
             put(e.h[k], FS.h[k], et * gg);
             x.ap[k] = ea;
@@ -1791,32 +1797,39 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     st_a[k] = vfma(oml_v, nw - st_a[k], st_a[k]);           // :538
                 }
             }
-            // MID: this sample's coefficients as the reference has them, from its own blend weights (:899-903, :242)
-            V a1x[NV], a2x[NV], a3x[NV];
             if constexpr (MID) {
+                // this sample's coefficients as the reference has them, from its own blend weights (:899-903, :242)
+                V a1x[NV], a2x[NV], a3x[NV];
                 const float al_h = vget(chain_alpha, h), jp_h = vget(chain_jp, h);
                 exact_band_pass_coeffs<NV, V>(X.freq, Y.freq, X.bw, Y.bw, ff_cur, ff_next, al_h, 1.0f - al_h, jp_h, 1.0f - jp_h,
                                               d_ffreq, a1x, a2x, a3x);
-            }
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const V g_ = vfma(FD.g[k], tiv, FS.g[k]);
+                    const V h_ = vfma(FD.h[k], tiv, FS.h[k]);
+                    const V v0 = st_a[k] * vfma(h_, nm1, g_);                   // :544-550
+                    const V v3 = v0 - st_c[k];                                  // :565
+                    const V w1 = vfma(a2x[k], v3, a1x[k] * st_b[k]);            // :566
+                    const V w2 = vfma(a3x[k], v3, vfma(a2x[k], st_b[k], st_c[k]));   // :567
+                    st_b[k] = vfma(vsplat(2.0f, V()), w1, -st_b[k]);            // :570
+                    st_c[k] = vfma(vsplat(2.0f, V()), w2, -st_c[k]);            // :571
+                    acc = k == 0 ? w1 : acc + w1;        // (tree order; the first term needs no 0 +)
+                }
+            } else {
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
+                const V a1 = vfma(FD.a1[k], tiv, FS.a1[k]);
+                const V tg = vfma(FD.tg[k], tiv, FS.tg[k]);
                 const V g_ = vfma(FD.g[k], tiv, FS.g[k]);
                 const V h_ = vfma(FD.h[k], tiv, FS.h[k]);
                 const V v0 = st_a[k] * vfma(h_, nm1, g_);                   // :544-550
                 const V v3 = v0 - st_c[k];                                  // :565
-                V w1, w2;
-                if constexpr (MID) {
-                    w1 = vfma(a2x[k], v3, a1x[k] * st_b[k]);                // :566
-                    w2 = vfma(a3x[k], v3, vfma(a2x[k], st_b[k], st_c[k]));  // :567
-                } else {
-                    const V a1 = vfma(FD.a1[k], tiv, FS.a1[k]);
-                    const V tg = vfma(FD.tg[k], tiv, FS.tg[k]);
-                    w1 = a1 * vfma(tg, v3, st_b[k]);                        // :566  a1 b + a2 v3
-                    w2 = vfma(tg, w1, st_c[k]);                             // :567  c + a2 b + a3 v3
-                }
+                const V w1 = a1 * vfma(tg, v3, st_b[k]);                    // :566  a1 b + a2 v3
+                const V w2 = vfma(tg, w1, st_c[k]);                         // :567  c + a2 b + a3 v3
                 st_b[k] = vfma(vsplat(2.0f, V()), w1, -st_b[k]);            // :570
                 st_c[k] = vfma(vsplat(2.0f, V()), w2, -st_c[k]);            // :571
                 acc = k == 0 ? w1 : acc + w1;            // (tree order; the first term needs no 0 +)
+            }
             }
             float part = vget(acc, 0);
             if constexpr (W == 2) part = part + vget(acc, 1);

@@ -331,7 +331,8 @@ int grail_time_split_grid(uint32_t span_samples, uint32_t warmup, uint32_t chunk
  * arithmetic a row's samples follow the family of ITS block, which this function predicts: rows keep batch order
  * (length-sorted batches: slot order), block i covers the next blocks[i].rows of them.
  *   compute_units: hipDeviceProp_t::multiProcessorCount (256 for a whole MI355X; option "compute_units" tells)
- *   arithmetic: 0 exact / 1 fast;  live_formants: 4 (formants 5-8 silent in every phoneme, as voices::generic()) or 8
+ *   arithmetic: 0 exact / 1 fast (voices the interpolating tier is served for) / 2 fast with the reference's own
+ *     coefficients (sharper voices);  live_formants: 4 (formants 5-8 silent in every phoneme, as voices::generic()) or 8
  *   warmup: grail_time_split_warmup() of the voice table's slowest voice (0: no time-split kernels)
  *   rows, span_samples: the batch size and its longest utterance
  * *n_blocks receives the number of blocks even when it exceeds cap. */

@@ -84,11 +84,24 @@ def test_short_utterances_move_the_scan_split_crossover_up():
     assert _one(2048, 1, span=30 * 48000)[0].chunks > 0
 
 
+def test_second_tier_takes_the_exact_kernels_where_they_are_faster():
+    """Sharp voices (arithmetic 2: the reference's own coefficients at every sample, 0.8 of the exact one-lane kernel):
+    time-split for mid-size batches, one lane per utterance for a whole machine, and the exact kernels' wider mappings
+    where those are faster — a few hundred utterances, or a voice that does not qualify for time-splitting."""
+    assert _one(65536, 2)[0].family() == "fastL1" and _one(65536, 2)[0].fast == 2
+    assert _one(16384, 2)[0].chunks == 4 and _one(16384, 2)[0].fast == 2
+    assert _one(256, 2)[0].chunks > 16 and _one(256, 2)[0].fast == 2
+    for n, fam in ((256, "pipe4r32"), (16384, "exactL4"), (32768, "exactL2")):
+        no_split = G.plan_blocks(n, SPAN, 2, 4, warmup=0)            # a voice whose filters ring too long to time-split
+        assert [(b.family(), b.fast) for b in no_split] == [(fam, 0)]
+    assert _cost(_one(65536, 2)) < _cost(_one(65536, 0)) < 1.3 * _cost(_one(65536, 2))
+
+
 def test_bad_arguments():
     with pytest.raises(G.GrailError):
         G.plan_blocks(10, SPAN, 0, 5)
     with pytest.raises(G.GrailError):
-        G.plan_blocks(10, SPAN, 2, 4)
+        G.plan_blocks(10, SPAN, 3, 4)
     with pytest.raises(G.GrailError):
         G.plan_blocks(10, SPAN, 0, 4, compute_units=0)
     assert G.plan_blocks(0, SPAN) == []
