@@ -54,7 +54,13 @@ def _drive(ctx, stream, per_utt, rng, stride, chunk_choices, finish_early=False,
                     fed[u] += k
                     offs.append(offs[-1] + k)
                 if offs[-1]:
-                    stream.append(np.concatenate(segs), offs)
+                    try:
+                        stream.append(np.concatenate(segs), offs)
+                    except G.GrailError as e:
+                        # a ring is full (nothing was appended): take it back, pull first, feed again next round
+                        assert e.status == G.ERR_BUFFER_TOO_SMALL
+                        for u in range(n_utt):
+                            fed[u] -= offs[u + 1] - offs[u]
                 if all(fed[u] == len(per_utt[u]) for u in range(n_utt)):
                     stream.finish()
                     finished = True
@@ -107,6 +113,33 @@ def test_appends_between_pulls_equal_the_one_shot_rendering(gpu_ctx, lanes):
         assert np.array_equal(got[u].view(np.uint32), ref.view(np.uint32)), u
         total += n
     assert total > 100000
+    gpu_ctx.set_voices(W.single_voice())
+
+
+@pytest.mark.parametrize("lanes,ring", [(1, 4), (2, 8), (8, 4)])
+def test_rings_wrap_around_many_times(gpu_ctx, lanes, ring):
+    """Scripts of up to 60 segments through rings of 4 / 8: every slot is reused many times, appends that do not fit are
+    refused whole (GRAIL_ERR_BUFFER_TOO_SMALL) and repeated after a pull."""
+    voices = W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    gpu_ctx.set_option("lanes_per_utterance", lanes)
+    rng = np.random.default_rng(900 + lanes)
+    n_utt = 21
+    per_utt = _script(rng, n_utt, 8, max_segs=60)
+    vids = (np.arange(n_utt) % 8).astype(np.uint32)
+    seeds = (np.arange(n_utt) * 7919 + 1).astype(np.uint32)
+    st = G.LiveStream(gpu_ctx, n_utt, vids, seeds, ring_segments=ring)
+    try:
+        got = _drive(gpu_ctx, st, per_utt, rng, 2048, [64, 500, 2048])
+    finally:
+        st.close()
+        gpu_ctx.set_option("lanes_per_utterance", 0)
+    ov = _ovoices(voices)
+    assert max(len(p) for p in per_utt) > 6 * ring
+    for u in range(n_utt):
+        ref, n = O.synthesize_phonemes(ov[vids[u]], per_utt[u], int(seeds[u]))
+        assert len(got[u]) == n, (u, len(got[u]), n)
+        assert np.array_equal(got[u].view(np.uint32), ref.view(np.uint32)), u
     gpu_ctx.set_voices(W.single_voice())
 
 
@@ -182,7 +215,7 @@ def test_live_stream_of_caller_built_elems(gpu_ctx, lanes):
     g_per, o_per = [], []
     for u in range(n_utt):
         gs, os_ = [], []
-        for i in range(int(rng.integers(2, 8))):
+        for i in range(int(rng.integers(2, 20))):
             mask = [lo, all8, None][int(rng.integers(0, 3))]
             has = mask is not None
             e = _elem(rng, mask if has else all8)
@@ -195,7 +228,7 @@ def test_live_stream_of_caller_built_elems(gpu_ctx, lanes):
     gpu_ctx.set_voices([v])
     gpu_ctx.set_option("lanes_per_utterance", lanes)
     seeds = (np.arange(n_utt) * 17 + 3).astype(np.uint32)
-    st = G.LiveStream(gpu_ctx, n_utt, None, seeds, ring_segments=8, elems=True)
+    st = G.LiveStream(gpu_ctx, n_utt, None, seeds, ring_segments=4, elems=True)      # (up to 19 segments: the rings wrap)
     d_out = gpu_ctx.device_alloc(n_utt * 1024 * 4)
     d_len = gpu_ctx.device_alloc(n_utt * 4)
     rows = [[] for _ in range(n_utt)]
@@ -211,7 +244,12 @@ def test_live_stream_of_caller_built_elems(gpu_ctx, lanes):
                     fed[u] += k
                     offs.append(len(segs))
                 if segs:
-                    st.append(segs, offs)
+                    try:
+                        st.append(segs, offs)
+                    except G.GrailError as e:        # a ring is full: nothing was appended, feed again after a pull
+                        assert e.status == G.ERR_BUFFER_TOO_SMALL
+                        for u in range(n_utt):
+                            fed[u] -= offs[u + 1] - offs[u]
                 if all(fed[u] == len(g_per[u]) for u in range(n_utt)):
                     st.finish()
                     finished = True
