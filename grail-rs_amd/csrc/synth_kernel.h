@@ -500,12 +500,13 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     // ---- Sequencer state: IntoSequencer::sequence, src/lib.rs:941-949
     // live streams (STREAM kernels only): the utterance's segments sit in a ring and more may be appended between
     // launches; seg_pos then counts the segments pulled so far and seg_end those appended so far
-    const bool ring = STREAM && A.ring_cap != 0u;
-    const uint32_t ring_base = ring ? uc * A.ring_cap : 0u;
-    const uint32_t ring_mask = ring ? A.ring_cap - 1u : 0xFFFFFFFFu;
-    const bool open_ended = ring && A.seg_open[uc] != 0u;
-    uint32_t seg_pos = ring ? 0u : A.seg_offsets[uc];
-    const uint32_t seg_end = ring ? A.seg_counts[uc] : A.seg_offsets[uc + 1];
+    // Only the general resumable instantiations (ANYBL: what a live stream always runs — nothing is known about the
+    // segments to come) carry the ring code: the lean ones stay what they were (a few instructions more in the general
+    // step moved the code of the calm loops and cost the lean one-lane stream kernel 9 %, same instruction counts).
+    // Everything else about the ring is worked out where a segment is pulled — a rare path.
+    constexpr bool LIVE = STREAM && ANYBL;
+    uint32_t seg_pos = (LIVE && A.ring_cap != 0u) ? 0u : A.seg_offsets[uc];
+    const uint32_t seg_end = (LIVE && A.ring_cap != 0u) ? A.seg_counts[uc] : A.seg_offsets[uc + 1];
     Seg cur, nxt;
     cur.some = false; cur.elem = -1; cur.length = 0.0f; cur.blend_length = 1.0f; cur.frequency = 0.0f;
     nxt = cur;
@@ -713,19 +714,23 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         }
 
         // ================= Sequencer::next, src/lib.rs:859-932
-        if constexpr (STREAM) {
+        if constexpr (LIVE) {
             // a live stream whose source has not delivered yet: this step would pull iter.next() (:870, :877-878) and
             // the segment is not in the ring — wait for it (nothing has been touched: the step is taken again, from
             // the same state, by the launch that follows the append).  The source ends only when the host says so.
-            if (open_ended && (clk - dt) < 0.0f) {
+            if (A.ring_cap != 0u && (clk - dt) < 0.0f) {
                 const uint32_t want = (cur.some && nxt.some) ? 1u : (!cur.some && !nxt.some) ? 2u : 0u;
-                if (seg_end - seg_pos < want) {
+                if (seg_end - seg_pos < want && A.seg_open[uc] != 0u) {
                     done = true;
                     paused = true;
                     return;
                 }
             }
         }
+        // where segment `pos` of this utterance sits: in its ring (live streams), or at segs[pos]
+        const bool ring = LIVE && A.ring_cap != 0u;
+        const uint32_t ring_base = ring ? uc * A.ring_cap : 0u;
+        const uint32_t ring_mask = ring ? A.ring_cap - 1u : 0xFFFFFFFFu;
         clk -= dt;                                            // :861
         if (__builtin_expect(clk < 0.0f, 0)) {                // :864
             if (cur.some && nxt.some) {                       // :868
@@ -2475,7 +2480,8 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     if (streaming && A.state && slot_used) {
         StateIO<false> io{A.state, A.state_stride, state_lane};
         visit_state(io);
-        if (ring && j == L - 1 && A.seg_consumed) A.seg_consumed[u] = seg_pos;
+        if constexpr (LIVE)
+            if (A.ring_cap != 0u && j == L - 1 && A.seg_consumed) A.seg_consumed[u] = seg_pos;
     }
     if (emit && lane == 0 && slow_steps) atomicAdd(A.truncated + 1, slow_steps);
     if (emit && lane == 0 && fast_tiles) atomicAdd(A.truncated + 2, fast_tiles);
