@@ -162,6 +162,7 @@ struct grail_ctx {
     int pipeline_option = 1;          // small qualifying batches: producer/consumer workgroups
     int pipe_round32 = 1;             // ... with rounds of 32 samples while one workgroup per CU suffices (8.20 -> 7.86 ms for config 2)
     uint64_t voices_epoch = 0;        // bumped by every install_voices
+    uint64_t options_epoch = 0;       // bumped by every grail_set_option (a batch caches its launch plan against both)
     int fast_option = 0;              // "arithmetic": 0 exact (bit-identical), 1 fast (stated tolerance: the tier the voices'
                                       // sharpness allows), 2 fast with the reference's own coefficients (MID) whatever the voices
     std::string last_kernel = "none"; // instantiation of the last synthesis launch
@@ -190,6 +191,11 @@ struct grail_stream {
     std::vector<uint8_t> open;        // host copy of d_open
     std::vector<grail_synthesis_elem> last_elem;   // elem mode: the last elem appended per utterance (sharpness of the next pair)
     std::vector<uint8_t> last_has;
+    // staging of an append (kept: an interactive front end appends a phoneme every half second for hours)
+    DevSeg *d_new = nullptr;
+    float *d_new_elems = nullptr;
+    uint32_t *d_new_offs = nullptr;
+    size_t new_cap = 0;
 };
 
 struct grail_batch {
@@ -210,6 +216,9 @@ struct grail_batch {
     float min_pitch = 0.0f;    // lowest frequency.min(0.5) of any segment (plain batches)
     double elems_sharpness = 0.0;   // elem mode: predicted fast-mode deviation of the caller's elems (elems_sharpness())
     std::vector<uint32_t> used_voices;   // the distinct voice ids of the batch, ascending
+    // the launch plan of the last synthesis call of this batch (plan_blocks lays out time-split grids by bisection: a
+    // fraction of a millisecond of host time, which a one-millisecond kernel should not pay at every launch)
+    mutable struct PlanCache *plan_cache = nullptr;
 };
 
 // the SIMDs and lanes the policy plans for: 4 SIMDs per compute unit, 64 lanes per wavefront.  Every family is laid out
@@ -242,8 +251,12 @@ int upload(Tp **dst, const void *src, size_t count, hipStream_t stream)
     return GRAIL_OK;
 }
 
+void free_plan_cache(struct PlanCache *p);
+
 void free_batch_buffers(grail_batch *b)
 {
+    free_plan_cache(b->plan_cache);
+    b->plan_cache = nullptr;
     if (b->d_segs) (void)hipFree(b->d_segs);
     if (b->d_offsets) (void)hipFree(b->d_offsets);
     if (b->d_voice_ids) (void)hipFree(b->d_voice_ids);
@@ -750,6 +763,7 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
 int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
 {
     if (!ctx || !name) return fail(GRAIL_ERR_INVALID_ARG, "NULL argument");
+    ++ctx->options_epoch;
     if (std::strcmp(name, "lanes_per_utterance") == 0) {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
             return fail(GRAIL_ERR_INVALID_ARG, "lanes_per_utterance must be 0, 1, 2, 4 or 8");
@@ -1299,7 +1313,17 @@ static void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64
         // (a fast-forwarded sample costs the same whatever is rendered afterwards; a rendered sample of eight live
         // formants costs 1.5 x one of four; 0.8 from a sweep, profiles/r03_small_batch.txt)
         const double ff_cost = 1e-3 * (double)ctx->split_ff_permille * (l4ab ? 1.0 : 0.8) * (f.fast == 2u ? 0.6 : 1.0);
-        while (K >= 2 && !split_grid((uint32_t)sp, ctx->max_warmup, K, ff_cost, split.split_bounds)) --K;
+        // the largest K <= K whose chunks fit (a chunk must render at least a tile): fitting is monotone in K
+        if (K >= 2 && !split_grid((uint32_t)sp, ctx->max_warmup, K, ff_cost, split.split_bounds)) {
+            int lo = 1, hi = K;                  // lo fits (or is 1), hi does not
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) / 2;
+                if (split_grid((uint32_t)sp, ctx->max_warmup, mid, ff_cost, split.split_bounds)) lo = mid;
+                else hi = mid;
+            }
+            K = lo;
+            if (K >= 2) (void)split_grid((uint32_t)sp, ctx->max_warmup, K, ff_cost, split.split_bounds);
+        }
         if (K >= 2) {
             split.split_k = K;
             split.split_bounds[K] = (uint32_t)out_stride;
@@ -1497,6 +1521,14 @@ static double plan_blocks(const grail_ctx *ctx, const grail_batch *batch, uint64
     return best.first;
 }
 
+struct PlanCache {
+    uint64_t key[6];
+    std::vector<Block> plan;
+};
+namespace {
+void free_plan_cache(PlanCache *p) { delete p; }
+}
+
 // Rows [first, first + count) of the batch (count = 0: all of it).  out_dev / out_len_dev point at the
 // first row RENDERED, i.e. the caller has already applied the row offset to them.
 // family_rows: the number of rows the kernel family is chosen for (0 = count).  A caller that renders a batch in
@@ -1518,14 +1550,25 @@ static int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_
     // the length-sorted slot assignment covers the whole batch: row-block launches keep launch order
     const bool use_perm = first == 0 && count == batch->n_utt && batch->d_perm;
     std::vector<Block> plan;
-    // one launch when the caller fixes the family (row blocks, a pinned lane mapping or chunk grid) or asks for it
-    const bool single = family_rows != 0 || !ctx->composite_option || ctx->lanes_option || ctx->split_chunks >= 2;
-    if (single) {
-        Family f;
-        choose_family(ctx, batch, out_stride, family_rows > count ? family_rows : count, f);
-        plan.push_back(Block{count, f});
+    const uint64_t key[6] = {count, out_stride, family_rows, ctx->options_epoch, ctx->voices_epoch,
+                             (uint64_t)(uintptr_t)ctx ^ (batch->phoneme_mode ? 0ull : (uint64_t)(batch->elems_sharpness * 1024.0))};
+    if (batch->plan_cache && std::memcmp(batch->plan_cache->key, key, sizeof key) == 0) {
+        plan = batch->plan_cache->plan;
     } else {
-        plan_blocks(ctx, batch, out_stride, count, batch_span(ctx, batch, out_stride), plan);
+        // one launch when the caller fixes the family (row blocks, a pinned lane mapping or chunk grid) or asks for it
+        const bool single = family_rows != 0 || !ctx->composite_option || ctx->lanes_option || ctx->split_chunks >= 2;
+        if (single) {
+            Family f;
+            choose_family(ctx, batch, out_stride, family_rows > count ? family_rows : count, f);
+            plan.push_back(Block{count, f});
+        } else {
+            plan_blocks(ctx, batch, out_stride, count, batch_span(ctx, batch, out_stride), plan);
+        }
+        if (!batch->plan_cache) batch->plan_cache = new (std::nothrow) PlanCache();
+        if (batch->plan_cache) {
+            std::memcpy(batch->plan_cache->key, key, sizeof key);
+            batch->plan_cache->plan = plan;
+        }
     }
     size_t main_block = 0;                     // the block with the most rows: the one the statistics describe
     for (size_t i = 1; i < plan.size(); ++i)
@@ -1721,6 +1764,9 @@ int grail_stream_close(grail_ctx *ctx, grail_stream *stream)
     if (stream->d_counts) (void)hipFree(stream->d_counts);
     if (stream->d_open) (void)hipFree(stream->d_open);
     if (stream->d_consumed) (void)hipFree(stream->d_consumed);
+    if (stream->d_new) (void)hipFree(stream->d_new);
+    if (stream->d_new_elems) (void)hipFree(stream->d_new_elems);
+    if (stream->d_new_offs) (void)hipFree(stream->d_new_offs);
     if (stream->own) {
         free_batch_buffers(stream->own);
         delete stream->own;
@@ -1839,23 +1885,30 @@ static int live_append(grail_ctx *ctx, grail_stream *s, const std::vector<DevSeg
     for (uint32_t u = 0; u < n_utt; ++u)
         if (seg_offsets[u + 1] > seg_offsets[u] && !s->open[u])
             return fail(GRAIL_ERR_INVALID_ARG, "an utterance of the live stream has been finished: nothing can be appended to it");
-    DevSeg *d_new = nullptr;
-    float *d_new_elems = nullptr;
-    uint32_t *d_offs = nullptr;
-    hipError_t e = hipMalloc((void **)&d_new, (size_t)n_new * sizeof(DevSeg));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_offs, ((size_t)n_utt + 1) * 4);
-    if (e == hipSuccess && elems) e = hipMalloc((void **)&d_new_elems, (size_t)n_new * ELEM_FLOATS * sizeof(float));
-    if (e == hipSuccess) e = hipMemcpyAsync(d_new, segs.data(), (size_t)n_new * sizeof(DevSeg), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_offs, seg_offsets, ((size_t)n_utt + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = hipSuccess;
+    if (s->new_cap < n_new || (elems && !s->d_new_elems)) {
+        const size_t cap_new = std::max<size_t>(std::max<size_t>(n_new, 2 * s->new_cap), 64);
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (s->d_new) (void)hipFree(s->d_new);
+        if (s->d_new_elems) (void)hipFree(s->d_new_elems);
+        s->d_new = nullptr;
+        s->d_new_elems = nullptr;
+        s->new_cap = 0;
+        e = hipMalloc((void **)&s->d_new, cap_new * sizeof(DevSeg));
+        if (e == hipSuccess && elems) e = hipMalloc((void **)&s->d_new_elems, cap_new * ELEM_FLOATS * sizeof(float));
+        if (e == hipSuccess && !s->d_new_offs) e = hipMalloc((void **)&s->d_new_offs, ((size_t)n_utt + 1) * 4);
+        if (e != hipSuccess) return hip_fail(e, "grail_stream_append staging");
+        s->new_cap = cap_new;
+    }
+    e = hipMemcpyAsync(s->d_new, segs.data(), (size_t)n_new * sizeof(DevSeg), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->d_new_offs, seg_offsets, ((size_t)n_utt + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && elems)
-        e = hipMemcpyAsync(d_new_elems, elems, (size_t)n_new * ELEM_FLOATS * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+        e = hipMemcpyAsync(s->d_new_elems, elems, (size_t)n_new * ELEM_FLOATS * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     // (stream order: behind every kernel that still reads the rings, ahead of every kernel that will)
     if (e == hipSuccess)
-        e = launch_ring_append(s->own->d_segs, s->own->d_elems, s->d_counts, cap, d_new, d_new_elems, d_offs, n_utt, ctx->stream);
+        e = launch_ring_append(s->own->d_segs, s->own->d_elems, s->d_counts, cap, s->d_new, elems ? s->d_new_elems : nullptr,
+                               s->d_new_offs, n_utt, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);      // the host buffers are the caller's / locals
-    if (d_new) (void)hipFree(d_new);
-    if (d_offs) (void)hipFree(d_offs);
-    if (d_new_elems) (void)hipFree(d_new_elems);
     if (e != hipSuccess) return hip_fail(e, "grail_stream_append");
     for (uint32_t u = 0; u < n_utt; ++u) s->appended[u] += seg_offsets[u + 1] - seg_offsets[u];
     return GRAIL_OK;
