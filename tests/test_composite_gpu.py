@@ -253,3 +253,44 @@ def test_create_reports_the_device_and_refuses_nothing_on_gfx950(gpu_ctx):
     cus = gpu_ctx.get_option("compute_units")
     assert cus in (32, 64, 128, 256) or cus > 0
     assert gpu_ctx.get_option("assume_compute_units") == 0
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_composite_fuzz_over_machine_sizes_batch_sizes_and_arithmetics(gpu_ctx, small_machine, seed):
+    """Random compute-unit counts (powers of two or not: every capacity is a multiple of the count), random batch sizes
+    around the families' capacities, aligned or ragged, one voice or eight: exact arithmetic bit for bit, fast
+    arithmetic within the tolerance, lengths always the oracle's; the cut is the one grail_plan_blocks predicts."""
+    rng = np.random.default_rng(7000 + seed)
+    cus = int(rng.choice([1, 2, 3, 5, 6]))
+    lanes = 256 * cus
+    n_utt = int(rng.choice([lanes + 1, lanes + int(rng.integers(2, 40)), lanes // 2 + int(rng.integers(1, 30)),
+                            lanes + lanes // 4 + 3, 2 * lanes + int(rng.integers(1, 20)), int(rng.integers(5, 3 * lanes))]))
+    n_voices = int(rng.choice([1, 8]))
+    voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    small_machine(cus)
+    if rng.random() < 0.5:
+        segs, offs, vids, seeds = _ragged(n_utt, n_voices, seed=seed)
+        stride = 12288
+    else:
+        segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=n_voices, length=0.04, blend_length=2.0 ** -5)
+        stride = W.max_samples(length=0.04)
+    ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, stride)
+    out, lens, status = _device_render(gpu_ctx, segs, offs, vids, seeds, stride)
+    blocks = gpu_ctx.get_option("last_launch_blocks")
+    assert status == G.OK
+    _bit_identical(out, lens, ref, ref_len, f"cus={cus} n={n_utt} voices={n_voices} blocks={blocks}")
+    gpu_ctx.set_option("arithmetic", 1)
+    fast, flens, status = _device_render(gpu_ctx, segs, offs, vids, seeds, stride)
+    fblocks = gpu_ctx.get_option("last_launch_blocks")
+    assert status == G.OK and np.array_equal(flens, ref_len)
+    worst = 0.0
+    for u in range(n_utt):
+        m = int(flens[u])
+        if m:
+            d = float(np.max(np.abs(fast[u, :m].astype(np.float64) - ref[u, :m].astype(np.float64))))
+            worst = max(worst, d / max(1.0, float(np.max(np.abs(ref[u, :m])))))
+    print(f"composite fuzz seed {seed}: cus={cus} n={n_utt} voices={n_voices}: {blocks} exact / {fblocks} fast launches, "
+          f"fast {worst / ULP:.1f} * 2^-23")
+    assert worst <= G.FAST_TOLERANCE
+    assert max(blocks, fblocks) >= 2 or n_utt <= lanes
