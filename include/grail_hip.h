@@ -50,6 +50,11 @@
  * the batch in ONE block).  The host-output calls render a batch in blocks of up to
  * 4096 rows (2 GB) and choose the family for that block size, the short last block
  * included: there the "batch size" is min(n_utt, 4096).
+ * A caller that needs the reference's contract in fast mode too — an utterance's
+ * samples a pure function of (segments, voice, seed), whatever batch it is part of —
+ * pins ONE family: "lanes_per_utterance" = 1 renders every batch size with the fast
+ * one-lane kernels (batch-invariant by construction; it gives up the time-split and
+ * scan kernels' speed on batches that do not fill the machine).
  *
  * There is no CPU fallback: every compute entry point fails with
  * GRAIL_ERR_NO_DEVICE when no HIP device is usable, and grail_create() refuses a

@@ -984,3 +984,34 @@ def test_a_sharp_voice_takes_fast_arithmetic_only_from_the_batches_that_use_it(g
     finally:
         gpu_ctx.set_option("fast_exact_coefficients", 1)
         gpu_ctx.set_voices(W.single_voice())
+
+
+def test_one_pinned_family_makes_fast_mode_a_function_of_the_utterance_alone(gpu_ctx):
+    """include/grail_hip.h, determinism contract: with "lanes_per_utterance" = 1 an utterance's fast-mode samples do
+    not depend on the batch it is rendered in — a batch of 3, of 700 (scan / time-split territory when left to the
+    library), a composite-sized one on a small machine, any position."""
+    voices = W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    stride = 16384
+    segs, offs, vids, seeds = _ragged_corpus(1500)
+    try:
+        gpu_ctx.set_option("assume_compute_units", 4)            # 1 500 utterances > 1 024 lanes: several rounds
+        big, big_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride, lanes=1)
+        assert "FAST" in gpu_ctx.last_kernel_name() and gpu_ctx.get_option("last_launch_blocks") == 1
+        gpu_ctx.set_option("assume_compute_units", 0)
+        for first, n in ((0, 3), (100, 700), (1499, 1), (640, 64)):
+            lo, hi = int(offs[first]), int(offs[first + n])
+            sub_offs = (offs[first:first + n + 1] - offs[first]).astype(np.uint32)
+            part, part_len = _render(gpu_ctx, True, segs[lo:hi], sub_offs, vids[first:first + n], seeds[first:first + n], stride, lanes=1)
+            assert np.array_equal(part_len, big_len[first:first + n])
+            for r in range(n):
+                m = int(part_len[r])
+                assert np.array_equal(part[r, :m].view(np.uint32), big[first + r, :m].view(np.uint32)), (first, r)
+        # ... whereas left to itself the library renders the small batch with another family: same tolerance, other bits
+        lo, hi = int(offs[100]), int(offs[800])
+        auto, _ = _render(gpu_ctx, True, segs[lo:hi], (offs[100:801] - offs[100]).astype(np.uint32), vids[100:800], seeds[100:800], stride)
+        assert "FAST" in gpu_ctx.last_kernel_name()
+        assert not np.array_equal(auto[:, :2000].view(np.uint32), big[100:800, :2000].view(np.uint32))
+    finally:
+        gpu_ctx.set_option("assume_compute_units", 0)
+        gpu_ctx.set_voices(W.single_voice())
