@@ -157,6 +157,7 @@ struct grail_ctx {
     uint32_t *d_truncated = nullptr;  // [0] truncation flag, [1] slow-path wave-steps, [2] fast wave-tiles, [3] general wave-steps
     uint64_t slow_steps = 0;          // of the kernels synced so far
     uint64_t fast_tiles = 0, general_steps = 0;
+    uint32_t seen_counters[4] = {0, 0, 0, 0};   // d_truncated[1..3] as last read: the device counters only ever grow
     int lanes_option = 0;             // 0 = auto
     int skip_silent_option = 1;       // skip band-pass filters of provably silent formants
     int pipeline_option = 1;          // small qualifying batches: producer/consumer workgroups
@@ -2022,13 +2023,16 @@ int grail_sync(grail_ctx *ctx)
     HIP_TRY(hipMemcpyAsync(flags, ctx->d_truncated, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const uint32_t flag = flags[0];
-    ctx->fast_tiles += flags[2];
-    ctx->general_steps += flags[3];
-    if (flags[0] || flags[1] || flags[2] || flags[3]) {
-        HIP_TRY(hipMemsetAsync(ctx->d_truncated, 0, sizeof flags, ctx->stream));
+    // the statistics counters are cumulative on the device (u32, wrapping): the host takes differences, so the usual
+    // call costs one copy and one synchronisation; only a truncation flag has to be cleared
+    ctx->slow_steps += (uint32_t)(flags[1] - ctx->seen_counters[1]);
+    ctx->fast_tiles += (uint32_t)(flags[2] - ctx->seen_counters[2]);
+    ctx->general_steps += (uint32_t)(flags[3] - ctx->seen_counters[3]);
+    for (int i = 1; i < 4; ++i) ctx->seen_counters[i] = flags[i];
+    if (flag) {
+        HIP_TRY(hipMemsetAsync(ctx->d_truncated, 0, sizeof(uint32_t), ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
-    ctx->slow_steps += flags[1];
     if (flag) {
         return fail(GRAIL_ERR_BUFFER_TOO_SMALL,
                     "at least one utterance did not end within out_stride samples");
