@@ -1268,6 +1268,7 @@ static void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64
     // (the fast lane kernels have four-formant instantiations for every blend length)
     if (f.fast && batch_live4_any_blend(ctx, batch)) f.live4 = 1u;
     int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(fam, simds);
+    if (f.fast == 2u) L = 1;          // (before the four-formant layout is decided: eight lanes would give it up)
     // small batches leave SIMDs idle: four-wave workgroups (one wave renders 16 utterances, one carries
     // the per-utterance chain, two prepare the filter coefficients), up to two per CU (tools/pipe4_range.py:
     // 11.5 ms up to 4 096 utterances, 15.7 up to 8 192 where the lane kernels take 18.0; three per CU lose)
@@ -1296,7 +1297,6 @@ static void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64
     // kernels: one lane per utterance runs the half-live loop and ties two lanes per utterance,
     // whose second lane would only hold silent formants
     if (!ctx->lanes_option && !f.live4 && L == 2 && batch_half_capable(ctx, batch)) L = 1;
-    if (f.fast == 2u) L = 1;
     f.L = L;
     if (!f.fast) return;
 
