@@ -1726,7 +1726,9 @@ static int stream_next(grail_ctx *ctx, grail_stream *stream, uint32_t max_sample
     a.any_blend = stream->any_blend ? 1u : 0u;
     a.live4 = stream->live4 ? 1u : 0u;
     // (may change between calls: both flavours share the state layout)
-    a.fast = fast_tier(ctx, batch) == 1 ? 1u : 0u;      // (no resumable MID kernels: sharper voices stream exactly)
+    // (sharper voices: the second tier has one-lane kernels only — streams on a wider mapping run the exact kernels)
+    const int tier = fast_tier(ctx, batch);
+    a.fast = tier == 1 ? 1u : (tier == 2 && stream->L == 1) ? 2u : 0u;
     a.state = stream->d_state;
     a.state_stride = stream->lanes;
     a.resume = stream->started ? 1u : 0u;
@@ -1737,6 +1739,8 @@ static int stream_next(grail_ctx *ctx, grail_stream *stream, uint32_t max_sample
     ctx->last_formants = a.live4 ? 4 : 8;
     ctx->last_lanes = stream->L;
     ctx->last_pipe = 0;
+    ctx->last_fast = (int)a.fast;
+    ctx->last_blocks = 1;
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->have_timing = true;
     stream->started = true;

@@ -103,7 +103,7 @@ hipError_t launch_synth(const SynthArgs &args, int L, hipStream_t stream)
         else launch_split(args, stream);
         return hipGetLastError();
     }
-    if (args.fast == 2u && (L != 1 || args.state)) return hipErrorInvalidValue;   // MID: one-shot, one lane per utterance
+    if (args.fast == 2u && L != 1) return hipErrorInvalidValue;   // MID: one lane per utterance
     switch (L) {
     case 1: args.fast == 2u ? launch_mid_l1(args, stream) : args.fast ? launch_fast_l1(args, stream) : launch_exact_l1(args, stream); break;
     case 2: args.fast ? launch_fast_l2(args, stream) : launch_exact_l2(args, stream); break;

@@ -274,7 +274,8 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *   "fast_exact_coefficients": 1 (default) / 0 — sharper batches, up to
  *       "fast_sharpness_limit_exact_coefficients" (default GRAIL_FAST_SHARPNESS_LIMIT_EXACT_COEFFICIENTS = 1024),
  *       get the second tier (one lane per utterance, or time-split); 0: the exact kernels.  Streams
- *       (grail_stream_*) of such voices always run the exact kernels.
+ *       (grail_stream_*) of such voices run it when they are laid out one lane per utterance (half a machine's
+ *       worth of streams, or "lanes_per_utterance" = 1 when the stream is opened), the exact kernels otherwise.
  *       Read-only "fast_arithmetic_served": what "arithmetic" = 1 gets for the current voice table as a whole —
  *       1 first tier, 2 second tier, 0 exact kernels (a batch is judged by the voices IT names);
  *       "last_launch_fast": what the last launch actually ran, same values (0 also when an exact family was the

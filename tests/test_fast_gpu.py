@@ -461,6 +461,56 @@ def test_fast_mode_streams(gpu_ctx, lanes):
     assert 0.0 < k * ULP <= TOL
 
 
+@pytest.mark.parametrize("sharpen,lanes,want", [(6.0, 1, 2), (6.0, 4, 0), (1.0, 1, 1)])
+def test_streams_of_sharp_voices_run_the_second_tier_on_one_lane_per_utterance(gpu_ctx, sharpen, lanes, want):
+    """Resumable kernels of the second tolerance tier (the reference's own coefficients): streams of a voice sharper than
+    the interpolating tier allows, laid out one lane per utterance; on a wider mapping the exact kernels; a mild voice
+    the interpolating tier.  Chunks concatenate to the oracle's lengths, samples within the tolerance (exact: its bits)."""
+    v = G.voice_generic(48000.0)
+    for p in range(2):
+        for i in range(8):
+            v.phonemes[p].formant_bw[i] /= sharpen
+    gpu_ctx.set_voices([v])
+    n_utt = 40
+    segs, offs, vids, seeds = W.make_batch(n_utt, length=0.06, blend_length=0.0625)
+    total = W.max_samples(length=0.06)
+    ref, ref_len = O.synthesize_batch(_ovoices([v]), segs, offs, vids, seeds, total)
+    gpu_ctx.set_option("lanes_per_utterance", lanes)
+    gpu_ctx.set_option("arithmetic", 1)
+    batch = gpu_ctx.upload(segs, offs, vids, seeds)
+    d_out = gpu_ctx.device_alloc(n_utt * 1024 * 4)
+    d_len = gpu_ctx.device_alloc(n_utt * 4)
+    got = np.zeros((n_utt, total), dtype=np.float32)
+    pos = np.zeros(n_utt, dtype=np.int64)
+    try:
+        st = G.Stream(batch)
+        for chunk in [96, 33, 1000, 7, 512] * 20:
+            st.next_async(chunk, d_out, 1024, d_len)
+            gpu_ctx.sync()
+            assert gpu_ctx.get_option("last_launch_fast") == want and ("MID" in gpu_ctx.last_kernel_name()) == (want == 2)
+            lens = np.zeros(n_utt, dtype=np.uint32)
+            gpu_ctx.d2h(lens, d_len, n_utt * 4)
+            buf = np.zeros((n_utt, 1024), dtype=np.float32)
+            gpu_ctx.d2h(buf, d_out, buf.nbytes)
+            for u in range(n_utt):
+                got[u, pos[u]:pos[u] + lens[u]] = buf[u, :lens[u]]
+            pos += lens
+            if not lens.any():
+                break
+        st.close()
+    finally:
+        gpu_ctx.set_option("arithmetic", 0)
+        gpu_ctx.set_option("lanes_per_utterance", 0)
+        gpu_ctx.device_free(d_out)
+        gpu_ctx.device_free(d_len)
+        batch.free()
+        gpu_ctx.set_voices(W.single_voice())
+    assert np.array_equal(pos.astype(np.uint32), ref_len)
+    k = _worst_rel(got, ref, ref_len)
+    print(f"streams, bandwidths / {sharpen}, lanes={lanes}: tier {want}, {k:.1f} * 2^-23")
+    assert (k == 0.0) if want == 0 else (0.0 < k * ULP <= TOL)
+
+
 # ---------------------------------------------------------------------------------------------
 # Time-split fast kernels (synth_kernel<..., SPLIT>): one lane per (utterance, chunk of its time axis).
 # A chunk's lane fast-forwards the exact chain, warms its filters up from zero state and renders its chunk.
