@@ -39,7 +39,8 @@ TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
 RCCL_TIMEOUT_S = float(os.environ.get("GRAIL_BENCH_RCCL_TIMEOUT", "240"))
 def kernel_sources():
     """Every device-side source of the library: the kernel template and its instantiation units
-    (csrc/*.hip) and the headers they include (csrc/*.h), sorted by name."""
+    (csrc/*.hip) and the headers they include (csrc/*.h), sorted by name.  (Host-only code is
+    csrc/*.cpp and csrc/*.hpp.)"""
     d = os.path.join(ROOT, "grail-rs_amd", "csrc")
     return sorted(f for f in os.listdir(d) if f.endswith(".hip") or f.endswith(".h"))
 

@@ -68,7 +68,7 @@ struct SynthArgs {
     uint32_t half_capable;        // host hint: every voice has amplitude 0 in formants 5-8 of every
                                   // phoneme (phoneme batches), so the half-live loops can be used
     uint32_t live4;               // host-verified: formants 5-8 contribute exactly +0.0 for the whole
-                                  // batch (see grail_api.cpp live4_ok); selects the NFA = 4 kernels
+                                  // batch (see voice_analysis.cpp live4_ok); selects the NFA = 4 kernels
     uint32_t pipe;                // live4 batches small enough to leave SIMDs idle: the four-wave
                                   // pipelined workgroups (synth_kernel<..., PIPE>)
     uint32_t fast;                // tolerance-mode arithmetic in calm tiles (option "arithmetic" = 1): 1 = coefficients

@@ -1,0 +1,355 @@
+// launch_plan.cpp — which kernel family renders a block of rows, what a block costs, how a batch is cut into blocks.
+// Pure host arithmetic over the context's options and the batch's summary (no HIP call): grail_plan_blocks runs it
+// without a device.
+#include "api_internal.hpp"
+
+using namespace grail;
+using namespace grail::host;
+
+namespace grail {
+namespace host {
+
+// the longest utterance of the batch in samples, as far as the host knows it (the f32 clock adds a few per segment)
+double batch_span(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride)
+{
+    double span = std::ceil((double)batch->max_seconds * ctx->max_rate) + 64.0;
+    if (!(span >= 64.0)) span = 64.0;                         // NaN / negative lengths
+    return std::fmin(span, (double)(out_stride ? out_stride : 1));
+}
+
+// Cost model of the planner, in milliseconds per SAMPLE OF THE LONGEST UTTERANCE for one round of a family (a round:
+// as many rows as give every SIMD one wave).  Calibrated on 2 s utterances at 48 kHz, one MI355X
+// (profiles/r03_small_batch.txt, profiles/r04_duration_sweep.txt); only the ratios matter.  Indexed [L = 1, 2, 4, 8].
+constexpr double MID_MS_4 = 32.6, MID_MS_8 = 57.2;     // 65 536 x 2 s, the MID kernels (profiles/r04_middle_tier.txt)
+static double lane_ms_per_sample(bool fast, bool live4, int L)
+{
+    static const double exact4[4] = {40.6, 26.9, 16.3, 18.2}, exact8[4] = {77.1, 43.5, 25.8, 15.7};
+    static const double fast4[4] = {15.6, 13.0, 12.1, 11.7}, fast8[4] = {23.2, 19.9, 13.3, 11.7};
+    const int i = L == 1 ? 0 : L == 2 ? 1 : L == 4 ? 2 : 3;
+    return (fast ? (live4 ? fast4 : fast8) : (live4 ? exact4 : exact8))[i] / 96006.0;
+}
+// ... of the second tolerance tier (MID, one lane per utterance)
+static double mid_ms_per_sample(bool live4) { return (live4 ? MID_MS_4 : MID_MS_8) / 96006.0; }
+
+// what launching `rows` rows with family f costs (model milliseconds)
+double family_cost(const grail_ctx *ctx, const Family &f, uint32_t rows, double span)
+{
+    const double cus = (double)ctx->cus, lanes = (double)ctx_lanes(ctx);
+    if (f.scan) {
+        // one workgroup per utterance; g = workgroups per compute unit.  Three-stage flavour: the latency of one
+        // utterance's chain up to ~2 per CU, then ~0.53 ms per workgroup and CU (2 s); two-stage: 0.41 (four live
+        // formants) / 0.65 (eight)
+        const double g = std::ceil((double)rows / cus);
+        const double ms2s = f.scan_pipe ? (f.live4 ? std::fmax(1.14, 0.53 * g) : std::fmax(1.67, 0.75 * g))
+                                        : (f.live4 ? 0.41 * g + 0.1 : 0.65 * g + 0.2);
+        return ms2s * span / 96006.0;
+    }
+    if (f.split_k) {
+        // every lane takes as long as the first chunk's, which renders split_bounds[1] samples and nothing else
+        const double rounds = std::ceil((double)rows * f.split_k / lanes);
+        // (+ 0.12 ms: what a launch of chunk lanes costs before any of them renders — short utterances see it)
+        if (f.fast == 2u) return rounds * ((double)f.split_bounds[1] * mid_ms_per_sample(f.live4 != 0) + 0.12);
+        return rounds * ((double)f.split_bounds[1] * (f.live4 ? 15.7 : 23.3) / 96006.0 + 0.12);
+    }
+    if (f.pipe) {
+        const double groups = std::ceil((double)rows / (f.live4 ? 16.0 : 8.0));
+        const double per_cu = std::ceil(groups / cus);
+        // rounds of 32: one workgroup per CU; rounds of 16: two per CU are resident together, further ones queue
+        const double ms2s = f.pipe == 2 ? (f.live4 ? 6.5 : 7.3) * per_cu : 11.2 * std::ceil(per_cu / 2.0);
+        return ms2s * span / 96006.0;
+    }
+    const double rounds = std::ceil((double)rows * f.L / lanes);
+    if (f.fast == 2u) return rounds * span * mid_ms_per_sample(f.live4 != 0);
+    return rounds * span * lane_ms_per_sample(f.fast != 0, f.live4 != 0, f.L);
+}
+
+bool batch_half_capable(const grail_ctx *ctx, const grail_batch *batch)
+{
+    return ctx->skip_silent_option && batch->phoneme_mode && ctx->voices_upper_silent;
+}
+
+// formants 5-8 left out altogether: the table qualifies (live4_ok); every segment is at least
+// two samples long, so the Sequencer clock never goes negative and alpha stays in [0,1]; and
+// every pitch stays >= 2^-20 under the pitch jitter, so the polyBLEP quotient and with it the
+// saw every formant is fed from stay finite (a dead formant fed +-inf would emit NaN)
+bool batch_live4_any_blend(const grail_ctx *ctx, const grail_batch *batch)
+{
+    return batch_half_capable(ctx, batch) && ctx->voices_live4_ok && batch->plain &&
+           batch->min_length >= 2.0f * ctx->max_dt &&
+           batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f;
+}
+// ... and (the lane kernels' four-formant instantiations) every blend length a power of two
+bool batch_live4(const grail_ctx *ctx, const grail_batch *batch)
+{
+    return batch_live4_any_blend(ctx, batch) && !batch->any_blend;
+}
+
+// The family a block of `fam` rows of this batch takes.  Exact arithmetic: the widest mapping that still gives every
+// SIMD at most one wave (pipelined workgroups, then 8 / 4 / 2 / 1 lanes per utterance).  Fast arithmetic: the cheapest
+// of the scan kernel, the time-split kernels and the fast lane kernels by the cost model above (which follows the
+// utterances' length: a time-split pays a warm-up per chunk, the scan kernel the latency of one utterance's chain),
+// unless an option pins the choice.
+void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t fam, Family &f,
+                   bool exact_only)
+{
+    const uint64_t simds = ctx_simds(ctx), lanes = ctx_lanes(ctx), cus = (uint64_t)ctx->cus;
+    f = Family();
+    f.live4 = batch_live4(ctx, batch) ? 1u : 0u;
+    // fast arithmetic is served up to a sharpness of the resonances (elems_sharpness); beyond it the exact kernels run
+    // ... in the tier the sharpness allows: 1 = coefficients interpolated, 2 = the reference's own coefficients (MID)
+    f.fast = exact_only ? 0u : (uint32_t)fast_tier(ctx, batch);
+    // (MID kernels exist one-shot with one lane per utterance, and time-split: a pinned wider mapping gets the exact kernels)
+    if (f.fast == 2u && ctx->lanes_option > 1) f.fast = 0u;
+    // (the fast lane kernels have four-formant instantiations for every blend length)
+    if (f.fast && batch_live4_any_blend(ctx, batch)) f.live4 = 1u;
+    int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(fam, simds);
+    if (f.fast == 2u) L = 1;          // (before the four-formant layout is decided: eight lanes would give it up)
+    // small batches leave SIMDs idle: four-wave workgroups (one wave renders 16 utterances, one carries
+    // the per-utterance chain, two prepare the filter coefficients), up to two per CU (tools/pipe4_range.py:
+    // 11.5 ms up to 4 096 utterances, 15.7 up to 8 192 where the lane kernels take 18.0; three per CU lose)
+    const bool want_pipe4 = batch_live4(ctx, batch) && !ctx->lanes_option && ctx->pipeline_option &&
+                            (int64_t)(((uint64_t)fam + 15) / 16) <= pipe4_groups(ctx);
+    const bool want_pipe8 = !batch_live4(ctx, batch) && !ctx->lanes_option && ctx->pipeline_option && !batch->any_blend &&
+                            (int64_t)(((uint64_t)fam + 7) / 8) <= pipe8_groups(ctx);
+    // one workgroup per CU suffices: rounds of 32 samples instead of 16 (pipe = 2)
+    const uint32_t pipe4_kind = ctx->pipe_round32 && ((uint64_t)fam + 15) / 16 <= cus ? 2u : 1u;
+    const uint32_t pipe8_kind = ctx->pipe_round32 && ((uint64_t)fam + 7) / 8 <= cus ? 2u : 1u;
+    if (want_pipe4 && !f.fast) {
+        f.pipe = pipe4_kind;
+        L = 4;
+    } else if (want_pipe8 && !f.fast) {
+        f.pipe = pipe8_kind;                              // eight formants: 8 utterances per workgroup
+        L = 8;
+    }
+    // eight lanes per utterance need eight formants to lay out; for batches that small the
+    // 8-lane kernel is also the fastest (18.2 against 18.8 ms: half the rows to flush per wave)
+    if (f.live4 && !f.pipe && L == 8) f.live4 = 0u;
+    if (f.live4 && !f.pipe && !ctx->lanes_option) {
+        // same rule as auto_lanes_per_utt — the widest mapping with one wave per SIMD — over 4 formants
+        L = ((uint64_t)fam * 4 + 63) / 64 <= simds ? 4 : ((uint64_t)fam * 2 + 63) / 64 <= simds ? 2 : 1;
+    }
+    // voices whose upper formants are never audible but that do not qualify for the 4-formant
+    // kernels: one lane per utterance runs the half-live loop and ties two lanes per utterance,
+    // whose second lane would only hold silent formants
+    if (!ctx->lanes_option && !f.live4 && L == 2 && batch_half_capable(ctx, batch)) L = 1;
+    f.L = L;
+    if (!f.fast) return;
+
+    const double span = batch_span(ctx, batch, out_stride);
+    const bool l4ab = batch_live4_any_blend(ctx, batch);
+    // fast arithmetic, mid-size batches: one lane per utterance would leave most of the machine idle, so the time
+    // axis of every utterance is cut into chunks with a lane each (synth_kernel<..., SPLIT>): as many chunks as
+    // fill the machine, laid out over the batch's longest utterance so that all lanes finish together
+    Family split = f;
+    if (ctx->split_option && !ctx->lanes_option && batch->phoneme_mode && ctx->voices_split_ok && batch->plain &&
+        out_stride <= 0xFFFFFFFFull && (ctx->split_chunks >= 2 || ctx->split_chunks == 0)) {
+        const double sp = ctx->split_span ? std::fmin((double)ctx->split_span, (double)out_stride) : span;
+        int K = ctx->split_chunks ? (int)ctx->split_chunks : (int)std::min<uint64_t>(lanes / fam, SPLIT_MAX_CHUNKS);
+        K = (int)std::fmin((double)K, sp / 512.0);
+        // (a fast-forwarded sample costs the same whatever is rendered afterwards; a rendered sample of eight live
+        // formants costs 1.5 x one of four; 0.8 from a sweep, profiles/r03_small_batch.txt)
+        const double ff_cost = 1e-3 * (double)ctx->split_ff_permille * (l4ab ? 1.0 : 0.8) * (f.fast == 2u ? 0.6 : 1.0);
+        // the largest K <= K whose chunks fit (a chunk must render at least a tile): fitting is monotone in K
+        if (K >= 2 && !split_grid((uint32_t)sp, ctx->max_warmup, K, ff_cost, split.split_bounds)) {
+            int lo = 1, hi = K;                  // lo fits (or is 1), hi does not
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) / 2;
+                if (split_grid((uint32_t)sp, ctx->max_warmup, mid, ff_cost, split.split_bounds)) lo = mid;
+                else hi = mid;
+            }
+            K = lo;
+            if (K >= 2) (void)split_grid((uint32_t)sp, ctx->max_warmup, K, ff_cost, split.split_bounds);
+        }
+        if (K >= 2) {
+            split.split_k = K;
+            split.split_bounds[K] = (uint32_t)out_stride;
+            split.live4 = l4ab ? 1u : 0u;
+            split.pipe = 0u;
+            split.L = 1;
+        }
+    }
+    // fast arithmetic, few utterances: one workgroup per utterance with the time axis across the lanes and the
+    // filter recurrences solved by parallel scans (scan_kernels.hip).  Needs every parameter inside the safe window
+    // (no IEEE fallback).
+    Family scan = f;
+    if (f.fast == 1u && ctx->scan_option && !ctx->lanes_option && (int64_t)fam * (l4ab ? 4 : 7) <= 4 * scan_max_utts(ctx) &&
+        batch->phoneme_mode && ctx->voices_scan_ok && batch->plain && batch->min_length >= 2.0f * ctx->max_dt &&
+        batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f) {
+        scan.scan = true;
+        scan.live4 = l4ab ? 1u : 0u;                          // (the scan kernel takes any blend length)
+        // three-stage workgroups for few utterances (tools/scan_split_crossover.py: up to ~1500 with four
+        // live formants, half that with eight, where the filter wave is the slower stage either way)
+        scan.scan_pipe = (int64_t)fam * (scan.live4 ? 1 : 2) <= scan_split_max(ctx) ? 1u : 0u;
+        scan.pipe = 0u;
+    }
+    // which of them: a pinned grid or an explicit "time_split_min_utterances" decide as they always did; otherwise
+    // the cost model does (2 s utterances: the scan kernel up to ~1 500 of them, the time-split kernels up to half the
+    // machine's lanes, the lane kernels beyond; shorter utterances move the first crossover up — a chunk's warm-up
+    // does not shrink with the utterance)
+    bool take_split = false, take_scan = false;
+    if (split.split_k && ctx->split_chunks >= 2) {
+        take_split = true;
+    } else if (ctx->split_min_utts >= 0) {
+        take_split = split.split_k && (int64_t)fam * 6 >= ctx->split_min_utts * (l4ab ? 6 : 5);
+        take_scan = !take_split && scan.scan;
+    } else {
+        const double c_lane = family_cost(ctx, f, fam, span);
+        const double c_split = split.split_k ? family_cost(ctx, split, fam, span) : INFINITY;
+        const double c_scan = scan.scan ? family_cost(ctx, scan, fam, span) : INFINITY;
+        take_split = c_split <= c_scan && c_split < c_lane;
+        take_scan = !take_split && c_scan < c_lane;
+    }
+    if (take_split) f = split;
+    else if (take_scan) f = scan;
+    if (f.fast == 2u && !ctx->lanes_option && ctx->split_chunks < 2) {
+        // The second tier costs 0.8 of the exact one-lane kernel (0.64 - 0.8 time-split): where the exact kernels have a
+        // wider mapping to fill the machine with — mid-size batches of voices that do not qualify for time-splitting —
+        // they are the faster way to the same tolerance (their bits satisfy it trivially).
+        Family exact;
+        choose_family(ctx, batch, out_stride, fam, exact, true);
+        if (family_cost(ctx, exact, fam, span) <= family_cost(ctx, f, fam, span)) f = exact;
+        return;
+    }
+    if (take_split || take_scan) return;
+    // fast arithmetic asked for, but the batch takes neither the scan kernel nor the time-split kernels (caller-built
+    // elems, a voice outside their windows, an option switched off) and is small enough for the pipelined exact
+    // workgroups: those are faster than the fast lane kernels there (8.1 - 11.5 against 12.4 ms), and exact bits
+    // satisfy the tolerance trivially
+    if (want_pipe4 || want_pipe8) {
+        f.fast = 0u;
+        f.live4 = batch_live4(ctx, batch) ? 1u : 0u;
+        f.pipe = want_pipe4 ? pipe4_kind : pipe8_kind;
+        f.L = want_pipe4 ? 4 : 8;
+    }
+}
+
+// Cut `rows` rows into blocks, each rendered by the family that suits ITS size, so that the time of a batch is not a
+// step function of its size: a family fills the machine with a fixed number of rows (one wave per SIMD), one row more
+// costs a whole further round of it — 65 537 utterances took two rounds of the one-lane kernel (81 ms) where one
+// round and a pipelined workgroup launch (40.6 + 6.5 ms) do.  Candidates: the whole of it in one launch; or a full
+// block of one of the families' capacities (as many rounds as fit for the one-lane kernels) followed by the best
+// plan for the rest.  Exact arithmetic is mapping-invariant, so the cut never changes a bit; in fast arithmetic a row's
+// samples follow the family of ITS block (include/grail_hip.h, "Determinism contract").
+struct Planner {
+    const grail_ctx *ctx;
+    const grail_batch *batch;
+    uint64_t out_stride;
+    double span;
+    static constexpr double LAUNCH_MS = 0.05;  // what a further launch costs by itself (measured: 0.02 - 0.06 ms)
+    // (choose_family lays out time-split grids by bisection: every size is looked at once)
+    std::map<uint32_t, std::pair<Family, double>> families;
+    std::map<uint32_t, std::pair<double, std::vector<Block>>> plans;
+
+    const std::pair<Family, double> &family(uint32_t rows)
+    {
+        auto it = families.find(rows);
+        if (it != families.end()) return it->second;
+        std::pair<Family, double> e;
+        choose_family(ctx, batch, out_stride, rows, e.first);
+        e.second = family_cost(ctx, e.first, rows, span);
+        return families.emplace(rows, e).first->second;
+    }
+    const std::pair<double, std::vector<Block>> &plan(uint32_t rows, int depth)
+    {
+        auto it = plans.find(rows);
+        if (it != plans.end()) return it->second;
+        const std::pair<Family, double> &whole = family(rows);
+        double best = whole.second;
+        std::vector<Block> best_plan{Block{rows, whole.first}};
+        if (depth < 4) {
+            const uint64_t lanes = ctx_lanes(ctx), cus = (uint64_t)ctx->cus;
+            // the capacities at which some family is exactly full (largest first: of two plans of equal cost the
+            // one with the larger head wins)
+            const uint64_t caps[] = {lanes, lanes / 2, lanes / 4, lanes / 8, 32 * cus, 16 * cus, 8 * cus};
+            uint64_t seen = 0;
+            for (const uint64_t c : caps) {
+                if (c == 0 || c >= rows || c == seen) continue;
+                seen = c;
+                const uint32_t m = c == lanes ? (uint32_t)(rows / c) : 1u;
+                const uint32_t head = (uint32_t)(m * c);
+                const std::pair<Family, double> &fc = family(head);
+                if (fc.second + LAUNCH_MS >= best) continue;
+                const std::pair<double, std::vector<Block>> &rest = plan(rows - head, depth + 1);
+                if (fc.second + LAUNCH_MS + rest.first < best) {
+                    best = fc.second + LAUNCH_MS + rest.first;
+                    best_plan.assign(1, Block{head, fc.first});
+                    best_plan.insert(best_plan.end(), rest.second.begin(), rest.second.end());
+                }
+            }
+        }
+        return plans.emplace(rows, std::make_pair(best, best_plan)).first->second;
+    }
+};
+
+double plan_blocks(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t rows, double span,
+                   std::vector<Block> &out)
+{
+    Planner p{ctx, batch, out_stride, span, {}, {}};
+    const std::pair<double, std::vector<Block>> &best = p.plan(rows, 0);
+    out = best.second;
+    if (out.size() > 1) {
+        // launch order: the block that is cheapest PER ROW first (in practice: the largest).  Two reasons.  Length-
+        // sorted (ragged) batches hand out their slots longest first and a block lasts as long as its longest
+        // utterance: with lengths falling by g per slot, moving a block of r rows and per-sample cost c behind one of
+        // r', c' saves g (c r' - c' r) — the long utterances belong where a ROW costs least.  And a small block leaves
+        // most of the machine idle for milliseconds: the large kernel behind it then starts on lowered clocks and
+        // loses 2.5 - 3 ms (65 537 utterances: 50.3 ms with the single utterance first, profiles/r04_tail.txt).
+        std::stable_sort(out.begin(), out.end(), [&](const Block &x, const Block &y) {
+            return family_cost(ctx, x.f, x.rows, span) * (double)y.rows < family_cost(ctx, y.f, y.rows, span) * (double)x.rows;
+        });
+    }
+    return best.first;
+}
+
+}  // namespace host
+}  // namespace grail
+
+extern "C" {
+
+int grail_plan_blocks(uint32_t compute_units, int arithmetic, int live_formants, uint32_t warmup, uint32_t rows,
+                      uint32_t span_samples, grail_plan_block *blocks, uint32_t cap, uint32_t *n_blocks)
+{
+    if (!n_blocks) return fail(GRAIL_ERR_INVALID_ARG, "n_blocks is NULL");
+    *n_blocks = 0;
+    if (compute_units == 0 || compute_units > 4096) return fail(GRAIL_ERR_INVALID_ARG, "compute_units must be 1 .. 4096");
+    if (live_formants != 4 && live_formants != 8) return fail(GRAIL_ERR_INVALID_ARG, "live_formants must be 4 or 8");
+    if (arithmetic != 0 && arithmetic != 1 && arithmetic != 2) return fail(GRAIL_ERR_INVALID_ARG, "arithmetic must be 0, 1 or 2");
+    if (rows == 0) return GRAIL_OK;
+    // a context and a batch as choose_family sees them: default options, a voice table that qualifies for every
+    // family (four or eight live formants), a plain phoneme batch with power-of-two blend lengths
+    grail_ctx ctx;
+    ctx.cus = ctx.device_cus = (int)compute_units;
+    ctx.fast_option = arithmetic;
+    ctx.voices_sharpness = 0.0;
+    ctx.voices_upper_silent = ctx.voices_live4_ok = live_formants == 4;
+    ctx.voices_scan_ok = true;
+    ctx.voices_split_ok = warmup != 0u;
+    ctx.max_warmup = warmup;
+    ctx.max_rate = 1.0f;                  // max_seconds below is in samples
+    ctx.max_dt = 1.0f;
+    grail_batch batch;
+    batch.n_utt = rows;
+    batch.phoneme_mode = true;
+    batch.plain = true;
+    batch.max_seconds = (float)span_samples;
+    batch.min_length = 1e9f;
+    batch.min_pitch = 0.25f;
+    const uint64_t stride = ((uint64_t)span_samples + 64u + 63u) / 64u * 64u;
+    std::vector<Block> plan;
+    plan_blocks(&ctx, &batch, stride, rows, batch_span(&ctx, &batch, stride), plan);
+    *n_blocks = (uint32_t)plan.size();
+    for (uint32_t i = 0; i < plan.size() && i < cap && blocks; ++i) {
+        const Family &f = plan[i].f;
+        blocks[i].rows = plan[i].rows;
+        blocks[i].lanes_per_utterance = f.scan ? 0u : (uint32_t)f.L;
+        blocks[i].pipelined = f.scan ? 0u : f.pipe;
+        blocks[i].chunks = (uint32_t)f.split_k;
+        blocks[i].scan = f.scan ? (f.scan_pipe ? 2u : 1u) : 0u;
+        blocks[i].fast = f.fast;
+        blocks[i].formants = f.live4 ? 4u : 8u;
+        blocks[i].model_ms = (float)family_cost(&ctx, f, plan[i].rows, batch_span(&ctx, &batch, stride));
+    }
+    return GRAIL_OK;
+}
+
+}  // extern "C"

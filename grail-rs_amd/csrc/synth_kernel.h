@@ -391,7 +391,7 @@ struct StateIO {
 // the short exact division).  The host asks for it only when the batch holds such a segment, so the
 // usual case (the Intonator always emits 0.5, src/lib.rs:1071) runs a kernel without that code.
 // NFA: formants laid out over the lanes, 8 or 4.  NFA = 4 (phoneme batches only) renders
-// formants 1-4 and nothing else: the host has verified (grail_api.cpp, live4_ok) that formants 5-8
+// formants 1-4 and nothing else: the host has verified (voice_analysis.cpp, live4_ok) that formants 5-8
 // of every phoneme of every voice have amplitude +0 and parameters for which the reference's own
 // arithmetic keeps their band-pass state and output at exactly +0 for the whole batch, so the fold
 // only gains literal +0.0 terms.

@@ -1,0 +1,156 @@
+// synthesize.cpp — a batch's rows to kernel launches: the cached block plan of a batch, one launch per block
+// (launch_plan.cpp chose the families), the device-resident entry points.
+#include "api_internal.hpp"
+
+using namespace grail;
+using namespace grail::host;
+
+// the launch plan of the last synthesis call of a batch (grail_batch::plan_cache), with what it was made for
+struct PlanCache {
+    uint64_t key[6];
+    std::vector<Block> plan;
+};
+
+namespace grail {
+namespace host {
+
+// One launch: `count` launch slots from slot `slot0` of the rows [first, first + n_rows) the caller renders, with
+// family f.  out_dev / out_len_dev point at row `first`.  use_perm: the batch's length-sorted slot order applies
+// (whole-batch calls): slot s renders utterance perm[s], and every per-utterance array is indexed by the utterance.
+static int launch_block(grail_ctx *ctx, const grail_batch *batch, const Family &f, float *out_dev, int16_t *out_pcm16_dev,
+                        uint64_t out_stride, uint32_t *out_len_dev, uint32_t first, uint32_t slot0, uint32_t count,
+                        bool use_perm)
+{
+    SynthArgs a{};
+    const uint32_t row0 = use_perm ? 0u : first + slot0;      // the utterance that index 0 of the launch's arrays is
+    const uint64_t out_shift = use_perm ? 0ull : (uint64_t)slot0 * out_stride;
+    a.out_pcm16 = out_pcm16_dev ? out_pcm16_dev + out_shift : nullptr;
+    a.segs = batch->d_segs;
+    a.seg_offsets = batch->d_offsets + row0;       // the offsets themselves are absolute into segs
+    a.voice_ids = batch->d_voice_ids ? batch->d_voice_ids + row0 : nullptr;
+    a.seeds = batch->d_seeds ? batch->d_seeds + row0 : nullptr;
+    a.perm = use_perm ? batch->d_perm + slot0 : nullptr;
+    a.elems = batch->phoneme_mode ? ctx->d_voice_elems : batch->d_elems;
+    a.voices = ctx->d_voices;
+    a.out = out_dev ? out_dev + out_shift : nullptr;
+    a.out_len = out_len_dev ? out_len_dev + (use_perm ? 0u : slot0) : nullptr;
+    a.truncated = ctx->d_truncated;
+    a.out_stride = out_stride;
+    a.cap = out_stride;
+    a.n_utt = count;
+    a.n_voices = (uint32_t)ctx->voices.size();
+    a.phoneme_mode = batch->phoneme_mode ? 1u : 0u;
+    a.skip_silent = ctx->skip_silent_option ? 1u : 0u;
+    a.half_capable = batch_half_capable(ctx, batch) ? 1u : 0u;
+    a.any_blend = batch->any_blend ? 1u : 0u;
+    a.live4 = f.live4;
+    a.fast = f.fast;
+    a.pipe = f.pipe;
+    hipError_t e;
+    if (f.scan) {
+        a.resume = (uint32_t)ctx->scan_debug;
+        a.pipe = f.scan_pipe;
+        e = launch_scan(a, ctx->stream);
+        ctx->last_kernel = a.live4 ? (a.pipe ? "scan_kernel<pairs=2,SPLIT,FAST>" : "scan_kernel<pairs=2,FAST>")
+                                   : (a.pipe ? "scan_kernel<pairs=4,SPLIT,FAST>" : "scan_kernel<pairs=4,FAST>");
+    } else {
+        if (f.split_k) {
+            a.split_chunks = (uint32_t)f.split_k;
+            std::memcpy(a.split_bounds, f.split_bounds, sizeof a.split_bounds);
+        }
+        e = launch_synth(a, f.L, ctx->stream);
+        ctx->last_kernel = last_kernel_name();
+    }
+    if (e != hipSuccess) return hip_fail(e, "synth kernel launch");
+    return GRAIL_OK;
+}
+
+void free_plan_cache(PlanCache *p) { delete p; }
+
+// Rows [first, first + count) of the batch (count = 0: all of it).  out_dev / out_len_dev point at the
+// first row RENDERED, i.e. the caller has already applied the row offset to them.
+// family_rows: the number of rows the kernel family is chosen for (0 = count).  A caller that renders a batch in
+// row blocks passes its block size for every block, the short last one included: in fast arithmetic a row's
+// samples depend on the family (lane mapping, chunk grid, scan kernel), and so they depend neither on the row's
+// position nor on n_utt modulo the block size.
+int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_dev,
+                           int16_t *out_pcm16_dev, uint64_t out_stride, uint32_t *out_len_dev,
+                           uint32_t first, uint32_t count, uint32_t family_rows)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if ((rc = check_ready(ctx, batch))) return rc;
+    if (batch->n_utt == 0) return GRAIL_OK;
+    if (!out_dev && !out_pcm16_dev && out_stride) return fail(GRAIL_ERR_INVALID_ARG, "out_dev is NULL");
+    if (first > batch->n_utt || count > batch->n_utt - first) return fail(GRAIL_ERR_INVALID_ARG, "row range");
+    if (count == 0) count = batch->n_utt - first;
+    if (count == 0) return GRAIL_OK;
+    // the length-sorted slot assignment covers the whole batch: row-block launches keep launch order
+    const bool use_perm = first == 0 && count == batch->n_utt && batch->d_perm;
+    std::vector<Block> plan;
+    const uint64_t key[6] = {count, out_stride, family_rows, ctx->options_epoch, ctx->voices_epoch,
+                             (uint64_t)(uintptr_t)ctx ^ (batch->phoneme_mode ? 0ull : (uint64_t)(batch->elems_sharpness * 1024.0))};
+    if (batch->plan_cache && std::memcmp(batch->plan_cache->key, key, sizeof key) == 0) {
+        plan = batch->plan_cache->plan;
+    } else {
+        // one launch when the caller fixes the family (row blocks, a pinned lane mapping or chunk grid) or asks for it
+        const bool single = family_rows != 0 || !ctx->composite_option || ctx->lanes_option || ctx->split_chunks >= 2;
+        if (single) {
+            Family f;
+            choose_family(ctx, batch, out_stride, family_rows > count ? family_rows : count, f);
+            plan.push_back(Block{count, f});
+        } else {
+            plan_blocks(ctx, batch, out_stride, count, batch_span(ctx, batch, out_stride), plan);
+        }
+        if (!batch->plan_cache) batch->plan_cache = new (std::nothrow) PlanCache();
+        if (batch->plan_cache) {
+            std::memcpy(batch->plan_cache->key, key, sizeof key);
+            batch->plan_cache->plan = plan;
+        }
+    }
+    size_t main_block = 0;                     // the block with the most rows: the one the statistics describe
+    for (size_t i = 1; i < plan.size(); ++i)
+        if (plan[i].rows > plan[main_block].rows) main_block = i;
+    const Family f0 = plan[main_block].f;
+    ctx->last_split = f0.split_k;
+    ctx->last_formants = f0.live4 ? 4 : 8;
+    ctx->last_lanes = f0.scan ? 0 : f0.L;
+    ctx->last_pipe = f0.pipe && !f0.scan ? 1 : 0;
+    ctx->last_fast = 0;
+    ctx->last_blocks = (int)plan.size();
+    HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    uint32_t slot0 = 0;
+    std::string first_kernel;
+    for (size_t i = 0; i < plan.size(); ++i) {
+        const Block &b = plan[i];
+        rc = launch_block(ctx, batch, b.f, out_dev, out_pcm16_dev, out_stride, out_len_dev, first, slot0, b.rows, use_perm);
+        if (rc) return rc;
+        if (i == main_block) first_kernel = ctx->last_kernel;
+        if ((int)b.f.fast > ctx->last_fast) ctx->last_fast = (int)b.f.fast;
+        slot0 += b.rows;
+    }
+    ctx->last_kernel = first_kernel;            // the largest block's instantiation names the launch
+    HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    ctx->have_timing = true;
+    return GRAIL_OK;
+}
+
+
+}  // namespace host
+}  // namespace grail
+
+extern "C" {
+
+int grail_batch_synthesize_async(grail_ctx *ctx, const grail_batch *batch, float *out_dev,
+                                 uint64_t out_stride, uint32_t *out_len_dev)
+{
+    return synthesize_rows(ctx, batch, out_dev, nullptr, out_stride, out_len_dev);
+}
+
+int grail_batch_synthesize_pcm16_async(grail_ctx *ctx, const grail_batch *batch, int16_t *out_dev,
+                                       uint64_t out_stride, uint32_t *out_len_dev)
+{
+    return synthesize_rows(ctx, batch, nullptr, out_dev, out_stride, out_len_dev);
+}
+
+}  // extern "C"

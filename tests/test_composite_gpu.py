@@ -1,4 +1,4 @@
-"""Composite launches: a batch is cut into blocks with a kernel family each (grail_api.cpp plan_blocks), so that one
+"""Composite launches: a batch is cut into blocks with a kernel family each (launch_plan.cpp plan_blocks), so that one
 utterance more than a family holds does not cost a whole further round of it.  Exact arithmetic is mapping-invariant:
 whatever the cut, every sample must equal the oracle's bit pattern.  The machine is made small with
 "assume_compute_units" (1 CU = 256 lanes), so that batches of a few hundred short utterances are cut the way batches

@@ -787,7 +787,7 @@ def test_scan_kernel_flavours_and_batches_give_the_same_bits(gpu_ctx):
 
 def test_host_output_blocks_share_one_kernel_family_in_fast_mode(gpu_ctx):
     """The host-output calls render in blocks of up to 4096 rows; the short last block takes the kernel family of
-    the full ones (grail_api.cpp synthesize_rows, family_rows), so a row's fast-mode samples depend neither on its
+    the full ones (synthesize.cpp synthesize_rows, family_rows), so a row's fast-mode samples depend neither on its
     position nor on n_utt modulo the block size.  Utterance u depends on u only: rows 4100.. of one batch sit in
     its short last block, the same utterances sit inside the full first block of a batch that starts 150 later."""
     voices = W.preset_voices(8)

@@ -2,7 +2,7 @@
 kernels, and the sharpness up to which fast arithmetic is served at all.
 
 grail_time_split_warmup / grail_time_split_grid are the functions the library itself plans its launches with
-(grail_api.cpp: voice_warmup, split_grid); here they are checked against a numpy restatement of the filter decay of
+(voice_analysis.cpp: voice_warmup, split_grid); here they are checked against a numpy restatement of the filter decay of
 Synthesize::next (src/lib.rs:530-575) and against the cost model the grid is meant to balance.
 """
 import math
