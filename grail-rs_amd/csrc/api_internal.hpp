@@ -212,6 +212,8 @@ struct Block {
     Family f;
 };
 
+// lanes per utterance when the option is 0 (auto): the widest mapping that gives each of `simds` SIMDs at most one wave
+int auto_lanes_per_utt(uint32_t n_utt, uint64_t simds);
 double batch_span(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride);
 double family_cost(const grail_ctx *ctx, const Family &f, uint32_t rows, double span);
 bool batch_half_capable(const grail_ctx *ctx, const grail_batch *batch);

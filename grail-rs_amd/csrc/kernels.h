@@ -130,7 +130,5 @@ hipError_t launch_compare(const float *a, const float *b, uint64_t stride, const
 // resumable synthesis: words per lane and lanes per launch of the state buffer
 uint32_t state_words(int lanes_per_utt);
 uint64_t state_lanes(uint32_t n_utt, int lanes_per_utt);
-// the choice made when the option is 0 (auto): the widest mapping that gives each of `simds` SIMDs at most one wave
-int auto_lanes_per_utt(uint32_t n_utt, uint64_t simds);
 
 }  // namespace grail

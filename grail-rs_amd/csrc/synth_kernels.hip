@@ -73,18 +73,6 @@ uint64_t state_lanes(uint32_t n_utt, int L)
     return blocks * threads;
 }
 
-int auto_lanes_per_utt(uint32_t n_utt, uint64_t simds)
-{
-    // Measured (profiles/r01_lanes_sweep.txt): a wave alone on its SIMD renders 2 s of audio
-    // in 92 / 60 / 42 / 38 ms for L = 1 / 2 / 4 / 8, and a second wave on the same SIMD costs
-    // more than it brings (the packed-f32 stream of one wave already keeps the VALU ~80 %
-    // busy).  So: the widest mapping that still fits one wave per SIMD (4 per compute unit: 1024 on a
-    // whole MI355X).
-    for (int L = 8; L > 1; L /= 2)
-        if (((uint64_t)n_utt * L + 63) / 64 <= simds) return L;
-    return 1;
-}
-
 // what the last launch_synth call started, for the bench line and the profile bookkeeping
 thread_local char g_kernel_name[96] = "none";
 const char *last_kernel_name() { return g_kernel_name; }

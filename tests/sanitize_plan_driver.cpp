@@ -1,0 +1,137 @@
+// sanitize_plan_driver.cpp — the host launch policy under AddressSanitizer + UBSan: voice analysis (warm-up lengths,
+// sharpness), time-split grids and the block planner, fed random and extreme arguments through their C entry points.
+// Built by tests/test_sanitizers.py from grail-rs_amd/csrc/{launch_plan,voice_analysis,voice_host}.cpp with g++ (those
+// units make no HIP call); the three error helpers of grail_api.cpp are defined here.  Invariants checked: a plan's
+// rows add up, grids are increasing multiples of 64 inside the span, sharpness / warm-up never trap on NaN or Inf.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../include/grail_hip.h"
+#include <hip/hip_runtime_api.h>
+
+namespace grail {
+namespace host {
+static thread_local std::string g_err;
+int fail(int status, const std::string &msg)
+{
+    g_err = msg;
+    return status;
+}
+int hip_fail(hipError_t, const char *what) { return fail(GRAIL_ERR_HIP, what); }
+std::string &last_error() { return g_err; }
+}  // namespace host
+}  // namespace grail
+
+static int fails = 0;
+#define CHECK(c) do { if (!(c)) { std::printf("FAIL line %d: %s\n", __LINE__, #c); ++fails; } } while (0)
+
+static uint32_t rng_state = 12345u;
+static uint32_t rnd()
+{
+    rng_state = rng_state * 1664525u + 1013904223u;
+    return rng_state >> 8;
+}
+static float special(int k)
+{
+    switch (k % 8) {
+    case 0: return 0.0f;
+    case 1: return -0.0f;
+    case 2: return NAN;
+    case 3: return INFINITY;
+    case 4: return -INFINITY;
+    case 5: return 1e-38f;
+    case 6: return 3e38f;
+    default: return -1.0f;
+    }
+}
+
+int main()
+{
+    // ---- time-split grids
+    int grids = 0;
+    for (int t = 0; t < 20000; ++t) {
+        const uint32_t span = t % 7 == 0 ? (rnd() % 8u) * 0x10000000u + rnd() : 1u + rnd() % 3000000u;
+        const uint32_t warm = t % 5 == 0 ? rnd() : (rnd() % 300u) * 64u;
+        const uint32_t K = t % 11 == 0 ? rnd() % 100u : 2u + rnd() % 63u;
+        const uint32_t ff = t % 13 == 0 ? rnd() % 2000u : rnd() % 1001u;
+        uint32_t b[64 + 2];
+        std::memset(b, 0xEE, sizeof b);
+        const int rc = grail_time_split_grid(span, warm, K, ff, b);
+        if (K < 2u || K > 64u || ff > 1000u) CHECK(rc == GRAIL_ERR_INVALID_ARG);
+        if (rc == GRAIL_OK) {
+            ++grids;
+            CHECK(b[0] == 0u);
+            for (uint32_t k = 1; k < K; ++k) CHECK(b[k] > b[k - 1] && b[k] % 64u == 0u && b[k] < span);
+            CHECK(b[K] == 0xEEEEEEEEu);               // nothing written past the K bounds
+        }
+    }
+    CHECK(grids > 1000);
+    CHECK(grail_time_split_grid(96006, 3904, 16, 165, nullptr) == GRAIL_ERR_INVALID_ARG);
+
+    // ---- the block planner
+    int plans = 0;
+    std::vector<grail_plan_block> blocks(64);
+    for (int t = 0; t < 12000; ++t) {
+        const uint32_t cus = t % 17 == 0 ? rnd() % 5000u : 1u + rnd() % 512u;
+        const int arith = t % 19 == 0 ? (int)(rnd() % 5u) - 1 : (int)(rnd() % 3u);
+        const int formants = t % 23 == 0 ? (int)(rnd() % 10u) : (rnd() & 1u ? 4 : 8);
+        const uint32_t warm = rnd() & 1u ? 0u : (1u + rnd() % 256u) * 64u;
+        const uint32_t rows = t % 29 == 0 ? rnd() : rnd() % 300000u;
+        const uint32_t span = t % 31 == 0 ? rnd() * 16u : 1u + rnd() % 2000000u;
+        uint32_t n = 0xFFFFFFFFu;
+        const uint32_t cap = rnd() % 65u;
+        const int rc = grail_plan_blocks(cus, arith, formants, warm, rows, span, blocks.data(), cap, &n);
+        const bool bad = cus == 0u || cus > 4096u || (formants != 4 && formants != 8) || arith < 0 || arith > 2;
+        CHECK((rc == GRAIL_ERR_INVALID_ARG) == bad);
+        if (rc != GRAIL_OK) continue;
+        ++plans;
+        CHECK((n == 0u) == (rows == 0u));
+        if (n <= cap) {
+            uint64_t sum = 0;
+            for (uint32_t i = 0; i < n; ++i) {
+                sum += blocks[i].rows;
+                CHECK(blocks[i].rows > 0u && (blocks[i].formants == 4u || blocks[i].formants == 8u));
+                CHECK(blocks[i].fast <= 2u && blocks[i].chunks <= 64u && std::isfinite(blocks[i].model_ms));
+                if (!arith) CHECK(blocks[i].fast == 0u && blocks[i].chunks == 0u && blocks[i].scan == 0u);
+            }
+            CHECK(sum == rows);
+        }
+    }
+    CHECK(plans > 1000);
+    uint32_t n = 0;
+    CHECK(grail_plan_blocks(256, 0, 4, 0, 70000, 96006, nullptr, 0, &n) == GRAIL_OK && n == 2u);
+    CHECK(grail_plan_blocks(256, 0, 4, 0, 70000, 96006, nullptr, 0, nullptr) == GRAIL_ERR_INVALID_ARG);
+
+    // ---- voice analysis on sane, random and hostile tables
+    grail_voice v;
+    grail_voice_generic_at(&v, 48000.0f);
+    const float s0 = grail_fast_sharpness(&v);
+    CHECK(s0 > 20.0f && s0 < 28.0f);
+    CHECK(grail_time_split_warmup(&v) == 3904u);
+    CHECK(std::isinf(grail_fast_sharpness(nullptr)) && grail_time_split_warmup(nullptr) == 0u);
+    for (int t = 0; t < 20000; ++t) {
+        grail_voice w = v;
+        float *f = (float *)&w;
+        const size_t nf = sizeof w / sizeof(float);
+        const int edits = 1 + (int)(rnd() % 6u);
+        for (int e = 0; e < edits; ++e) {
+            const size_t at = rnd() % nf;
+            f[at] = rnd() & 1u ? special((int)rnd()) : f[at] * (0.01f + (float)(rnd() % 4000u) * 0.001f);
+        }
+        const float s = grail_fast_sharpness(&w);
+        CHECK(!(s < 0.0f));                               // a number >= 0, +inf or NaN-free by construction
+        CHECK(!std::isnan(s));
+        const uint32_t wu = grail_time_split_warmup(&w);
+        CHECK(wu <= 16384u + 64u && wu % 64u == 0u);
+    }
+    if (fails) {
+        std::printf("sanitize plan driver: %d failure(s)\n", fails);
+        return 1;
+    }
+    std::printf("sanitize plan driver: ok (%d grids, %d plans)\n", grids, plans);
+    return 0;
+}
