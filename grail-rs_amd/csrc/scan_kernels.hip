@@ -39,7 +39,7 @@
 // (thousands of utterances) are bound by instruction issue, not by the latency of the serial chain.
 // Tolerance mode only (the scans reassociate the recurrences); the discontinuous state is the reference's
 // to the bit, so lengths and every boundary / wrap / saw edge sit where the reference puts them.  The host
-// only sends batches here whose every parameter is inside the proven-safe window (grail_api.cpp
+// only sends batches here whose every parameter is inside the proven-safe window (voice_analysis.cpp
 // scan_voice_ok): no NaN / Inf special cases exist on this path.
 #include <cstdio>
 
@@ -767,7 +767,7 @@ hipError_t launch_scan(const SynthArgs &args, hipStream_t stream)
 {
     if (args.n_utt == 0) return hipSuccess;
     // few utterances: the time per batch is the chain's; three-stage workgroups halve it.  Many: two waves
-    // per utterance keep more utterances resident per CU (args.pipe: the host's choice, grail_api.cpp)
+    // per utterance keep more utterances resident per CU (args.pipe: the host's choice, launch_plan.cpp)
     if (args.pipe) {
         if (args.live4) hipLaunchKernelGGL((scan_kernel<2, true>), dim3(args.n_utt), dim3(192), 0, stream, args);
         else hipLaunchKernelGGL((scan_kernel<4, true>), dim3(args.n_utt), dim3(192), 0, stream, args);

@@ -1,6 +1,7 @@
 // synth_inst_exact_l8.hip — synth_kernel instantiations: 8 lane(s) per utterance, exact arithmetic.
-// <L, T, WAVES, MINW>: 64-thread workgroups are admitted 8 per CU (2 waves per SIMD, measured); L = 4 / 8 use
-// 256-thread workgroups so that more waves can be resident.
+// <L, T, WAVES, MINW>: T samples per tile; WAVES waves per workgroup (L = 4 / 8: 256-thread workgroups, whose four
+// waves share the workgroup's LDS tiles); MINW = 1: compiled for ONE resident wave per SIMD, all 512 registers a lane
+// can have (DESIGN.md §4.1 — a second wave on a SIMD costs more than it brings, profiles/r04_two_waves.txt).
 #include "synth_launch_impl.h"
 
 namespace grail {
