@@ -111,11 +111,11 @@ impl<I: IntoIterator<Item = Utterance>> IntoSynthesizeBatch for I {
         let stride = (*lens.iter().max().unwrap_or(&0) as u64 + 63) / 64 * 64;
         // Results of up to PINNED_LIMIT bytes land in PINNED host memory: grail_synthesize_batch renders rows in
         // blocks of up to 4096 utterances and copies each block out on a second stream while the next one
-        // renders; a pinned destination receives those copies directly (measured 50.9 GB/s end to end = 89 %
-        // of a plain pinned hipMemcpy, profiles/r02_host_output.txt; the hipHostMalloc / hipHostFree of the
+        // renders; a pinned destination receives those copies directly (measured 53 GB/s end to end = 93 %
+        // of a plain pinned hipMemcpy, profiles/r04_host_output.txt; the hipHostMalloc / hipHostFree of the
         // block itself is not in that figure and costs about a second per 10 GB).  Larger results, and hosts
         // that refuse the pinned allocation (locked-memory limit, little free RAM), take a plain Vec — the
-        // library then feeds it through its own ring of pinned staging buffers and copier threads (~39 GB/s).
+        // library then feeds it through its own ring of pinned staging buffers and copier threads (~49 GB/s).
         const PINNED_LIMIT: usize = 2 << 30;
         let floats = n as usize * stride as usize;
         let mut pinned: *mut std::ffi::c_void = std::ptr::null_mut();
