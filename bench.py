@@ -278,9 +278,9 @@ def main():
                     help="0 skips the clock-ramp launches of a small sub-batch before the warm-up "
                          "(counter passes: only the measured kernel should appear)")
     ap.add_argument("--rccl-diagnose", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-utts", type=int, default=512,
-                    help="utterances for the CPU baseline (0 = skip); 512 is ~4-7 s of CPU on one "
-                         "thread (samples/s does not depend on it)")
+    ap.add_argument("--cpu-utts", type=int, default=1536,
+                    help="utterances for the CPU baseline (0 = skip); 1536 is ~11 s of CPU on one "
+                         "thread of the GPU box's host (samples/s does not depend on it)")
     args = ap.parse_args()
     if args.config == 2:
         args.utts, args.voices = 4096, 1
