@@ -1,0 +1,123 @@
+"""The gfx950 code objects inside libgrail_hip.so, read without a GPU: every kernel the library can launch is there,
+compiled for gfx950 only, free of scratch where the design says so — and ONE WAVE PER SIMD holds by construction:
+the lane kernels claim more than half of a SIMD's 512 registers (profiles/r04_dispatch.txt), so the
+dispatcher cannot put two of their waves on one SIMD whatever launch came before."""
+import os
+import re
+import struct
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "grail-rs_amd", "lib", "libgrail_hip.so")
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def _code_objects():
+    """(triple, bytes) of every device entry of the clang offload bundles in the library's .hip_fatbin."""
+    blob = open(LIB, "rb").read()
+    out = []
+    for m in re.finditer(re.escape(MAGIC), blob):
+        p = m.start()
+        (n,) = struct.unpack_from("<Q", blob, p + 24)
+        q = p + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", blob, q)
+            q += 24
+            triple = blob[q:q + tl].decode()
+            q += tl
+            if size and not triple.startswith("host-"):
+                out.append((triple, blob[p + off:p + off + size]))
+    return out
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    """{kernel symbol: metadata dict} over all gfx950 code objects (AMDGPU metadata note, via llvm-readelf)."""
+    if not os.path.exists(READELF):
+        pytest.skip("llvm-readelf not found")
+    tmp = tmp_path_factory.mktemp("co")
+    found = {}
+    for i, (triple, data) in enumerate(_code_objects()):
+        assert triple.endswith("gfx950"), f"a code object for {triple}: this library is gfx950 only"
+        path = tmp / f"co{i}.elf"
+        path.write_bytes(data)
+        text = subprocess.run([READELF, "--notes", str(path)], capture_output=True, text=True, check=True).stdout
+        for block in text.split("- .agpr_count:")[1:]:
+            block = ".agpr_count:" + block
+            meta = {}
+            for key in ("agpr_count", "vgpr_count", "sgpr_count", "private_segment_fixed_size", "group_segment_fixed_size",
+                        "max_flat_workgroup_size", "wavefront_size", "vgpr_spill_count", "sgpr_spill_count"):
+                mm = re.search(r"\.%s:\s+(\d+)" % key, block)
+                if mm:
+                    meta[key] = int(mm.group(1))
+            name = re.search(r"\.name:\s+(\S+)", block).group(1)
+            found[name] = meta
+    return found
+
+
+def _synth(kernels):
+    """[(template arguments as a tuple of ints / bools, metadata)] of the synth_kernel instantiations.
+    <L, T, WAVES, MINW, STREAM, HALF, ANYBL, NFA, PIPE, FAST, PQP, SPLIT, MID>"""
+    out = []
+    for name, meta in kernels.items():
+        m = re.search(r"synth_kernelI((?:L[ib]\d+E)+)E", name)
+        if not m:
+            continue
+        args = tuple(int(x) for x in re.findall(r"L[ib](\d+)E", m.group(1)))
+        assert len(args) == 13, name
+        out.append((args, meta))
+    return out
+
+
+def test_every_kernel_family_is_in_the_library(kernels):
+    synth = _synth(kernels)
+    assert len(synth) >= 60, len(synth)
+    have = {(a[0], bool(a[4]), a[7], bool(a[8]), bool(a[9]), bool(a[11]), bool(a[12])) for a, _ in synth}
+    for L in (1, 2, 4, 8):
+        for nfa in ((4, 8) if L <= 4 else (8,)):
+            assert (L, False, nfa, False, False, False, False) in have, ("exact one-shot", L, nfa)
+            assert (L, False, nfa, False, True, False, False) in have, ("fast one-shot", L, nfa)
+        assert (L, True, 8, False, False, False, False) in have, ("exact stream", L)
+        assert (L, True, 8, False, True, False, False) in have, ("fast stream", L)
+    for nfa in (4, 8):
+        assert (1, False, nfa, False, True, True, False) in have, ("time-split", nfa)
+        assert (1, False, nfa, False, True, False, True) in have, ("second tier", nfa)
+        assert (1, False, nfa, False, True, True, True) in have, ("second tier, time-split", nfa)
+    assert (4, False, 4, True, False, False, False) in have and (8, False, 8, True, False, False, False) in have   # pipelined
+    names = " ".join(kernels)
+    for other in ("scan_kernel", "ring_append_kernel", "lengths_kernel"):
+        assert other in names, other
+    for meta in kernels.values():
+        assert meta.get("wavefront_size", 64) == 64
+
+
+def test_lane_kernels_hold_one_wave_per_simd_by_construction(kernels):
+    """A SIMD has 512 registers per lane (VGPRs + AGPRs, one file on gfx950): a kernel that holds more than 256 cannot
+    share a SIMD with a second wave of itself.  Every lane kernel (all but the pipelined four-wave workgroups, which
+    are placed by their LDS footprint) must, because the host sizes every launch for exactly that."""
+    for args, meta in _synth(kernels):
+        L, T, waves, minw, stream, half, anybl, nfa, pipe = args[:9]
+        total = meta["vgpr_count"]          # (the metadata's vgpr_count is the unified total: arch VGPRs + AGPRs)
+        assert total <= 512, (args, meta)
+        assert meta["agpr_count"] <= total
+        if pipe:
+            # four waves of a workgroup on the four SIMDs of a CU; LDS decides how many workgroups a CU takes
+            assert meta["group_segment_fixed_size"] >= 64 * 1024, (args, meta)
+            continue
+        assert total > 256, ("two waves of this kernel would fit one SIMD", args, meta)
+        assert meta["max_flat_workgroup_size"] == 64 * waves, (args, meta)
+
+
+def test_hot_kernels_have_no_scratch(kernels):
+    """The four-formant one-lane kernels (the headline batch, exact and both fast tiers, time-split) keep everything in
+    registers: a private segment would be HBM traffic the roofline does not count."""
+    checked = 0
+    for args, meta in _synth(kernels):
+        L, T, waves, minw, stream, half, anybl, nfa, pipe, fast, pqp, split, mid = args
+        if L == 1 and nfa == 4 and not stream and not pipe:
+            assert meta.get("private_segment_fixed_size", 0) == 0, (args, meta)
+            checked += 1
+    assert checked >= 8, checked
