@@ -146,3 +146,52 @@ def test_mixed_sample_rates_fast_within_the_tolerance(gpu_ctx, n_utt, rates, tie
     print(f"mixed sample rates up to {rates[-1]:.0f} Hz, {n_utt} utterances (ran {name}, arithmetic {served}): "
           f"worst |fast - oracle| = {worst * 2 ** 23:.1f} * 2^-23")
     assert worst <= G.FAST_TOLERANCE
+
+
+def test_long_segments_cross_the_binades_of_the_clock(gpu_ctx):
+    """Segments of 2 - 9 s with blends of 0.25 - 8 s (the Sequencer clock starts each segment at its length and walks
+    down through the binades 8, 4, 2, 1, ... in steps of dt: where the scan kernel's closed-form clock and the
+    time-split fast-forward have to reproduce the serial f32 accumulation), at 16 and 22.05 kHz so that half a minute is
+    half a million samples: exact kernels bit for bit, every fast family within the tolerance
+    (tools/long_utterance_check.py is the same at 48 kHz, by hand)."""
+    rng = np.random.default_rng(41)
+    rates = (16000.0, 22050.0)
+    voices = _voices(rates)
+    gpu_ctx.set_voices(voices)
+    n_utt = 12
+    segs, offs, vids, seeds = _batch(rng, n_utt, 1.0, ragged=False, rates=rates)
+    k = len(segs)
+    segs["length"] = rng.uniform(2.0, 9.0, k).astype(np.float32)
+    segs["blend_length"] = rng.choice([0.5, 2.0, 0.25, 4.0, 8.0, 3.3], k).astype(np.float32)
+    stride = (int(4 * 9.0 * 22050) + 64 + 63) // 64 * 64
+    ref, ref_len = _oracle(voices, segs, offs, vids, seeds, stride)
+    assert ref_len.max() < stride and ref_len.min() > 60000
+    ran = []
+    try:
+        for fast, opts in ((0, {}), (0, {"lanes_per_utterance": 1}), (0, {"lanes_per_utterance": 8}), (1, {}),
+                           (1, {"time_split": 0, "time_parallel_scan": 0, "lanes_per_utterance": 1}),
+                           (1, {"time_parallel_scan": 0}), (1, {"time_split_chunks": 16}), (1, {"time_split_chunks": 64})):
+            gpu_ctx.set_option("arithmetic", fast)
+            for name, value in opts.items():
+                gpu_ctx.set_option(name, value)
+            try:
+                out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+                kernel = gpu_ctx.last_kernel_name()
+            finally:
+                for name in opts:
+                    gpu_ctx.set_option(name, 1 if name in ("time_split", "time_parallel_scan") else 0)
+            assert np.array_equal(out_len, ref_len), (fast, opts, kernel)
+            worst = 0.0
+            for u in range(n_utt):
+                n = int(ref_len[u])
+                if fast:
+                    peak = max(1.0, float(np.abs(ref[u, :n]).max()))
+                    worst = max(worst, float(np.abs(out[u, :n] - ref[u, :n]).max()) / peak)
+                else:
+                    assert np.array_equal(out[u, :n].view(np.uint32), ref[u, :n].view(np.uint32)), (opts, kernel, u)
+            assert worst <= G.FAST_TOLERANCE, (opts, kernel, worst * 2 ** 23)
+            ran.append(f"{kernel}: {'%.1f * 2^-23' % (worst * 2 ** 23) if fast else 'bit-exact'}")
+    finally:
+        gpu_ctx.set_option("arithmetic", 0)
+    print("long segments:", "; ".join(ran))
+    assert any("scan_kernel" in r for r in ran) and any("SPLIT" in r for r in ran)
