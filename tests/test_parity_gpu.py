@@ -582,3 +582,78 @@ def test_host_destinations_pinned_and_pageable_get_the_same_rows(gpu_ctx):
     assert ei.value.status == G.ERR_BUFFER_TOO_SMALL
     assert np.array_equal(out_len, np.minimum(ref_len, short))
     assert np.array_equal(dst.view(np.uint32), ref[:, :short].view(np.uint32))
+
+
+HOSTILE_SCALARS = [
+    ("jitter_frequency", 0.0), ("jitter_frequency", 1.0), ("jitter_frequency", 1.5), ("jitter_frequency", -0.25),
+    ("jitter_frequency", float("nan")), ("jitter_frequency", float("inf")), ("jitter_frequency", 1e-30),
+    ("jitter_delta_frequency", 0.0), ("jitter_delta_frequency", -0.01), ("jitter_delta_frequency", 0.6),
+    ("jitter_delta_frequency", float("nan")), ("jitter_delta_frequency", float("inf")),
+    ("jitter_delta_formant_frequency", 0.0), ("jitter_delta_formant_frequency", 0.3),
+    ("jitter_delta_formant_frequency", float("nan")), ("jitter_delta_formant_frequency", -float("inf")),
+    ("jitter_delta_amplitude", 0.0), ("jitter_delta_amplitude", -3.0), ("jitter_delta_amplitude", 1e30),
+    ("jitter_delta_amplitude", float("nan")),
+    ("sample_rate", 1.0), ("sample_rate", 1.0e6), ("sample_rate", 1.0e-3), ("sample_rate", float("inf")),
+    ("sample_rate", -48000.0), ("sample_rate", float("nan")),
+    ("center_frequency", float("nan")),
+]
+
+
+@pytest.mark.parametrize("lanes", [0, 1, 8])
+def test_hostile_voice_scalars_propagate_as_in_the_reference(gpu_ctx, lanes):
+    """The reference sanitises nothing on this path ("Errors"): a jitter rate of 0, 1, above 1, negative,
+    NaN or Inf, jitter depths of any size or sign, a sample rate of 1, 1e6, 1e-3, Inf, negative or NaN (dt = 1 / rate
+    decides whether the clock ever runs down: rows end by exhaustion or fill up) all give SOME sequence of bits and
+    lengths, and the kernels must give the same — every case is a voice of one table, rendered in one batch."""
+    voices = []
+    for field, value in HOSTILE_SCALARS:
+        v = G.voice_generic(48000.0)
+        setattr(v, field, value)
+        voices.append(v)
+    n_utt = 3 * len(voices)
+    segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=len(voices), length=0.004, blend_length=2.0 ** -8)
+    vids = (np.arange(n_utt) % len(voices)).astype(np.uint32)
+    stride = 1088                       # rows of voices whose clock never runs down fill up: truncation is the expected end
+    try:
+        gpu_ctx.set_voices(voices)
+        gpu_ctx.set_option("lanes_per_utterance", lanes)
+        with np.errstate(all="ignore"):
+            out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride, allow_truncation=True)
+            ref, ref_len = O.synthesize_batch(ovoices(voices), segs, offs, vids, seeds, stride)
+    finally:
+        gpu_ctx.set_option("lanes_per_utterance", 0)
+    ref_len = np.minimum(ref_len, stride)
+    assert (ref_len == stride).any() and (ref_len < stride).any()
+    for u in range(n_utt):
+        field, value = HOSTILE_SCALARS[vids[u]]
+        assert out_len[u] == ref_len[u], (field, value, u, int(out_len[u]), int(ref_len[u]))
+        n = int(ref_len[u])
+        a, b = out[u, :n].view(np.uint32).copy(), ref[u, :n].view(np.uint32).copy()
+        # a NaN that comes IN through a parameter keeps the sign and payload rules of the machine it travels on
+        # (x86 hands on the first operand's, the GPU its canonical one): NaN where the oracle has NaN is all IEEE-754
+        # promises; everything else bit for bit
+        both_nan = np.isnan(out[u, :n]) & np.isnan(ref[u, :n])
+        a[both_nan] = 0
+        b[both_nan] = 0
+        assert np.array_equal(a, b), (field, value, u, int(np.argmax(a != b)))
+    # fast arithmetic on the same table: same lengths, NaN / Inf where the reference has them, the tolerance elsewhere
+    # (relative to the utterance's peak: some of these voices reach 1e30)
+    try:
+        gpu_ctx.set_option("lanes_per_utterance", lanes)
+        gpu_ctx.set_option("arithmetic", 1)
+        with np.errstate(all="ignore"):
+            fast, fast_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride, allow_truncation=True)
+    finally:
+        gpu_ctx.set_option("arithmetic", 0)
+        gpu_ctx.set_option("lanes_per_utterance", 0)
+    for u in range(n_utt):
+        field, value = HOSTILE_SCALARS[vids[u]]
+        assert fast_len[u] == ref_len[u], ("fast", field, value, u)
+        n = int(ref_len[u])
+        r, f = ref[u, :n].astype(np.float64), fast[u, :n].astype(np.float64)
+        fin = np.isfinite(r)
+        assert np.array_equal(np.isnan(r), np.isnan(f)), ("fast", field, value, u)
+        assert np.array_equal(r[~fin & ~np.isnan(r)], f[~fin & ~np.isnan(r)]), ("fast", field, value, u)
+        if fin.any():
+            peak = max(1.0, float(np.abs(r[fin]).max()))
+            assert float(np.abs(r[fin] - f[fin]).max()) <= G.FAST_TOLERANCE * peak, ("fast", field, value, u)
