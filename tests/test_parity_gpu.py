@@ -657,3 +657,52 @@ def test_hostile_voice_scalars_propagate_as_in_the_reference(gpu_ctx, lanes):
         if fin.any():
             peak = max(1.0, float(np.abs(r[fin]).max()))
             assert float(np.abs(r[fin] - f[fin]).max()) <= G.FAST_TOLERANCE * peak, ("fast", field, value, u)
+
+
+HOSTILE_VALUES = (0.0, -0.0, float("nan"), float("inf"), -1.0, 0.5, 0.75, 1e-39, 3e38)
+ELEM_ARRAYS = ("formant_freq", "formant_bw", "formant_smooth", "formant_breath", "formant_turb", "formant_amp")
+
+
+def _same_but_for_nan_payloads(out_row, ref_row):
+    a, b = out_row.view(np.uint32).copy(), ref_row.view(np.uint32).copy()
+    both_nan = np.isnan(out_row) & np.isnan(ref_row)
+    a[both_nan] = 0
+    b[both_nan] = 0
+    return np.array_equal(a, b), int(np.argmax(a != b))
+
+
+@pytest.mark.parametrize("lanes", [0, 1, 2, 8])
+def test_hostile_formant_parameters_propagate_as_in_the_reference(gpu_ctx, lanes):
+    """One entry of one formant array of phoneme A set to 0, -0, NaN, Inf, -1, 1/2 (tan_approx's pole), 3/4 (beyond it),
+    a denormal, 3e38 — in an audible formant (2) and in one voices::generic() leaves silent (7): 108 voices of one table,
+    three utterances each.  Whatever the reference's arithmetic makes of it (k = bw / 0, a band-pass that blows up, NaN
+    from the first sample on) the kernels make the same of it: safe-window checks, the four-formant gate and the silent-
+    formant skip must all refuse what they cannot reproduce."""
+    voices, what = [], []
+    for arr in ELEM_ARRAYS:
+        for value in HOSTILE_VALUES:
+            for formant in (1, 6):
+                v = G.voice_generic(48000.0)
+                getattr(v.phonemes[0], arr)[formant] = value
+                voices.append(v)
+                what.append((arr, value, formant))
+    n_utt = 3 * len(voices)
+    segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=len(voices), length=0.005, blend_length=2.0 ** -8)
+    vids = (np.arange(n_utt) % len(voices)).astype(np.uint32)
+    stride = W.max_samples(length=0.005)
+    try:
+        gpu_ctx.set_voices(voices)
+        gpu_ctx.set_option("lanes_per_utterance", lanes)
+        with np.errstate(all="ignore"):
+            out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+            ref, ref_len = O.synthesize_batch(ovoices(voices), segs, offs, vids, seeds, stride)
+    finally:
+        gpu_ctx.set_option("lanes_per_utterance", 0)
+    assert np.array_equal(out_len, ref_len)
+    nonfinite = 0
+    for u in range(n_utt):
+        n = int(ref_len[u])
+        same, at = _same_but_for_nan_payloads(out[u, :n], ref[u, :n])
+        assert same, (what[vids[u]], u, at, out[u, at], ref[u, at])
+        nonfinite += int(not np.isfinite(ref[u, :n]).all())
+    assert nonfinite > 20          # (the table does produce NaN / Inf rows: the comparison is not vacuous)
