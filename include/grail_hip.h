@@ -86,8 +86,9 @@ extern "C" {
 /* fast mode is served for voices whose grail_fast_sharpness() is at most this (predicted deviation, units of 2^-23) */
 #define GRAIL_FAST_SHARPNESS_LIMIT 28.0
 /* sharper voices get the second tolerance tier — the reference's own band-pass coefficients at every sample, fast
- * arithmetic elsewhere: at most 16 * 2^-23 from the reference on 3000 random voice tables at any sharpness
- * (profiles/r04_middle_tier.txt) — up to this sharpness; beyond it the exact kernels */
+ * arithmetic elsewhere: at most 17.3 * 2^-23 from the reference on 1000 random voice tables of any sharpness on the
+ * device, 16.3 in the CPU experiment over 3000 (profiles/r04_middle_tier.txt) — up to this sharpness; beyond it the exact
+ * kernels */
 #define GRAIL_FAST_SHARPNESS_LIMIT_EXACT_COEFFICIENTS 1024.0
 
 /* src/lib.rs:24  NUM_FORMANTS, src/lib.rs:21 DEFAULT_SAMPLE_RATE */
