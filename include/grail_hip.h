@@ -283,7 +283,7 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       faster way to render the block).
  *   "composite_launches": 1 (default) / 0 — a batch is cut into blocks with a kernel family each
  *       (grail_plan_blocks): 65537 utterances take one round of the one-lane kernel and one pipelined
- *       workgroup (50 ms) instead of two rounds (81 ms).  0: one launch per call, whatever it costs.  Read-only
+ *       workgroup (50 - 52 ms) instead of two rounds (83 ms).  0: one launch per call, whatever it costs.  Read-only
  *       "last_launch_blocks".
  *   "assume_compute_units": plan for so many compute units instead of what the device reports (0 = the
  *       device's own count; read-only "compute_units" tells what is in force): tests, and callers that share a
@@ -332,7 +332,7 @@ int grail_time_split_grid(uint32_t span_samples, uint32_t warmup, uint32_t chunk
  * number of utterances (one wavefront per SIMD: 16 / 32 per compute unit for the pipelined workgroups, 256 / L for L
  * lanes per utterance), and one utterance more costs it a whole further round.  A batch is therefore cut into BLOCKS,
  * each rendered by the family that suits the block's size: whole rounds of the one-lane kernels first, the rest with
- * wider mappings (65537 utterances: 65536 on one lane each + 1 on a pipelined workgroup, 47 ms instead of 81).  The
+ * wider mappings (65537 utterances: 65536 on one lane each + 1 on a pipelined workgroup, 50 - 52 ms instead of 83).  The
  * cut minimises a cost model calibrated on the device (profiles/r04_duration_sweep.txt) that follows the compute-unit
  * count and the utterances' length.  Exact arithmetic is mapping-invariant: the cut never changes a bit.  In fast
  * arithmetic a row's samples follow the family of ITS block, which this function predicts: rows keep batch order
