@@ -20,6 +20,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/grail_hip.h"
@@ -134,6 +135,9 @@ struct grail_batch {
     float min_length = 0.0f;   // shortest segment (plain batches)
     float min_pitch = 0.0f;    // lowest frequency.min(0.5) of any segment (plain batches)
     double elems_sharpness = 0.0;   // elem mode: predicted fast-mode deviation of the caller's elems (elems_sharpness())
+    uint32_t elems_warmup = 0;      // elem mode: warm-up length of the time-split kernels over the batch's distinct elems and the
+                                    // jitter of the voices it names (elems_warmup()); 0: the batch does not qualify
+    uint64_t elems_warmup_epoch = 0;   // ... computed against this voice table (ctx->voices_epoch)
     std::vector<uint32_t> used_voices;   // the distinct voice ids of the batch, ascending
     // the launch plan of the last synthesis call of this batch (plan_blocks lays out time-split grids by bisection: a
     // fraction of a millisecond of host time, which a one-millisecond kernel should not pay at every launch)
@@ -189,6 +193,7 @@ int check_ready(grail_ctx *ctx, const grail_batch *batch);
 bool live4_ok(const grail_voice &v);
 bool scan_voice_ok(const grail_voice &v);
 uint32_t voice_warmup(const grail_voice &v);
+uint32_t elems_warmup(const grail_synthesis_elem *elems, size_t n_elems, double jitter_delta_formant_frequency);
 double elems_sharpness(const grail_synthesis_elem *elems, size_t n);
 double batch_sharpness(const grail_ctx *ctx, const grail_batch *batch);
 int fast_tier_for(const grail_ctx *ctx, const grail_batch *batch, int arithmetic);

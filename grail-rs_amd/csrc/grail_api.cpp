@@ -634,10 +634,23 @@ int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
         ds[i].frequency = segs[i].elem.frequency;
         std::memcpy(&elems[(size_t)i * ELEM_FLOATS], &segs[i].elem, sizeof(grail_synthesis_elem));
     }
+    // (what the launch policy asks of a batch, as for phoneme batches; a caller-built elem keeps its frequency as it is,
+    // copy_with_frequency's min(f, 0.5) :445-450 belongs to the Selector)
+    bool plain = true;
+    float min_length = INFINITY, min_pitch = INFINITY;
+    for (uint32_t i = 0; i < n_segs; ++i) {
+        plain = plain && std::isfinite(segs[i].length) && std::isfinite(segs[i].blend_length) &&
+                std::isfinite(segs[i].elem.frequency) && segs[i].blend_length > 0.0f;
+        if (segs[i].length < min_length) min_length = segs[i].length;
+        if (segs[i].elem.frequency < min_pitch) min_pitch = segs[i].elem.frequency;
+    }
     grail_batch *b = new (std::nothrow) grail_batch();
     if (!b) return fail(GRAIL_ERR_OUT_OF_MEMORY, "host allocation failed");
     b->phoneme_mode = false;
     b->any_blend = any_blend;
+    b->plain = plain;
+    b->min_length = min_length;
+    b->min_pitch = min_pitch;
     b->n_segs = n_segs;
     // the sharpness of the batch (elems_sharpness): parameters only ever blend between the elems of two consecutive
     // segments of an utterance (Sequencer::next :897-921), so every such pair is judged like a voice of two phonemes
@@ -661,6 +674,25 @@ int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
         free_batch_buffers(b);
         delete b;
         return rc;
+    }
+    // the warm-up length of the time-split fast kernels for THESE elems (elems_warmup: the slowest filter over the distinct
+    // elems of the batch, the formant-frequency jitter of the voices it names), valid for the voice table of this moment;
+    // 0: the batch does not qualify and fast arithmetic renders it with the lane kernels
+    if (!ctx->voices.empty() && b->max_voice_id < ctx->voices.size()) {
+        double jd = 0.0;
+        bool rates_ok = true;
+        for (const uint32_t v : b->used_voices) {
+            jd = std::fmax(jd, std::fabs((double)ctx->voices[v].jitter_delta_formant_frequency));
+            rates_ok = rates_ok && ctx->voices[v].sample_rate > 0.0f && std::isfinite(ctx->voices[v].sample_rate);
+        }
+        std::vector<grail_synthesis_elem> distinct;
+        std::unordered_set<std::string> seen;
+        for (uint32_t i = 0; i < n_segs; ++i) {
+            if (!segs[i].has_elem) continue;
+            if (seen.emplace((const char *)&segs[i].elem, sizeof(grail_synthesis_elem)).second) distinct.push_back(segs[i].elem);
+        }
+        b->elems_warmup = rates_ok ? elems_warmup(distinct.data(), distinct.size(), jd) : 0u;
+        b->elems_warmup_epoch = ctx->voices_epoch;
     }
     *out = b;
     return GRAIL_OK;

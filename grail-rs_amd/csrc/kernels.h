@@ -89,6 +89,7 @@ struct SynthArgs {
     // time-split fast kernels (synth_kernel<..., SPLIT>): chunk k of every utterance is the samples
     // [split_bounds[k], split_bounds[k + 1]) (multiples of 64; the last bound is `cap`), one lane each
     uint32_t split_chunks;        // K, 0: not a time-split launch
+    uint32_t split_warmup;        // caller-built elems: the warm-up length of the batch (0: the lane's voice has it, DevVoice::warmup)
     uint32_t split_bounds[SPLIT_MAX_CHUNKS + 1];
 };
 

@@ -58,7 +58,8 @@ double family_cost(const grail_ctx *ctx, const Family &f, uint32_t rows, double 
     }
     if (f.split_k) {
         // every lane takes as long as the first chunk's, which renders split_bounds[1] samples and nothing else
-        const double rounds = std::ceil((double)rows * f.split_k / lanes);
+        // (a wave holds 64 utterances at ONE chunk index: ceil(rows / 64) waves per chunk, whatever rows modulo 64 is)
+        const double rounds = std::ceil(std::ceil((double)rows / 64.0) * f.split_k / (double)ctx_simds(ctx));
         // (+ 0.12 ms: what a launch of chunk lanes costs before any of them renders — short utterances see it)
         if (f.fast == 2u) return rounds * ((double)f.split_bounds[1] * mid_ms_per_sample(f.live4 != 0) + 0.12);
         return rounds * ((double)f.split_bounds[1] * (f.live4 ? 15.7 : 23.3) / 96006.0 + 0.12);
@@ -104,7 +105,7 @@ bool batch_live4(const grail_ctx *ctx, const grail_batch *batch)
 void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t fam, Family &f,
                    bool exact_only)
 {
-    const uint64_t simds = ctx_simds(ctx), lanes = ctx_lanes(ctx), cus = (uint64_t)ctx->cus;
+    const uint64_t simds = ctx_simds(ctx), cus = (uint64_t)ctx->cus;
     f = Family();
     f.live4 = batch_live4(ctx, batch) ? 1u : 0u;
     // fast arithmetic is served up to a sharpness of the resonances (elems_sharpness); beyond it the exact kernels run
@@ -153,24 +154,32 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
     // axis of every utterance is cut into chunks with a lane each (synth_kernel<..., SPLIT>): as many chunks as
     // fill the machine, laid out over the batch's longest utterance so that all lanes finish together
     Family split = f;
-    if (ctx->split_option && !ctx->lanes_option && batch->phoneme_mode && ctx->voices_split_ok && batch->plain &&
+    // (which voices / elems qualify: voice_warmup.  A phoneme batch is covered by its voice table; caller-built elems
+    // by the warm-up computed over them at upload, against the voice table of that moment)
+    const bool split_ok = batch->phoneme_mode ? ctx->voices_split_ok
+                                              : (batch->elems_warmup != 0u && batch->elems_warmup_epoch == ctx->voices_epoch);
+    const uint32_t warmup = batch->phoneme_mode ? ctx->max_warmup : batch->elems_warmup;
+    if (ctx->split_option && !ctx->lanes_option && split_ok && batch->plain &&
         out_stride <= 0xFFFFFFFFull && (ctx->split_chunks >= 2 || ctx->split_chunks == 0)) {
         const double sp = ctx->split_span ? std::fmin((double)ctx->split_span, (double)out_stride) : span;
-        int K = ctx->split_chunks ? (int)ctx->split_chunks : (int)std::min<uint64_t>(lanes / fam, SPLIT_MAX_CHUNKS);
+        // as many chunks as give every SIMD one wave: ceil(fam / 64) waves per chunk index (5 000 utterances are 79 waves
+        // per chunk: 12 chunks, not 65 536 / 5 000 = 13, which would be 1 027 waves and a second round for three of them)
+        int K = ctx->split_chunks ? (int)ctx->split_chunks
+                                  : (int)std::min<uint64_t>(simds / (((uint64_t)fam + 63u) / 64u), SPLIT_MAX_CHUNKS);
         K = (int)std::fmin((double)K, sp / 512.0);
         // (a fast-forwarded sample costs the same whatever is rendered afterwards; a rendered sample of eight live
         // formants costs 1.5 x one of four; 0.8 from a sweep, profiles/r03_small_batch.txt)
         const double ff_cost = 1e-3 * (double)ctx->split_ff_permille * (l4ab ? 1.0 : 0.8) * (f.fast == 2u ? 0.6 : 1.0);
         // the largest K <= K whose chunks fit (a chunk must render at least a tile): fitting is monotone in K
-        if (K >= 2 && !split_grid((uint32_t)sp, ctx->max_warmup, K, ff_cost, split.split_bounds)) {
+        if (K >= 2 && !split_grid((uint32_t)sp, warmup, K, ff_cost, split.split_bounds)) {
             int lo = 1, hi = K;                  // lo fits (or is 1), hi does not
             while (hi - lo > 1) {
                 const int mid = (lo + hi) / 2;
-                if (split_grid((uint32_t)sp, ctx->max_warmup, mid, ff_cost, split.split_bounds)) lo = mid;
+                if (split_grid((uint32_t)sp, warmup, mid, ff_cost, split.split_bounds)) lo = mid;
                 else hi = mid;
             }
             K = lo;
-            if (K >= 2) (void)split_grid((uint32_t)sp, ctx->max_warmup, K, ff_cost, split.split_bounds);
+            if (K >= 2) (void)split_grid((uint32_t)sp, warmup, K, ff_cost, split.split_bounds);
         }
         if (K >= 2) {
             split.split_k = K;

@@ -2099,7 +2099,8 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     uint32_t base0 = 0;
     uint32_t reset_at = 0;       // the tile at which this lane's filters start from zero state
     if constexpr (SPLIT) {
-        uint32_t w = slot_used ? VO.warmup : 0u, w_max = w;
+        // (a voice's phonemes decide its warm-up; a batch of caller-built elems brings its own)
+        uint32_t w = slot_used ? (A.split_warmup != 0u ? A.split_warmup : VO.warmup) : 0u, w_max = w;
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
             const uint32_t o = (uint32_t)__shfl_xor((int)w_max, m);

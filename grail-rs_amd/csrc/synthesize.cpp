@@ -56,6 +56,7 @@ static int launch_block(grail_ctx *ctx, const grail_batch *batch, const Family &
     } else {
         if (f.split_k) {
             a.split_chunks = (uint32_t)f.split_k;
+            a.split_warmup = batch->phoneme_mode ? 0u : batch->elems_warmup;
             std::memcpy(a.split_bounds, f.split_bounds, sizeof a.split_bounds);
         }
         e = launch_synth(a, f.L, ctx->stream);

@@ -78,7 +78,9 @@ bool scan_voice_ok(const grail_voice &v)
 // the band-pass decay at nearly the same rate the cascade's n rho^n is solved for instead of rho^n.  Formants that are silent in
 // every phoneme have nothing to converge.  0: the voice does not qualify (a parameter outside the window, or a
 // warm-up longer than 16384 samples).
-uint32_t voice_warmup(const grail_voice &v)
+// (elems_warmup: the same over any set of elems — a voice's phonemes, or the caller-built elems of a batch, between
+// consecutive ones of which the parameters blend — with jd = the largest |jitter_delta_formant_frequency| that applies)
+uint32_t elems_warmup(const grail_synthesis_elem *elems, size_t n_elems, double jd)
 {
     // per-sample decay rate of the band-pass envelope at formant frequency f, bandwidth w (0: not a decaying filter)
     auto svf_rate = [](double f, double w) -> double {
@@ -96,17 +98,17 @@ uint32_t voice_warmup(const grail_voice &v)
         return (z > 0.0 && z < 1.0) ? -std::log(z) : 0.0;
     };
     const double eps = 1.0 / 2097152.0;                     // 2^-21
-    const double jd = std::fabs((double)v.jitter_delta_formant_frequency);
+    jd = std::fabs(jd);
     if (!std::isfinite(jd)) return 0;
     double longest = 0.0;                                   // samples
     bool any = false;
     for (int i = 0; i < NF; ++i) {
         bool audible = false;
-        for (int p = 0; p < NUM_VOICED; ++p) audible = audible || !(v.phonemes[p].formant_amp[i] == 0.0f);
+        for (size_t p = 0; p < n_elems; ++p) audible = audible || !(elems[p].formant_amp[i] == 0.0f);
         if (!audible) continue;
         any = true;
-        for (int p = 0; p < NUM_VOICED; ++p) {
-            const grail_synthesis_elem &e = v.phonemes[p];
+        for (size_t p = 0; p < n_elems; ++p) {
+            const grail_synthesis_elem &e = elems[p];
             const double f = e.formant_freq[i], w = e.formant_bw[i], sm = e.formant_smooth[i];
             if (!(f > 0.0 && f < 0.5 && w > 0.0 && sm > 0.0 && sm < 1.0) || !std::isfinite(w)) return 0;
             // the formant-frequency jitter moves the band-pass by up to +-jitter_delta_formant_frequency (Jitter::next
@@ -131,6 +133,11 @@ uint32_t voice_warmup(const grail_voice &v)
     if (!any) return 64;                                    // nothing audible: any state is the right one
     if (!(longest <= 16384.0)) return 0;
     return ((uint32_t)std::ceil(longest) + 63u) / 64u * 64u;
+}
+
+uint32_t voice_warmup(const grail_voice &v)
+{
+    return elems_warmup(v.phonemes, NUM_VOICED, (double)v.jitter_delta_formant_frequency);
 }
 
 // Fast arithmetic and sharp resonances.  The fast kernels interpolate the filter coefficients of Synthesize::next

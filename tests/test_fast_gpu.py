@@ -1065,3 +1065,73 @@ def test_one_pinned_family_makes_fast_mode_a_function_of_the_utterance_alone(gpu
     finally:
         gpu_ctx.set_option("assume_compute_units", 0)
         gpu_ctx.set_voices(W.single_voice())
+
+
+def _custom_phoneme_set(rng, n, sharp):
+    """n caller-built elems of a voice with more phonemes than the reference's two, the upper three formants silent.
+    sharp: formants up to 0.08 fs with bandwidths of 60 - 200 Hz at 48 kHz (second tolerance tier); else formants below
+    0.05 fs with bandwidths of 0.008 fs and more (first tier)."""
+    elems = []
+    for _ in range(n):
+        e = np.zeros(49, dtype=np.float32)
+        e[0] = 0.0025
+        e[1:9] = np.sort(rng.uniform(0.005, 0.08 if sharp else 0.05, 8))
+        e[9:17] = rng.uniform(0.00125, 0.004, 8) if sharp else rng.uniform(0.008, 0.02, 8)
+        e[17:25] = rng.uniform(0.03, 0.12)
+        e[25:33] = rng.uniform(0.0, 0.3, 8)
+        e[33:41] = rng.uniform(0.0, 0.3, 8)
+        amp = rng.uniform(0.2, 1.0, 8)
+        amp[5:] = 0.0
+        e[41:49] = amp / amp.sum()
+        elems.append(e)
+    return elems
+
+
+@pytest.mark.parametrize("sharp", [False, True])
+@pytest.mark.parametrize("n_utt", [700, 5000])
+def test_time_split_serves_caller_built_elems(gpu_ctx, n_utt, sharp):
+    """grail_synthesize_batch_elems in fast mode, mid-size batches: the time-split kernels take caller-built
+    SequenceElems too — the warm-up length comes from the batch's own elems (computed at upload over the distinct ones)
+    instead of a voice's phonemes.  Against the oracle on sampled utterances; the lane kernels took 3 - 4 x as long."""
+    rng = np.random.default_rng(500 + n_utt + int(sharp))
+    v = G.voice_generic(48000.0)
+    gpu_ctx.set_voices([v])
+    ov = O.Voice.from_buffer_copy(bytes(v))
+    phonemes = _custom_phoneme_set(rng, 6, sharp)
+    gsegs, osegs, offs = [], [], [0]
+    for u in range(n_utt):
+        for i in range(4):
+            has = i > 0 and bool(rng.integers(0, 6))
+            e = phonemes[int(rng.integers(0, len(phonemes)))].copy()
+            e[0] = np.float32(rng.uniform(90, 220)) / np.float32(48000.0)
+            ln, bl = 0.125, float(rng.choice([0.125, 0.0625, 0.03]))
+            gsegs.append(G.SequenceElem(int(has), G.SynthesisElem.from_np(e), ln, bl))
+            osegs.append(O.SequenceElem(int(has), O.SynthesisElem.from_buffer_copy(e.tobytes()), ln, bl))
+        offs.append(len(gsegs))
+    seeds = rng.integers(0, 2 ** 32, n_utt, dtype=np.uint64).astype(np.uint32)
+    stride = 24064
+    gpu_ctx.set_option("arithmetic", 1)
+    try:
+        out, out_len = gpu_ctx.synthesize_elems(gsegs, offs, None, seeds, out_stride=stride)
+        name = gpu_ctx.last_kernel_name()
+        chunks = gpu_ctx.get_option("last_launch_chunks")
+        split_ms = gpu_ctx.last_kernel_ms()
+        gpu_ctx.set_option("time_split", 0)
+        lane, lane_len = gpu_ctx.synthesize_elems(gsegs, offs, None, seeds, out_stride=stride)
+        lane_name, lane_ms = gpu_ctx.last_kernel_name(), gpu_ctx.last_kernel_ms()
+    finally:
+        gpu_ctx.set_option("time_split", 1)
+        gpu_ctx.set_option("arithmetic", 0)
+    assert "SPLIT" in name and chunks >= 2 and ("MID" in name) == sharp, (name, chunks)
+    assert "SPLIT" not in lane_name
+    assert np.array_equal(out_len, lane_len)
+    worst = 0.0
+    for u in rng.choice(n_utt, size=40, replace=False):
+        ref = O.synthesize_sequence(ov, osegs[offs[u]:offs[u + 1]], int(seeds[u]))
+        assert out_len[u] == len(ref), u
+        peak = max(1.0, float(np.abs(ref).max()))
+        worst = max(worst, float(np.abs(out[u, :len(ref)].astype(np.float64) - ref).max()) / peak)
+        assert float(np.abs(lane[u, :len(ref)].astype(np.float64) - ref).max()) <= G.FAST_TOLERANCE * peak
+    print(f"caller-built elems ({'sharp' if sharp else 'tame'}), {n_utt} utterances: {name} x{chunks} {split_ms:.2f} ms (lane kernels {lane_name}: {lane_ms:.2f} ms); "
+          f"worst |fast - oracle| = {worst * 2 ** 23:.1f} * 2^-23")
+    assert worst <= G.FAST_TOLERANCE
