@@ -258,11 +258,15 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       throughput).  Same results either way.
  *   "time_split": 1 (default) / 0 — fast arithmetic, both tiers: blocks of up to half as many utterances as
  *       the device has lanes (32768), of voices whose filters forget their past within 16384 samples, cut every
- *       utterance's time axis into chunks with a wavefront lane each, as many as fill the machine.  A chunk's
+ *       utterance's time axis into chunks with a wavefront lane each, as many as give every SIMD one wave (a wave
+ *       holds 64 utterances at one chunk index: 5000 utterances are 79 waves per chunk and take 12 chunks).  A chunk's
  *       lane fast-forwards the exact per-utterance state to its chunk, starts the filters from zero a warm-up
  *       length earlier (the voice's slowest filter decides: 3904 samples for voices::generic() at 48 kHz,
  *       residual < 2^-21 of the state) and renders its chunk: 4096 utterances x 2 s in 3.3 ms instead of 6.5
- *       (exact).  "time_split_min_utterances" (-1 = the cost model decides; >= 0: smaller batches stay with
+ *       (exact).  Caller-built SequenceElems take these kernels too: the warm-up length is computed when the batch is
+ *       uploaded, over its distinct elems and the jitter of the voices it names (valid until the voice table changes;
+ *       the bench corpus handed over as elems: 4096 utterances in 4.4 ms instead of 11.1).
+ *       "time_split_min_utterances" (-1 = the cost model decides; >= 0: smaller batches stay with
  *       the scan kernel whatever their length); "time_split_chunks" (0 = auto, 2..64) and
  *       "time_split_span_samples" (0 = the batch's longest utterance) pin the grid;
  *       "time_split_ff_cost_permille" (default 165) is the cost of a fast-forwarded sample against a rendered

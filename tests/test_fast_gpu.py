@@ -1092,7 +1092,8 @@ def _custom_phoneme_set(rng, n, sharp):
 def test_time_split_serves_caller_built_elems(gpu_ctx, n_utt, sharp):
     """grail_synthesize_batch_elems in fast mode, mid-size batches: the time-split kernels take caller-built
     SequenceElems too — the warm-up length comes from the batch's own elems (computed at upload over the distinct ones)
-    instead of a voice's phonemes.  Against the oracle on sampled utterances; the lane kernels took 3 - 4 x as long."""
+    instead of a voice's phonemes.  Against the oracle on sampled utterances (utterances of half a second here; the
+    bench corpus as elems: tools/elems_split_bench.py)."""
     rng = np.random.default_rng(500 + n_utt + int(sharp))
     v = G.voice_generic(48000.0)
     gpu_ctx.set_voices([v])
@@ -1112,13 +1113,17 @@ def test_time_split_serves_caller_built_elems(gpu_ctx, n_utt, sharp):
     stride = 24064
     gpu_ctx.set_option("arithmetic", 1)
     try:
-        out, out_len = gpu_ctx.synthesize_elems(gsegs, offs, None, seeds, out_stride=stride)
+        split_ms = lane_ms = 1e9
+        for _ in range(3):                       # (kernel time: the best of three, the first launch runs on idle clocks)
+            out, out_len = gpu_ctx.synthesize_elems(gsegs, offs, None, seeds, out_stride=stride)
+            split_ms = min(split_ms, gpu_ctx.last_kernel_ms())
         name = gpu_ctx.last_kernel_name()
         chunks = gpu_ctx.get_option("last_launch_chunks")
-        split_ms = gpu_ctx.last_kernel_ms()
         gpu_ctx.set_option("time_split", 0)
-        lane, lane_len = gpu_ctx.synthesize_elems(gsegs, offs, None, seeds, out_stride=stride)
-        lane_name, lane_ms = gpu_ctx.last_kernel_name(), gpu_ctx.last_kernel_ms()
+        for _ in range(3):
+            lane, lane_len = gpu_ctx.synthesize_elems(gsegs, offs, None, seeds, out_stride=stride)
+            lane_ms = min(lane_ms, gpu_ctx.last_kernel_ms())
+        lane_name = gpu_ctx.last_kernel_name()
     finally:
         gpu_ctx.set_option("time_split", 1)
         gpu_ctx.set_option("arithmetic", 0)
