@@ -692,6 +692,11 @@ int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
             if (seen.emplace((const char *)&segs[i].elem, sizeof(grail_synthesis_elem)).second) distinct.push_back(segs[i].elem);
         }
         b->elems_warmup = rates_ok ? elems_warmup(distinct.data(), distinct.size(), jd) : 0u;
+        // ... and whether the scan kernel may take them (its window has no IEEE fallback; pitches as the Selector
+        // would have left them: at most 1/2)
+        float max_pitch = 0.0f;
+        for (uint32_t i = 0; i < n_segs; ++i) max_pitch = std::fmax(max_pitch, segs[i].elem.frequency);
+        b->elems_scan_ok = rates_ok && max_pitch <= 0.5f && scan_elems_ok(distinct.data(), distinct.size(), (float)jd);
         b->elems_warmup_epoch = ctx->voices_epoch;
     }
     *out = b;

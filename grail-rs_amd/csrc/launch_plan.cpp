@@ -194,7 +194,8 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
     // (no IEEE fallback).
     Family scan = f;
     if (f.fast == 1u && ctx->scan_option && !ctx->lanes_option && (int64_t)fam * (l4ab ? 4 : 7) <= 4 * scan_max_utts(ctx) &&
-        batch->phoneme_mode && ctx->voices_scan_ok && batch->plain && batch->min_length >= 2.0f * ctx->max_dt &&
+        ctx->voices_scan_ok && (batch->phoneme_mode || (batch->elems_scan_ok && batch->elems_warmup_epoch == ctx->voices_epoch)) &&
+        batch->plain && batch->min_length >= 2.0f * ctx->max_dt &&
         batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f) {
         scan.scan = true;
         scan.live4 = l4ab ? 1u : 0u;                          // (the scan kernel takes any blend length)

@@ -295,11 +295,11 @@ __global__ __launch_bounds__(SPLIT ? 192 : 128) __attribute__((amdgpu_waves_per_
                         if (uni(clk_first < 0.0f)) {                                // :864
                             if (cur.some && nxt.some) {                             // :868
                                 cur = nxt;
-                                fetch_seg(nxt, A.segs, seg_pos, seg_end, true, VO.elem_base);
+                                fetch_seg(nxt, A.segs, seg_pos, seg_end, A.phoneme_mode != 0u, VO.elem_base);
                                 clk_first += cur.length;                            // :873
                             } else if (!cur.some && !nxt.some) {                    // :876
-                                fetch_seg(cur, A.segs, seg_pos, seg_end, true, VO.elem_base);
-                                fetch_seg(nxt, A.segs, seg_pos, seg_end, true, VO.elem_base);
+                                fetch_seg(cur, A.segs, seg_pos, seg_end, A.phoneme_mode != 0u, VO.elem_base);
+                                fetch_seg(nxt, A.segs, seg_pos, seg_end, A.phoneme_mode != 0u, VO.elem_base);
                                 if (cur.some) clk_first += cur.length;              // :881-883
                             } else {
                                 finished = true;                                    // :886

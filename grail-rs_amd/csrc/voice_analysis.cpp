@@ -48,15 +48,24 @@ bool live4_ok(const grail_voice &v)
 // with the jitter margin, and the jitter parameters must be sane.  SynthesisElem::silent() qualifies.
 bool scan_voice_ok(const grail_voice &v)
 {
-    constexpr float X_LO = 9.5367431640625e-07f, X_HI = 0.5f - 9.5367431640625e-07f;
-    constexpr float W_LO = 1.8189894035458565e-12f, W_HI = 512.0f;
     const float amp_scale = 0.5f * v.jitter_delta_amplitude;
     const float jm = 1.002f * std::fabs(v.jitter_delta_formant_frequency);
     bool ok = std::isfinite(amp_scale) && (jm <= 1.0f) && (v.jitter_frequency >= 0.0f) &&
               (v.jitter_frequency <= 0.25f) && (v.sample_rate > 0.0f) && std::isfinite(v.sample_rate) &&
               std::isfinite(v.jitter_delta_frequency);
-    for (int p = 0; p < NUM_VOICED && ok; ++p) {
-        const grail_synthesis_elem &e = v.phonemes[p];
+    return ok && scan_elems_ok(v.phonemes, NUM_VOICED, v.jitter_delta_formant_frequency);
+}
+
+// ... the part of it that concerns the elems (a voice's phonemes, or the caller-built elems of a batch with the
+// largest |jitter_delta_formant_frequency| of the voices it names)
+bool scan_elems_ok(const grail_synthesis_elem *elems, size_t n_elems, float jitter_delta_formant_frequency)
+{
+    constexpr float X_LO = 9.5367431640625e-07f, X_HI = 0.5f - 9.5367431640625e-07f;
+    constexpr float W_LO = 1.8189894035458565e-12f, W_HI = 512.0f;
+    const float jm = 1.002f * std::fabs(jitter_delta_formant_frequency);
+    bool ok = jm <= 1.0f;
+    for (size_t p = 0; p < n_elems && ok; ++p) {
+        const grail_synthesis_elem &e = elems[p];
         for (int i = 0; i < NF && ok; ++i) {
             const float f = e.formant_freq[i], w = e.formant_bw[i];
             ok = std::isfinite(e.formant_amp[i]) && std::isfinite(e.formant_breath[i]) &&

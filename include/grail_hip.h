@@ -245,8 +245,8 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       GRAIL_FAST_TOLERANCE (DESIGN.md "Fast mode"; tests/test_fast_gpu.py: configs 2 / 3 / 4 at full size,
  *       edge cases, random voice tables of any sharpness).  2 = the second tier whatever the voices.  This is
  *       the ONE knob that changes result bits.
- *   "time_parallel_scan": 1 (default) / 0 — fast arithmetic, first tier: blocks of few utterances whose
- *       every parameter is inside the safe window run one workgroup per utterance with the time axis across
+ *   "time_parallel_scan": 1 (default) / 0 — fast arithmetic, first tier: blocks of few utterances (PhonemeElems or
+ *       caller-built SequenceElems) whose every parameter is inside the safe window run one workgroup per utterance with the time axis across
  *       the lanes and the filter recurrences solved by parallel scans (csrc/scan_kernels.hip): 256 utterances
  *       x 2 s in 1.15 ms instead of 6.5 ms (exact arithmetic).  A cost model picks between it, the time-split
  *       kernels and the lane kernels: ~1500 utterances of 2 s, ~6000 of 0.25 s (a time-split chunk pays a

@@ -1088,9 +1088,9 @@ def _custom_phoneme_set(rng, n, sharp):
 
 
 @pytest.mark.parametrize("sharp", [False, True])
-@pytest.mark.parametrize("n_utt", [700, 5000])
+@pytest.mark.parametrize("n_utt", [90, 700, 5000])
 def test_time_split_serves_caller_built_elems(gpu_ctx, n_utt, sharp):
-    """grail_synthesize_batch_elems in fast mode, mid-size batches: the time-split kernels take caller-built
+    """grail_synthesize_batch_elems in fast mode, small and mid-size batches: the scan and time-split kernels take caller-built
     SequenceElems too — the warm-up length comes from the batch's own elems (computed at upload over the distinct ones)
     instead of a voice's phonemes.  Against the oracle on sampled utterances (utterances of half a second here; the
     bench corpus as elems: tools/elems_split_bench.py)."""
@@ -1127,8 +1127,14 @@ def test_time_split_serves_caller_built_elems(gpu_ctx, n_utt, sharp):
     finally:
         gpu_ctx.set_option("time_split", 1)
         gpu_ctx.set_option("arithmetic", 0)
-    assert "SPLIT" in name and chunks >= 2 and ("MID" in name) == sharp, (name, chunks)
-    assert "SPLIT" not in lane_name
+    if n_utt <= 700 and not sharp:
+        # few utterances of the first tier: the time-parallel scan kernel (it reads caller-built elems like phonemes)
+        assert "scan_kernel" in name, name
+    elif n_utt == 90:
+        pass                                         # (sharp and few: second-tier time-split or an exact family, by cost)
+    else:
+        assert "SPLIT" in name and chunks >= 2 and ("MID" in name) == sharp, (name, chunks)
+    assert not ("synth_kernel" in lane_name and "SPLIT" in lane_name), lane_name
     assert np.array_equal(out_len, lane_len)
     worst = 0.0
     for u in rng.choice(n_utt, size=40, replace=False):
@@ -1137,6 +1143,9 @@ def test_time_split_serves_caller_built_elems(gpu_ctx, n_utt, sharp):
         peak = max(1.0, float(np.abs(ref).max()))
         worst = max(worst, float(np.abs(out[u, :len(ref)].astype(np.float64) - ref).max()) / peak)
         assert float(np.abs(lane[u, :len(ref)].astype(np.float64) - ref).max()) <= G.FAST_TOLERANCE * peak
-    print(f"caller-built elems ({'sharp' if sharp else 'tame'}), {n_utt} utterances: {name} x{chunks} {split_ms:.2f} ms (lane kernels {lane_name}: {lane_ms:.2f} ms); "
+    # (kernel times: tools/elems_split_bench.py — the one-call form renders in blocks of 4 096 rows, so the last
+    # launch's time says little here)
+    del split_ms, lane_ms
+    print(f"caller-built elems ({'sharp' if sharp else 'tame'}), {n_utt} utterances: {name} x{chunks} (time_split = 0: {lane_name}); "
           f"worst |fast - oracle| = {worst * 2 ** 23:.1f} * 2^-23")
     assert worst <= G.FAST_TOLERANCE
