@@ -138,6 +138,7 @@ struct grail_batch {
     uint32_t elems_warmup = 0;      // elem mode: warm-up length of the time-split kernels over the batch's distinct elems and the
                                     // jitter of the voices it names (elems_warmup()); 0: the batch does not qualify
     uint64_t elems_warmup_epoch = 0;   // ... computed against this voice table (ctx->voices_epoch)
+    bool elems_live4_ok = false;    // elem mode: formants 5-8 of every elem (and the voices named) can be left out (live4_ok); same epoch
     bool elems_scan_ok = false;     // elem mode: every elem inside the scan kernel's window (scan_elems_ok), pitches <= 1/2; same epoch
     std::vector<uint32_t> used_voices;   // the distinct voice ids of the batch, ascending
     // the launch plan of the last synthesis call of this batch (plan_blocks lays out time-split grids by bisection: a
@@ -192,6 +193,7 @@ int check_ready(grail_ctx *ctx, const grail_batch *batch);
 // voice_analysis.cpp: what a voice qualifies for (four-formant kernels, scan kernel, time-split warm-up), the predicted
 // deviation of fast arithmetic (sharpness), the tier a batch is served in, the chunk grid of a time-split launch
 bool live4_ok(const grail_voice &v);
+bool live4_elems_ok(const grail_synthesis_elem *elems, size_t n_elems, float jitter_delta_formant_frequency);
 bool scan_voice_ok(const grail_voice &v);
 bool scan_elems_ok(const grail_synthesis_elem *elems, size_t n_elems, float jitter_delta_formant_frequency);
 uint32_t voice_warmup(const grail_voice &v);

@@ -691,6 +691,15 @@ int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
             if (!segs[i].has_elem) continue;
             if (seen.emplace((const char *)&segs[i].elem, sizeof(grail_synthesis_elem)).second) distinct.push_back(segs[i].elem);
         }
+        // can formants 5-8 be left out (the four-formant kernels)?  As for a voice table (live4_ok): the scalars of the
+        // voices named, and every distinct elem of the batch
+        bool voices4 = true;
+        for (const uint32_t v : b->used_voices) {
+            grail_voice scalars = ctx->voices[v];
+            for (int ph = 0; ph < NUM_VOICED; ++ph) grail_elem_silent(&scalars.phonemes[ph]);     // (only the scalars count here)
+            voices4 = voices4 && live4_ok(scalars);
+        }
+        b->elems_live4_ok = voices4 && live4_elems_ok(distinct.data(), distinct.size(), (float)jd);
         b->elems_warmup = rates_ok ? elems_warmup(distinct.data(), distinct.size(), jd) : 0u;
         // ... and whether the scan kernel may take them (its window has no IEEE fallback; pitches as the Selector
         // would have left them: at most 1/2)

@@ -78,7 +78,10 @@ double family_cost(const grail_ctx *ctx, const Family &f, uint32_t rows, double 
 
 bool batch_half_capable(const grail_ctx *ctx, const grail_batch *batch)
 {
-    return ctx->skip_silent_option && batch->phoneme_mode && ctx->voices_upper_silent;
+    // (caller-built elems: judged at upload over the batch's distinct elems, against the voice table of that moment)
+    if (!batch->phoneme_mode)
+        return ctx->skip_silent_option && batch->elems_live4_ok && batch->elems_warmup_epoch == ctx->voices_epoch;
+    return ctx->skip_silent_option && ctx->voices_upper_silent;
 }
 
 // formants 5-8 left out altogether: the table qualifies (live4_ok); every segment is at least
@@ -87,7 +90,7 @@ bool batch_half_capable(const grail_ctx *ctx, const grail_batch *batch)
 // saw every formant is fed from stay finite (a dead formant fed +-inf would emit NaN)
 bool batch_live4_any_blend(const grail_ctx *ctx, const grail_batch *batch)
 {
-    return batch_half_capable(ctx, batch) && ctx->voices_live4_ok && batch->plain &&
+    return batch_half_capable(ctx, batch) && (!batch->phoneme_mode || ctx->voices_live4_ok) && batch->plain &&
            batch->min_length >= 2.0f * ctx->max_dt &&
            batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f;
 }

@@ -20,16 +20,25 @@ namespace host {
 // formants").  SynthesisElem::silent() (0.25 / 0.25 / 0.25 / 0 / 0 / 0) satisfies all of it.
 bool live4_ok(const grail_voice &v)
 {
-    constexpr float X_LO = 9.5367431640625e-07f, X_HI = 0.5f - 9.5367431640625e-07f;
-    constexpr float W_LO = 1.8189894035458565e-12f, W_HI = 512.0f;
     const float amp_scale = 0.5f * v.jitter_delta_amplitude;
     const float jm = 1.002f * std::fabs(v.jitter_delta_formant_frequency);
-    bool ok = (amp_scale >= 0.0f) && (amp_scale <= 0.25f) && (jm <= 1.0f) &&
-              (v.jitter_frequency >= 0.0f) && (v.jitter_frequency <= 1.0f) &&
-              (v.sample_rate > 0.0f) && std::isfinite(v.sample_rate) &&
-              std::isfinite(v.jitter_delta_frequency);
-    for (int p = 0; p < NUM_VOICED && ok; ++p) {
-        const grail_synthesis_elem &e = v.phonemes[p];
+    const bool ok = (amp_scale >= 0.0f) && (amp_scale <= 0.25f) && (jm <= 1.0f) &&
+                    (v.jitter_frequency >= 0.0f) && (v.jitter_frequency <= 1.0f) &&
+                    (v.sample_rate > 0.0f) && std::isfinite(v.sample_rate) &&
+                    std::isfinite(v.jitter_delta_frequency);
+    return ok && live4_elems_ok(v.phonemes, NUM_VOICED, v.jitter_delta_formant_frequency);
+}
+
+// ... the part of it that concerns the elems (a voice's phonemes, or the caller-built elems of a batch with the largest
+// |jitter_delta_formant_frequency| of the voices it names)
+bool live4_elems_ok(const grail_synthesis_elem *elems, size_t n_elems, float jitter_delta_formant_frequency)
+{
+    constexpr float X_LO = 9.5367431640625e-07f, X_HI = 0.5f - 9.5367431640625e-07f;
+    constexpr float W_LO = 1.8189894035458565e-12f, W_HI = 512.0f;
+    const float jm = 1.002f * std::fabs(jitter_delta_formant_frequency);
+    bool ok = jm <= 1.0f;
+    for (size_t p = 0; p < n_elems && ok; ++p) {
+        const grail_synthesis_elem &e = elems[p];
         for (int i = NF / 2; i < NF && ok; ++i) {
             uint32_t bits;
             std::memcpy(&bits, &e.formant_amp[i], sizeof bits);

@@ -227,7 +227,8 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       their band-pass filters are skipped (voices::generic() has four such formants,
  *       src/voices/generic.rs:19,31).  When in addition the whole voice table and the batch
  *       guarantee it for every sample (formants 5-8 of every phoneme: amplitude +0, parameters
- *       inside the safe window; no segment shorter than two samples; one-shot phoneme batches),
+ *       inside the safe window; no segment shorter than two samples; phoneme batches, and batches of
+ *       caller-built elems whose every distinct elem qualifies — checked at upload),
  *       formants 5-8 are not laid out over the lanes at all.  0 forces the literal evaluation
  *       of all eight.
  *   "small_batch_pipeline": 1 (default) / 0 — blocks of at most 32 utterances per compute unit (8192 on

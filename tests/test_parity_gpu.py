@@ -706,3 +706,68 @@ def test_hostile_formant_parameters_propagate_as_in_the_reference(gpu_ctx, lanes
         assert same, (what[vids[u]], u, at, out[u, at], ref[u, at])
         nonfinite += int(not np.isfinite(ref[u, :n]).all())
     assert nonfinite > 20          # (the table does produce NaN / Inf rows: the comparison is not vacuous)
+
+
+def _as_sequence_elems(voices, segs, offs, vids):
+    """The PhonemeElems of a batch as the SequenceElems the Selector would hand on (src/lib.rs:990-1005)."""
+    import ctypes as C
+    arr = (G.SequenceElem * max(len(segs), 1))()
+    for u in range(len(offs) - 1):
+        v = voices[int(vids[u])]
+        for i in range(int(offs[u]), int(offs[u + 1])):
+            ph = int(segs["phoneme"][i])
+            arr[i].has_elem = 1 if ph >= G.PH_A else 0
+            if ph >= G.PH_A:
+                arr[i].elem = v.phonemes[ph - G.PH_A]
+            arr[i].elem.frequency = min(float(segs["frequency"][i]), 0.5)
+            arr[i].length = float(segs["length"][i])
+            arr[i].blend_length = float(segs["blend_length"][i])
+    return arr
+
+
+@pytest.mark.parametrize("n_utt,blend", [(300, 2.0 ** -6), (3000, 2.0 ** -6), (20000, 2.0 ** -6), (3000, 0.013)])
+def test_caller_built_elems_get_the_four_formant_kernels(gpu_ctx, n_utt, blend):
+    """grail_synthesize_batch_elems with the elems of voices::generic(): formants 5-8 are silent in every elem of the
+    batch, which the host establishes at upload over the batch's distinct elems (as it does for a voice table), so the
+    four-formant kernels and pipelines serve caller-built elems too — the same bits as the PhonemeElem batch the elems
+    were made from (the Selector does nothing else), and the oracle's."""
+    import ctypes as C
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
+    segs, offs, vids, seeds = W.make_batch(n_utt, length=0.02, blend_length=blend)
+    stride = W.max_samples(length=0.02)
+    arr = _as_sequence_elems(voices, segs, offs, vids)
+    h = C.c_void_p()
+    G._check(G.load().grail_batch_upload_elems(gpu_ctx.handle, C.cast(arr, C.c_void_p), offs.ctypes.data, vids.ctypes.data,
+                                               seeds.ctypes.data, n_utt, C.byref(h)))
+    ebatch = G.Batch(gpu_ctx, h, n_utt)
+    pbatch = gpu_ctx.upload(segs, offs, vids, seeds)
+    d_e = gpu_ctx.device_alloc(n_utt * stride * 4)
+    d_p = gpu_ctx.device_alloc(n_utt * stride * 4)
+    d_le = gpu_ctx.device_alloc(n_utt * 4)
+    d_lp = gpu_ctx.device_alloc(n_utt * 4)
+    try:
+        pbatch.synthesize_async(d_p, stride, d_lp)
+        gpu_ctx.sync()
+        p_name, p_formants = gpu_ctx.last_kernel_name(), gpu_ctx.get_option("last_launch_formants")
+        ebatch.synthesize_async(d_e, stride, d_le)
+        gpu_ctx.sync()
+        e_name, e_formants = gpu_ctx.last_kernel_name(), gpu_ctx.get_option("last_launch_formants")
+        md, _, bad = gpu_ctx.compare(d_e, d_p, stride, d_le, d_lp, n_utt)
+        rows = np.zeros((8, stride), dtype=np.float32)
+        lens = np.zeros(n_utt, dtype=np.uint32)
+        gpu_ctx.d2h(rows, d_e, rows.nbytes)
+        gpu_ctx.d2h(lens, d_le, lens.nbytes)
+    finally:
+        for p in (d_e, d_p, d_le, d_lp):
+            gpu_ctx.device_free(p)
+        ebatch.free()
+        pbatch.free()
+    want = 4 if blend == 2.0 ** -6 else 8         # (exact arithmetic: the four-formant lane kernels need power-of-two blends)
+    assert e_formants == p_formants == want, (e_name, p_name)
+    assert e_name == p_name, (e_name, p_name)
+    assert float(md.max()) == 0.0 and int(bad.sum()) == 0
+    ref, ref_len = O.synthesize_batch(ovoices(voices), segs[:offs[8]], offs[:9], vids[:8], seeds[:8], stride)
+    assert np.array_equal(lens[:8], ref_len)
+    for u in range(8):
+        assert np.array_equal(rows[u, :ref_len[u]].view(np.uint32), ref[u, :ref_len[u]].view(np.uint32)), u

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Caller-built SequenceElems (grail_synthesize_batch_elems) in fast mode: the bench corpus handed over as elems — every
-segment carrying the phoneme's elem itself, which is what a caller with a voice of its own does — with and without the
-time-split kernels, next to the same batch as PhonemeElems.   usage: elems_split_bench.py [n ...]"""
+"""Caller-built SequenceElems (grail_synthesize_batch_elems): the bench corpus handed over as elems — every
+segment carrying the phoneme's elem itself, which is what a caller with a voice of its own does — exact and fast (with and without the
+time-split kernels), next to the same batch as PhonemeElems.   usage: elems_split_bench.py [n ...]"""
 import os
 import sys
 
@@ -37,9 +37,11 @@ for n_voices in (1, 8):
         pbatch = ctx.upload(segs, offs, vids, seeds)
         d_out = ctx.device_alloc(n * stride * 4)
         d_len = ctx.device_alloc(n * 4)
-        ctx.set_option("arithmetic", 1)
         row = [f"voices={n_voices} n={n:6d}:"]
-        for what, batch, split in (("PhonemeElems", pbatch, 1), ("SequenceElems", ebatch, 1), ("SequenceElems, time_split = 0", ebatch, 0)):
+        for what, batch, split, fast in (("exact: PhonemeElems", pbatch, 1, 0), ("SequenceElems", ebatch, 1, 0),
+                                         ("fast: PhonemeElems", pbatch, 1, 1), ("SequenceElems", ebatch, 1, 1),
+                                         ("SequenceElems, time_split = 0", ebatch, 0, 1)):
+            ctx.set_option("arithmetic", fast)
             ctx.set_option("time_split", split)
             ms = []
             for _ in range(4):
