@@ -66,7 +66,8 @@ struct SynthArgs {
     uint32_t phoneme_mode;        // 1: run the Selector on the device
     uint32_t skip_silent;         // 1: skip the band-pass of formant vectors proven silent (same bits)
     uint32_t half_capable;        // host hint: every voice has amplitude 0 in formants 5-8 of every
-                                  // phoneme (phoneme batches), so the half-live loops can be used
+                                  // phoneme (phoneme batches) / every elem of the batch has (caller-built elems,
+                                  // with parameters that keep them at +0: live4_elems_ok), so the half-live loops can be used
     uint32_t live4;               // host-verified: formants 5-8 contribute exactly +0.0 for the whole
                                   // batch (see voice_analysis.cpp live4_ok); selects the NFA = 4 kernels
     uint32_t pipe;                // live4 batches small enough to leave SIMDs idle: the four-wave

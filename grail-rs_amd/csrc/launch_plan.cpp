@@ -110,22 +110,22 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
 {
     const uint64_t simds = ctx_simds(ctx), cus = (uint64_t)ctx->cus;
     f = Family();
-    f.live4 = batch_live4(ctx, batch) ? 1u : 0u;
+    // (the lane kernels and the pipelined workgroups have four-formant instantiations for every blend length; the lean
+    // stream kernels for power-of-two blend lengths only: batch_live4)
+    f.live4 = batch_live4_any_blend(ctx, batch) ? 1u : 0u;
     // fast arithmetic is served up to a sharpness of the resonances (elems_sharpness); beyond it the exact kernels run
     // ... in the tier the sharpness allows: 1 = coefficients interpolated, 2 = the reference's own coefficients (MID)
     f.fast = exact_only ? 0u : (uint32_t)fast_tier(ctx, batch);
     // (MID kernels exist one-shot with one lane per utterance, and time-split: a pinned wider mapping gets the exact kernels)
     if (f.fast == 2u && ctx->lanes_option > 1) f.fast = 0u;
-    // (the fast lane kernels have four-formant instantiations for every blend length)
-    if (f.fast && batch_live4_any_blend(ctx, batch)) f.live4 = 1u;
     int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(fam, simds);
     if (f.fast == 2u) L = 1;          // (before the four-formant layout is decided: eight lanes would give it up)
     // small batches leave SIMDs idle: four-wave workgroups (one wave renders 16 utterances, one carries
     // the per-utterance chain, two prepare the filter coefficients), up to two per CU (tools/pipe4_range.py:
     // 11.5 ms up to 4 096 utterances, 15.7 up to 8 192 where the lane kernels take 18.0; three per CU lose)
-    const bool want_pipe4 = batch_live4(ctx, batch) && !ctx->lanes_option && ctx->pipeline_option &&
+    const bool want_pipe4 = batch_live4_any_blend(ctx, batch) && !ctx->lanes_option && ctx->pipeline_option &&
                             (int64_t)(((uint64_t)fam + 15) / 16) <= pipe4_groups(ctx);
-    const bool want_pipe8 = !batch_live4(ctx, batch) && !ctx->lanes_option && ctx->pipeline_option && !batch->any_blend &&
+    const bool want_pipe8 = !batch_live4_any_blend(ctx, batch) && !ctx->lanes_option && ctx->pipeline_option &&
                             (int64_t)(((uint64_t)fam + 7) / 8) <= pipe8_groups(ctx);
     // one workgroup per CU suffices: rounds of 32 samples instead of 16 (pipe = 2)
     const uint32_t pipe4_kind = ctx->pipe_round32 && ((uint64_t)fam + 15) / 16 <= cus ? 2u : 1u;
@@ -242,7 +242,7 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
     // satisfy the tolerance trivially
     if (want_pipe4 || want_pipe8) {
         f.fast = 0u;
-        f.live4 = batch_live4(ctx, batch) ? 1u : 0u;
+        f.live4 = batch_live4_any_blend(ctx, batch) ? 1u : 0u;
         f.pipe = want_pipe4 ? pipe4_kind : pipe8_kind;
         f.L = want_pipe4 ? 4 : 8;
     }

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     static_assert(!MID || FAST, "MID is a flavour of the tolerance kernels");
     static_assert(!SPLIT || (FAST && !STREAM && L == 1 && WAVES == 1 && T == 64), "SPLIT");
     static_assert(NFA == NF || (NFA == 4 && !HALF), "NFA");
-    static_assert(!PIPE || (WAVES == 4 && NFA / L == 1 && L >= 4 && !STREAM && !HALF && !ANYBL && T % 4 == 0), "PIPE");
+    static_assert(!PIPE || (WAVES == 4 && NFA / L == 1 && L >= 4 && !STREAM && !HALF && T % 4 == 0), "PIPE");
     constexpr int FPL = NFA / L;         // formants per lane
     constexpr int W = FPL >= 2 ? 2 : 1;  // formants per packed value
     constexpr int NV = FPL / W;          // packed values per lane and field
@@ -604,17 +604,22 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     bool quiet_ok = false;
 
     bool finished = false;   // the chain has returned None (persistent); `done` also covers pauses
-    // one-shot phoneme batches: the lane's upper formants have amplitude +0 in every phoneme of
-    // the voice table, so nothing in this launch can ever make them audible
+    // one-shot batches: the lane's upper formants have amplitude +0 in every phoneme of the voice table (phoneme
+    // batches: looked up here) or in every elem of the batch (caller-built elems: formants 5-8, established by the
+    // host at upload — half_capable), so nothing in this launch can ever make them audible
     bool upper_never_live = false;
     if constexpr (HALF && NV >= 2 && !STREAM) {
-        upper_never_live = phoneme_mode;
+        if (phoneme_mode) {
+            upper_never_live = true;
 #pragma unroll
-        for (int p = 0; p < NUM_VOICED; ++p)
+            for (int p = 0; p < NUM_VOICED; ++p)
 #pragma unroll
-            for (int i = (NV / 2) * W; i < NV * W; ++i)
-                upper_never_live = upper_never_live &&
-                    (__float_as_uint(elems[(size_t)(VO.elem_base + p) * ELEM_FLOATS + F_AMP + f0 + i]) == 0u);
+                for (int i = (NV / 2) * W; i < NV * W; ++i)
+                    upper_never_live = upper_never_live &&
+                        (__float_as_uint(elems[(size_t)(VO.elem_base + p) * ELEM_FLOATS + F_AMP + f0 + i]) == 0u);
+        } else {
+            upper_never_live = A.half_capable != 0u && f0 + (NV / 2) * W >= NF / 2;
+        }
     }
     bool smooth_uniform = false; // this pair: X.smooth and Y.smooth are each one number for all formants
     bool upper_silent = false;   // this pair: the lane's upper NV/2 formant vectors are silent

@@ -24,10 +24,12 @@ void launch_one_exact(const SynthArgs &args, hipStream_t stream)
             start<L, T, WAVES, MINW, true, false, false, 4>(args, grid, block, stream);
             return;
         }
-        if (!args.state && !args.any_blend && args.live4) {
+        if (!args.state && args.live4) {
             // L = 4 parks 4 floats per sample instead of 8: room for the 64-step tiles of L = 8
+            // (any blend length: the four-formant layout does not depend on how alpha is divided out)
             constexpr int T4 = L == 4 ? 64 : T;
-            start<L, T4, WAVES, MINW, false, false, false, 4>(args, grid, block, stream);
+            if (args.any_blend) start<L, T4, WAVES, MINW, false, false, true, 4>(args, grid, block, stream);
+            else start<L, T4, WAVES, MINW, false, false, false, 4>(args, grid, block, stream);
             return;
         }
     }

@@ -763,11 +763,65 @@ def test_caller_built_elems_get_the_four_formant_kernels(gpu_ctx, n_utt, blend):
             gpu_ctx.device_free(p)
         ebatch.free()
         pbatch.free()
-    want = 4 if blend == 2.0 ** -6 else 8         # (exact arithmetic: the four-formant lane kernels need power-of-two blends)
-    assert e_formants == p_formants == want, (e_name, p_name)
+    assert e_formants == p_formants == 4, (e_name, p_name)      # (power-of-two blend lengths or not)
     assert e_name == p_name, (e_name, p_name)
     assert float(md.max()) == 0.0 and int(bad.sum()) == 0
     ref, ref_len = O.synthesize_batch(ovoices(voices), segs[:offs[8]], offs[:9], vids[:8], seeds[:8], stride)
     assert np.array_equal(lens[:8], ref_len)
     for u in range(8):
         assert np.array_equal(rows[u, :ref_len[u]].view(np.uint32), ref[u, :ref_len[u]].view(np.uint32)), u
+
+
+@pytest.mark.parametrize("n_voices", [1, 8])
+@pytest.mark.parametrize("n_utt", [17, 300])
+def test_small_batch_pipeline_with_any_blend_length(gpu_ctx, n_utt, n_voices):
+    """Blend lengths that are not powers of two (0.3 s, 0.013 s, 1/3 s among powers of two): the pipelined workgroups
+    take them too — their chain wave divides the clock by the blend length (the short exact division) where it
+    multiplied by 2^-k — with four live formants and with eight, rounds of 32 and of 16 samples.  Whole 2-second
+    utterances and short ones against the oracle, pipeline on and off."""
+    voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
+    rng = np.random.default_rng(70 + n_utt + n_voices)
+    try:
+        for length, r32 in ((0.5, 1), (0.5, 0), (0.037, 1)):
+            segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=n_voices, length=length)
+            segs["blend_length"] = rng.choice([0.3, 0.013, 1.0 / 3.0, 0.25, 0.5, 0.0625], len(segs)).astype(np.float32)
+            stride = W.max_samples(length=length)
+            ref, ref_len = O.synthesize_batch(ovoices(voices), segs, offs, vids, seeds, stride)
+            gpu_ctx.set_option("pipeline_round32", r32)
+            for pipeline in (1, 0):
+                gpu_ctx.set_option("small_batch_pipeline", pipeline)
+                gpu_ctx.set_voices(voices)
+                out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+                name = gpu_ctx.last_kernel_name()
+                assert gpu_ctx.get_option("last_launch_pipelined") == pipeline, name
+                assert "ANYBL" in name, name
+                assert gpu_ctx.get_option("last_launch_formants") == (4 if n_voices == 1 and pipeline else 8), name
+                assert_bit_identical(out, out_len, ref, ref_len, f"{name} length={length}")
+    finally:
+        gpu_ctx.set_option("small_batch_pipeline", 1)
+        gpu_ctx.set_option("pipeline_round32", 1)
+        gpu_ctx.set_voices(W.single_voice())
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4])
+def test_four_formant_lane_kernels_with_any_blend_length(gpu_ctx, lanes):
+    """The four-formant lane kernels (voices::generic(): formants 5-8 never laid out) for blend lengths that are not
+    powers of two: random batches against the oracle, which evaluates all eight."""
+    rng = np.random.default_rng(90 + lanes)
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
+    n_utt = 200
+    segs, offs, vids, seeds = W.make_batch(n_utt, length=0.03)
+    segs["length"] = rng.uniform(0.004, 0.05, len(segs)).astype(np.float32)
+    segs["blend_length"] = rng.choice([0.3, 0.013, 1.0 / 3.0, 0.007, 0.0625, 0.05], len(segs)).astype(np.float32)
+    stride = 9984
+    ref, ref_len = O.synthesize_batch(ovoices(voices), segs, offs, vids, seeds, stride)
+    assert ref_len.max() < stride
+    gpu_ctx.set_option("lanes_per_utterance", lanes)
+    try:
+        out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+        name = gpu_ctx.last_kernel_name()
+    finally:
+        gpu_ctx.set_option("lanes_per_utterance", 0)
+    assert "ANYBL" in name and "NFA=4" in name, name
+    assert_bit_identical(out, out_len, ref, ref_len, name)
