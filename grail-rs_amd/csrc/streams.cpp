@@ -19,7 +19,7 @@ int grail_stream_open(grail_ctx *ctx, const grail_batch *batch, grail_stream **o
     s->batch = batch;
     s->half_capable = batch_half_capable(ctx, batch);
     s->any_blend = batch->any_blend;
-    s->live4 = batch_live4(ctx, batch);
+    s->live4 = batch_live4_any_blend(ctx, batch);      // (the lean resumable kernels exist for every blend length)
     s->voices_epoch = ctx->voices_epoch;
     s->L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(batch->n_utt, ctx_simds(ctx));
     if (s->live4) {

@@ -11,7 +11,9 @@ void launch_mid_l1(const SynthArgs &args, hipStream_t stream)
         // resumable (streams of sharp voices, one lane per utterance): the lean four-formant instantiation when the
         // stream was opened for it, the general one otherwise — the state layout is the exact kernels'
         const dim3 grid = lane_grid<1, 1>(args), block(64);
-        if (!args.any_blend && args.live4) start<1, 32, 1, 1, true, false, false, 4, false, true, 2, false, true>(args, grid, block, stream);
+        // (a stream opened for the four-formant layout keeps it whatever arithmetic a call runs: any blend length)
+        if (args.live4 && args.any_blend) start<1, 32, 1, 1, true, false, true, 4, false, true, 2, false, true>(args, grid, block, stream);
+        else if (args.live4) start<1, 32, 1, 1, true, false, false, 4, false, true, 2, false, true>(args, grid, block, stream);
         else start<1, 32, 1, 1, true, false, true, NF, false, true, 2, false, true>(args, grid, block, stream);
         return;
     }

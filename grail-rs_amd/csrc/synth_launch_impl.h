@@ -20,8 +20,10 @@ void launch_one_exact(const SynthArgs &args, hipStream_t stream)
 {
     const dim3 grid = lane_grid<L, WAVES>(args), block(64 * WAVES);
     if constexpr (L <= 4) {
-        if (args.state && !args.any_blend && args.live4) {
-            start<L, T, WAVES, MINW, true, false, false, 4>(args, grid, block, stream);
+        if (args.state && args.live4) {
+            // the lean resumable instantiations: four formants laid out, any blend length
+            if (args.any_blend) start<L, T, WAVES, MINW, true, false, true, 4>(args, grid, block, stream);
+            else start<L, T, WAVES, MINW, true, false, false, 4>(args, grid, block, stream);
             return;
         }
         if (!args.state && args.live4) {
@@ -57,8 +59,9 @@ void launch_one_fast(const SynthArgs &args, hipStream_t stream)
     // 43.1 against 40.4 ms, same box)
     constexpr int TF = L == 1 ? 64 : T;
     if constexpr (L <= 4) {
-        if (args.state && !args.any_blend && args.live4) {
-            start<L, T, WAVES, MINW, true, false, false, 4, false, true>(args, grid, block, stream);
+        if (args.state && args.live4) {
+            if (args.any_blend) start<L, T, WAVES, MINW, true, false, true, 4, false, true>(args, grid, block, stream);
+            else start<L, T, WAVES, MINW, true, false, false, 4, false, true>(args, grid, block, stream);
             return;
         }
         if (!args.state && args.live4) {

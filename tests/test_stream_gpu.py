@@ -164,3 +164,42 @@ def test_stream_pcm16_chunks_mixed_with_f32(gpu_ctx, lanes):
         for d in (d_f, d_i, d_len):
             gpu_ctx.device_free(d)
         gpu_ctx.set_option("lanes_per_utterance", 0)
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4])
+@pytest.mark.parametrize("arithmetic", [0, 1, 2])
+def test_lean_stream_kernels_take_any_blend_length(gpu_ctx, lanes, arithmetic):
+    """Streams of voices::generic() (four live formants) with blend lengths that are not powers of two: the lean
+    resumable kernels — four formants laid out — in exact arithmetic (chunks concatenate to the oracle's bits), in fast
+    arithmetic and in its second tier (within the tolerance of the oracle; L = 1 only for the second tier, the exact
+    lean kernels otherwise)."""
+    import oracle_lib as O
+    rng = np.random.default_rng(17 + lanes)
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
+    n_utt = 40
+    segs, offs, vids, seeds = W.make_batch(n_utt, length=0.03)
+    segs["blend_length"] = rng.choice([0.3, 0.013, 1.0 / 3.0, 0.007, 0.0625], len(segs)).astype(np.float32)
+    stride = 2048
+    ov = [O.Voice.from_buffer_copy(bytes(v)) for v in voices]
+    ref, ref_len = O.synthesize_batch(ov, segs, offs, vids, seeds, W.max_samples(length=0.03))
+    gpu_ctx.set_option("lanes_per_utterance", lanes)
+    gpu_ctx.set_option("arithmetic", arithmetic)
+    b = gpu_ctx.upload(segs, offs, vids, seeds)
+    try:
+        got = stream_all(gpu_ctx, b, n_utt, [700, 64, 33, 2048], stride)
+        name = gpu_ctx.last_kernel_name()
+    finally:
+        b.free()
+        gpu_ctx.set_option("arithmetic", 0)
+        gpu_ctx.set_option("lanes_per_utterance", 0)
+    assert "STREAM" in name and "ANYBL" in name and "NFA=4" in name, name
+    assert ("MID" in name) == (arithmetic == 2 and lanes == 1), name
+    for u in range(n_utt):
+        n = int(ref_len[u])
+        assert len(got[u]) == n, (u, name)
+        if arithmetic == 0 or (arithmetic == 2 and lanes > 1):
+            assert np.array_equal(got[u].view(np.uint32), ref[u, :n].view(np.uint32)), (u, name)
+        else:
+            peak = max(1.0, float(np.abs(ref[u, :n]).max()))
+            assert float(np.abs(got[u].astype(np.float64) - ref[u, :n]).max()) <= G.FAST_TOLERANCE * peak, (u, name)
