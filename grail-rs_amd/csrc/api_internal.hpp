@@ -40,6 +40,13 @@ struct grail_ctx {
     std::vector<grail_voice> voices;  // host copy of the table
     grail::DevVoice *d_voices = nullptr;
     float *d_voice_elems = nullptr;   // [n_voices * NUM_VOICED][49]
+    // what each voice of the table qualifies for (a batch is judged by the voices IT names: used_voices); the table-wide
+    // flags below are what a context without per-voice records (grail_plan_blocks) goes by
+    struct VoiceInfo {
+        bool upper_silent = false, live4_ok = false, scan_ok = false, split_ok = false;
+        uint32_t warmup = 0;
+    };
+    std::vector<VoiceInfo> voice_info;
     bool voices_upper_silent = false; // every voice: formants 5-8 have amplitude +0 in every phoneme
     bool voices_live4_ok = false;     // ... and parameters that keep their output at exactly +0 (live4_ok)
     bool voices_scan_ok = false;      // every formant of every voice inside the safe window (scan_voice_ok)

@@ -181,10 +181,22 @@ int install_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices)
         ctx->voice_sharpness[v] = elems_sharpness(voices[v].phonemes, NUM_VOICED);
         ctx->voices_sharpness = std::fmax(ctx->voices_sharpness, ctx->voice_sharpness[v]);
     }
+    ctx->voice_info.assign(n_voices, grail_ctx::VoiceInfo());
     for (uint32_t v = 0; v < n_voices; ++v) {
-        ctx->voices_live4_ok = ctx->voices_live4_ok && live4_ok(voices[v]);
-        ctx->voices_split_ok = ctx->voices_split_ok && dv[v].warmup != 0u && voices[v].sample_rate > 0.0f &&
-                               std::isfinite(voices[v].sample_rate);
+        grail_ctx::VoiceInfo &vi = ctx->voice_info[v];
+        vi.upper_silent = true;
+        for (int p = 0; p < NUM_VOICED; ++p)
+            for (int i = NF / 2; i < NF; ++i) {
+                uint32_t bits;
+                std::memcpy(&bits, &voices[v].phonemes[p].formant_amp[i], sizeof bits);
+                vi.upper_silent = vi.upper_silent && bits == 0u;
+            }
+        vi.live4_ok = live4_ok(voices[v]);
+        vi.scan_ok = scan_voice_ok(voices[v]);
+        vi.warmup = dv[v].warmup;
+        vi.split_ok = dv[v].warmup != 0u && voices[v].sample_rate > 0.0f && std::isfinite(voices[v].sample_rate);
+        ctx->voices_live4_ok = ctx->voices_live4_ok && vi.live4_ok;
+        ctx->voices_split_ok = ctx->voices_split_ok && vi.split_ok;
         if (dv[v].warmup > ctx->max_warmup) ctx->max_warmup = dv[v].warmup;
         if (voices[v].sample_rate > ctx->max_rate) ctx->max_rate = voices[v].sample_rate;
         const float dt = 1.0f / voices[v].sample_rate;

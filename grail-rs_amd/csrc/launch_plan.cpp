@@ -76,12 +76,33 @@ double family_cost(const grail_ctx *ctx, const Family &f, uint32_t rows, double 
     return rounds * span * lane_ms_per_sample(f.fast != 0, f.live4 != 0, f.L);
 }
 
+// A phoneme batch is judged by the voices IT names (batch->used_voices), not by the whole table: a preset with eight
+// live formants somewhere in the table does not take the four-formant kernels away from batches that never use it.
+// (A context without per-voice records — grail_plan_blocks — goes by the table-wide flag.)
+template <typename Pred>
+static bool used_voices_all(const grail_ctx *ctx, const grail_batch *batch, bool table_wide, Pred pred)
+{
+    if (ctx->voice_info.empty()) return table_wide;
+    for (const uint32_t v : batch->used_voices)
+        if (v >= ctx->voice_info.size() || !pred(ctx->voice_info[v])) return false;
+    return true;
+}
+static uint32_t used_voices_warmup(const grail_ctx *ctx, const grail_batch *batch)
+{
+    if (ctx->voice_info.empty()) return ctx->max_warmup;
+    uint32_t w = 0;
+    for (const uint32_t v : batch->used_voices)
+        if (v < ctx->voice_info.size()) w = std::max(w, ctx->voice_info[v].warmup);
+    return w;
+}
+
 bool batch_half_capable(const grail_ctx *ctx, const grail_batch *batch)
 {
     // (caller-built elems: judged at upload over the batch's distinct elems, against the voice table of that moment)
     if (!batch->phoneme_mode)
         return ctx->skip_silent_option && batch->elems_live4_ok && batch->elems_warmup_epoch == ctx->voices_epoch;
-    return ctx->skip_silent_option && ctx->voices_upper_silent;
+    return ctx->skip_silent_option &&
+           used_voices_all(ctx, batch, ctx->voices_upper_silent, [](const grail_ctx::VoiceInfo &v) { return v.upper_silent; });
 }
 
 // formants 5-8 left out altogether: the table qualifies (live4_ok); every segment is at least
@@ -90,7 +111,10 @@ bool batch_half_capable(const grail_ctx *ctx, const grail_batch *batch)
 // saw every formant is fed from stay finite (a dead formant fed +-inf would emit NaN)
 bool batch_live4_any_blend(const grail_ctx *ctx, const grail_batch *batch)
 {
-    return batch_half_capable(ctx, batch) && (!batch->phoneme_mode || ctx->voices_live4_ok) && batch->plain &&
+    return batch_half_capable(ctx, batch) &&
+           (!batch->phoneme_mode ||
+            used_voices_all(ctx, batch, ctx->voices_live4_ok, [](const grail_ctx::VoiceInfo &v) { return v.live4_ok; })) &&
+           batch->plain &&
            batch->min_length >= 2.0f * ctx->max_dt &&
            batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f;
 }
@@ -159,9 +183,10 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
     Family split = f;
     // (which voices / elems qualify: voice_warmup.  A phoneme batch is covered by its voice table; caller-built elems
     // by the warm-up computed over them at upload, against the voice table of that moment)
-    const bool split_ok = batch->phoneme_mode ? ctx->voices_split_ok
+    const bool split_ok = batch->phoneme_mode ? used_voices_all(ctx, batch, ctx->voices_split_ok,
+                                                                [](const grail_ctx::VoiceInfo &v) { return v.split_ok; })
                                               : (batch->elems_warmup != 0u && batch->elems_warmup_epoch == ctx->voices_epoch);
-    const uint32_t warmup = batch->phoneme_mode ? ctx->max_warmup : batch->elems_warmup;
+    const uint32_t warmup = batch->phoneme_mode ? used_voices_warmup(ctx, batch) : batch->elems_warmup;
     if (ctx->split_option && !ctx->lanes_option && split_ok && batch->plain &&
         out_stride <= 0xFFFFFFFFull && (ctx->split_chunks >= 2 || ctx->split_chunks == 0)) {
         const double sp = ctx->split_span ? std::fmin((double)ctx->split_span, (double)out_stride) : span;
@@ -197,7 +222,8 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
     // (no IEEE fallback).
     Family scan = f;
     if (f.fast == 1u && ctx->scan_option && !ctx->lanes_option && (int64_t)fam * (l4ab ? 4 : 7) <= 4 * scan_max_utts(ctx) &&
-        ctx->voices_scan_ok && (batch->phoneme_mode || (batch->elems_scan_ok && batch->elems_warmup_epoch == ctx->voices_epoch)) &&
+        used_voices_all(ctx, batch, ctx->voices_scan_ok, [](const grail_ctx::VoiceInfo &v) { return v.scan_ok; }) &&
+        (batch->phoneme_mode || (batch->elems_scan_ok && batch->elems_warmup_epoch == ctx->voices_epoch)) &&
         batch->plain && batch->min_length >= 2.0f * ctx->max_dt &&
         batch->min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f) {
         scan.scan = true;

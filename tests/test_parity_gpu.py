@@ -825,3 +825,68 @@ def test_four_formant_lane_kernels_with_any_blend_length(gpu_ctx, lanes):
         gpu_ctx.set_option("lanes_per_utterance", 0)
     assert "ANYBL" in name and "NFA=4" in name, name
     assert_bit_identical(out, out_len, ref, ref_len, name)
+
+
+@pytest.mark.parametrize("n_utt", [200, 20000])
+def test_a_batch_is_judged_by_the_voices_it_names(gpu_ctx, n_utt):
+    """A table of voices::generic() next to presets with eight live formants, a voice with a formant at frequency 0 (no
+    kernel family but the general one can reproduce its NaN) and one with a bandwidth of 1 Hz (no time-split warm-up):
+    batches that name only voices::generic() keep the four-formant kernels, the pipelined workgroups and — in fast mode —
+    the scan and time-split kernels; a batch that names one of the others gets what that voice allows.  All against the
+    oracle."""
+    bad = G.voice_generic(48000.0)
+    bad.phonemes[1].formant_freq[6] = 0.0
+    narrow = G.voice_generic(48000.0)
+    narrow.phonemes[0].formant_bw[1] = 1.0 / 48000.0
+    voices = [G.voice_generic(48000.0)] + W.preset_voices(8)[1:4] + [bad, narrow]
+    gpu_ctx.set_voices(voices)
+    segs, offs, _, seeds = W.make_batch(n_utt, length=0.03, blend_length=0.03)
+    stride = W.max_samples(length=0.03)
+    sample = np.arange(0, n_utt, max(1, n_utt // 24))[:24]
+
+    def check(vids, fast):
+        gpu_ctx.set_option("arithmetic", fast)
+        try:
+            with np.errstate(all="ignore"):
+                out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+        finally:
+            gpu_ctx.set_option("arithmetic", 0)
+        name, formants = gpu_ctx.last_kernel_name(), gpu_ctx.get_option("last_launch_formants")
+        sub_offs = np.zeros(len(sample) + 1, dtype=np.uint32)
+        sub = []
+        for i, u in enumerate(sample):
+            sub.append(segs[offs[u]:offs[u + 1]])
+            sub_offs[i + 1] = sub_offs[i] + offs[u + 1] - offs[u]
+        with np.errstate(all="ignore"):
+            ref, ref_len = O.synthesize_batch(ovoices(voices), np.concatenate(sub), sub_offs, vids[sample], seeds[sample], stride)
+        for i, u in enumerate(sample):
+            n = int(ref_len[i])
+            assert out_len[u] == n, (name, u)
+            if fast:
+                fin = np.isfinite(ref[i, :n])
+                peak = max(1.0, float(np.abs(ref[i, :n][fin]).max())) if fin.any() else 1.0
+                assert np.array_equal(np.isnan(ref[i, :n]), np.isnan(out[u, :n])), (name, u)
+                assert float(np.abs(out[u, :n][fin].astype(np.float64) - ref[i, :n][fin]).max(initial=0.0)) <= G.FAST_TOLERANCE * peak, (name, u)
+            else:
+                same, at = _same_but_for_nan_payloads(out[u, :n], ref[i, :n])
+                assert same, (name, u, at)
+        return name, formants
+
+    only_generic = np.zeros(n_utt, dtype=np.uint32)
+    name, formants = check(only_generic, 0)
+    assert formants == 4, name                                    # (the presets in the table do not matter)
+    name, formants = check(only_generic, 1)
+    assert formants == 4 and ("scan_kernel" in name or "SPLIT" in name), name
+    with_presets = (np.arange(n_utt) % 4).astype(np.uint32)
+    name, formants = check(with_presets, 0)
+    assert formants == 8, name
+    name, formants = check(with_presets, 1)
+    assert formants == 8 and ("scan_kernel" in name or "SPLIT" in name), name
+    with_bad = (np.arange(n_utt) % 5).astype(np.uint32)           # names the voice with a formant at frequency 0
+    name, formants = check(with_bad, 0)
+    assert formants == 8, name
+    name, formants = check(with_bad, 1)
+    assert "scan_kernel" not in name, name
+    with_narrow = np.where(np.arange(n_utt) % 7 == 0, 5, 0).astype(np.uint32)
+    name, formants = check(with_narrow, 1)
+    assert "SPLIT" not in name or "scan" in name, name            # (1 Hz of bandwidth: no warm-up within 16 384 samples)
