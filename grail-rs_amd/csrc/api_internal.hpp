@@ -58,6 +58,7 @@ struct grail_ctx {
     int64_t scan_max_utts = -1;       // ... up to this many utterances (x 4/7 with eight live formants; -1: 34 per CU = 8704)
     int64_t scan_split_max = -1;      // ... and up to this many with the carrier phase on a wave of its own (-1: 6 per CU = 1536)
     int composite_option = 1;         // a batch may be cut into blocks with a kernel family each (plan_blocks)
+    int row_groups_option = 1;        // rows the lean families cannot take are planned apart: 1 where the cost model says so, 2 always, 0 never
     double voices_sharpness = INFINITY;   // the largest predicted fast-mode deviation of the table, units of 2^-23
     std::vector<double> voice_sharpness;  // ... per voice (a batch is judged by the voices it uses)
     int64_t fast_limit = (int64_t)GRAIL_FAST_SHARPNESS_LIMIT;   // "fast_sharpness_limit": fast kernels up to this
@@ -151,6 +152,13 @@ struct grail_batch {
     // the launch plan of the last synthesis call of this batch (plan_blocks lays out time-split grids by bisection: a
     // fraction of a millisecond of host time, which a one-millisecond kernel should not pay at every launch)
     mutable PlanCache *plan_cache = nullptr;
+    // Row groups (whole-batch launches of length-sorted batches).  A few rows that the lean kernel families cannot take —
+    // a segment shorter than two samples, a non-finite length or pitch — would cost the whole batch its four-formant
+    // kernels, pipelined workgroups and fast families, because those are gated on the batch's worst row.  Such rows are
+    // put LAST in the slot order and the batch is planned as two batches that share the device buffers: groups[0] = the
+    // lean rows (slots [0, groups[0].n_utt)), groups[1] = the rest.  Valid for the voice table they were judged against.
+    std::vector<grail_batch> groups;
+    uint64_t groups_epoch = 0;
 };
 
 namespace grail {
@@ -216,6 +224,7 @@ struct Family {
     int L = 1;                 // lanes per utterance (lane kernels, pipelined workgroups)
     uint32_t pipe = 0;         // exact pipelined workgroups: 1 = rounds of 16 samples, 2 = rounds of 32
     uint32_t live4 = 0;        // formants 5-8 not laid out
+    bool half = false;         // one lane per utterance, exact, eight formants laid out but 5-8 silent: the half-live loops
     uint32_t fast = 0;         // tolerance arithmetic
     int split_k = 0;           // time-split kernels: chunks per utterance (0: not time-split)
     uint32_t split_bounds[SPLIT_MAX_CHUNKS + 1] = {};

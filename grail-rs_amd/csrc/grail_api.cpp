@@ -49,6 +49,11 @@ void free_batch_buffers(grail_batch *b)
 {
     free_plan_cache(b->plan_cache);
     b->plan_cache = nullptr;
+    for (grail_batch &g : b->groups) {          // (views: they share the device buffers below)
+        free_plan_cache(g.plan_cache);
+        g.plan_cache = nullptr;
+    }
+    b->groups.clear();
     if (b->d_segs) (void)hipFree(b->d_segs);
     if (b->d_offsets) (void)hipFree(b->d_offsets);
     if (b->d_voice_ids) (void)hipFree(b->d_voice_ids);
@@ -76,27 +81,79 @@ int check_offsets(const uint32_t *seg_offsets, uint32_t n_utt, uint32_t *n_segs)
     return GRAIL_OK;
 }
 
+// What the launch policy asks of an utterance's segments (the batch's fields of the same names are these over all rows)
+struct RowStats {
+    bool plain = true;          // every length / blend length / pitch finite, blend lengths > 0
+    bool any_blend = false;     // some blend length is not +-2^k
+    float min_length = INFINITY, min_pitch = INFINITY, seconds = 0.0f;
+};
+
 // Ragged batches: the lanes of a wave run in lockstep, so a wave lasts as long as its longest utterance.
 // Launch slots are therefore filled in order of decreasing length (sum of the segment lengths, in seconds
 // — close enough to the sample count for sorting): the utterances of a wave end together, and when the
 // batch is larger than the machine the longest waves start first.  Results do not depend on the slot
 // (batch invariance), rows stay where the caller put them.  Aligned batches (all sums equal) keep the
 // identity assignment and pay nothing.
-int upload_length_order(grail_ctx *ctx, grail_batch *b, const std::vector<float> &seconds, uint32_t n_utt)
+// Rows the lean kernel families cannot take (grail_batch::groups) go last, whatever their length: the batch is then
+// planned as two batches.  (Judged against the voice table of this moment: the bounds involve its sample rates and
+// pitch jitter; a batch uploaded before any table, or rendered with another one, is planned as one.)
+int upload_length_order(grail_ctx *ctx, grail_batch *b, const std::vector<RowStats> &rows, uint32_t n_utt)
 {
     if (n_utt < 2 || !ctx->sort_option) return GRAIL_OK;
-    float lo = seconds[0], hi = seconds[0];
-    for (uint32_t u = 1; u < n_utt; ++u) {
-        lo = std::fmin(lo, seconds[u]);
-        hi = std::fmax(hi, seconds[u]);
+    std::vector<uint8_t> outlier(n_utt, 0);
+    uint32_t n_out = 0;
+    if (!ctx->voices.empty()) {
+        for (uint32_t u = 0; u < n_utt; ++u) {
+            const RowStats &r = rows[u];
+            const bool lean = r.plain && r.min_length >= 2.0f * ctx->max_dt &&
+                              r.min_pitch * 0.999f - 1.002f * ctx->max_pitch_jitter >= 9.5367431640625e-07f;
+            outlier[u] = lean ? 0 : 1;
+            n_out += outlier[u];
+        }
+        if (n_out == n_utt) n_out = 0;                  // nothing to separate them from
     }
-    if (!(hi - lo > 0.002f)) return GRAIL_OK;       // aligned (or NaN lengths): nothing to gain
+    float lo = rows[0].seconds, hi = rows[0].seconds;
+    for (uint32_t u = 1; u < n_utt; ++u) {
+        lo = std::fmin(lo, rows[u].seconds);
+        hi = std::fmax(hi, rows[u].seconds);
+    }
+    const bool ragged = hi - lo > 0.002f;           // (aligned, or NaN lengths: nothing to gain from sorting)
+    if (!ragged && n_out == 0) return GRAIL_OK;
     std::vector<uint32_t> perm(n_utt);
     for (uint32_t u = 0; u < n_utt; ++u) perm[u] = u;
-    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t c) { return seconds[a] > seconds[c]; });
+    auto key = [&](uint32_t u) { return std::isfinite(rows[u].seconds) ? rows[u].seconds : 0.0f; };   // (a strict weak order)
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t c) {
+        if (n_out && outlier[a] != outlier[c]) return outlier[a] < outlier[c];
+        return ragged && key(a) > key(c);
+    });
     int rc = upload(&b->d_perm, perm.data(), n_utt, ctx->stream);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n_out) {
+        // two views of the batch: same device buffers, each with the summary of its own rows
+        b->groups.assign(2, *b);
+        for (int g = 0; g < 2; ++g) {
+            grail_batch &v = b->groups[g];
+            v.groups.clear();
+            v.plan_cache = nullptr;
+            v.n_utt = g ? n_out : n_utt - n_out;
+            v.plain = true;
+            v.any_blend = false;
+            v.min_length = INFINITY;
+            v.min_pitch = INFINITY;
+            v.max_seconds = 0.0f;        // (used_voices: the batch's — a superset of the group's)
+        }
+        for (uint32_t u = 0; u < n_utt; ++u) {
+            grail_batch &v = b->groups[outlier[u]];
+            const RowStats &r = rows[u];
+            v.plain = v.plain && r.plain;
+            v.any_blend = v.any_blend || r.any_blend;
+            if (r.min_length < v.min_length) v.min_length = r.min_length;
+            if (r.min_pitch < v.min_pitch) v.min_pitch = r.min_pitch;
+            if (r.seconds > v.max_seconds) v.max_seconds = r.seconds;
+        }
+        b->groups_epoch = ctx->voices_epoch;
+    }
     return GRAIL_OK;
 }
 
@@ -413,6 +470,11 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         ctx->composite_option = value ? 1 : 0;
         return GRAIL_OK;
     }
+    if (std::strcmp(name, "row_groups") == 0) {
+        if (value < 0 || value > 2) return fail(GRAIL_ERR_INVALID_ARG, "row_groups must be 0 (off), 1 (by cost) or 2 (always)");
+        ctx->row_groups_option = (int)value;
+        return GRAIL_OK;
+    }
     if (std::strcmp(name, "pipeline8_max_groups") == 0) {   // tuning: 0 keeps eight-formant batches off the pipeline
         ctx->pipe8_max_groups = value;
         return GRAIL_OK;
@@ -473,6 +535,10 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
     }
     if (std::strcmp(name, "composite_launches") == 0) {
         *value = ctx->composite_option;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "row_groups") == 0) {
+        *value = ctx->row_groups_option;
         return GRAIL_OK;
     }
     if (std::strcmp(name, "pipeline4_max_groups") == 0) {
@@ -585,36 +651,40 @@ int grail_batch_upload(grail_ctx *ctx, const grail_phoneme_elem *segs, const uin
     uint32_t n_segs = 0;
     if ((rc = check_offsets(seg_offsets, n_utt, &n_segs))) return rc;
     if (n_segs && !segs) return fail(GRAIL_ERR_INVALID_ARG, "segs is NULL");
-    bool any_blend = false;
-    for (uint32_t i = 0; i < n_segs && !any_blend; ++i) any_blend = !blend_is_pow2(segs[i].blend_length);
-    bool plain = true;
-    float min_length = INFINITY, min_pitch = INFINITY;
-    for (uint32_t i = 0; i < n_segs; ++i) {
-        plain = plain && std::isfinite(segs[i].length) && std::isfinite(segs[i].blend_length) &&
-                std::isfinite(segs[i].frequency) && segs[i].blend_length > 0.0f;
-        if (segs[i].length < min_length) min_length = segs[i].length;
-        const float pitch = std::fmin(segs[i].frequency, 0.5f);   // copy_with_frequency :445-450
-        if (pitch < min_pitch) min_pitch = pitch;
-    }
     for (uint32_t i = 0; i < n_segs; ++i)
         if (segs[i].phoneme < 0 || segs[i].phoneme >= GRAIL_PH_COUNT)
             return fail(GRAIL_ERR_INVALID_ARG, "phoneme discriminant out of range");
+    // per utterance, then over the batch: what the launch policy asks of the segments
+    std::vector<RowStats> rows(n_utt);
+    for (uint32_t u = 0; u < n_utt; ++u) {
+        RowStats &r = rows[u];
+        for (uint32_t i = seg_offsets[u]; i < seg_offsets[u + 1]; ++i) {
+            r.plain = r.plain && std::isfinite(segs[i].length) && std::isfinite(segs[i].blend_length) &&
+                      std::isfinite(segs[i].frequency) && segs[i].blend_length > 0.0f;
+            r.any_blend = r.any_blend || !blend_is_pow2(segs[i].blend_length);
+            if (segs[i].length < r.min_length) r.min_length = segs[i].length;
+            const float pitch = std::fmin(segs[i].frequency, 0.5f);   // copy_with_frequency :445-450
+            if (pitch < r.min_pitch) r.min_pitch = pitch;
+            r.seconds += segs[i].length;
+        }
+    }
     grail_batch *b = new (std::nothrow) grail_batch();
     if (!b) return fail(GRAIL_ERR_OUT_OF_MEMORY, "host allocation failed");
     b->phoneme_mode = true;
-    b->any_blend = any_blend;
-    b->plain = plain;
-    b->min_length = min_length;
-    b->min_pitch = min_pitch;
+    b->plain = true;
+    b->min_length = INFINITY;
+    b->min_pitch = INFINITY;
+    for (const RowStats &r : rows) {
+        b->plain = b->plain && r.plain;
+        b->any_blend = b->any_blend || r.any_blend;
+        if (r.min_length < b->min_length) b->min_length = r.min_length;
+        if (r.min_pitch < b->min_pitch) b->min_pitch = r.min_pitch;
+        if (r.seconds > b->max_seconds) b->max_seconds = r.seconds;
+    }
     b->n_segs = n_segs;
-    std::vector<float> seconds(n_utt, 0.0f);
-    for (uint32_t u = 0; u < n_utt; ++u)
-        for (uint32_t i = seg_offsets[u]; i < seg_offsets[u + 1]; ++i) seconds[u] += segs[i].length;
-    for (uint32_t u = 0; u < n_utt; ++u)
-        if (seconds[u] > b->max_seconds) b->max_seconds = seconds[u];
     if ((rc = upload(&b->d_segs, segs, n_segs, ctx->stream)) ||
         (rc = upload_common(ctx, b, seg_offsets, voice_ids, jitter_seeds, n_utt)) ||
-        (rc = upload_length_order(ctx, b, seconds, n_utt))) {
+        (rc = upload_length_order(ctx, b, rows, n_utt))) {
         free_batch_buffers(b);
         delete b;
         return rc;
@@ -637,32 +707,40 @@ int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
     // Split the SequenceElems into the 16-B segment records and the elem table.
     std::vector<DevSeg> ds(n_segs);
     std::vector<float> elems((size_t)(n_segs ? n_segs : 1) * ELEM_FLOATS);
-    bool any_blend = false;
     for (uint32_t i = 0; i < n_segs; ++i) {
         ds[i].elem = segs[i].has_elem ? (int32_t)i : -1;
         ds[i].length = segs[i].length;
         ds[i].blend_length = segs[i].blend_length;
-        any_blend = any_blend || !blend_is_pow2(segs[i].blend_length);
         ds[i].frequency = segs[i].elem.frequency;
         std::memcpy(&elems[(size_t)i * ELEM_FLOATS], &segs[i].elem, sizeof(grail_synthesis_elem));
     }
-    // (what the launch policy asks of a batch, as for phoneme batches; a caller-built elem keeps its frequency as it is,
-    // copy_with_frequency's min(f, 0.5) :445-450 belongs to the Selector)
-    bool plain = true;
-    float min_length = INFINITY, min_pitch = INFINITY;
-    for (uint32_t i = 0; i < n_segs; ++i) {
-        plain = plain && std::isfinite(segs[i].length) && std::isfinite(segs[i].blend_length) &&
-                std::isfinite(segs[i].elem.frequency) && segs[i].blend_length > 0.0f;
-        if (segs[i].length < min_length) min_length = segs[i].length;
-        if (segs[i].elem.frequency < min_pitch) min_pitch = segs[i].elem.frequency;
+    // (what the launch policy asks of the segments, per utterance and over the batch, as for phoneme batches; a
+    // caller-built elem keeps its frequency as it is, copy_with_frequency's min(f, 0.5) :445-450 belongs to the Selector)
+    std::vector<RowStats> rows(n_utt);
+    for (uint32_t u = 0; u < n_utt; ++u) {
+        RowStats &r = rows[u];
+        for (uint32_t i = seg_offsets[u]; i < seg_offsets[u + 1]; ++i) {
+            r.plain = r.plain && std::isfinite(segs[i].length) && std::isfinite(segs[i].blend_length) &&
+                      std::isfinite(segs[i].elem.frequency) && segs[i].blend_length > 0.0f;
+            r.any_blend = r.any_blend || !blend_is_pow2(segs[i].blend_length);
+            if (segs[i].length < r.min_length) r.min_length = segs[i].length;
+            if (segs[i].elem.frequency < r.min_pitch) r.min_pitch = segs[i].elem.frequency;
+            r.seconds += segs[i].length;
+        }
     }
     grail_batch *b = new (std::nothrow) grail_batch();
     if (!b) return fail(GRAIL_ERR_OUT_OF_MEMORY, "host allocation failed");
     b->phoneme_mode = false;
-    b->any_blend = any_blend;
-    b->plain = plain;
-    b->min_length = min_length;
-    b->min_pitch = min_pitch;
+    b->plain = true;
+    b->min_length = INFINITY;
+    b->min_pitch = INFINITY;
+    for (const RowStats &r : rows) {
+        b->plain = b->plain && r.plain;
+        b->any_blend = b->any_blend || r.any_blend;
+        if (r.min_length < b->min_length) b->min_length = r.min_length;
+        if (r.min_pitch < b->min_pitch) b->min_pitch = r.min_pitch;
+        if (r.seconds > b->max_seconds) b->max_seconds = r.seconds;
+    }
     b->n_segs = n_segs;
     // the sharpness of the batch (elems_sharpness): parameters only ever blend between the elems of two consecutive
     // segments of an utterance (Sequencer::next :897-921), so every such pair is judged like a voice of two phonemes
@@ -674,15 +752,10 @@ int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
             if (i + 1 < seg_offsets[u + 1] && segs[i + 1].has_elem) pair[n_pair++] = segs[i + 1].elem;
             b->elems_sharpness = std::fmax(b->elems_sharpness, elems_sharpness(pair, n_pair));
         }
-    std::vector<float> seconds(n_utt, 0.0f);
-    for (uint32_t u = 0; u < n_utt; ++u)
-        for (uint32_t i = seg_offsets[u]; i < seg_offsets[u + 1]; ++i) seconds[u] += segs[i].length;
-    for (uint32_t u = 0; u < n_utt; ++u)
-        if (seconds[u] > b->max_seconds) b->max_seconds = seconds[u];
     if ((rc = upload(&b->d_segs, ds.data(), n_segs, ctx->stream)) ||
         (rc = upload(&b->d_elems, elems.data(), elems.size(), ctx->stream)) ||
         (rc = upload_common(ctx, b, seg_offsets, voice_ids, jitter_seeds, n_utt)) ||
-        (rc = upload_length_order(ctx, b, seconds, n_utt))) {
+        (rc = upload_length_order(ctx, b, rows, n_utt))) {
         free_batch_buffers(b);
         delete b;
         return rc;
@@ -719,6 +792,12 @@ int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
         for (uint32_t i = 0; i < n_segs; ++i) max_pitch = std::fmax(max_pitch, segs[i].elem.frequency);
         b->elems_scan_ok = rates_ok && max_pitch <= 0.5f && scan_elems_ok(distinct.data(), distinct.size(), (float)jd);
         b->elems_warmup_epoch = ctx->voices_epoch;
+        for (grail_batch &g : b->groups) {          // (the views were made before these were known)
+            g.elems_warmup = b->elems_warmup;
+            g.elems_warmup_epoch = b->elems_warmup_epoch;
+            g.elems_live4_ok = b->elems_live4_ok;
+            g.elems_scan_ok = b->elems_scan_ok;
+        }
     }
     *out = b;
     return GRAIL_OK;

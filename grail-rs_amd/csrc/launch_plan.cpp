@@ -73,6 +73,9 @@ double family_cost(const grail_ctx *ctx, const Family &f, uint32_t rows, double 
     }
     const double rounds = std::ceil((double)rows * f.L / lanes);
     if (f.fast == 2u) return rounds * span * mid_ms_per_sample(f.live4 != 0);
+    // (eight formants laid out, the upper four silent: the half-live loops of the one-lane kernel, 45.7 ms where all
+    // eight live take 77.1)
+    if (f.half) return rounds * span * 45.7 / 96006.0;
     return rounds * span * lane_ms_per_sample(f.fast != 0, f.live4 != 0, f.L);
 }
 
@@ -82,14 +85,14 @@ double family_cost(const grail_ctx *ctx, const Family &f, uint32_t rows, double 
 template <typename Pred>
 static bool used_voices_all(const grail_ctx *ctx, const grail_batch *batch, bool table_wide, Pred pred)
 {
-    if (ctx->voice_info.empty()) return table_wide;
+    if (ctx->voice_info.empty() || batch->used_voices.empty()) return table_wide;
     for (const uint32_t v : batch->used_voices)
         if (v >= ctx->voice_info.size() || !pred(ctx->voice_info[v])) return false;
     return true;
 }
 static uint32_t used_voices_warmup(const grail_ctx *ctx, const grail_batch *batch)
 {
-    if (ctx->voice_info.empty()) return ctx->max_warmup;
+    if (ctx->voice_info.empty() || batch->used_voices.empty()) return ctx->max_warmup;
     uint32_t w = 0;
     for (const uint32_t v : batch->used_voices)
         if (v < ctx->voice_info.size()) w = std::max(w, ctx->voice_info[v].warmup);
@@ -173,6 +176,7 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
     // whose second lane would only hold silent formants
     if (!ctx->lanes_option && !f.live4 && L == 2 && batch_half_capable(ctx, batch)) L = 1;
     f.L = L;
+    f.half = !f.fast && !f.live4 && !f.pipe && L == 1 && batch_half_capable(ctx, batch);
     if (!f.fast) return;
 
     const double span = batch_span(ctx, batch, out_stride);

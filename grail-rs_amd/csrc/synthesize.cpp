@@ -88,31 +88,55 @@ int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_dev,
     if (count == 0) return GRAIL_OK;
     // the length-sorted slot assignment covers the whole batch: row-block launches keep launch order
     const bool use_perm = first == 0 && count == batch->n_utt && batch->d_perm;
-    std::vector<Block> plan;
-    const uint64_t key[6] = {count, out_stride, family_rows, ctx->options_epoch, ctx->voices_epoch,
-                             (uint64_t)(uintptr_t)ctx ^ (batch->phoneme_mode ? 0ull : (uint64_t)(batch->elems_sharpness * 1024.0))};
-    if (batch->plan_cache && std::memcmp(batch->plan_cache->key, key, sizeof key) == 0) {
-        plan = batch->plan_cache->plan;
-    } else {
+    // the launch plan of `rows` rows of a (view of the) batch, cached with what it was made for
+    auto plan_of = [&](const grail_batch *view, const uint32_t rows) {
+        std::vector<Block> plan;
+        const uint64_t key[6] = {rows, out_stride, family_rows, ctx->options_epoch, ctx->voices_epoch,
+                                 (uint64_t)(uintptr_t)ctx ^ (view->phoneme_mode ? 0ull : (uint64_t)(view->elems_sharpness * 1024.0))};
+        if (view->plan_cache && std::memcmp(view->plan_cache->key, key, sizeof key) == 0) return view->plan_cache->plan;
         // one launch when the caller fixes the family (row blocks, a pinned lane mapping or chunk grid) or asks for it
         const bool single = family_rows != 0 || !ctx->composite_option || ctx->lanes_option || ctx->split_chunks >= 2;
         if (single) {
             Family f;
-            choose_family(ctx, batch, out_stride, family_rows > count ? family_rows : count, f);
-            plan.push_back(Block{count, f});
+            choose_family(ctx, view, out_stride, family_rows > rows ? family_rows : rows, f);
+            plan.push_back(Block{rows, f});
         } else {
-            plan_blocks(ctx, batch, out_stride, count, batch_span(ctx, batch, out_stride), plan);
+            plan_blocks(ctx, view, out_stride, rows, batch_span(ctx, view, out_stride), plan);
         }
-        if (!batch->plan_cache) batch->plan_cache = new (std::nothrow) PlanCache();
-        if (batch->plan_cache) {
-            std::memcpy(batch->plan_cache->key, key, sizeof key);
-            batch->plan_cache->plan = plan;
+        if (!view->plan_cache) view->plan_cache = new (std::nothrow) PlanCache();
+        if (view->plan_cache) {
+            std::memcpy(view->plan_cache->key, key, sizeof key);
+            view->plan_cache->plan = plan;
         }
+        return plan;
+    };
+    // Row groups (grail_batch::groups): the rows the lean families cannot take sit last in the slot order and are planned
+    // as a batch of their own, so that a few of them do not decide the kernels of all.  Whole-batch launches only, and
+    // only while the voice table is the one the rows were judged against.
+    struct Part {
+        const grail_batch *view;
+        Block block;
+    };
+    std::vector<Part> plan;
+    for (const Block &b : plan_of(batch, count)) plan.push_back(Part{batch, b});
+    if (use_perm && family_rows == 0 && ctx->row_groups_option && batch->groups.size() == 2 && batch->groups_epoch == ctx->voices_epoch) {
+        // ... where that is cheaper by the cost model: a separate launch for four odd rows behind a full round of the
+        // one-lane kernel costs more than it saves (53.7 against 46.7 ms), behind 20 000 rows it does not
+        auto cost_of = [&](const std::vector<Part> &parts) {
+            double c = 0.0;
+            for (const Part &p : parts)
+                c += family_cost(ctx, p.block.f, p.block.rows, batch_span(ctx, p.view, out_stride)) + 0.05;
+            return c;
+        };
+        std::vector<Part> grouped;
+        for (const grail_batch &g : batch->groups)
+            for (const Block &b : plan_of(&g, g.n_utt)) grouped.push_back(Part{&g, b});
+        if (ctx->row_groups_option == 2 || cost_of(grouped) < cost_of(plan)) plan.swap(grouped);
     }
     size_t main_block = 0;                     // the block with the most rows: the one the statistics describe
     for (size_t i = 1; i < plan.size(); ++i)
-        if (plan[i].rows > plan[main_block].rows) main_block = i;
-    const Family f0 = plan[main_block].f;
+        if (plan[i].block.rows > plan[main_block].block.rows) main_block = i;
+    const Family f0 = plan[main_block].block.f;
     ctx->last_split = f0.split_k;
     ctx->last_formants = f0.live4 ? 4 : 8;
     ctx->last_lanes = f0.scan ? 0 : f0.L;
@@ -123,8 +147,8 @@ int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_dev,
     uint32_t slot0 = 0;
     std::string first_kernel;
     for (size_t i = 0; i < plan.size(); ++i) {
-        const Block &b = plan[i];
-        rc = launch_block(ctx, batch, b.f, out_dev, out_pcm16_dev, out_stride, out_len_dev, first, slot0, b.rows, use_perm);
+        const Block &b = plan[i].block;
+        rc = launch_block(ctx, plan[i].view, b.f, out_dev, out_pcm16_dev, out_stride, out_len_dev, first, slot0, b.rows, use_perm);
         if (rc) return rc;
         if (i == main_block) first_kernel = ctx->last_kernel;
         if ((int)b.f.fast > ctx->last_fast) ctx->last_fast = (int)b.f.fast;

@@ -290,6 +290,10 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       (grail_plan_blocks): 65537 utterances take one round of the one-lane kernel and one pipelined
  *       workgroup (50 - 52 ms) instead of two rounds (83 ms).  0: one launch per call, whatever it costs.  Read-only
  *       "last_launch_blocks".
+ *   "row_groups": 1 (default) / 0 / 2 — utterances the lean kernel families cannot take (a segment shorter than two
+ *       samples, a non-finite length, blend length or pitch) are put last in the launch order and planned as a batch of
+ *       their own where that is cheaper by the cost model (1), never (0), always (2): a few such rows do not cost the
+ *       others their four-formant kernels.  Results never depend on it.
  *   "assume_compute_units": plan for so many compute units instead of what the device reports (0 = the
  *       device's own count; read-only "compute_units" tells what is in force): tests, and callers that share a
  *       device.

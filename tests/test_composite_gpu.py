@@ -294,3 +294,62 @@ def test_composite_fuzz_over_machine_sizes_batch_sizes_and_arithmetics(gpu_ctx, 
           f"fast {worst / ULP:.1f} * 2^-23")
     assert worst <= G.FAST_TOLERANCE
     assert max(blocks, fblocks) >= 2 or n_utt <= lanes
+
+
+@pytest.mark.parametrize("fast", [0, 1])
+def test_a_few_odd_rows_do_not_decide_the_kernels_of_all(gpu_ctx, fast):
+    """20 000 ordinary utterances and a handful the lean kernel families cannot take — a segment of one sample, a
+    segment of length zero, a NaN pitch, an infinite pitch, a blend length of zero: those rows go last in the slot order
+    and are planned as a batch of their own (grail_batch::groups), the others keep the four-formant kernels (in fast mode: the
+    fast ones).  Lengths and samples: the oracle's, odd rows included."""
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
+    n_utt = 20000
+    segs, offs, vids, seeds = W.make_batch(n_utt, length=0.02, blend_length=2.0 ** -6)
+    odd = {17: ("length", 1.0 / 48000.0), 4000: ("length", 0.0), 9999: ("frequency", float("nan")),
+           12345: ("frequency", float("inf")), 19999: ("blend_length", 0.0)}
+    for u, (field, value) in odd.items():
+        segs[field][offs[u] + 1] = value
+    stride = W.max_samples(length=0.02)
+    b = gpu_ctx.upload(segs, offs, vids, seeds)
+    d_out = gpu_ctx.device_alloc(n_utt * stride * 4)
+    d_len = gpu_ctx.device_alloc(n_utt * 4)
+    gpu_ctx.set_option("arithmetic", fast)
+    try:
+        b.synthesize_async(d_out, stride, d_len)
+        gpu_ctx.sync()
+        name, formants, blocks = gpu_ctx.last_kernel_name(), gpu_ctx.get_option("last_launch_formants"), gpu_ctx.get_option("last_launch_blocks")
+        out_len = np.zeros(n_utt, dtype=np.uint32)
+        gpu_ctx.d2h(out_len, d_len, n_utt * 4)
+        rows = sorted(set(list(odd) + [0, 1, 16, 18, 3999, 4001, 10000, 19998] + list(range(5000, 5016))))
+        out = np.zeros((len(rows), stride), dtype=np.float32)
+        for i, u in enumerate(rows):
+            gpu_ctx.d2h(out[i], d_out, stride * 4, offset=u * stride * 4)
+    finally:
+        gpu_ctx.set_option("arithmetic", 0)
+        gpu_ctx.device_free(d_out)
+        gpu_ctx.device_free(d_len)
+        b.free()
+    assert formants == 4 and blocks >= 2, (name, formants, blocks)
+    if fast:
+        assert "FAST" in name, name
+    sub_offs = np.zeros(len(rows) + 1, dtype=np.uint32)
+    sub = []
+    for i, u in enumerate(rows):
+        sub.append(segs[offs[u]:offs[u + 1]])
+        sub_offs[i + 1] = sub_offs[i] + offs[u + 1] - offs[u]
+    with np.errstate(all="ignore"):
+        ref, ref_len = O.synthesize_batch(_ovoices(voices), np.concatenate(sub), sub_offs, vids[rows], seeds[rows], stride)
+    ref_len = np.minimum(ref_len, stride)
+    for i, u in enumerate(rows):
+        n = int(ref_len[i])
+        assert out_len[u] == n, (u, int(out_len[u]), n)
+        a, r = out[i, :n], ref[i, :n]
+        if fast and u not in odd:
+            assert float(np.abs(a.astype(np.float64) - r).max(initial=0.0)) <= G.FAST_TOLERANCE * max(1.0, float(np.abs(r).max(initial=0.0))), u
+        elif not fast:
+            both_nan = np.isnan(a) & np.isnan(r)
+            x, y = a.view(np.uint32).copy(), r.view(np.uint32).copy()
+            x[both_nan] = 0
+            y[both_nan] = 0
+            assert np.array_equal(x, y), (u, int(np.argmax(x != y)))

@@ -52,6 +52,17 @@ def test_random_batches_every_lane_mapping(gpu_ctx, seed):
             for u in range(len(ref_len)):
                 assert np.array_equal(out[u, :ref_len[u]].view(np.uint32),
                                       ref[u, :ref_len[u]].view(np.uint32)), (lanes, u)
+        # rows with zero-length segments planned apart from the others whatever the cost model says ("row_groups" = 2)
+        gpu_ctx.set_option("row_groups", 2)
+        for lanes in (0, 1, 4):
+            gpu_ctx.set_option("lanes_per_utterance", lanes)
+            out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+            assert gpu_ctx.get_option("last_launch_blocks") >= 2, lanes
+            assert np.array_equal(out_len, ref_len), lanes
+            for u in range(len(ref_len)):
+                assert np.array_equal(out[u, :ref_len[u]].view(np.uint32),
+                                      ref[u, :ref_len[u]].view(np.uint32)), ("row groups", lanes, u)
+        gpu_ctx.set_option("row_groups", 1)
         # the batch pre-pass agrees with what was rendered
         b = gpu_ctx.upload(segs, offs, vids, seeds)
         try:
@@ -60,6 +71,7 @@ def test_random_batches_every_lane_mapping(gpu_ctx, seed):
             b.free()
     finally:
         gpu_ctx.set_option("lanes_per_utterance", 0)
+        gpu_ctx.set_option("row_groups", 1)
 
 
 @pytest.mark.parametrize("seed", [11, 12] + EXTRA_SEEDS)
