@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Kernel time on a SPEECH-LIKE corpus: utterances of 8 - 32 phonemes of 40 - 160 ms each (blends of 30 - 80 ms, pitch
+contours of 90 - 220 Hz), so that utterances differ in length by a factor of four and every lane of a wave has a segment
+boundary every few thousand samples at a time of its own — next to the bench corpus (4 aligned segments of 0.5 s).
+Reports samples/s over the samples actually rendered.   usage: speech_like_bench.py [n_utt] [--blend-is-length]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "grail-rs_amd"))
+import numpy as np
+import grail_hip as G
+from grail_hip import workload as W
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 65536
+ctx = G.Context(0)
+rng = np.random.default_rng(7)
+for n_voices in (1, 8):
+    voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
+    ctx.set_voices(voices)
+    counts = rng.integers(8, 33, n)
+    offs = np.zeros(n + 1, dtype=np.uint32)
+    offs[1:] = np.cumsum(counts)
+    k = int(offs[-1])
+    segs = np.zeros(k, dtype=G.PHONEME_DTYPE)
+    segs["phoneme"] = rng.choice([G.PH_A, G.PH_E, G.PH_SILENCE, G.PH_STOP], k, p=[.4, .4, .12, .08])
+    segs["phoneme"][offs[:-1]] = G.PH_SILENCE
+    segs["length"] = rng.uniform(0.04, 0.16, k).astype(np.float32)
+    segs["blend_length"] = rng.uniform(0.03, 0.08, k).astype(np.float32)
+    if "--blend-is-length" in sys.argv:            # (no flat stretch of alpha, no kink: what the kinks cost)
+        segs["blend_length"] = segs["length"]
+    segs["frequency"] = (rng.uniform(90, 220, k) / 48000.0).astype(np.float32)
+    vids = (np.arange(n) % n_voices).astype(np.uint32)
+    seeds = np.arange(n, dtype=np.uint32)
+    stride = (int(32 * 0.16 * 48000) + 64 + 63) // 64 * 64
+    batch = ctx.upload(segs, offs, vids, seeds)
+    d_out = ctx.device_alloc(n * stride * 4)
+    d_len = ctx.device_alloc(n * 4)
+    for fast in (0, 1):
+        ctx.set_option("arithmetic", fast)
+        ms = []
+        for _ in range(3):
+            t0, g0 = ctx.get_option("fast_wave_tiles"), ctx.get_option("general_wave_steps")
+            batch.synthesize_async(d_out, stride, d_len)
+            ctx.sync()
+            ms.append(ctx.last_kernel_ms())
+            stats = (ctx.get_option("fast_wave_tiles") - t0, ctx.get_option("general_wave_steps") - g0)
+        lens = np.zeros(n, dtype=np.uint32)
+        ctx.d2h(lens, d_len, lens.nbytes)
+        total = int(lens.astype(np.uint64).sum())
+        print(f"speech-like, {n_voices} voice(s), {n} utterances ({total / n / 48000:.2f} s on average, {lens.min() / 48000:.2f} .. {lens.max() / 48000:.2f} s), "
+              f"{'fast ' if fast else 'exact'}: {min(ms):7.2f} ms = {total / (min(ms) * 1e-3):.3e} samples/s  ({ctx.last_kernel_name()}, "
+              f"{ctx.get_option('last_launch_blocks')} block(s))"
+              + (f"  [per wave: {stats[0] * 64 / n:.0f} tight tiles, {stats[1] * 64 / n:.0f} general steps, longest row {lens.max() // 64} tiles]" if fast else ""), flush=True)
+    ctx.set_option("arithmetic", 0)
+    ctx.device_free(d_out)
+    ctx.device_free(d_len)
+    batch.free()
