@@ -87,6 +87,16 @@ def test_every_kernel_family_is_in_the_library(kernels):
         assert (1, False, nfa, False, True, False, True) in have, ("second tier", nfa)
         assert (1, False, nfa, False, True, True, True) in have, ("second tier, time-split", nfa)
     assert (4, False, 4, True, False, False, False) in have and (8, False, 8, True, False, False, False) in have   # pipelined
+    # ... and for blend lengths that are not powers of two (ANYBL): the four-formant lane kernels, the lean stream
+    # kernels, the pipelined workgroups with rounds of 32 and of 16 samples
+    anybl = {(a[0], bool(a[4]), bool(a[6]), a[7], bool(a[8]), bool(a[9]), a[10]) for a, _ in synth}
+    for L in (1, 2, 4):
+        assert (L, False, True, 4, False, False, 2) in anybl, ("exact, four formants, any blend", L)
+        assert (L, True, True, 4, False, False, 2) in anybl, ("exact stream, four formants, any blend", L)
+        assert (L, True, True, 4, False, True, 2) in anybl, ("fast stream, four formants, any blend", L)
+    for L, nfa in ((4, 4), (8, 8)):
+        for pqp in (8, 4):
+            assert (L, False, True, nfa, True, False, pqp) in anybl, ("pipelined, any blend", L, pqp)
     names = " ".join(kernels)
     for other in ("scan_kernel", "ring_append_kernel", "lengths_kernel"):
         assert other in names, other
