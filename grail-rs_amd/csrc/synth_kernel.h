@@ -2430,7 +2430,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             // (not for the one-lane eight-formant kernels: they hold 256 VGPRs and AGPRs besides, and the extra
             // path cost their f32 rows 4 %; their i16 rows take the general loop below)
             constexpr bool PCM_FULL_TILE = !(L == 1 && NFA == NF);
-            if (all_full && !A.out_pcm16 && !vec_ok) {
+            if (all_full && (A.out_pcm16 ? (PCM_FULL_TILE && !vec16_ok) : !vec_ok)) {
                 // ... and rows that do not start 16-byte aligned (an out_stride that is not a multiple of 4 samples — the
                 // rows' own length, 96 006, is the natural one): the same tile with 4-byte stores, lane rl of a row
                 // taking samples rl, rl + T/4, ...: every store instruction writes runs of T/4 consecutive samples per row
@@ -2444,9 +2444,15 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 #pragma unroll
                 for (int i = 0; i < S / ROWS_PER_IT; ++i) {
                     const uint64_t row = A.perm ? rowid[i * ROWS_PER_IT + rr] : u0 + i * ROWS_PER_IT + rr;
-                    float *dst = A.out + row * A.out_stride + base + rl;
+                    if (PCM_FULL_TILE && A.out_pcm16) {      // (2-byte stores, the WAV sink's conversion on the way out)
+                        int16_t *dst = A.out_pcm16 + row * A.out_stride + base + rl;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) dst[q * ROW_LANES] = w[i][q];
+                        for (int q = 0; q < 4; ++q) dst[q * ROW_LANES] = (int16_t)pcm16_from_f32(w[i][q]);
+                    } else {
+                        float *dst = A.out + row * A.out_stride + base + rl;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) dst[q * ROW_LANES] = w[i][q];
+                    }
                 }
                 wave_lds_sync();
                 if (__builtin_amdgcn_ballot_w64(!done) == 0) break;

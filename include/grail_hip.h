@@ -508,7 +508,7 @@ int grail_pcm16_async(grail_ctx *ctx, const float *in_dev, uint64_t in_stride,
 /* grail_batch_synthesize_async() with the examples/cli.rs:49 conversion fused into the kernel's
  * store: rows of i16 PCM in device memory, out_stride in samples; 2 B instead of 4 B of HBM
  * written per sample and no f32 copy anywhere.  out_dev 8-byte aligned and out_stride % 4 == 0
- * give vector stores. */
+ * give vector stores (any other stride: 2-byte stores in runs of 16 samples, + 2 % on the headline batch). */
 int grail_batch_synthesize_pcm16_async(grail_ctx *ctx, const grail_batch *batch, int16_t *out_dev,
                                        uint64_t out_stride, uint32_t *out_len_dev);
 /* grail_synthesize_batch() with the conversion fused the same way: rows of i16 PCM (half the

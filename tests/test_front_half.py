@@ -160,17 +160,18 @@ def test_one_call_pcm16_rows(gpu_ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_voices", [8, 1])
 @pytest.mark.parametrize("lanes", [1, 2, 4, 8])
-def test_fused_pcm16_store_every_lane_mapping(gpu_ctx, lanes):
+def test_fused_pcm16_store_every_lane_mapping(gpu_ctx, lanes, n_voices):
     """grail_batch_synthesize_pcm16_async: the i16 rows written by the synthesis kernel's own flush
     are the examples/cli.rs:49 conversion of the oracle's f32 samples; ragged lengths, a row
     stride that forces the scalar tail, and a truncating stride."""
     import grail_hip as G
     from grail_hip import workload as W
-    voices = W.preset_voices(8)
+    voices = W.preset_voices(8) if n_voices == 8 else W.single_voice()     # (eight live formants / the four-formant kernels)
     gpu_ctx.set_voices(voices)
     n_utt = 70
-    segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=8, length=0.013, blend_length=0.008)
+    segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=n_voices, length=0.013, blend_length=0.008)
     ov = [O.Voice.from_buffer_copy(bytes(v)) for v in voices]
     full = W.max_samples(length=0.013)
     ref, ref_len = O.synthesize_batch(ov, segs, offs, vids, seeds, full)
@@ -178,7 +179,7 @@ def test_fused_pcm16_store_every_lane_mapping(gpu_ctx, lanes):
     batch = gpu_ctx.upload(segs, offs, vids, seeds)
     gpu_ctx.set_option("lanes_per_utterance", lanes)
     try:
-        for stride in (full, full + 2, 1001):          # aligned / unaligned rows / truncating
+        for stride in (full, full + 2, full + 1, 1001):          # aligned / unaligned rows (even, odd) / truncating
             d_out = gpu_ctx.device_alloc(n_utt * stride * 2 + 16)
             d_len = gpu_ctx.device_alloc(n_utt * 4)
             try:
