@@ -2430,11 +2430,12 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             // (not for the one-lane eight-formant kernels: they hold 256 VGPRs and AGPRs besides, and the extra
             // path cost their f32 rows 4 %; their i16 rows take the general loop below)
             constexpr bool PCM_FULL_TILE = !(L == 1 && NFA == NF);
-            if (all_full && (A.out_pcm16 ? (PCM_FULL_TILE && !vec16_ok) : !vec_ok)) {
+            if (PCM_FULL_TILE && all_full && (A.out_pcm16 ? !vec16_ok : !vec_ok)) {
                 // ... and rows that do not start 16-byte aligned (an out_stride that is not a multiple of 4 samples — the
                 // rows' own length, 96 006, is the natural one): the same tile with 4-byte stores, lane rl of a row
                 // taking samples rl, rl + T/4, ...: every store instruction writes runs of T/4 consecutive samples per row
-                // (the general flush below cost such strides 14 % of the exact and 33 % of the fast headline kernel)
+                // (the general flush below cost such strides 14 % of the exact and 33 % of the fast headline kernel; not for
+                // the one-lane eight-formant kernels, as for i16 rows: the extra path cost their aligned rows 8 %)
                 wave_lds_sync();
                 float w[S / ROWS_PER_IT][4];
 #pragma unroll
@@ -2444,7 +2445,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 #pragma unroll
                 for (int i = 0; i < S / ROWS_PER_IT; ++i) {
                     const uint64_t row = A.perm ? rowid[i * ROWS_PER_IT + rr] : u0 + i * ROWS_PER_IT + rr;
-                    if (PCM_FULL_TILE && A.out_pcm16) {      // (2-byte stores, the WAV sink's conversion on the way out)
+                    if (A.out_pcm16) {      // (2-byte stores, the WAV sink's conversion on the way out)
                         int16_t *dst = A.out_pcm16 + row * A.out_stride + base + rl;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) dst[q * ROW_LANES] = (int16_t)pcm16_from_f32(w[i][q]);
