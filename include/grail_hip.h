@@ -394,8 +394,9 @@ int grail_batch_lengths(grail_ctx *ctx, const grail_batch *batch, uint32_t max_l
  * (samples written, <= out_stride) or NULL.  Returns without waiting.
  * Any out_stride >= the longest utterance works (grail_batch_lengths tells).  Rows that start 16-byte aligned — out_dev
  * from grail_device_alloc and out_stride a multiple of 4 samples — are written with 16-byte stores, and a multiple of 64
- * makes every 64-sample tile one aligned 256-byte run; an odd stride takes 4-byte stores in runs of 16 samples: + 2 %
- * (exact) / + 7 % (fast) on the headline batch (96006 instead of 96064 samples per row). */
+ * makes every 64-sample tile one aligned 256-byte run; an odd stride takes 4-byte stores in runs of 16 samples: + 2 - 4 %
+ * (exact) / + 7 - 8 % (fast) on the headline batch (96006 instead of 96064 samples per row; with all eight formants
+ * live on one lane the general flush: + 7 % / + 14 %). */
 int grail_batch_synthesize_async(grail_ctx *ctx, const grail_batch *batch, float *out_dev,
                                  uint64_t out_stride, uint32_t *out_len_dev);
 /* Wait for ctx's stream.  Returns GRAIL_ERR_BUFFER_TOO_SMALL if any utterance
