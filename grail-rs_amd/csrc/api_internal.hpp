@@ -20,7 +20,7 @@
 #include <cstring>
 #include <new>
 #include <string>
-#include <unordered_set>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/grail_hip.h"

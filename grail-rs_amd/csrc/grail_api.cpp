@@ -742,15 +742,48 @@ int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
         if (r.seconds > b->max_seconds) b->max_seconds = r.seconds;
     }
     b->n_segs = n_segs;
+    // The elems of the batch, interned by their formant arrays (everything but the pitch, which none of the analyses
+    // below looks at): a corpus names a few dozen distinct parameter sets in hundreds of thousands of segments.
+    struct FormantsHash {
+        size_t operator()(const float *p) const
+        {
+            uint64_t h = 0x9E3779B97F4A7C15ull, w;
+            for (int i = 0; i < 24; ++i) {                   // 48 floats after the frequency
+                std::memcpy(&w, p + 1 + 2 * i, sizeof w);
+                h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+                h ^= h >> 29;
+            }
+            return (size_t)h;
+        }
+    };
+    struct FormantsEq {
+        bool operator()(const float *a, const float *c) const { return std::memcmp(a + 1, c + 1, 48 * sizeof(float)) == 0; }
+    };
+    std::unordered_map<const float *, uint32_t, FormantsHash, FormantsEq> ids;
+    std::vector<grail_synthesis_elem> distinct;
+    std::vector<uint32_t> id_of(n_segs, 0xFFFFFFFFu);
+    for (uint32_t i = 0; i < n_segs; ++i) {
+        if (!segs[i].has_elem) continue;
+        const auto it = ids.emplace((const float *)&segs[i].elem, (uint32_t)distinct.size());
+        if (it.second) distinct.push_back(segs[i].elem);
+        id_of[i] = it.first->second;
+    }
     // the sharpness of the batch (elems_sharpness): parameters only ever blend between the elems of two consecutive
     // segments of an utterance (Sequencer::next :897-921), so every such pair is judged like a voice of two phonemes
+    // (once per distinct pair)
+    std::unordered_map<uint64_t, double> pair_sharpness;
     for (uint32_t u = 0; u < n_utt; ++u)
         for (uint32_t i = seg_offsets[u]; i < seg_offsets[u + 1]; ++i) {
             if (!segs[i].has_elem) continue;
-            grail_synthesis_elem pair[2] = {segs[i].elem, segs[i].elem};
-            size_t n_pair = 1;
-            if (i + 1 < seg_offsets[u + 1] && segs[i + 1].has_elem) pair[n_pair++] = segs[i + 1].elem;
-            b->elems_sharpness = std::fmax(b->elems_sharpness, elems_sharpness(pair, n_pair));
+            const uint32_t a = id_of[i];
+            const uint32_t c = (i + 1 < seg_offsets[u + 1] && segs[i + 1].has_elem) ? id_of[i + 1] : a;
+            const uint64_t key = ((uint64_t)std::min(a, c) << 32) | std::max(a, c);
+            auto it = pair_sharpness.find(key);
+            if (it == pair_sharpness.end()) {
+                const grail_synthesis_elem pair[2] = {distinct[a], distinct[c]};
+                it = pair_sharpness.emplace(key, elems_sharpness(pair, a == c ? 1 : 2)).first;
+            }
+            b->elems_sharpness = std::fmax(b->elems_sharpness, it->second);
         }
     if ((rc = upload(&b->d_segs, ds.data(), n_segs, ctx->stream)) ||
         (rc = upload(&b->d_elems, elems.data(), elems.size(), ctx->stream)) ||
@@ -769,12 +802,6 @@ int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
         for (const uint32_t v : b->used_voices) {
             jd = std::fmax(jd, std::fabs((double)ctx->voices[v].jitter_delta_formant_frequency));
             rates_ok = rates_ok && ctx->voices[v].sample_rate > 0.0f && std::isfinite(ctx->voices[v].sample_rate);
-        }
-        std::vector<grail_synthesis_elem> distinct;
-        std::unordered_set<std::string> seen;
-        for (uint32_t i = 0; i < n_segs; ++i) {
-            if (!segs[i].has_elem) continue;
-            if (seen.emplace((const char *)&segs[i].elem, sizeof(grail_synthesis_elem)).second) distinct.push_back(segs[i].elem);
         }
         // can formants 5-8 be left out (the four-formant kernels)?  As for a voice table (live4_ok): the scalars of the
         // voices named, and every distinct elem of the batch
