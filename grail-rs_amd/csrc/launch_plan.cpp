@@ -90,15 +90,6 @@ static bool used_voices_all(const grail_ctx *ctx, const grail_batch *batch, bool
         if (v >= ctx->voice_info.size() || !pred(ctx->voice_info[v])) return false;
     return true;
 }
-static uint32_t used_voices_warmup(const grail_ctx *ctx, const grail_batch *batch)
-{
-    if (ctx->voice_info.empty() || batch->used_voices.empty()) return ctx->max_warmup;
-    uint32_t w = 0;
-    for (const uint32_t v : batch->used_voices)
-        if (v < ctx->voice_info.size()) w = std::max(w, ctx->voice_info[v].warmup);
-    return w;
-}
-
 bool batch_half_capable(const grail_ctx *ctx, const grail_batch *batch)
 {
     // (caller-built elems: judged at upload over the batch's distinct elems, against the voice table of that moment)
@@ -190,7 +181,9 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
     const bool split_ok = batch->phoneme_mode ? used_voices_all(ctx, batch, ctx->voices_split_ok,
                                                                 [](const grail_ctx::VoiceInfo &v) { return v.split_ok; })
                                               : (batch->elems_warmup != 0u && batch->elems_warmup_epoch == ctx->voices_epoch);
-    const uint32_t warmup = batch->phoneme_mode ? used_voices_warmup(ctx, batch) : batch->elems_warmup;
+    // (the grid is laid out for the longest warm-up of the TABLE, not of the voices the batch names: for a pinned grid an
+    // utterance's samples may not depend on what else is in the batch; each lane still warms up for its own voice's length)
+    const uint32_t warmup = batch->phoneme_mode ? ctx->max_warmup : batch->elems_warmup;
     if (ctx->split_option && !ctx->lanes_option && split_ok && batch->plain &&
         out_stride <= 0xFFFFFFFFull && (ctx->split_chunks >= 2 || ctx->split_chunks == 0)) {
         const double sp = ctx->split_span ? std::fmin((double)ctx->split_span, (double)out_stride) : span;

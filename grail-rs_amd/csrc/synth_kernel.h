@@ -1665,7 +1665,19 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     auto fast_flat_left = [&]() __attribute__((always_inline)) -> int {
         const float c1 = clk - dt;
         const bool flat = !silent_pair & (c1 * inv_blend_length > 1.0f);
-        const float n = (c1 - blend_length) * __builtin_amdgcn_rcpf(dt) - 2.0f;
+        // Sample k from now (k = 1 is the next one) has the clock c1 - (k - 1) dt and is on the flat side while that is
+        // above the blend length: floor(x) + 1 samples with x = (c1 - blend_length) / dt (the difference is exact: the two
+        // are within a factor of two of each other wherever the answer matters; v_rcp is good to an ulp).  A sub-tile of
+        // n samples takes its end point from sample n + 1 (where the next one starts), which has to be on the flat side
+        // too: n <= floor(x).  The serial f32 clock strays from the straight line by up to half an ulp of clk per step,
+        // always the same way inside a binade: 17 ulp over the 33 steps a sub-tile can ask about — a twentieth of a sample
+        // for a clock of a quarter second, three quarters of one for a clock of eight seconds — so that much and a
+        // quarter sample are taken off before rounding down (the safe side: the pairs up to the kink take general steps).
+        // It used to be x - 2 throughout: the run ended two samples early and every kink cost the wave two or three pairs
+        // of general steps instead of one or two (profiles/r04_speech_like.txt).
+        const float rdt = __builtin_amdgcn_rcpf(dt);
+        const float stray = 17.0f * __builtin_ldexpf(1.0f, __builtin_amdgcn_frexp_expf(c1) - 24) * rdt;
+        const float n = (c1 - blend_length) * rdt - (0.25f + stray);
         const int ni = n < 0.0f ? 0 : (n > 1.0e6f ? 1000000 : (int)n);
         return flat ? (ni & ~1) : 1000000;
     };
