@@ -34,7 +34,7 @@ def _code_objects():
 
 
 @pytest.fixture(scope="module")
-def kernels(tmp_path_factory):
+def kernels(tmp_path_factory, built):
     """{kernel symbol: metadata dict} over all gfx950 code objects (AMDGPU metadata note, via llvm-readelf)."""
     if not os.path.exists(READELF):
         pytest.skip("llvm-readelf not found")
