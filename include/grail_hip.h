@@ -293,7 +293,8 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *   "row_groups": 1 (default) / 0 / 2 — utterances the lean kernel families cannot take (a segment shorter than two
  *       samples, a non-finite length, blend length or pitch) are put last in the launch order and planned as a batch of
  *       their own where that is cheaper by the cost model (1), never (0), always (2): a few such rows do not cost the
- *       others their four-formant kernels.  Results never depend on it.
+ *       others their four-formant kernels.  Results never depend on it.  (The groups are a launch order: batches uploaded
+ *       with "sort_by_length" = 0, and row-block launches, are planned as one.)
  *   "assume_compute_units": plan for so many compute units instead of what the device reports (0 = the
  *       device's own count; read-only "compute_units" tells what is in force): tests, and callers that share a
  *       device.
