@@ -57,6 +57,7 @@ struct grail_ctx {
     int scan_option = 1;              // fast arithmetic: small batches go to the time-parallel scan kernel
     int64_t scan_max_utts = -1;       // ... up to this many utterances (x 4/7 with eight live formants; -1: 34 per CU = 8704)
     int64_t scan_split_max = -1;      // ... and up to this many with the carrier phase on a wave of its own (-1: 6 per CU = 1536)
+    int ragged_option = 1;            // length-sorted batches: lane mappings weighed by the rows' lengths (ragged_plan)
     int composite_option = 1;         // a batch may be cut into blocks with a kernel family each (plan_blocks)
     int row_groups_option = 1;        // rows the lean families cannot take are planned apart: 1 where the cost model says so, 2 always, 0 never
     double voices_sharpness = INFINITY;   // the largest predicted fast-mode deviation of the table, units of 2^-23
@@ -159,6 +160,11 @@ struct grail_batch {
     // lean rows (slots [0, groups[0].n_utt)), groups[1] = the rest.  Valid for the voice table they were judged against.
     std::vector<grail_batch> groups;
     uint64_t groups_epoch = 0;
+    // Ragged (length-sorted) batches, per granule of 8 consecutive launch slots: the longest row in samples (at the
+    // context's highest rate), the rows' segments and their kinks of alpha (blend_length < length) — what ragged_plan()
+    // weighs the lane mappings with.  Empty for aligned batches.
+    std::vector<float> granule_samples;
+    std::vector<uint32_t> granule_segs, granule_kinks;
 };
 
 namespace grail {
@@ -245,7 +251,11 @@ bool batch_half_capable(const grail_ctx *ctx, const grail_batch *batch);
 bool batch_live4_any_blend(const grail_ctx *ctx, const grail_batch *batch);
 bool batch_live4(const grail_ctx *ctx, const grail_batch *batch);
 void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t fam, Family &f,
-                   bool exact_only = false);
+                   bool exact_only = false, int pin_lanes = 0);
+// ragged batches: what a block costs given the lengths and events of ITS rows; the whole-batch plan weighed against
+// one launch of each lane mapping with as many rounds as it takes (launch_plan.cpp)
+double ragged_cost(const grail_ctx *ctx, const grail_batch *batch, const Family &f, uint32_t slot0, uint32_t rows, double span);
+void ragged_plan(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t rows, std::vector<Block> &plan);
 double plan_blocks(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t rows, double span,
                    std::vector<Block> &out);
 

@@ -86,6 +86,7 @@ struct RowStats {
     bool plain = true;          // every length / blend length / pitch finite, blend lengths > 0
     bool any_blend = false;     // some blend length is not +-2^k
     float min_length = INFINITY, min_pitch = INFINITY, seconds = 0.0f;
+    uint32_t segs = 0, kinks = 0;   // segments; those whose alpha = min(clk / blend_length, 1) has a kink (blend_length < length)
 };
 
 // Ragged batches: the lanes of a wave run in lockstep, so a wave lasts as long as its longest utterance.
@@ -153,6 +154,20 @@ int upload_length_order(grail_ctx *ctx, grail_batch *b, const std::vector<RowSta
             if (r.seconds > v.max_seconds) v.max_seconds = r.seconds;
         }
         b->groups_epoch = ctx->voices_epoch;
+    }
+    if (ragged && n_out == 0) {
+        // what ragged_plan() weighs the lane mappings with (batches without row groups: those are planned by size)
+        const size_t n_gran = ((size_t)n_utt + 7) / 8;
+        b->granule_samples.assign(n_gran, 0.0f);
+        b->granule_segs.assign(n_gran, 0u);
+        b->granule_kinks.assign(n_gran, 0u);
+        for (uint32_t s = 0; s < n_utt; ++s) {
+            const RowStats &r = rows[perm[s]];
+            const float samples = key(perm[s]) * ctx->max_rate;
+            if (samples > b->granule_samples[s / 8]) b->granule_samples[s / 8] = samples;
+            b->granule_segs[s / 8] += r.segs;
+            b->granule_kinks[s / 8] += r.kinks;
+        }
     }
     return GRAIL_OK;
 }
@@ -470,6 +485,10 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         ctx->composite_option = value ? 1 : 0;
         return GRAIL_OK;
     }
+    if (std::strcmp(name, "ragged_plan") == 0) {
+        ctx->ragged_option = value ? 1 : 0;
+        return GRAIL_OK;
+    }
     if (std::strcmp(name, "row_groups") == 0) {
         if (value < 0 || value > 2) return fail(GRAIL_ERR_INVALID_ARG, "row_groups must be 0 (off), 1 (by cost) or 2 (always)");
         ctx->row_groups_option = (int)value;
@@ -539,6 +558,10 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
     }
     if (std::strcmp(name, "row_groups") == 0) {
         *value = ctx->row_groups_option;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "ragged_plan") == 0) {
+        *value = ctx->ragged_option;
         return GRAIL_OK;
     }
     if (std::strcmp(name, "pipeline4_max_groups") == 0) {
@@ -666,6 +689,8 @@ int grail_batch_upload(grail_ctx *ctx, const grail_phoneme_elem *segs, const uin
             const float pitch = std::fmin(segs[i].frequency, 0.5f);   // copy_with_frequency :445-450
             if (pitch < r.min_pitch) r.min_pitch = pitch;
             r.seconds += segs[i].length;
+            r.segs += 1u;
+            r.kinks += segs[i].blend_length < segs[i].length ? 1u : 0u;
         }
     }
     grail_batch *b = new (std::nothrow) grail_batch();
@@ -726,6 +751,8 @@ int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
             if (segs[i].length < r.min_length) r.min_length = segs[i].length;
             if (segs[i].elem.frequency < r.min_pitch) r.min_pitch = segs[i].elem.frequency;
             r.seconds += segs[i].length;
+            r.segs += 1u;
+            r.kinks += segs[i].blend_length < segs[i].length ? 1u : 0u;
         }
     }
     grail_batch *b = new (std::nothrow) grail_batch();

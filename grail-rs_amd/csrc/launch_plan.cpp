@@ -3,6 +3,9 @@
 // without a device.
 #include "api_internal.hpp"
 
+#include <functional>
+#include <queue>
+
 using namespace grail;
 using namespace grail::host;
 
@@ -124,9 +127,10 @@ bool batch_live4(const grail_ctx *ctx, const grail_batch *batch)
 // utterances' length: a time-split pays a warm-up per chunk, the scan kernel the latency of one utterance's chain),
 // unless an option pins the choice.
 void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t fam, Family &f,
-                   bool exact_only)
+                   bool exact_only, int pin_lanes)
 {
     const uint64_t simds = ctx_simds(ctx), cus = (uint64_t)ctx->cus;
+    const int lanes_option = pin_lanes ? pin_lanes : ctx->lanes_option;   // (pin_lanes: as if the option named it)
     f = Family();
     // (the lane kernels and the pipelined workgroups have four-formant instantiations for every blend length; the lean
     // stream kernels for power-of-two blend lengths only: batch_live4)
@@ -135,15 +139,15 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
     // ... in the tier the sharpness allows: 1 = coefficients interpolated, 2 = the reference's own coefficients (MID)
     f.fast = exact_only ? 0u : (uint32_t)fast_tier(ctx, batch);
     // (MID kernels exist one-shot with one lane per utterance, and time-split: a pinned wider mapping gets the exact kernels)
-    if (f.fast == 2u && ctx->lanes_option > 1) f.fast = 0u;
-    int L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(fam, simds);
+    if (f.fast == 2u && lanes_option > 1) f.fast = 0u;
+    int L = lanes_option ? lanes_option : auto_lanes_per_utt(fam, simds);
     if (f.fast == 2u) L = 1;          // (before the four-formant layout is decided: eight lanes would give it up)
     // small batches leave SIMDs idle: four-wave workgroups (one wave renders 16 utterances, one carries
     // the per-utterance chain, two prepare the filter coefficients), up to two per CU (tools/pipe4_range.py:
     // 11.5 ms up to 4 096 utterances, 15.7 up to 8 192 where the lane kernels take 18.0; three per CU lose)
-    const bool want_pipe4 = batch_live4_any_blend(ctx, batch) && !ctx->lanes_option && ctx->pipeline_option &&
+    const bool want_pipe4 = batch_live4_any_blend(ctx, batch) && !lanes_option && ctx->pipeline_option &&
                             (int64_t)(((uint64_t)fam + 15) / 16) <= pipe4_groups(ctx);
-    const bool want_pipe8 = !batch_live4_any_blend(ctx, batch) && !ctx->lanes_option && ctx->pipeline_option &&
+    const bool want_pipe8 = !batch_live4_any_blend(ctx, batch) && !lanes_option && ctx->pipeline_option &&
                             (int64_t)(((uint64_t)fam + 7) / 8) <= pipe8_groups(ctx);
     // one workgroup per CU suffices: rounds of 32 samples instead of 16 (pipe = 2)
     const uint32_t pipe4_kind = ctx->pipe_round32 && ((uint64_t)fam + 15) / 16 <= cus ? 2u : 1u;
@@ -158,14 +162,14 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
     // eight lanes per utterance need eight formants to lay out; for batches that small the
     // 8-lane kernel is also the fastest (18.2 against 18.8 ms: half the rows to flush per wave)
     if (f.live4 && !f.pipe && L == 8) f.live4 = 0u;
-    if (f.live4 && !f.pipe && !ctx->lanes_option) {
+    if (f.live4 && !f.pipe && !lanes_option) {
         // same rule as auto_lanes_per_utt — the widest mapping with one wave per SIMD — over 4 formants
         L = ((uint64_t)fam * 4 + 63) / 64 <= simds ? 4 : ((uint64_t)fam * 2 + 63) / 64 <= simds ? 2 : 1;
     }
     // voices whose upper formants are never audible but that do not qualify for the 4-formant
     // kernels: one lane per utterance runs the half-live loop and ties two lanes per utterance,
     // whose second lane would only hold silent formants
-    if (!ctx->lanes_option && !f.live4 && L == 2 && batch_half_capable(ctx, batch)) L = 1;
+    if (!lanes_option && !f.live4 && L == 2 && batch_half_capable(ctx, batch)) L = 1;
     f.L = L;
     f.half = !f.fast && !f.live4 && !f.pipe && L == 1 && batch_half_capable(ctx, batch);
     if (!f.fast) return;
@@ -184,7 +188,7 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
     // (the grid is laid out for the longest warm-up of the TABLE, not of the voices the batch names: for a pinned grid an
     // utterance's samples may not depend on what else is in the batch; each lane still warms up for its own voice's length)
     const uint32_t warmup = batch->phoneme_mode ? ctx->max_warmup : batch->elems_warmup;
-    if (ctx->split_option && !ctx->lanes_option && split_ok && batch->plain &&
+    if (ctx->split_option && !lanes_option && split_ok && batch->plain &&
         out_stride <= 0xFFFFFFFFull && (ctx->split_chunks >= 2 || ctx->split_chunks == 0)) {
         const double sp = ctx->split_span ? std::fmin((double)ctx->split_span, (double)out_stride) : span;
         // as many chunks as give every SIMD one wave: ceil(fam / 64) waves per chunk index (5 000 utterances are 79 waves
@@ -218,7 +222,7 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
     // filter recurrences solved by parallel scans (scan_kernels.hip).  Needs every parameter inside the safe window
     // (no IEEE fallback).
     Family scan = f;
-    if (f.fast == 1u && ctx->scan_option && !ctx->lanes_option && (int64_t)fam * (l4ab ? 4 : 7) <= 4 * scan_max_utts(ctx) &&
+    if (f.fast == 1u && ctx->scan_option && !lanes_option && (int64_t)fam * (l4ab ? 4 : 7) <= 4 * scan_max_utts(ctx) &&
         used_voices_all(ctx, batch, ctx->voices_scan_ok, [](const grail_ctx::VoiceInfo &v) { return v.scan_ok; }) &&
         (batch->phoneme_mode || (batch->elems_scan_ok && batch->elems_warmup_epoch == ctx->voices_epoch)) &&
         batch->plain && batch->min_length >= 2.0f * ctx->max_dt &&
@@ -249,7 +253,7 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
     }
     if (take_split) f = split;
     else if (take_scan) f = scan;
-    if (f.fast == 2u && !ctx->lanes_option && ctx->split_chunks < 2) {
+    if (f.fast == 2u && !lanes_option && ctx->split_chunks < 2) {
         // The second tier costs 0.8 of the exact one-lane kernel (0.64 - 0.8 time-split): where the exact kernels have a
         // wider mapping to fill the machine with — mid-size batches of voices that do not qualify for time-splitting —
         // they are the faster way to the same tolerance (their bits satisfy it trivially).
@@ -349,13 +353,125 @@ double plan_blocks(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
     return best.first;
 }
 
+
+// ---- Ragged batches ------------------------------------------------------------------------------------------------------
+// The families above are laid out for ONE round: the widest lane mapping that gives every SIMD one wave, priced by the
+// batch's longest utterance.  On a length-sorted batch whose utterances differ much in length that leaves most SIMDs idle
+// most of the time — the one wave of a SIMD lasts as long as ITS longest row, the launch as long as the longest of all —
+// where a wider mapping in several rounds keeps them busy: its waves are shorter, they start longest first, and a SIMD that
+// finishes a short one takes the next.  And a wave holds fewer utterances, so fewer of its tiles hold some lane's event.
+// (Speech-like corpus, 65 536 utterances of 0.5 - 3.8 s: exact 90.0 ms one lane per utterance, 71.7 two; eight formants
+// 171.6 / 113.6; fast 87.7 / 73.6 and 145.7 / 88.8.  profiles/r04_ragged_plan.txt.)
+// Model: a wave costs its longest row's samples at the mapping's rate plus its rows' events (exact: a segment boundary
+// costs the wave 6 / 12 us with four / eight formants; fast: a tile of 64 samples is tight with probability exp(-events per
+// tile) and costs 0.035 ms (four formants; eight: 0.062 / 0.039 / 0.035 / 0.034 for L = 1 / 2 / 4 / 8) otherwise); waves are
+// handed to the SIMDs in launch order as they fall free.  Fitted on that corpus at 16 384 ... 65 536 utterances, L = 1 ... 8
+// (within 10 %, the order of the mappings right in every cell).
+static double ragged_wave_ms(const Family &f, double samples, double segs, double kinks)
+{
+    const bool nfa4 = f.live4 != 0;
+    if (!f.fast) {
+        double per_2s = lane_ms_per_sample(false, nfa4, f.L) * 96006.0;
+        if (f.half) {
+            // the half-live loops serve the tiles (32 samples) no lane has an event in
+            const double tight = std::exp(-segs / std::fmax(samples / 32.0, 1.0));
+            per_2s = tight * 45.7 + (1.0 - tight) * per_2s;
+        }
+        return samples * per_2s / 96006.0 + segs * (nfa4 ? 0.006 : 0.012);
+    }
+    const double T = (!nfa4 && f.L == 4) ? 32.0 : 64.0;
+    const double tiles = std::fmax(samples / T, 1.0);
+    const double fast_tile = lane_ms_per_sample(true, nfa4, f.L) * T;
+    double tight_tile = fast_tile;
+    static const double mixed8[4] = {0.062, 0.039, 0.0175, 0.034};       // (L = 4: tiles of 32 samples)
+    double mixed_tile = nfa4 ? 0.035 : mixed8[f.L == 1 ? 0 : f.L == 2 ? 1 : f.L == 4 ? 2 : 3];
+    if (f.fast == 2u) {                                                    // second tier: the same events, its own rate
+        tight_tile = mid_ms_per_sample(nfa4) * T;
+        mixed_tile += tight_tile - fast_tile;
+    }
+    const double tight = std::exp(-(segs + kinks) / tiles);
+    return tiles * (tight * tight_tile + (1.0 - tight) * mixed_tile);
+}
+
+double ragged_cost(const grail_ctx *ctx, const grail_batch *batch, const Family &f, uint32_t slot0, uint32_t rows, double span)
+{
+    const size_t n_gran = batch->granule_samples.size();
+    if (n_gran == 0 || rows == 0) return family_cost(ctx, f, rows, span);
+    const size_t g0 = std::min<size_t>(slot0 / 8, n_gran - 1), g1 = std::min<size_t>(((size_t)slot0 + rows + 7) / 8, n_gran);
+    // (families that render an utterance with many lanes: by the block's own longest row)
+    if (f.scan || f.pipe) return family_cost(ctx, f, rows, std::fmin(span, std::fmax((double)batch->granule_samples[g0], 0.0) + 64.0));
+    const uint64_t simds = ctx_simds(ctx);
+    if (f.split_k) {
+        // every wave holds 64 utterances at one chunk index: the events of a one-lane wave; the first chunk of the
+        // longest rows sets the time (x 1.2: fast-forward and restarts, from the same corpus)
+        double segs = 0.0, kinks = 0.0;
+        for (size_t g = g0; g < std::min(g0 + 8, g1); ++g) {
+            segs += batch->granule_segs[g];
+            kinks += batch->granule_kinks[g];
+        }
+        const double len = std::fmax((double)batch->granule_samples[g0], 64.0), part = (double)f.split_bounds[1] / len;
+        Family lane = f;
+        lane.split_k = 0;
+        lane.L = 1;
+        const double rounds = std::ceil(std::ceil((double)rows / 64.0) * f.split_k / (double)simds);
+        return rounds * (1.2 * ragged_wave_ms(lane, (double)f.split_bounds[1], segs * part, kinks * part) + 0.12);
+    }
+    // waves of 64 / L consecutive slots, handed out in launch order to the SIMD that falls free first
+    const size_t per_wave = (size_t)(8 / f.L > 0 ? 8 / f.L : 1);
+    std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
+    double makespan = 0.0;
+    for (size_t g = g0; g < g1; g += per_wave) {
+        double samples = 0.0, segs = 0.0, kinks = 0.0;
+        for (size_t k = g; k < std::min(g + per_wave, g1); ++k) {
+            samples = std::fmax(samples, (double)batch->granule_samples[k]);
+            segs += batch->granule_segs[k];
+            kinks += batch->granule_kinks[k];
+        }
+        samples = std::fmin(samples + 64.0, span);
+        double t = ragged_wave_ms(f, samples, segs, kinks);
+        if (free_at.size() >= simds) {
+            t += free_at.top();
+            free_at.pop();
+        }
+        free_at.push(t);
+        if (t > makespan) makespan = t;
+    }
+    return makespan;
+}
+
+void ragged_plan(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t rows, std::vector<Block> &plan)
+{
+    if (!ctx->ragged_option || batch->granule_samples.empty() || rows != batch->n_utt || plan.empty()) return;
+    if (plan.size() == 1 && (plan[0].f.scan || plan[0].f.pipe)) return;   // (batches that small: many lanes per utterance)
+    const double span = batch_span(ctx, batch, out_stride);
+    double current = 0.0;
+    uint32_t slot0 = 0;
+    for (const Block &b : plan) {
+        current += ragged_cost(ctx, batch, b.f, slot0, b.rows, span) + Planner::LAUNCH_MS;
+        slot0 += b.rows;
+    }
+    double best = 0.95 * current;                // (a candidate has to be worth the change)
+    for (int L = 1; L <= 8; L *= 2) {
+        Family f;
+        choose_family(ctx, batch, out_stride, rows, f, false, L);
+        if (f.scan || f.pipe || f.split_k) continue;
+        const double c = ragged_cost(ctx, batch, f, 0, rows, span) + Planner::LAUNCH_MS;
+        if (c < best) {
+            best = c;
+            plan.assign(1, Block{rows, f});
+        }
+    }
+}
+
 }  // namespace host
 }  // namespace grail
 
 extern "C" {
 
-int grail_plan_blocks(uint32_t compute_units, int arithmetic, int live_formants, uint32_t warmup, uint32_t rows,
-                      uint32_t span_samples, grail_plan_block *blocks, uint32_t cap, uint32_t *n_blocks)
+// grail_plan_blocks / grail_plan_ragged_blocks: row_samples == nullptr is the aligned batch
+static int plan_preview(uint32_t compute_units, int arithmetic, int live_formants, uint32_t warmup, uint32_t rows,
+                        uint32_t span_samples, const uint32_t *row_samples, const uint32_t *row_segments,
+                        const uint32_t *row_kinks, grail_plan_block *blocks, uint32_t cap, uint32_t *n_blocks)
 {
     if (!n_blocks) return fail(GRAIL_ERR_INVALID_ARG, "n_blocks is NULL");
     *n_blocks = 0;
@@ -382,22 +498,58 @@ int grail_plan_blocks(uint32_t compute_units, int arithmetic, int live_formants,
     batch.max_seconds = (float)span_samples;
     batch.min_length = 1e9f;
     batch.min_pitch = 0.25f;
+    if (row_samples) {
+        // (what upload_length_order keeps of a length-sorted batch)
+        const size_t n_gran = ((size_t)rows + 7) / 8;
+        batch.granule_samples.assign(n_gran, 0.0f);
+        batch.granule_segs.assign(n_gran, 0u);
+        batch.granule_kinks.assign(n_gran, 0u);
+        for (uint32_t s = 0; s < rows; ++s) {
+            batch.granule_samples[s / 8] = std::fmax(batch.granule_samples[s / 8], (float)row_samples[s]);
+            batch.granule_segs[s / 8] += row_segments ? row_segments[s] : 0u;
+            batch.granule_kinks[s / 8] += row_kinks ? row_kinks[s] : 0u;
+        }
+    }
     const uint64_t stride = ((uint64_t)span_samples + 64u + 63u) / 64u * 64u;
     std::vector<Block> plan;
     plan_blocks(&ctx, &batch, stride, rows, batch_span(&ctx, &batch, stride), plan);
+    ragged_plan(&ctx, &batch, stride, rows, plan);
     *n_blocks = (uint32_t)plan.size();
-    for (uint32_t i = 0; i < plan.size() && i < cap && blocks; ++i) {
+    uint32_t slot0 = 0;
+    for (uint32_t i = 0; i < plan.size(); ++i) {
         const Family &f = plan[i].f;
-        blocks[i].rows = plan[i].rows;
-        blocks[i].lanes_per_utterance = f.scan ? 0u : (uint32_t)f.L;
-        blocks[i].pipelined = f.scan ? 0u : f.pipe;
-        blocks[i].chunks = (uint32_t)f.split_k;
-        blocks[i].scan = f.scan ? (f.scan_pipe ? 2u : 1u) : 0u;
-        blocks[i].fast = f.fast;
-        blocks[i].formants = f.live4 ? 4u : 8u;
-        blocks[i].model_ms = (float)family_cost(&ctx, f, plan[i].rows, batch_span(&ctx, &batch, stride));
+        if (i < cap && blocks) {
+            blocks[i].rows = plan[i].rows;
+            blocks[i].lanes_per_utterance = f.scan ? 0u : (uint32_t)f.L;
+            blocks[i].pipelined = f.scan ? 0u : f.pipe;
+            blocks[i].chunks = (uint32_t)f.split_k;
+            blocks[i].scan = f.scan ? (f.scan_pipe ? 2u : 1u) : 0u;
+            blocks[i].fast = f.fast;
+            blocks[i].formants = f.live4 ? 4u : 8u;
+            blocks[i].model_ms = (float)ragged_cost(&ctx, &batch, f, slot0, plan[i].rows, batch_span(&ctx, &batch, stride));
+        }
+        slot0 += plan[i].rows;
     }
     return GRAIL_OK;
+}
+
+int grail_plan_blocks(uint32_t compute_units, int arithmetic, int live_formants, uint32_t warmup, uint32_t rows,
+                      uint32_t span_samples, grail_plan_block *blocks, uint32_t cap, uint32_t *n_blocks)
+{
+    return plan_preview(compute_units, arithmetic, live_formants, warmup, rows, span_samples, nullptr, nullptr, nullptr,
+                        blocks, cap, n_blocks);
+}
+
+int grail_plan_ragged_blocks(uint32_t compute_units, int arithmetic, int live_formants, uint32_t warmup, uint32_t rows,
+                             const uint32_t *row_samples, const uint32_t *row_segments, const uint32_t *row_kinks,
+                             grail_plan_block *blocks, uint32_t cap, uint32_t *n_blocks)
+{
+    if (n_blocks) *n_blocks = 0;
+    if (rows && !row_samples) return fail(GRAIL_ERR_INVALID_ARG, "row_samples is NULL");
+    uint32_t span = 0;
+    for (uint32_t s = 0; s < rows; ++s) span = std::max(span, row_samples[s]);
+    return plan_preview(compute_units, arithmetic, live_formants, warmup, rows, span, row_samples, row_segments, row_kinks,
+                        blocks, cap, n_blocks);
 }
 
 }  // extern "C"

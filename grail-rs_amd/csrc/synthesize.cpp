@@ -102,6 +102,9 @@ int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_dev,
             plan.push_back(Block{rows, f});
         } else {
             plan_blocks(ctx, view, out_stride, rows, batch_span(ctx, view, out_stride), plan);
+            // length-sorted batches: the plan weighed against each lane mapping in as many rounds as it takes, by the
+            // lengths and events of the rows (launch_plan.cpp, "Ragged batches")
+            if (use_perm && view == batch) ragged_plan(ctx, view, out_stride, rows, plan);
         }
         if (!view->plan_cache) view->plan_cache = new (std::nothrow) PlanCache();
         if (view->plan_cache) {

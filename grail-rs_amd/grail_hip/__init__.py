@@ -54,7 +54,7 @@ EXPORTS = [
     "grail_elem_silent", "grail_elem_new_phoneme", "grail_elem_new", "grail_elem_resample",
     "grail_elem_blend", "grail_voice_generic", "grail_voice_generic_at", "grail_voice_get",
     "grail_create", "grail_destroy", "grail_device_count", "grail_device_pci_bus_id", "grail_time_split_warmup",
-    "grail_time_split_grid", "grail_fast_sharpness", "grail_plan_blocks", "grail_set_voices",
+    "grail_time_split_grid", "grail_fast_sharpness", "grail_plan_blocks", "grail_plan_ragged_blocks", "grail_set_voices",
     "grail_get_voices", "grail_set_option", "grail_get_option",
     "grail_batch_upload", "grail_batch_upload_elems", "grail_batch_free", "grail_batch_size",
     "grail_batch_lengths", "grail_batch_synthesize_async", "grail_sync",
@@ -216,6 +216,8 @@ def load():
     L.grail_time_split_grid.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     L.grail_plan_blocks.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.POINTER(PlanBlock), C.c_uint32, u32p]
+    L.grail_plan_ragged_blocks.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_uint32, u32p, u32p, u32p,
+                                           C.POINTER(PlanBlock), C.c_uint32, u32p]
     L.grail_set_voices.argtypes = [vp, vp, C.c_uint32]
     L.grail_get_voices.argtypes = [vp, vp, C.c_uint32, u32p]
     L.grail_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
@@ -425,6 +427,22 @@ def plan_blocks(rows, span_samples, arithmetic=0, live_formants=4, warmup=3904, 
     n = C.c_uint32()
     _check(load().grail_plan_blocks(compute_units, arithmetic, live_formants, warmup, rows, span_samples, arr, 16,
                                     C.byref(n)))
+    return [PlanBlock.from_buffer_copy(bytes(arr[i])) for i in range(min(n.value, 16))]
+
+
+def plan_ragged_blocks(row_samples, row_segments=None, row_kinks=None, arithmetic=0, live_formants=4, warmup=3904,
+                       compute_units=256):
+    """... of a batch whose utterances differ in length: row_samples descending (launch order), the rows' segments and
+    kinks of alpha (option "ragged_plan"): [PlanBlock]."""
+    def u32(a):
+        return None if a is None else np.ascontiguousarray(a, dtype=np.uint32)
+    rs, sg, kk = u32(row_samples), u32(row_segments), u32(row_kinks)
+    u32p = C.POINTER(C.c_uint32)
+    arr = (PlanBlock * 16)()
+    n = C.c_uint32()
+    _check(load().grail_plan_ragged_blocks(compute_units, arithmetic, live_formants, warmup, len(rs),
+                                           rs.ctypes.data_as(u32p), None if sg is None else sg.ctypes.data_as(u32p),
+                                           None if kk is None else kk.ctypes.data_as(u32p), arr, 16, C.byref(n)))
     return [PlanBlock.from_buffer_copy(bytes(arr[i])) for i in range(min(n.value, 16))]
 
 

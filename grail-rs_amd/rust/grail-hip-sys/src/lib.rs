@@ -127,6 +127,9 @@ extern "C" {
                                  bounds: *mut u32) -> c_int;
     pub fn grail_plan_blocks(compute_units: u32, arithmetic: c_int, live_formants: c_int, warmup: u32, rows: u32,
                              span_samples: u32, blocks: *mut grail_plan_block, cap: u32, n_blocks: *mut u32) -> c_int;
+    pub fn grail_plan_ragged_blocks(compute_units: u32, arithmetic: c_int, live_formants: c_int, warmup: u32, rows: u32,
+                                    row_samples: *const u32, row_segments: *const u32, row_kinks: *const u32,
+                                    blocks: *mut grail_plan_block, cap: u32, n_blocks: *mut u32) -> c_int;
     pub fn grail_set_voices(ctx: *mut grail_ctx, voices: *const grail_voice, n: u32) -> c_int;
     pub fn grail_get_voices(ctx: *mut grail_ctx, voices: *mut grail_voice, cap: u32, n: *mut u32) -> c_int;
     pub fn grail_set_option(ctx: *mut grail_ctx, name: *const c_char, value: i64) -> c_int;

@@ -295,6 +295,15 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       their own where that is cheaper by the cost model (1), never (0), always (2): a few such rows do not cost the
  *       others their four-formant kernels.  Results never depend on it.  (The groups are a launch order: batches uploaded
  *       with "sort_by_length" = 0, and row-block launches, are planned as one.)
+ *   "ragged_plan": 1 (default) / 0 — batches whose utterances differ in length ("sort_by_length" = 1, whole-batch
+ *       launches).  The lanes of a wavefront run in lockstep: a wavefront lasts as long as its longest utterance, and
+ *       a launch laid out for ONE wavefront per SIMD as long as the longest of all, most SIMDs idle most of that
+ *       time.  A wider lane mapping in several rounds keeps them busy (shorter wavefronts, started longest first,
+ *       a SIMD that finishes one takes the next) and puts fewer utterances' segment boundaries into a wavefront.  The
+ *       plan is therefore weighed against one launch of each lane mapping, by the lengths and the events of the rows
+ *       (grail_plan_ragged_blocks).  Speech-like corpus — 65 536 utterances of 8 - 32 phonemes, 0.5 - 3.8 s — exact
+ *       71 ms instead of 90 (eight live formants: 113 instead of 172), fast 74 instead of 88 (98 instead of 146);
+ *       profiles/r04_ragged_plan.txt.  Exact results never depend on it; fast ones follow the family (below).
  *   "assume_compute_units": plan for so many compute units instead of what the device reports (0 = the
  *       device's own count; read-only "compute_units" tells what is in force): tests, and callers that share a
  *       device.
@@ -365,6 +374,14 @@ typedef struct grail_plan_block {
 } grail_plan_block;
 int grail_plan_blocks(uint32_t compute_units, int arithmetic, int live_formants, uint32_t warmup, uint32_t rows,
                       uint32_t span_samples, grail_plan_block *blocks, uint32_t cap, uint32_t *n_blocks);
+/* ... of a batch whose utterances differ in length (option "ragged_plan"), rows in launch order = longest first:
+ *   row_samples[rows]: the utterances' lengths in samples, descending
+ *   row_segments[rows], row_kinks[rows]: their segments, and those among them with blend_length < length (the kink of
+ *     alpha = min(clk / blend_length, 1), an event of its own in fast arithmetic); NULL: none
+ * model_ms is then the estimate for the block's own rows. */
+int grail_plan_ragged_blocks(uint32_t compute_units, int arithmetic, int live_formants, uint32_t warmup, uint32_t rows,
+                             const uint32_t *row_samples, const uint32_t *row_segments, const uint32_t *row_kinks,
+                             grail_plan_block *blocks, uint32_t cap, uint32_t *n_blocks);
 
 /* ---- batches ----------------------------------------------------------- */
 /* Uploads the inputs of n_utt utterances: utterance u is

@@ -106,6 +106,42 @@ int main()
     CHECK(grail_plan_blocks(256, 0, 4, 0, 70000, 96006, nullptr, 0, &n) == GRAIL_OK && n == 2u);
     CHECK(grail_plan_blocks(256, 0, 4, 0, 70000, 96006, nullptr, 0, nullptr) == GRAIL_ERR_INVALID_ARG);
 
+    // ---- ... of batches whose utterances differ in length (grail_plan_ragged_blocks): random, unsorted and extreme rows
+    int ragged = 0;
+    std::vector<uint32_t> samples, segs, kinks;
+    for (int t = 0; t < 400; ++t) {
+        const uint32_t cus = 1u + rnd() % 300u;
+        const uint32_t rows = t % 9 == 0 ? rnd() % 9u : 1u + rnd() % 200000u;
+        samples.resize(rows);
+        segs.resize(rows);
+        kinks.resize(rows);
+        uint32_t len = t % 7 == 0 ? 0xFFFFFFFFu : 64u + rnd() % 400000u;
+        for (uint32_t r = 0; r < rows; ++r) {
+            samples[r] = t % 5 == 0 ? rnd() * (rnd() % 300u) : len;       // (every fifth: unsorted, up to 2^32)
+            len -= len > 8u ? rnd() % 8u : 0u;
+            segs[r] = t % 11 == 0 ? rnd() * 256u : rnd() % 64u;
+            kinks[r] = t % 13 == 0 ? 0xFFFFFFFFu : rnd() % 64u;
+        }
+        uint32_t nb = 0xFFFFFFFFu;
+        const uint32_t cap = rnd() % 65u;
+        const int rc = grail_plan_ragged_blocks(cus, (int)(rnd() % 3u), rnd() & 1u ? 4 : 8, rnd() & 1u ? 0u : 3904u, rows,
+                                                samples.data(), t % 3 ? segs.data() : nullptr, t % 4 ? kinks.data() : nullptr,
+                                                blocks.data(), cap, &nb);
+        CHECK(rc == GRAIL_OK);
+        CHECK((nb == 0u) == (rows == 0u));
+        if (nb <= cap) {
+            uint64_t sum = 0;
+            for (uint32_t i = 0; i < nb; ++i) {
+                sum += blocks[i].rows;
+                CHECK(blocks[i].rows > 0u && !std::isnan(blocks[i].model_ms) && blocks[i].model_ms >= 0.0f);
+            }
+            CHECK(sum == rows);
+        }
+        ++ragged;
+    }
+    CHECK(grail_plan_ragged_blocks(256, 0, 4, 0, 10, nullptr, nullptr, nullptr, blocks.data(), 64, &n) == GRAIL_ERR_INVALID_ARG);
+    CHECK(ragged == 400);
+
     // ---- voice analysis on sane, random and hostile tables
     grail_voice v;
     grail_voice_generic_at(&v, 48000.0f);

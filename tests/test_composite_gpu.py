@@ -75,10 +75,13 @@ def _bit_identical(out, lens, ref, ref_len, what):
 
 @pytest.fixture
 def small_machine(gpu_ctx):
-    def set_cus(c):
+    def set_cus(c, ragged_plan=0):
         gpu_ctx.set_option("assume_compute_units", c)
+        # (these tests are about the cut by size: ragged batches keep it; the plan by the rows' lengths has its own test)
+        gpu_ctx.set_option("ragged_plan", ragged_plan)
     yield set_cus
     gpu_ctx.set_option("assume_compute_units", 0)
+    gpu_ctx.set_option("ragged_plan", 1)
     gpu_ctx.set_option("composite_launches", 1)
     gpu_ctx.set_option("sort_by_length", 1)
     gpu_ctx.set_option("arithmetic", 0)
@@ -353,3 +356,58 @@ def test_a_few_odd_rows_do_not_decide_the_kernels_of_all(gpu_ctx, fast):
             x[both_nan] = 0
             y[both_nan] = 0
             assert np.array_equal(x, y), (u, int(np.argmax(x != y)))
+
+
+def _speech_like(n_utt, n_voices, seed=13):
+    """Utterances of 4 - 24 phonemes of 5 - 20 ms (blends of 4 - 10 ms, any length; pitches of 90 - 220 Hz): lengths
+    differ by a factor of ten and no two utterances have a segment boundary at the same time."""
+    rng = np.random.default_rng(seed)
+    counts = rng.integers(4, 25, n_utt)
+    offs = np.zeros(n_utt + 1, dtype=np.uint32)
+    offs[1:] = np.cumsum(counts)
+    k = int(offs[-1])
+    segs = np.zeros(k, dtype=G.PHONEME_DTYPE)
+    segs["phoneme"] = rng.choice([G.PH_A, G.PH_E, G.PH_SILENCE, G.PH_STOP], k, p=[.4, .4, .12, .08])
+    segs["phoneme"][offs[:-1]] = G.PH_SILENCE
+    segs["length"] = rng.uniform(0.005, 0.02, k).astype(np.float32)
+    segs["blend_length"] = rng.uniform(0.004, 0.01, k).astype(np.float32)
+    segs["frequency"] = (rng.uniform(90, 220, k) / 48000.0).astype(np.float32)
+    ids = np.arange(n_utt, dtype=np.uint32)
+    return segs, offs, ids % np.uint32(n_voices), ids * np.uint32(17) + np.uint32(3)
+
+
+@pytest.mark.parametrize("fast", [0, 1])
+@pytest.mark.parametrize("n_voices", [1, 8])
+def test_ragged_batches_take_wider_mappings_in_several_rounds(gpu_ctx, small_machine, n_voices, fast):
+    """A machine's worth of utterances (4 CUs: 1 024) that differ in length by a factor of ten.  Laid out for one wave per
+    SIMD (one lane per utterance) the launch lasts as long as its longest utterance; option "ragged_plan" weighs that
+    against wider mappings in several rounds by the rows' lengths and events and takes one of them (launch_plan.cpp,
+    "Ragged batches"; on the whole device: profiles/r04_ragged_plan.txt).  Exact: the oracle's bits whichever way;
+    fast: within the tolerance."""
+    voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    n_utt = 1024
+    segs, offs, vids, seeds = _speech_like(n_utt, n_voices)
+    stride = 24 * 960 + 128
+    ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, stride)
+    assert ref_len.max() < stride and ref_len.max() > 6 * ref_len.min()
+    gpu_ctx.set_option("arithmetic", fast)
+    seen = {}
+    for ragged_plan in (0, 1):
+        small_machine(4, ragged_plan)
+        out, lens, status = _device_render(gpu_ctx, segs, offs, vids, seeds, stride)
+        seen[ragged_plan] = (gpu_ctx.get_option("last_launch_lanes"), gpu_ctx.get_option("last_launch_blocks"),
+                             gpu_ctx.last_kernel_name())
+        assert status == G.OK and np.array_equal(lens, ref_len)
+        if fast:
+            assert gpu_ctx.get_option("last_launch_fast") == 1, seen
+            worst = max(float(np.abs(out[u, :lens[u]].astype(np.float64) - ref[u, :lens[u]]).max()) /
+                        max(1.0, float(np.abs(ref[u, :lens[u]]).max())) for u in range(n_utt))
+            assert worst <= G.FAST_TOLERANCE, (ragged_plan, worst / ULP)
+        else:
+            _bit_identical(out, lens, ref, ref_len, f"ragged_plan={ragged_plan}")
+    assert seen[0][0] == 1 or "SPLIT" in seen[0][2], seen          # one round: a lane (or a chunk lane) per utterance
+    # several rounds of a wider mapping in one launch (fast arithmetic, four formants: events this dense leave the
+    # model no 5 % to gain — the one-lane kernel stays)
+    if not fast or n_voices == 8:
+        assert seen[1][0] in (2, 4, 8) and seen[1][1] == 1, seen

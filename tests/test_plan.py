@@ -121,3 +121,60 @@ def test_time_split_grids_count_waves_not_lanes(cus):
                     waves = -(-b.rows // 64) * b.chunks
                     # (whole rounds only: a block that needs a second round for a few waves is what the planner avoids)
                     assert waves <= simds or waves % simds == 0 or waves > 2 * simds, (cus, span, n, b.rows, b.chunks, waves)
+
+
+def _speech_like_rows(n, seed=7):
+    """Lengths, segments and kinks of utterances of 8 - 32 phonemes of 40 - 160 ms (blends of 30 - 80 ms), longest first."""
+    rng = np.random.default_rng(seed)
+    counts = rng.integers(8, 33, n)
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    length = rng.uniform(0.04, 0.16, offs[-1])
+    blend = rng.uniform(0.03, 0.08, offs[-1])
+    samples = np.add.reduceat(length, offs[:-1]) * 48000.0
+    kinks = np.add.reduceat((blend < length).astype(np.int64), offs[:-1])
+    order = np.argsort(-samples, kind="stable")
+    return samples[order].astype(np.uint32), counts[order].astype(np.uint32), kinks[order].astype(np.uint32)
+
+
+@pytest.mark.parametrize("fast", [0, 1])
+@pytest.mark.parametrize("formants", [4, 8])
+def test_ragged_batches_take_wider_mappings_in_several_rounds(fast, formants):
+    """A machine's worth of utterances that differ in length by a factor of seven (profiles/r04_ragged_plan.txt): one wave
+    per SIMD lasts as long as the longest utterance of all; two or four lanes per utterance in two or four rounds are
+    shorter by the model, as they are on the device (exact 71 against 90 ms, fast 74 against 88)."""
+    samples, segs, kinks = _speech_like_rows(65536)
+    plan = G.plan_ragged_blocks(samples, segs, kinks, arithmetic=fast, live_formants=formants)
+    assert sum(b.rows for b in plan) == 65536 and len(plan) == 1
+    assert plan[0].lanes_per_utterance in (2, 4) and plan[0].chunks == 0 and plan[0].scan == 0
+    # ... against the one-round plan of the same batch priced by the same rows
+    one_round = G.plan_blocks(65536, int(samples[0]), fast, formants)
+    assert len(one_round) == 1 and one_round[0].lanes_per_utterance == 1
+    aligned = np.full(65536, samples[0], dtype=np.uint32)
+    worst = G.plan_ragged_blocks(aligned, segs, kinks, arithmetic=fast, live_formants=formants)
+    assert sum(b.model_ms for b in plan) < 0.9 * sum(b.model_ms for b in worst)
+
+
+@pytest.mark.parametrize("fast", [0, 1])
+@pytest.mark.parametrize("formants", [4, 8])
+@pytest.mark.parametrize("rows", [300, 4096, 20000, 65536, 70000, 131072])
+def test_aligned_rows_keep_the_plan_of_aligned_batches(rows, fast, formants):
+    """All utterances of one length, four segments each (the bench corpus): nothing to gain from further rounds — the
+    ragged planner returns the cut grail_plan_blocks makes."""
+    samples = np.full(rows, 96006, dtype=np.uint32)
+    four = np.full(rows, 4, dtype=np.uint32)
+    ragged = G.plan_ragged_blocks(samples, four, four if fast else None, arithmetic=fast, live_formants=formants)
+    plain = G.plan_blocks(rows, 96006, fast, formants)
+    assert [(b.rows, b.lanes_per_utterance, b.pipelined, b.chunks, b.scan, b.fast) for b in ragged] == \
+           [(b.rows, b.lanes_per_utterance, b.pipelined, b.chunks, b.scan, b.fast) for b in plain]
+
+
+def test_ragged_planner_bad_and_hostile_arguments():
+    assert G.plan_ragged_blocks(np.zeros(0, dtype=np.uint32)) == []
+    huge = np.full(1000, 0xFFFFFFFF, dtype=np.uint32)
+    plan = G.plan_ragged_blocks(huge, huge, huge, arithmetic=1, live_formants=8)
+    assert sum(b.rows for b in plan) == 1000
+    with pytest.raises(G.GrailError):
+        G.plan_ragged_blocks(np.ones(10, dtype=np.uint32), compute_units=0)
+    # ascending instead of descending lengths, no events: still a plan of all rows
+    plan = G.plan_ragged_blocks(np.arange(1, 100001, dtype=np.uint32), arithmetic=0)
+    assert sum(b.rows for b in plan) == 100000

@@ -2,7 +2,7 @@
 """Kernel time on a RAGGED corpus: per-segment lengths drawn from [0.3, 0.7] s and (optionally)
 per-voice jitter rates that differ, so segment boundaries and jitter wraps of the 64 utterances of
 a wave do not coincide (the bench corpus has them all aligned).
-usage: ragged_bench.py [n_utt [sort_by_length [arithmetic [time_split_chunks]]]]"""
+usage: ragged_bench.py [n_utt [sort_by_length [arithmetic [time_split_chunks]]]] [--lanes=L] [--no-ragged-plan]   (A/B)"""
 import os
 import sys
 
@@ -12,12 +12,19 @@ import numpy as np
 import grail_hip as G
 from grail_hip import workload as W
 
+pin = [a for a in sys.argv[1:] if a.startswith("--lanes=")]
+no_ragged_plan = "--no-ragged-plan" in sys.argv
+sys.argv = [a for a in sys.argv if not a.startswith("--")]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 sort = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 fast = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 ctx = G.Context(0)
 ctx.set_option("sort_by_length", sort)
 ctx.set_option("arithmetic", fast)
+if pin:
+    ctx.set_option("lanes_per_utterance", int(pin[0][8:]))
+if no_ragged_plan:
+    ctx.set_option("ragged_plan", 0)
 if len(sys.argv) > 4:
     ctx.set_option("time_split_chunks", int(sys.argv[4]))      # 0 = the library's own choice
 print(f"n = {n} utterances, sort_by_length = {sort}, arithmetic = {'fast' if fast else 'exact'}", flush=True)

@@ -2,7 +2,9 @@
 """Kernel time on a SPEECH-LIKE corpus: utterances of 8 - 32 phonemes of 40 - 160 ms each (blends of 30 - 80 ms, pitch
 contours of 90 - 220 Hz), so that utterances differ in length by a factor of four and every lane of a wave has a segment
 boundary every few thousand samples at a time of its own — next to the bench corpus (4 aligned segments of 0.5 s).
-Reports samples/s over the samples actually rendered.   usage: speech_like_bench.py [n_utt] [--blend-is-length]"""
+Reports samples/s over the samples actually rendered.
+usage: speech_like_bench.py [n_utt] [--blend-is-length] [--lanes=L] [--no-split] [--no-ragged-plan]   (A/B: pinned lane
+mapping, no time-split, the one-round launch policy)"""
 import os
 import sys
 
@@ -14,6 +16,13 @@ from grail_hip import workload as W
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 65536
 ctx = G.Context(0)
+for a in sys.argv[1:]:
+    if a.startswith("--lanes="):
+        ctx.set_option("lanes_per_utterance", int(a[8:]))
+    if a == "--no-split":
+        ctx.set_option("time_split", 0)
+    if a == "--no-ragged-plan":
+        ctx.set_option("ragged_plan", 0)
 rng = np.random.default_rng(7)
 for n_voices in (1, 8):
     voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
@@ -50,7 +59,7 @@ for n_voices in (1, 8):
         total = int(lens.astype(np.uint64).sum())
         print(f"speech-like, {n_voices} voice(s), {n} utterances ({total / n / 48000:.2f} s on average, {lens.min() / 48000:.2f} .. {lens.max() / 48000:.2f} s), "
               f"{'fast ' if fast else 'exact'}: {min(ms):7.2f} ms = {total / (min(ms) * 1e-3):.3e} samples/s  ({ctx.last_kernel_name()}, "
-              f"{ctx.get_option('last_launch_blocks')} block(s))"
+              f"{ctx.get_option('last_launch_blocks')} block(s), L = {ctx.get_option('last_launch_lanes')})"
               + (f"  [per wave: {stats[0] * 64 / n:.0f} tight tiles, {stats[1] * 64 / n:.0f} general steps, longest row {lens.max() // 64} tiles]" if fast else ""), flush=True)
     ctx.set_option("arithmetic", 0)
     ctx.device_free(d_out)
