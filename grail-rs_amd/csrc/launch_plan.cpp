@@ -361,10 +361,10 @@ double plan_blocks(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
 // where a wider mapping in several rounds keeps them busy: its waves are shorter, they start longest first, and a SIMD that
 // finishes a short one takes the next.  And a wave holds fewer utterances, so fewer of its tiles hold some lane's event.
 // (Speech-like corpus, 65 536 utterances of 0.5 - 3.8 s: exact 90.0 ms one lane per utterance, 71.7 two; eight formants
-// 171.6 / 113.6; fast 87.7 / 73.6 and 145.7 / 88.8.  profiles/r04_ragged_plan.txt.)
+// 171.6 / 113.6; fast 87.7 / 73.6 and 145.7 / 88.8; 100 000: 125 -> 94 in ONE launch of the one-lane kernel.  profiles/r04_ragged_plan.txt.)
 // Model: a wave costs its longest row's samples at the mapping's rate plus its rows' events (exact: a segment boundary
 // costs the wave 6 / 12 us with four / eight formants; fast: a tile of 64 samples is tight with probability exp(-events per
-// tile) and costs 0.035 ms (four formants; eight: 0.062 / 0.039 / 0.035 / 0.034 for L = 1 / 2 / 4 / 8) otherwise); waves are
+// tile) and costs 0.035 ms (four formants; eight: 0.062 / 0.039 / 0.048 / 0.034 for L = 1 / 2 / 4 / 8) otherwise); waves are
 // handed to the SIMDs in launch order as they fall free.  Fitted on that corpus at 16 384 ... 65 536 utterances, L = 1 ... 8
 // (within 10 %, the order of the mappings right in every cell).
 static double ragged_wave_ms(const Family &f, double samples, double segs, double kinks)
@@ -383,7 +383,7 @@ static double ragged_wave_ms(const Family &f, double samples, double segs, doubl
     const double tiles = std::fmax(samples / T, 1.0);
     const double fast_tile = lane_ms_per_sample(true, nfa4, f.L) * T;
     double tight_tile = fast_tile;
-    static const double mixed8[4] = {0.062, 0.039, 0.0175, 0.034};       // (L = 4: tiles of 32 samples)
+    static const double mixed8[4] = {0.062, 0.039, 0.024, 0.034};        // (L = 4: tiles of 32 samples)
     double mixed_tile = nfa4 ? 0.035 : mixed8[f.L == 1 ? 0 : f.L == 2 ? 1 : f.L == 4 ? 2 : 3];
     if (f.fast == 2u) {                                                    // second tier: the same events, its own rate
         tight_tile = mid_ms_per_sample(nfa4) * T;

@@ -302,7 +302,7 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       a SIMD that finishes one takes the next) and puts fewer utterances' segment boundaries into a wavefront.  The
  *       plan is therefore weighed against one launch of each lane mapping, by the lengths and the events of the rows
  *       (grail_plan_ragged_blocks).  Speech-like corpus — 65 536 utterances of 8 - 32 phonemes, 0.5 - 3.8 s — exact
- *       71 ms instead of 90 (eight live formants: 113 instead of 172), fast 74 instead of 88 (98 instead of 146);
+ *       71 ms instead of 90 (eight live formants: 114 instead of 172), fast 74 instead of 88 (89 instead of 146);
  *       profiles/r04_ragged_plan.txt.  Exact results never depend on it; fast ones follow the family (below).
  *   "assume_compute_units": plan for so many compute units instead of what the device reports (0 = the
  *       device's own count; read-only "compute_units" tells what is in force): tests, and callers that share a
