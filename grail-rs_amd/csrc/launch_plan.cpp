@@ -362,34 +362,38 @@ double plan_blocks(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
 // finishes a short one takes the next.  And a wave holds fewer utterances, so fewer of its tiles hold some lane's event.
 // (Speech-like corpus, 65 536 utterances of 0.5 - 3.8 s: exact 90.0 ms one lane per utterance, 71.7 two; eight formants
 // 171.6 / 113.6; fast 87.7 / 73.6 and 145.7 / 88.8; 100 000: 125 -> 94 in ONE launch of the one-lane kernel.  profiles/r04_ragged_plan.txt.)
-// Model: a wave costs its longest row's samples at the mapping's rate plus its rows' events (exact: a segment boundary
-// costs the wave 6 / 12 us with four / eight formants; fast: a tile of 64 samples is tight with probability exp(-events per
-// tile) and costs 0.035 ms (four formants; eight: 0.062 / 0.039 / 0.048 / 0.034 for L = 1 / 2 / 4 / 8) otherwise); waves are
-// handed to the SIMDs in launch order as they fall free.  Fitted on that corpus at 16 384 ... 65 536 utterances, L = 1 ... 8
-// (within 10 %, the order of the mappings right in every cell).
+// Model: a wave costs its longest row's samples at the mapping's rate plus what its rows' events cost.  Exact: the tiles
+// that hold some lane's segment boundary, tiles x (1 - exp(-boundaries per tile)), at 7 / 8 us per 32 samples (four / eight
+// formants), and 1.5 / 3.7 us per boundary on one lane per utterance.  Fast: a tile is tight with probability
+// exp(-events per tile) (events: boundaries and kinks of alpha) and costs a + b x events per tile otherwise (general steps:
+// the denser the events, the more and the shorter the runs between them).  Waves are handed to the SIMDs in launch order as
+// they fall free.  Fitted on pinned-mapping measurements of the speech-like corpus at 65 536 utterances with phonemes of
+// 40 - 160, 16 - 64 and 4 - 16 ms, L = 1 / 2 / 4, four and eight formants (36 cells within 10 %, three L = 1 cells of the
+// densest corpus 20 - 28 % under) and checked at 16 384 ... 131 072 utterances: profiles/r04_ragged_plan.txt.
 static double ragged_wave_ms(const Family &f, double samples, double segs, double kinks)
 {
     const bool nfa4 = f.live4 != 0;
+    const int li = f.L == 1 ? 0 : f.L == 2 ? 1 : f.L == 4 ? 2 : 3;
     if (!f.fast) {
-        double per_2s = lane_ms_per_sample(false, nfa4, f.L) * 96006.0;
-        if (f.half) {
-            // the half-live loops serve the tiles (32 samples) no lane has an event in
-            const double tight = std::exp(-segs / std::fmax(samples / 32.0, 1.0));
-            per_2s = tight * 45.7 + (1.0 - tight) * per_2s;
-        }
-        return samples * per_2s / 96006.0 + segs * (nfa4 ? 0.006 : 0.012);
+        // (the half-live loops of the one-lane kernel, 45.7 ms per 2 s, showed on aligned batches only: not priced in)
+        const double T = (f.L == 1 || (!nfa4 && f.L == 4)) ? 32.0 : 64.0;
+        const double tiles = std::fmax(samples / T, 1.0);
+        const double event_tiles = tiles * (1.0 - std::exp(-segs / tiles));
+        return samples * lane_ms_per_sample(false, nfa4, f.L) + event_tiles * (nfa4 ? 0.007 : 0.008) * (T / 32.0) +
+               (f.L == 1 ? segs * (nfa4 ? 0.0015 : 0.0037) : 0.0);
     }
-    const double T = (!nfa4 && f.L == 4) ? 32.0 : 64.0;
+    const double T = (!nfa4 && f.L == 4) ? 32.0 : 64.0;                  // (tile of the fast kernels)
     const double tiles = std::fmax(samples / T, 1.0);
+    const double per_tile = std::fmin((segs + kinks) / tiles, T);
+    static const double a4[4] = {0.0325, 0.0325, 0.035, 0.032}, b4[4] = {0.006, 0.0075, 0.010, 0.010};
+    static const double a8[4] = {0.0525, 0.035, 0.025, 0.032}, b8[4] = {0.011, 0.010, 0.009, 0.010};
     const double fast_tile = lane_ms_per_sample(true, nfa4, f.L) * T;
-    double tight_tile = fast_tile;
-    static const double mixed8[4] = {0.062, 0.039, 0.024, 0.034};        // (L = 4: tiles of 32 samples)
-    double mixed_tile = nfa4 ? 0.035 : mixed8[f.L == 1 ? 0 : f.L == 2 ? 1 : f.L == 4 ? 2 : 3];
+    double tight_tile = fast_tile, mixed_tile = (nfa4 ? a4 : a8)[li] + (nfa4 ? b4 : b8)[li] * per_tile;
     if (f.fast == 2u) {                                                    // second tier: the same events, its own rate
         tight_tile = mid_ms_per_sample(nfa4) * T;
         mixed_tile += tight_tile - fast_tile;
     }
-    const double tight = std::exp(-(segs + kinks) / tiles);
+    const double tight = std::exp(-per_tile);
     return tiles * (tight * tight_tile + (1.0 - tight) * mixed_tile);
 }
 
@@ -451,16 +455,19 @@ void ragged_plan(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_st
         slot0 += b.rows;
     }
     double best = 0.95 * current;                // (a candidate has to be worth the change)
-    for (int L = 1; L <= 8; L *= 2) {
-        Family f;
-        choose_family(ctx, batch, out_stride, rows, f, false, L);
-        if (f.scan || f.pipe || f.split_k) continue;
-        const double c = ragged_cost(ctx, batch, f, 0, rows, span) + Planner::LAUNCH_MS;
-        if (c < best) {
-            best = c;
-            plan.assign(1, Block{rows, f});
+    // (fast arithmetic asked for: the exact mappings stand too — events this dense cost the fast kernels more than they
+    // save, and exact bits satisfy the tolerance trivially.  Phonemes of 16 - 64 ms: 32 ms exact against 57 fast.)
+    for (int exact_only = 0; exact_only <= (ctx->fast_option ? 1 : 0); ++exact_only)
+        for (int L = 1; L <= 8; L *= 2) {
+            Family f;
+            choose_family(ctx, batch, out_stride, rows, f, exact_only != 0, L);
+            if (f.scan || f.pipe || f.split_k || (exact_only && f.fast)) continue;
+            const double c = ragged_cost(ctx, batch, f, 0, rows, span) + Planner::LAUNCH_MS;
+            if (c < best) {
+                best = c;
+                plan.assign(1, Block{rows, f});
+            }
         }
-    }
 }
 
 }  // namespace host

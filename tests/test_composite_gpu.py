@@ -383,7 +383,7 @@ def test_ragged_batches_take_wider_mappings_in_several_rounds(gpu_ctx, small_mac
     SIMD (one lane per utterance) the launch lasts as long as its longest utterance; option "ragged_plan" weighs that
     against wider mappings in several rounds by the rows' lengths and events and takes one of them (launch_plan.cpp,
     "Ragged batches"; on the whole device: profiles/r04_ragged_plan.txt).  Exact: the oracle's bits whichever way;
-    fast: within the tolerance."""
+    fast: within the tolerance — or, where events this dense make an exact mapping the cheaper one, the oracle's bits."""
     voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
     gpu_ctx.set_voices(voices)
     n_utt = 1024
@@ -399,15 +399,14 @@ def test_ragged_batches_take_wider_mappings_in_several_rounds(gpu_ctx, small_mac
         seen[ragged_plan] = (gpu_ctx.get_option("last_launch_lanes"), gpu_ctx.get_option("last_launch_blocks"),
                              gpu_ctx.last_kernel_name())
         assert status == G.OK and np.array_equal(lens, ref_len)
-        if fast:
-            assert gpu_ctx.get_option("last_launch_fast") == 1, seen
+        if gpu_ctx.get_option("last_launch_fast"):
             worst = max(float(np.abs(out[u, :lens[u]].astype(np.float64) - ref[u, :lens[u]]).max()) /
                         max(1.0, float(np.abs(ref[u, :lens[u]]).max())) for u in range(n_utt))
-            assert worst <= G.FAST_TOLERANCE, (ragged_plan, worst / ULP)
+            assert fast and worst <= G.FAST_TOLERANCE, (ragged_plan, worst / ULP)
         else:
+            # (fast arithmetic asked for, events this dense: the planner may take an exact mapping — cheaper by its model,
+            # and exact bits satisfy the tolerance trivially)
+            assert not fast or ragged_plan, seen
             _bit_identical(out, lens, ref, ref_len, f"ragged_plan={ragged_plan}")
     assert seen[0][0] == 1 or "SPLIT" in seen[0][2], seen          # one round: a lane (or a chunk lane) per utterance
-    # several rounds of a wider mapping in one launch (fast arithmetic, four formants: events this dense leave the
-    # model no 5 % to gain — the one-lane kernel stays)
-    if not fast or n_voices == 8:
-        assert seen[1][0] in (2, 4, 8) and seen[1][1] == 1, seen
+    assert seen[1][0] in (2, 4, 8) and seen[1][1] == 1, seen       # several rounds of a wider mapping, one launch

@@ -3,8 +3,8 @@
 contours of 90 - 220 Hz), so that utterances differ in length by a factor of four and every lane of a wave has a segment
 boundary every few thousand samples at a time of its own — next to the bench corpus (4 aligned segments of 0.5 s).
 Reports samples/s over the samples actually rendered.
-usage: speech_like_bench.py [n_utt] [--blend-is-length] [--lanes=L] [--no-split] [--no-ragged-plan]   (A/B: pinned lane
-mapping, no time-split, the one-round launch policy)"""
+usage: speech_like_bench.py [n_utt] [--blend-is-length] [--lanes=L] [--no-split] [--no-ragged-plan] [--scale=F]   (A/B: pinned
+lane mapping, no time-split, the one-round launch policy; every length and blend length times F)"""
 import os
 import sys
 
@@ -16,7 +16,10 @@ from grail_hip import workload as W
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 65536
 ctx = G.Context(0)
+scale = 1.0
 for a in sys.argv[1:]:
+    if a.startswith("--scale="):
+        scale = float(a[8:])
     if a.startswith("--lanes="):
         ctx.set_option("lanes_per_utterance", int(a[8:]))
     if a == "--no-split":
@@ -34,14 +37,14 @@ for n_voices in (1, 8):
     segs = np.zeros(k, dtype=G.PHONEME_DTYPE)
     segs["phoneme"] = rng.choice([G.PH_A, G.PH_E, G.PH_SILENCE, G.PH_STOP], k, p=[.4, .4, .12, .08])
     segs["phoneme"][offs[:-1]] = G.PH_SILENCE
-    segs["length"] = rng.uniform(0.04, 0.16, k).astype(np.float32)
-    segs["blend_length"] = rng.uniform(0.03, 0.08, k).astype(np.float32)
+    segs["length"] = (rng.uniform(0.04, 0.16, k) * scale).astype(np.float32)
+    segs["blend_length"] = (rng.uniform(0.03, 0.08, k) * scale).astype(np.float32)
     if "--blend-is-length" in sys.argv:            # (no flat stretch of alpha, no kink: what the kinks cost)
         segs["blend_length"] = segs["length"]
     segs["frequency"] = (rng.uniform(90, 220, k) / 48000.0).astype(np.float32)
     vids = (np.arange(n) % n_voices).astype(np.uint32)
     seeds = np.arange(n, dtype=np.uint32)
-    stride = (int(32 * 0.16 * 48000) + 64 + 63) // 64 * 64
+    stride = (int(32 * 0.16 * scale * 48000) + 64 + 63) // 64 * 64
     batch = ctx.upload(segs, offs, vids, seeds)
     d_out = ctx.device_alloc(n * stride * 4)
     d_len = ctx.device_alloc(n * 4)
