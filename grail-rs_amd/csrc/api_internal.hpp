@@ -257,7 +257,7 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
 double ragged_cost(const grail_ctx *ctx, const grail_batch *batch, const Family &f, uint32_t slot0, uint32_t rows, double span);
 void ragged_plan(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t rows, std::vector<Block> &plan);
 double plan_blocks(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t rows, double span,
-                   std::vector<Block> &out);
+                   std::vector<Block> &out, bool exact_only = false);
 
 // synthesize.cpp: one launch per block; a batch's cached plan
 void free_plan_cache(PlanCache *p);

@@ -287,6 +287,7 @@ struct Planner {
     const grail_batch *batch;
     uint64_t out_stride;
     double span;
+    bool exact_only;                           // (the plan a fast request is weighed against: ragged_plan)
     static constexpr double LAUNCH_MS = 0.05;  // what a further launch costs by itself (measured: 0.02 - 0.06 ms)
     // (choose_family lays out time-split grids by bisection: every size is looked at once)
     std::map<uint32_t, std::pair<Family, double>> families;
@@ -297,7 +298,7 @@ struct Planner {
         auto it = families.find(rows);
         if (it != families.end()) return it->second;
         std::pair<Family, double> e;
-        choose_family(ctx, batch, out_stride, rows, e.first);
+        choose_family(ctx, batch, out_stride, rows, e.first, exact_only);
         e.second = family_cost(ctx, e.first, rows, span);
         return families.emplace(rows, e).first->second;
     }
@@ -334,9 +335,9 @@ struct Planner {
 };
 
 double plan_blocks(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t rows, double span,
-                   std::vector<Block> &out)
+                   std::vector<Block> &out, bool exact_only)
 {
-    Planner p{ctx, batch, out_stride, span, {}, {}};
+    Planner p{ctx, batch, out_stride, span, exact_only, {}, {}};
     const std::pair<double, std::vector<Block>> &best = p.plan(rows, 0);
     out = best.second;
     if (out.size() > 1) {
@@ -402,8 +403,22 @@ double ragged_cost(const grail_ctx *ctx, const grail_batch *batch, const Family 
     const size_t n_gran = batch->granule_samples.size();
     if (n_gran == 0 || rows == 0) return family_cost(ctx, f, rows, span);
     const size_t g0 = std::min<size_t>(slot0 / 8, n_gran - 1), g1 = std::min<size_t>(((size_t)slot0 + rows + 7) / 8, n_gran);
-    // (families that render an utterance with many lanes: by the block's own longest row)
-    if (f.scan || f.pipe) return family_cost(ctx, f, rows, std::fmin(span, std::fmax((double)batch->granule_samples[g0], 0.0) + 64.0));
+    // (families that render an utterance with many lanes: by the block's own longest row.  A pipelined workgroup renders its
+    // 16 / 8 utterances in rounds of 32 samples; a round that holds a segment boundary of one of them costs it ~14 us more:
+    // 256 utterances with phonemes of 4 - 16 ms take 5.7 ms where their 0.39 s alone would take 1.3)
+    if (f.scan || f.pipe) {
+        const double longest = std::fmin(span, std::fmax((double)batch->granule_samples[g0], 0.0) + 64.0);
+        double c = family_cost(ctx, f, rows, longest);
+        if (f.pipe) {
+            c *= 1.15;      // (ragged corpora measure 15 - 25 % over the aligned rate before any event: pitch contours, stops)
+            double segs = batch->granule_segs[g0];
+            if (f.live4 && g0 + 1 < g1) segs += batch->granule_segs[g0 + 1];
+            const double rounds = std::fmax(longest / 32.0, 1.0);
+            const double groups = std::ceil((double)rows / (f.live4 ? 16.0 : 8.0));
+            c += 0.014 * rounds * (1.0 - std::exp(-segs / rounds)) * std::ceil(groups / ((f.pipe == 2 ? 1.0 : 2.0) * (double)ctx->cus));
+        }
+        return c;
+    }
     const uint64_t simds = ctx_simds(ctx);
     if (f.split_k) {
         // every wave holds 64 utterances at one chunk index: the events of a one-lane wave; the first chunk of the
@@ -446,22 +461,36 @@ double ragged_cost(const grail_ctx *ctx, const grail_batch *batch, const Family 
 void ragged_plan(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t rows, std::vector<Block> &plan)
 {
     if (!ctx->ragged_option || batch->granule_samples.empty() || rows != batch->n_utt || plan.empty()) return;
-    if (plan.size() == 1 && (plan[0].f.scan || plan[0].f.pipe)) return;   // (batches that small: many lanes per utterance)
+    if (plan.size() == 1 && plan[0].f.scan) return;   // (a few utterances in fast arithmetic: the scan kernel's)
     const double span = batch_span(ctx, batch, out_stride);
-    double current = 0.0;
-    uint32_t slot0 = 0;
-    for (const Block &b : plan) {
-        current += ragged_cost(ctx, batch, b.f, slot0, b.rows, span) + Planner::LAUNCH_MS;
-        slot0 += b.rows;
+    auto cost_of = [&](const std::vector<Block> &blocks) {
+        double c = 0.0;
+        uint32_t slot0 = 0;
+        for (const Block &b : blocks) {
+            c += ragged_cost(ctx, batch, b.f, slot0, b.rows, span) + Planner::LAUNCH_MS;
+            slot0 += b.rows;
+        }
+        return c;
+    };
+    double best = 0.95 * cost_of(plan);          // (a candidate has to be worth the change)
+    if (ctx->fast_option) {
+        // fast arithmetic asked for: the cut exact arithmetic would get stands too (small batches: the pipelined
+        // workgroups) — events this dense cost the fast kernels more than they save, and exact bits satisfy the tolerance
+        // trivially.  Phonemes of 16 - 64 ms, 65 536 utterances: 32 ms exact against 57 fast.
+        std::vector<Block> exact;
+        plan_blocks(ctx, batch, out_stride, rows, span, exact, true);
+        const double c = cost_of(exact);
+        if (c < best) {
+            best = c;
+            plan = exact;
+        }
     }
-    double best = 0.95 * current;                // (a candidate has to be worth the change)
-    // (fast arithmetic asked for: the exact mappings stand too — events this dense cost the fast kernels more than they
-    // save, and exact bits satisfy the tolerance trivially.  Phonemes of 16 - 64 ms: 32 ms exact against 57 fast.)
+    // ... and ONE launch of each lane mapping in as many rounds as it takes
     for (int exact_only = 0; exact_only <= (ctx->fast_option ? 1 : 0); ++exact_only)
         for (int L = 1; L <= 8; L *= 2) {
             Family f;
             choose_family(ctx, batch, out_stride, rows, f, exact_only != 0, L);
-            if (f.scan || f.pipe || f.split_k || (exact_only && f.fast)) continue;
+            if (f.scan || f.pipe || f.split_k) continue;
             const double c = ragged_cost(ctx, batch, f, 0, rows, span) + Planner::LAUNCH_MS;
             if (c < best) {
                 best = c;
