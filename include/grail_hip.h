@@ -301,8 +301,9 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *       time.  A wider lane mapping in several rounds keeps them busy (shorter wavefronts, started longest first,
  *       a SIMD that finishes one takes the next) and puts fewer utterances' segment boundaries into a wavefront.  The
  *       plan is therefore weighed against one launch of each lane mapping, by the lengths and the events of the rows
- *       (grail_plan_ragged_blocks); in fast arithmetic the exact mappings are candidates too (events of some lane in
- *       nearly every tile cost the fast kernels more than they save; "last_launch_fast" = 0 tells).  Speech-like
+ *       (grail_plan_ragged_blocks); in fast arithmetic the exact mappings — and for small batches the cut exact
+ *       arithmetic would get — are candidates too (events of some lane in nearly every tile cost the fast kernels
+ *       more than they save; "last_launch_fast" = 0 tells).  Speech-like
  *       corpus — 65 536 utterances of 8 - 32 phonemes, 0.5 - 3.8 s — exact 71 ms instead of 90 (eight live formants:
  *       114 instead of 172), fast asked for 71 instead of 88 (89 instead of 147); phonemes of 4 - 16 ms, fast asked
  *       for: 10.5 instead of 30.8; profiles/r04_ragged_plan.txt.  Exact results never depend on it; fast ones follow

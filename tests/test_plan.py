@@ -178,3 +178,27 @@ def test_ragged_planner_bad_and_hostile_arguments():
     # ascending instead of descending lengths, no events: still a plan of all rows
     plan = G.plan_ragged_blocks(np.arange(1, 100001, dtype=np.uint32), arithmetic=0)
     assert sum(b.rows for b in plan) == 100000
+
+
+def test_dense_events_serve_a_fast_request_with_the_exact_cut():
+    """Phonemes of 4 - 16 ms: an event of some lane in nearly every tile costs the fast kernels more than they save
+    (4 096 utterances: 12.7 ms time-split, 5.1 ms exact; 65 536: 30.7 against 10.5) — the planner prices both and takes the
+    exact families, whose bits satisfy the tolerance trivially.  A few utterances keep the scan kernel; the speech-like
+    corpus itself (phonemes of 40 - 160 ms) keeps its time-split kernels at 4 096."""
+    rng = np.random.default_rng(3)
+    def rows(n, scale):
+        counts = rng.integers(8, 33, n)
+        offs = np.concatenate([[0], np.cumsum(counts)])
+        length = rng.uniform(0.04, 0.16, offs[-1]) * scale
+        blend = rng.uniform(0.03, 0.08, offs[-1]) * scale
+        samples = np.add.reduceat(length, offs[:-1]) * 48000.0
+        kinks = np.add.reduceat((blend < length).astype(np.int64), offs[:-1])
+        o = np.argsort(-samples, kind="stable")
+        return samples[o].astype(np.uint32), counts[o].astype(np.uint32), kinks[o].astype(np.uint32)
+    for n in (4096, 8192, 65536, 200000):
+        plan = G.plan_ragged_blocks(*rows(n, 0.1), arithmetic=1, live_formants=4)
+        assert sum(b.rows for b in plan) == n and all(b.fast == 0 and b.chunks == 0 and b.scan == 0 for b in plan), n
+    few = G.plan_ragged_blocks(*rows(256, 0.1), arithmetic=1, live_formants=4)
+    assert len(few) == 1 and few[0].scan and few[0].fast == 1
+    speech = G.plan_ragged_blocks(*rows(4096, 1.0), arithmetic=1, live_formants=4)
+    assert len(speech) == 1 and speech[0].chunks >= 2 and speech[0].fast == 1
