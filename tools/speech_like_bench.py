@@ -3,8 +3,9 @@
 contours of 90 - 220 Hz), so that utterances differ in length by a factor of four and every lane of a wave has a segment
 boundary every few thousand samples at a time of its own — next to the bench corpus (4 aligned segments of 0.5 s).
 Reports samples/s over the samples actually rendered.
-usage: speech_like_bench.py [n_utt] [--blend-is-length] [--lanes=L] [--no-split] [--no-ragged-plan] [--scale=F]   (A/B: pinned
-lane mapping, no time-split, the one-round launch policy; every length and blend length times F)"""
+usage: speech_like_bench.py [n_utt] [--blend-is-length] [--lanes=L] [--no-split] [--no-ragged-plan] [--scale=F] [--long-tail]   (A/B:
+pinned lane mapping, no time-split, the one-round launch policy; every length and blend length times F; one utterance in a hundred
+of 60 - 80 phonemes among utterances of 4 - 12)"""
 import os
 import sys
 
@@ -31,6 +32,8 @@ for n_voices in (1, 8):
     voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
     ctx.set_voices(voices)
     counts = rng.integers(8, 33, n)
+    if "--long-tail" in sys.argv:
+        counts = np.where(rng.random(n) < 0.01, rng.integers(60, 81, n), rng.integers(4, 13, n))
     offs = np.zeros(n + 1, dtype=np.uint32)
     offs[1:] = np.cumsum(counts)
     k = int(offs[-1])
@@ -44,7 +47,7 @@ for n_voices in (1, 8):
     segs["frequency"] = (rng.uniform(90, 220, k) / 48000.0).astype(np.float32)
     vids = (np.arange(n) % n_voices).astype(np.uint32)
     seeds = np.arange(n, dtype=np.uint32)
-    stride = (int(32 * 0.16 * scale * 48000) + 64 + 63) // 64 * 64
+    stride = (int(int(counts.max()) * 0.16 * scale * 48000) + 64 + 63) // 64 * 64
     batch = ctx.upload(segs, offs, vids, seeds)
     d_out = ctx.device_alloc(n * stride * 4)
     d_len = ctx.device_alloc(n * 4)
