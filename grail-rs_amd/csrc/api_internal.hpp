@@ -29,6 +29,14 @@
 // (the opaque types of the C ABI are global; everything else the units share lives in grail::host)
 struct PlanCache;                     // synthesize.cpp
 
+// words of the device block behind grail_ctx::d_truncated: the flag and three statistics counters; debug builds
+// (-DGRAIL_FAST_PROF) keep 32 u64 profile counters behind word 8
+#ifdef GRAIL_FAST_PROF
+constexpr size_t TRUNCATED_WORDS = 8 + 64;
+#else
+constexpr size_t TRUNCATED_WORDS = 4;
+#endif
+
 struct grail_ctx {
     int device = 0;
     int cus = 256;                    // compute units the launch policy plans for (hipDeviceProp_t::multiProcessorCount;

@@ -359,8 +359,8 @@ int grail_create(int device, grail_ctx **out)
     if ((err = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (err = hipEventCreate(&ctx->ev_start)) != hipSuccess ||
         (err = hipEventCreate(&ctx->ev_stop)) != hipSuccess ||
-        (err = hipMalloc((void **)&ctx->d_truncated, 4 * sizeof(uint32_t))) != hipSuccess ||
-        (err = hipMemsetAsync(ctx->d_truncated, 0, 4 * sizeof(uint32_t), ctx->stream)) != hipSuccess ||
+        (err = hipMalloc((void **)&ctx->d_truncated, TRUNCATED_WORDS * sizeof(uint32_t))) != hipSuccess ||
+        (err = hipMemsetAsync(ctx->d_truncated, 0, TRUNCATED_WORDS * sizeof(uint32_t), ctx->stream)) != hipSuccess ||
         (err = hipStreamSynchronize(ctx->stream)) != hipSuccess) {
         grail_destroy(ctx);
         return hip_fail(err, "grail_create");
@@ -632,6 +632,17 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
         *value = ctx->scan_split_max;
         return GRAIL_OK;
     }
+#ifdef GRAIL_FAST_PROF
+    if (std::strncmp(name, "debug_prof_", 11) == 0) {          // debug builds: counter k of the tolerance-mode tile loop
+        const int k = std::atoi(name + 11);
+        if (k < 0 || k >= 32) return fail(GRAIL_ERR_INVALID_ARG, "debug_prof_<k>: k in 0 .. 31");
+        unsigned long long v = 0;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMemcpy(&v, reinterpret_cast<unsigned long long *>(ctx->d_truncated + 8) + k, sizeof v, hipMemcpyDeviceToHost));
+        *value = (int64_t)v;
+        return GRAIL_OK;
+    }
+#endif
     if (std::strcmp(name, "slow_division_wave_steps") == 0) {  // read-only statistic
         *value = (int64_t)ctx->slow_steps;
         return GRAIL_OK;

@@ -64,6 +64,16 @@
                                   // config 2, 24: 7.49, 64: 7.41; a run ends at the next event anyway, ~40 tiles)
 #endif
 
+// GRAIL_FAST_PROF (debug builds only, `make EXTRA=-DGRAIL_FAST_PROF`): cycle and event counters of the tolerance-mode
+// tile loop, summed over the waves of a launch into 32 u64 words behind A.truncated[8] (tools/fast_prof.py reads them)
+#ifdef GRAIL_FAST_PROF
+#define PROF_ADD(k) do { const unsigned long long n_ = clock64(); prof_c[k] += n_ - prof_t0; prof_t0 = n_; } while (0)
+#define PROF_CNT(k, v) do { prof_c[k] += (unsigned long long)(v); } while (0)
+#else
+#define PROF_ADD(k) do { } while (0)
+#define PROF_CNT(k, v) do { } while (0)
+#endif
+
 namespace grail {
 
 // what the last launch_synth call of this thread started (synth_kernels.hip)
@@ -595,6 +605,12 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     uint32_t n_out = 0;
     uint32_t slow_steps = 0;                 // wave-steps that took the IEEE-division body
     uint32_t fast_tiles = 0, general_steps = 0;   // statistics: tiles rendered by fast_tile, general steps taken
+#ifdef GRAIL_FAST_PROF
+    unsigned long long prof_c[32] = {};
+    unsigned long long prof_t0 = clock64();
+    const unsigned long long prof_start = prof_t0;
+    unsigned long long prof_lane_levels = 0;
+#endif
     bool truncated = false;
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(A.out) & 15u) == 0) && ((A.out_stride & 3u) == 0);
     const bool vec16_ok = ((reinterpret_cast<uintptr_t>(A.out_pcm16) & 7u) == 0) && ((A.out_stride & 3u) == 0);
@@ -709,8 +725,20 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     // jitter noise, hit the row capacity, or need the IEEE-division body.
     // CHAIN_ONLY (SPLIT's fast-forward): the per-utterance chain alone — Sequencer, Jitter state, pitch, carrier
     // phase — exactly as below; no formant is evaluated and nothing is staged
+    // FAST kernels take the step apart in the slow samples of a mixed tile (fast_slow_sample): mode 2 is the chain part —
+    // Sequencer, Jitter state, pitch, carrier phase, the carrier noise, the sample counted — which leaves what the
+    // formants need in cv_*; mode 3 is the formant part of the same sample from those values, for a lane whose new
+    // segment pair turned out to lie outside the safe window (every other lane goes on in the shared tolerance-mode body).
+    float cv_alpha = 1.0f, cv_freq = 0.0f, cv_ph = 0.0f, cv_noise = 0.0f;
+    // (an int, not a bool: with a second bool stored `true` next to `done = true` the optimiser merges the two stores into
+    // one through a pointer it selects — and both variables live in scratch memory from then on)
+    [[maybe_unused]] int cv_live = 0;          // mode 2 rendered a sample (the lane did not end, pause or fill its row in this step)
     auto general_step = [&](const int t, auto chain_only_tag) __attribute__((always_inline)) {
-        constexpr bool CHAIN_ONLY = decltype(chain_only_tag)::value;
+        constexpr int MODE = (int)decltype(chain_only_tag)::value;   // 0: the whole step, 1: CHAIN_ONLY, 2: chain part, 3: formant part
+        constexpr bool CHAIN_ONLY = MODE == 1;
+        float alpha, oma, frequency;
+        if constexpr (MODE == 2) cv_live = 0;
+        if constexpr (MODE != 3) {
         if (done) return;
         if (PAUSES && n_out >= pause_at) {   // this launch's share is used up: pause BEFORE advancing
             done = true;
@@ -773,12 +801,17 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             ratio = clk * inv_blend_length;
         else
             ratio = blend_pow2 ? clk * inv_blend_length : clk / blend_length;
-        float alpha = __builtin_fminf(ratio, 1.0f);
+        alpha = __builtin_fminf(ratio, 1.0f);
         alpha = silent_pair ? 1.0f : alpha;
-        const float oma = 1.0f - alpha;
+        oma = 1.0f - alpha;
 
         // SynthesisElem::blend, src/lib.rs:404-414
-        float frequency = X.frequency * oma + Y.frequency * alpha;
+        frequency = X.frequency * oma + Y.frequency * alpha;
+        } else {
+            alpha = cv_alpha;
+            oma = 1.0f - alpha;
+            frequency = cv_freq;
+        }
         V e_freq[NV], e_bw[NV], e_smooth[NV], e_breath[NV], e_turb[NV], e_amp[NV];
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
@@ -791,6 +824,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         }
 
         // ================= Jitter::next, src/lib.rs:753-777
+        if constexpr (MODE != 3) {
         jphase += jinc;                                       // :242 / :291
         if (__builtin_expect(jphase > 1.0f, 0)) {             // :245 / :294
             jphase -= 1.0f;
@@ -812,15 +846,30 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             ff_state = s1;
             fa_state = s2;
         }
+        }
         const float jomp = 1.0f - jphase;
+        if constexpr (MODE != 3) {
         const float n_freq = fn_cur * jomp + fn_next * jphase;         // :254
         frequency = frequency + n_freq * d_freq;                       // :763
+        }
         if constexpr (CHAIN_ONLY) {
             phase += frequency;                                        // :520
             if (phase >= 1.0f) phase -= 1.0f;                          // :523-525
             ++n_out;                                                   // (the carrier noise state follows from n_out)
             return;
         }
+        if constexpr (MODE == 2) {
+            cv_alpha = alpha;
+            cv_freq = frequency;
+            cv_ph = phase;
+            phase += frequency;                                        // :520
+            if (phase >= 1.0f) phase -= 1.0f;                          // :523-525
+            cv_noise = lcg_f32(noise_seed);                            // :528
+            ++n_out;
+            cv_live = 1;
+            return;
+        }
+        const float ph_b = MODE == 3 ? cv_ph : phase;                  // the carrier phase before this sample's step
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const V n_ff = ff_cur[k] * jomp + ff_next[k] * jphase;     // :305
@@ -833,18 +882,23 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 
         // ================= Synthesize::next, src/lib.rs:497-578
         // polyBLEP saw: both branches divide by the jittered frequency  :503-514
-        const bool head = phase < frequency;
-        const bool tail = phase > (1.0f - frequency);
+        const bool head = ph_b < frequency;
+        const bool tail = ph_b > (1.0f - frequency);
         float polyblep = 0.0f;
         if (__builtin_expect(head || tail, 0)) {
-            const float tt = (head ? phase : (phase - 1.0f)) / frequency;
+            const float tt = (head ? ph_b : (ph_b - 1.0f)) / frequency;
             polyblep = head ? ((2.0f * tt - (tt * tt)) - 1.0f)
                             : (((tt * tt) + 2.0f * tt) + 1.0f);
         }
-        const float saw = (2.0f * phase - 1.0f) - polyblep;            // :517
-        phase += frequency;                                            // :520
-        if (phase >= 1.0f) phase -= 1.0f;                              // :523-525
-        const float noise = lcg_f32(noise_seed);                       // :528
+        const float saw = (2.0f * ph_b - 1.0f) - polyblep;             // :517
+        float noise;
+        if constexpr (MODE == 3) {
+            noise = cv_noise;
+        } else {
+            phase += frequency;                                        // :520
+            if (phase >= 1.0f) phase -= 1.0f;                          // :523-525
+            noise = lcg_f32(noise_seed);                               // :528
+        }
 
         // events are rare: this step always takes the IEEE-division body (same bits)
         V v1[NV];
@@ -921,7 +975,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             }
             if (j == L - 1) stage[t * SP + slot] = acc * 0.5f;
         }
-        ++n_out;
+        if constexpr (MODE != 3) ++n_out;
     };
 
     // ---- the quiet sample step: taken when a single ballot shows that NO lane of the wave
@@ -1452,7 +1506,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     };
 
 
-    // ---- FAST: calm tiles of T samples in tolerance-mode arithmetic.
+    // ---- FAST: tolerance-mode arithmetic.
     // Exact, as everywhere: clk (:861), alpha, the pitch blend and its jitter (:404, :254, :763), the
     // jitter phase (:242) and the carrier phase with its wrap (:520-525) — two samples per packed
     // slot, the same operations on the same operands as the exact kernels.  Within tolerance:
@@ -1461,23 +1515,27 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     //     v1 = a1 (b + g v3),  v2 = c + g v1,  so only a1 and g = tan_approx(x) are needed per sample;
     //   * per formant, everything that is a smooth function of (alpha, jitter phase) — a1, g, the
     //     jittered amplitude G, amplitude x turbulence H, breath, 1 - exp_approx(smooth) — is evaluated
-    //     at the ends of sub-tiles of TS <= 32 samples and interpolated linearly in between (alpha and the
-    //     jitter phase are linear in time inside a calm tile; a tile that holds the kink of
-    //     alpha = min(., 1) is not calm).  The end of a sub-tile is the start of the next one.
-    //   * the interpolation error is bounded when a lane's run of calm tiles starts (after every event of
-    //     ITS OWN): a relative change r of a1, g or 1 - exp_approx over 32 samples gives an error below
-    //     r^2/16 <= 2^-23 for r <= 2^-9.5 (g is close to linear in x: far below that); G and H are
-    //     products of linear functions, error <= |dA dM| / 4 and |dT dG| / 4 <= 2^-22 absolute.
-    //     Faster parameter motion halves TS (error / 4) until it fits; below TS = 2 the lane takes the
-    //     general steps.  The reference's own front end always emits 0.5 s blends (Intonator :1070-1071),
-    //     for which TS = 32.
+    //     at the ends of SUB-TILES of TS <= 32 samples and interpolated linearly in between.  Alpha and the
+    //     jitter phase are linear in time between two events of the lane — a segment advance (:864-888), a noise wrap
+    //     (:245), the kink of alpha = min(clk / blend_length, 1) (:899) — and NO SUB-TILE REACHES ACROSS AN EVENT
+    //     (fast_horizon): a sub-tile lives in one regime, alpha standing at one or falling with the clock, and takes
+    //     its far end from that regime's own formulas.  The end of a sub-tile is the start of the next one.
+    //   * the interpolation error is bounded where a lane begins anew behind an event of ITS OWN (fast_level): a relative
+    //     change r of a1 or 1 - exp_approx over 32 samples gives an error below r^2/16 <= 2^-23 for r <= 2^-9.5; g =
+    //     tan_approx(x) of an x that is linear in time has the curvature of the tangent only, r^2 g^2 / (4 (1 + g^2))
+    //     (checked numerically for the reference's rational function, whose own curvature dominates below x = 0.02:
+    //     its change is weighed by min(max(2.5 g, 0.1), 2)); G and H are products of linear functions, error
+    //     <= |dA dM| / 4 and |dT dG| / 4 <= 2^-22 absolute.  Faster parameter motion halves TS (error / 4) until it fits,
+    //     down to TS = 1: every sample from its own evaluation.  The reference's own front end always emits 0.5 s blends
+    //     (Intonator :1070-1071), for which TS = 32.
     //   * :531 as saw + breath (noise - saw), :538 as fma, :544-550 as a (G + H (noise - 1)), the
     //     eight-term sum (:574) in tree order.
-    // BATCH INVARIANCE.  Whether a tile of a lane is calm, where its runs of calm tiles start, its sub-tile
-    // length and its smoothness flavour are decided from the lane's own state on the utterance's own grid of
-    // T-sample tiles; a lane next to lanes that decide otherwise computes exactly what it would compute among
-    // its like (the mixed tile of the main loop runs the same functions under the lane's own predicate).  The
-    // samples of an utterance therefore do not depend on which utterances share its wave.
+    // BATCH INVARIANCE.  Where a lane's sub-tiles begin and end, their length, its smoothness flavour, whether a
+    // sample of it is stepped by the packed chain or by the reference's control flow — all of it follows from the lane's
+    // own state on the utterance's own grid of T-sample tiles; the wave decides only which COPY of the code runs (the
+    // tight loops of a tile in which every lane is calm, the plain pairs of a mixed tile, its slow samples), and the
+    // copies perform the same operations on a lane's values.  The samples of an utterance therefore do not depend on
+    // which utterances share its wave.
     struct FastEnds {
         V a1[NV], tg[NV], g[NV], h[NV], b[NV], om[NV];   // tg = tan_approx(x), g = amplitude
         float oml;
@@ -1485,20 +1543,25 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     struct FastAux {
         V ap[NV], mu[NV], tb[NV];
     };
-    FastEnds FS;             // the interpolated quantities at the first sample of the lane's next sub-tile
+    FastEnds FS;             // the interpolated quantities at the first sample of the lane's sub-tile
     FastEnds FD;             // their per-sample slopes over the lane's current sub-tile
     f2 FTI = vsplat(0.0f, f2());   // position of the next sample pair inside the lane's sub-tile: (i, i + 1)
     int fast_have = -1;      // the flavour (1: shared smoothness, 0: per formant) of the run FS belongs to; -1: no run
-    int fast_shift = 0;      // the lane's sub-tile length is 32 >> fast_shift, chosen when its run starts
-    int fast_sub_left = 0;   // samples of the lane's current sub-tile still to render (0: the next pair begins a
-                             // sub-tile on the lane's grid of 32 >> fast_shift samples)
-    float fast_sub_len = 32.0f;   // length of the lane's current sub-tile (a run that starts between grid points
-                                  // begins with a shorter one, up to the next grid point)
+    int fast_shift = 0;      // the lane's sub-tile length is 32 >> fast_shift (5: one sample), chosen where it begins anew
+    int fast_sub_left = 0;   // samples of the lane's current sub-tile still to render (0: between sub-tiles — FS holds the
+                             // values of the next sample, the slopes are due)
+    float fast_sub_len = 32.0f;   // length of the lane's current sub-tile (one that begins between grid points, or in front
+                                  // of an event, is shorter than 32 >> fast_shift)
     constexpr int FAST_TS0 = 32;
     static_assert(!FAST || T % FAST_TS0 == 0, "whole sub-tiles");
-    // the smooth quantities `after` samples from now (the clock and the jitter phase extrapolated:
-    // they only feed continuous functions here).  SLOPE: e receives (value - FS) * scale instead.
-    auto fast_endpoint = [&](auto su_tag, auto slope_tag, const float after, const float scale, FastEnds &e,
+    // the lane's regime at a sample with clock c: alpha stands at one (both sides silent: alpha = 1, :926; or the
+    // quotient is above one), or falls with the clock
+    auto fast_flat_at = [&](const float c) __attribute__((always_inline)) -> bool {
+        return silent_pair | (c * inv_blend_length > 1.0f);
+    };
+    // the smooth quantities `after` samples from the state (clk, jphase) along the lane's regime (the clock and the
+    // jitter phase extrapolated: they only feed continuous functions here).  SLOPE: e receives (value - FS) * scale instead.
+    auto fast_endpoint = [&](auto su_tag, auto slope_tag, const float after, const float scale, const bool flat, FastEnds &e,
                              FastAux &x) __attribute__((always_inline)) {
         constexpr bool SU = decltype(su_tag)::value;
         constexpr bool SLOPE = decltype(slope_tag)::value;
@@ -1506,8 +1569,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         const V five = vsplat(5.0f, V()), m4 = vsplat(-4.0f, V());
         const float c = clk - after * dt;
         const float jp = jphase + after * jinc;
-        float alpha = __builtin_fminf(c * inv_blend_length, 1.0f);
-        alpha = silent_pair ? 1.0f : alpha;
+        const float alpha = flat ? 1.0f : c * inv_blend_length;
         const float oma = 1.0f - alpha, jomp = 1.0f - jp;
         auto put = [&](V &dst, const V &start, const V value) __attribute__((always_inline)) {
             if constexpr (SLOPE) dst = (value - start) * scale;
@@ -1580,19 +1642,14 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         }
         e.oml = SU ? (SLOPE ? (oml_here - FS.oml) * scale : oml_here) : 1.0f;
     };
-    // A run of this lane starts at step t_at (even) of the tile: the values now, the slopes over 32 samples, the
-    // error guard and with it the lane's sub-tile length; the first sub-tile reaches to the next point of the
-    // lane's grid.  false: its parameters move faster than TS = 2 can follow.
-    // (The slopes aim at values extrapolated along the present segment pair and jitter period.  An event of the
-    // lane before the sub-tile's end — a segment advance, a noise wrap — ends the run there; up to that sample
-    // the extrapolated end is the smooth continuation the interpolation assumes.  Only the kink of
-    // alpha = min(clk / blend_length, 1) is different, and no sub-tile reaches across it: fast_flat_left.)
-    auto fast_begin_run = [&](auto su_tag, const int t_at, const int n_cap) __attribute__((always_inline)) -> bool {
+    // The error guard: how many halvings of the 32-sample sub-tile the motion of the lane's parameters asks for, from the
+    // values FS at a sample, the slopes FD towards a point `span` samples later and the factors of G and H at both
+    // (xs, xe).  0 .. 4: sub-tiles of 32 .. 2 samples; 5: faster than two samples can follow (or not a number): every
+    // sample from its own evaluation.
+    auto fast_level = [&](auto su_tag, const FastAux &xs, const FastAux &xe, const float span) __attribute__((always_inline)) -> int {
         constexpr bool SU = decltype(su_tag)::value;
         constexpr int TS0 = FAST_TS0;
-        FastAux xs, xe;
-        fast_endpoint(su_tag, std::false_type(), 1.0f, 1.0f, FS, xs);
-        fast_endpoint(su_tag, std::true_type(), (float)(TS0 + 1), 1.0f / (float)TS0, FD, xe);
+        const float to32 = (float)TS0 * __builtin_amdgcn_rcpf(span);      // (span <= 32: exact where it matters, 32 / 32)
         float ra = 0.0f, rg = 0.0f;
 #pragma unroll
         for (int k = 0; k < NV; ++k)
@@ -1602,12 +1659,15 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 if constexpr (!MID) {
                     ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(FD.a1[k], c)) * (float)TS0 *
                                                  __builtin_amdgcn_rcpf(vget(FS.a1[k], c)));
+                    // (g: the curvature of the tangent, not of a reciprocal — see above)
+                    const float tg0 = vget(FS.tg[k], c);
+                    const float weight = __builtin_fminf(__builtin_fmaxf(2.5f * tg0, 0.1f), 2.0f);
                     ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(FD.tg[k], c)) * (float)TS0 *
-                                                 __builtin_amdgcn_rcpf(vget(FS.tg[k], c)));
+                                                 __builtin_amdgcn_rcpf(tg0) * weight);
                 }
                 rg = __builtin_fmaxf(rg, __builtin_fabsf((vget(xe.ap[k], c) - vget(xs.ap[k], c)) *
-                                                         (vget(xe.mu[k], c) - vget(xs.mu[k], c))));
-                rg = __builtin_fmaxf(rg, __builtin_fabsf((vget(xe.tb[k], c) - vget(xs.tb[k], c)) *
+                                                         (vget(xe.mu[k], c) - vget(xs.mu[k], c))) * (to32 * to32));
+                rg = __builtin_fmaxf(rg, __builtin_fabsf((vget(xe.tb[k], c) - vget(xs.tb[k], c)) * to32 *
                                                          vget(FD.g[k], c) * (float)TS0));
             }
         if constexpr (SU) {
@@ -1625,61 +1685,53 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         const int lg = (__builtin_amdgcn_frexp_expf(rg * GRAIL_FAST_G_SCALE) + 1) >> 1;
         int level = la > lg ? la : lg;
         level = level < 0 ? 0 : level;
-        if (!(ra == ra) || !(rg == rg)) level = 99;                                // NaN: not here
+        if (!(ra == ra) || !(rg == rg)) level = 5;                                 // NaN: not here
+        level = level > 5 ? 5 : level;
+#ifdef GRAIL_FAST_FORCE_LEVEL0
+        level = 0;
+#endif
         // the L lanes of an utterance hold different formants: they take the largest of their levels (they run
-        // in lockstep — the per-sample sum goes down the lanes — and all of them start this run together)
+        // in lockstep — the per-sample sum goes down the lanes — and all of them begin anew together)
 #pragma unroll
         for (int m = 1; m < L; m <<= 1) {
             const int o = __shfl_xor(level, m);
             level = o > level ? o : level;
         }
-        if (level > 4) return false;
-        fast_shift = level;
-        const int tsl = TS0 >> level;
-        const int n_grid = tsl - (t_at & (tsl - 1));
-        const int n = n_grid < n_cap ? n_grid : n_cap;       // (n_cap: the flat stretch before the kink of alpha)
-        if (n != TS0) {                 // (1 / n by IEEE division: exactly 2^-k for the sub-tiles on the grid)
-            FastAux xn;
-            fast_endpoint(su_tag, std::true_type(), (float)(n + 1), 1.0f / (float)n, FD, xn);
-        }
-        fast_sub_left = n;
-        fast_sub_len = (float)n;
-        FTI.x = 0.0f; FTI.y = 1.0f;
-        fast_have = SU ? 1 : 0;
-        return true;
+        return level;
     };
-    // no event of this lane within the next two samples.  clk >= m dt implies RN(clk - dt) >= (m - 1.01) dt, so
-    // clk > 2.5 dt leaves the clock positive after two steps; the noise phase wraps on phase > 1 (:245), and
-    // phase + 2.01 inc < 1 keeps it below after two steps.  A lane that is calm for a whole tile (clk > (T + 8) dt,
-    // phase + (T + 1) inc < 0.999 at its start) satisfies both at every pair of it.
-    auto fast_pair_calm = [&]() __attribute__((always_inline)) -> bool {
-        return !done & quiet_ok & (dt > 0.0f) & (clk > 2.5f * dt) & (jphase + 2.01f * jinc < 1.0f) &
-               (room_end - n_out >= 2u) & (n_out <= room_end) &
+    // the lane can render in tolerance mode at all: its segment pair inside the safe window, and pitch < 1/2 (fast_pair's
+    // polyBLEP needs the head and tail tests to exclude each other)
+    auto fast_lane_ok = [&]() __attribute__((always_inline)) -> bool {
+        return !done & quiet_ok & (dt > 0.0f) &
                (__builtin_fmaxf(X.frequency, Y.frequency) + __builtin_fabsf(d_freq) < 0.5f);
     };
-    // The kink of alpha = min(clk / blend_length, 1): while the quotient is above one the blended parameters
-    // stand still, below it they move linearly, and no sub-tile may reach across.  How many of the next samples
-    // are certainly still on the flat side (even, two samples of margin; "no limit" when the lane is already on
-    // the slope or its pair is silent on both sides)?  A sub-tile begun on the flat side ends there; the lane
-    // then takes general steps through the kink and begins a new run on the slope.
-    auto fast_flat_left = [&]() __attribute__((always_inline)) -> int {
-        const float c1 = clk - dt;
-        const bool flat = !silent_pair & (c1 * inv_blend_length > 1.0f);
-        // Sample k from now (k = 1 is the next one) has the clock c1 - (k - 1) dt and is on the flat side while that is
-        // above the blend length: floor(x) + 1 samples with x = (c1 - blend_length) / dt (the difference is exact: the two
-        // are within a factor of two of each other wherever the answer matters; v_rcp is good to an ulp).  A sub-tile of
-        // n samples takes its end point from sample n + 1 (where the next one starts), which has to be on the flat side
-        // too: n <= floor(x).  The serial f32 clock strays from the straight line by up to half an ulp of clk per step,
-        // always the same way inside a binade: 17 ulp over the 33 steps a sub-tile can ask about — a twentieth of a sample
-        // for a clock of a quarter second, three quarters of one for a clock of eight seconds — so that much and a
-        // quarter sample are taken off before rounding down (the safe side: the pairs up to the kink take general steps).
-        // It used to be x - 2 throughout: the run ended two samples early and every kink cost the wave two or three pairs
-        // of general steps instead of one or two (profiles/r04_speech_like.txt).
+    // How many further steps from the state (c, p, n_done) — the clock and the jitter phase of the sample stepped last,
+    // the samples rendered so far — are certainly free of events of this lane: the clock stays >= 0 (no segment advance,
+    // :864), the noise phase stays <= 1 (no wrap, :245 / :294), the row and this launch's share of it have room, and — a
+    // lane on the flat side of the kink of alpha = min(clk / blend_length, 1) — the quotient stays above one.  Step k
+    // has the clock c - k dt.  The serial f32 clock strays from that line by up to half an ulp of itself per step, always
+    // the same way inside a binade: next to dt that is nothing where the answer is small (a clock of a few dt), and where
+    // the clock is compared with the blend length (seconds, possibly) 17 ulp cover the 33 steps a sub-tile can ask about:
+    // that much and a quarter step are taken off (the safe side: a sub-tile that ends early costs a slow sample).  0 .. 127.
+    auto fast_horizon = [&](const float c, const float p, const uint32_t n_done, const bool flat) __attribute__((always_inline)) -> int {
         const float rdt = __builtin_amdgcn_rcpf(dt);
-        const float stray = 17.0f * __builtin_ldexpf(1.0f, __builtin_amdgcn_frexp_expf(c1) - 24) * rdt;
-        const float n = (c1 - blend_length) * rdt - (0.25f + stray);
-        const int ni = n < 0.0f ? 0 : (n > 1.0e6f ? 1000000 : (int)n);
-        return flat ? (ni & ~1) : 1000000;
+        float e = c * rdt - 0.01f;
+        e = __builtin_fminf(e, (1.0f - p) * __builtin_amdgcn_rcpf(jinc) - 0.01f);      // (jinc = 0: never; NaN is ignored by min)
+        if (flat & !silent_pair) {
+            const float stray = 17.0f * __builtin_ldexpf(1.0f, __builtin_amdgcn_frexp_expf(c) - 24) * rdt;
+            e = __builtin_fminf(e, (c - blend_length) * rdt - (0.25f + stray));
+        }
+        const int h = e >= 127.0f ? 127 : (e > 0.0f ? (int)e : 0);                      // (NaN: 0)
+        const uint32_t room = room_end > n_done ? room_end - n_done : 0u;
+        return room < (uint32_t)h ? (int)room : h;
+    };
+    // the lane's sub-tile length by its level, and how far the next point of its grid is from step t of the tile.
+    // Level 5 — the lane's parameters move faster than the line through two samples two apart can follow — keeps the
+    // sub-tiles of two samples but takes BOTH from their own evaluation: the start afresh, the slope towards the second
+    // sample (fast_refresh, fast_restart); its end value is never used.
+    auto fast_grid_left = [&](const int t) __attribute__((always_inline)) -> int {
+        const int tsl = FAST_TS0 >> (fast_shift > 4 ? 4 : fast_shift);
+        return tsl - (t & (tsl - 1));
     };
     // ---- the per-utterance chain of samples tc, tc+1: exact (see scalar_packed_steps).  Advances
     // clk, jphase and phase; returns the phases before the two samples and their pitch.
@@ -1730,26 +1782,58 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         phase = __builtin_amdgcn_fractf(ph1 + frequency.y);
         PH.x = ph0; PH.y = ph1;
     };
-    // the lane's next sub-tile, from a point of its grid: the slopes, position 0
-    auto fast_subtile_begin = [&](auto su_tag) __attribute__((always_inline)) {
-        const int tsl = FAST_TS0 >> fast_shift;
-        const float inv_ts = __builtin_bit_cast(float, (uint32_t)(127 - 5 + fast_shift) << 23);   // 1 / TS
-        FastAux xe;
-        fast_endpoint(su_tag, std::true_type(), (float)(tsl + 1), inv_ts, FD, xe);
-        fast_sub_left = tsl;
-        fast_sub_len = (float)tsl;
-        FTI.x = 0.0f; FTI.y = 1.0f;
+    // A lane between two sub-tiles (fast_sub_left == 0, FS holds the values of its next sample, step t of the tile) takes
+    // new slopes — BEFORE that sample is stepped: to the next point of its grid, or as far as its next samples are
+    // certainly free of events of its own (fast_horizon), whichever is nearer.  If not even the next sample is — an
+    // event of the lane is due — nothing happens here: the lane takes a slow sample and begins anew behind the event
+    // (fast_restart).  A lane that follows every sample by itself (level 5) asks the guard again at every point of the
+    // 32-sample grid, the same way.
+    auto fast_refresh = [&](auto su_tag, const int t) __attribute__((always_inline)) {
+        const bool flat = fast_flat_at(clk);            // the regime of the sample stepped last: that of the next ones, or none of them is free
+        const int hz = fast_horizon(clk, jphase, n_out, flat);
+        const int n_grid = fast_grid_left(t);
+        int n = n_grid < hz ? n_grid : hz;
+        if (fast_shift >= 5 && (t & (FAST_TS0 - 1)) == 0) n = 0;
+        if (n >= 1) {
+            FastAux xe;
+            const bool own = fast_shift >= 5;            // (level 5: both samples from their own evaluation)
+            if (own) fast_endpoint(su_tag, std::false_type(), 1.0f, 1.0f, flat, FS, xe);
+            // (1 / n by IEEE division: exactly 2^-k for the sub-tiles on the grid)
+            fast_endpoint(su_tag, std::true_type(), own ? 2.0f : (float)(n + 1), own ? 1.0f : 1.0f / (float)n, flat, FD, xe);
+            fast_sub_left = n;
+            fast_sub_len = (float)n;
+            FTI.x = 0.0f; FTI.y = 1.0f;
+        }
     };
-    // ... from step t_at of the tile (anywhere) to the next point of its grid, n_cap samples at most
-    auto fast_subtile_begin_at = [&](auto su_tag, const int t_at, const int n_cap) __attribute__((always_inline)) {
-        const int tsl = FAST_TS0 >> fast_shift;
-        const int n_grid = tsl - (t_at & (tsl - 1));
-        const int n = n_grid < n_cap ? n_grid : n_cap;
-        FastAux xe;
-        fast_endpoint(su_tag, std::true_type(), (float)(n + 1), 1.0f / (float)n, FD, xe);
+    // A lane begins anew AT the sample it has just stepped (step t of the tile; clk, jphase, n_out are that sample's):
+    // behind an event of its own — the segment pair, the noises or the regime of alpha are new — or wherever it has no run.
+    // The values at this sample, the slopes towards the next point of the 32-sample grid or as far as the regime reaches,
+    // the error guard and with it the lane's sub-tile length.
+    auto fast_restart = [&](auto su_tag, const int t) __attribute__((always_inline)) {
+        constexpr bool SU = decltype(su_tag)::value;
+        const bool flat = fast_flat_at(clk);
+        const int reach = 1 + fast_horizon(clk, jphase, n_out, flat);     // this sample and the free ones behind it
+        const int g0 = FAST_TS0 - (t & (FAST_TS0 - 1));
+        const int far0 = g0 < reach ? g0 : reach;
+        FastAux xs, xe;
+        fast_endpoint(su_tag, std::false_type(), 0.0f, 1.0f, flat, FS, xs);
+        int far = far0, n = far0;
+        // (a loop so that the far end's code exists once: a second trip where the guard asks for a shorter sub-tile)
+#pragma unroll 1
+        for (int trip = 0; trip < 2; ++trip) {
+            fast_endpoint(su_tag, std::true_type(), (float)far, 1.0f / (float)far, flat, FD, xe);
+            if (trip == 1) break;
+            fast_shift = fast_level(su_tag, xs, xe, (float)far0);
+            const int n_grid = fast_grid_left(t);
+            n = n_grid < reach ? n_grid : reach;
+            const int far1 = fast_shift >= 5 ? 1 : n;     // (level 5: the slope towards the sub-tile's second sample)
+            if (far1 == far) break;
+            far = far1;
+        }
         fast_sub_left = n;
         fast_sub_len = (float)n;
         FTI.x = 0.0f; FTI.y = 1.0f;
+        fast_have = SU ? 1 : 0;
     };
     // the sub-tile's end is the next one's start: start + TS * slope (the end value the slopes were
     // made from, to within an ulp; every sub-tile's end is evaluated afresh, so nothing accumulates)
@@ -1768,20 +1852,13 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         }
         if constexpr (SU) FS.oml = __builtin_fmaf(FD.oml, fts, FS.oml);
     };
-    // two samples tc, tc + 1 of the lane: the chain, polyBLEP, the formants with interpolated coefficients;
-    // nz / nm: the carrier noise of the two samples and noise - 1
-    auto fast_pair = [&](auto su_tag, const int tc, const float nz0, const float nz1, const float nm0,
-                         const float nm1_) __attribute__((always_inline)) {
-        constexpr bool SU = decltype(su_tag)::value;
+    // polyBLEP :503-517 of two samples without branches or selects: with d_h = f - p (> 0: the head test
+    // p < f) and d_t = p - (1 - f) (> 0: the tail test p > 1 - f; never both), u = max(d_h, d_t, 0) / f
+    // is 1 - t for the head (:505) and 1 + t for the tail (:509), and the correction is -u^2 or
+    // +u^2 (:506, :510) — zero when neither test holds.  d_h - d_t = 1 - 2p = -(2p - 1): the sign
+    // of the uncorrected saw says which.  Same tests as the reference, quotient by v_rcp.
+    auto fast_saw = [&](const f2 PH, const f2 frequency) __attribute__((always_inline)) -> f2 {
         const f2 one2 = vsplat(1.0f, f2());
-        const float nz[2] = {nz0, nz1}, nm[2] = {nm0, nm1_};
-        f2 PH, frequency;
-        chain_pair(std::true_type(), PH, frequency);
-        // polyBLEP :503-517 without branches or selects: with d_h = f - p (> 0: the head test
-        // p < f) and d_t = p - (1 - f) (> 0: the tail test p > 1 - f; never both), u = max(d_h, d_t, 0) / f
-        // is 1 - t for the head (:505) and 1 + t for the tail (:509), and the correction is -u^2 or
-        // +u^2 (:506, :510) — zero when neither test holds.  d_h - d_t = 1 - 2p = -(2p - 1): the sign
-        // of the uncorrected saw says which.  Same tests as the reference, quotient by v_rcp.
         const f2 omf = 1.0f - frequency;
         const f2 d_h = frequency - PH, d_t = PH - omf;
         f2 u;
@@ -1792,8 +1869,15 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         f2 su;    // u with the sign of -saw_nb: + for the head (saw + u^2), - for the tail (saw - u^2)
         su.x = __uint_as_float((__float_as_uint(u.x) & 0x7FFFFFFFu) | (~__float_as_uint(saw_nb.x) & 0x80000000u));
         su.y = __uint_as_float((__float_as_uint(u.y) & 0x7FFFFFFFu) | (~__float_as_uint(saw_nb.y) & 0x80000000u));
-        const f2 saw2 = vfma(su, u, saw_nb);                               // :517
-        // ---- the formants, sample by sample, coefficients by interpolation
+        return vfma(su, u, saw_nb);                                        // :517
+    };
+    // the formants of NH samples tc .. (tc + NH - 1) of the lane, coefficients by interpolation at the positions FTI;
+    // nz / nm: the carrier noise of the samples and noise - 1
+    auto fast_formants = [&](auto su_tag, auto nh_tag, const int tc, const f2 saw2, const float nz0, const float nz1,
+                             const float nm0, const float nm1_) __attribute__((always_inline)) {
+        constexpr bool SU = decltype(su_tag)::value;
+        constexpr int NH = decltype(nh_tag)::value;
+        const f2 one2 = vsplat(1.0f, f2());
         f2 keep2 = one2, ksaw2 = one2;          // shared smoothness: 1 - k and k * saw of both samples
         if constexpr (SU) {
             const f2 k2 = vfma(vsplat(FD.oml, f2()), FTI, vsplat(FS.oml, f2()));
@@ -1801,11 +1885,11 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             ksaw2 = k2 * saw2;
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             const float ti = vget(FTI, h), saw = vget(saw2, h);
             const V tiv = vsplat(ti, V());
-            const V nms = vsplat(nz[h] - saw, V());
-            const V nm1 = vsplat(nm[h], V());
+            const V nms = vsplat((h == 0 ? nz0 : nz1) - saw, V());
+            const V nm1 = vsplat(h == 0 ? nm0 : nm1_, V());
             const V sawv = vsplat(saw, V());
             V acc = vsplat(0.0f, V());
 #pragma unroll
@@ -1868,34 +1952,15 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 if (j == L - 1) stage[t_ * SP + slot] = tot * 0.5f;
             }
         }
-        FTI = FTI + 2.0f;
+        FTI = FTI + (float)NH;
     };
-    // One whole tile in which every rendering lane is calm with the same flavour and the same carrier-noise
-    // state: the tight loops.  The lanes may differ in their sub-tile lengths: the wave walks the tile in
-    // sub-tiles of the shortest (32 >> shift_max) and a lane takes new slopes / moves its start on where its OWN
-    // sub-tiles begin and end, so what it computes does not depend on the others' lengths.
-    // `noise_of_lane`: lane l holds the noise of the tile's step l.
-    auto fast_tile_uniform = [&](auto su_tag, const int shift_max, const float noise_of_lane) __attribute__((always_inline)) {
-        const int TS = FAST_TS0 >> shift_max;
-        const int my_mask = (FAST_TS0 >> fast_shift) - 1;
-        const float nm1_of_lane = noise_of_lane - 1.0f;
-#pragma unroll 1
-        for (int ts = 0; ts < T; ts += TS) {
-            // (a lane whose run started with this tile has its first sub-tile already)
-            const bool begins = ((ts & my_mask) == 0) & !((ts == 0) & (fast_sub_left != 0));
-            if (__builtin_amdgcn_ballot_w64(begins) != 0) {
-                if (begins) fast_subtile_begin(su_tag);
-            }
-#pragma unroll 1
-            for (int tc = ts; tc < ts + TS; tc += 2) {
-                const float nz0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc));
-                const float nz1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc + 1));
-                const float nm0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nm1_of_lane), tc));
-                const float nm1_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nm1_of_lane), tc + 1));
-                fast_pair(su_tag, tc, nz0, nz1, nm0, nm1_);
-            }
-            if (((ts + TS) & my_mask) == 0) fast_subtile_end(su_tag);
-        }
+    // two samples tc, tc + 1 of the lane: the chain, polyBLEP, the formants with interpolated coefficients
+    auto fast_pair = [&](auto su_tag, const int tc, const float nz0, const float nz1, const float nm0,
+                         const float nm1_) __attribute__((always_inline)) {
+        f2 PH, frequency;
+        chain_pair(std::true_type(), PH, frequency);
+        const f2 saw2 = fast_saw(PH, frequency);
+        fast_formants(su_tag, std::integral_constant<int, 2>(), tc, saw2, nz0, nz1, nm0, nm1_);
     };
     // ---- the staged tile's rows to memory: row `slot` holds samples [base_, base_ + T), mine_ of them valid
     // (the general flush; the main loop below has a shortcut for the usual full tile of the lane kernels)
@@ -1966,27 +2031,14 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         else wave_lds_sync();
     };
 
-    // ---- FAST: one tile of T steps.  Every lane decides for itself (see BATCH INVARIANCE above); the wave then
-    // takes the tight loops when all its rendering lanes agree, and the mixed tile otherwise.
+    // ---- FAST: one tile of T steps.  Every lane decides for itself (see BATCH INVARIANCE above).
     auto fast_render_tile = [&](auto) __attribute__((always_inline)) {   // (generic: instantiated by FAST kernels only)
-        static_assert(T <= 64, "calm-tile margins are written for T <= 64");
+        static_assert(T <= 64, "the horizon of a calm tile is written for T <= 64");
+        PROF_ADD(8);     // (flush and everything else between two tiles)
         // lanes that will not render again in this launch (chain exhausted, row full, no utterance) ride along
         // in the tight loops: what they compute is never read and their sample count stands still.  A lane
         // that has PAUSED (stream quota, end of its chunk) keeps its state: it is not idle.
         const bool idle = done && !paused;
-        // calm: no event of this lane before the tile ends (margins as in the exact kernels' calm tiles),
-        // alpha linear in time across the tile (a tile that holds the kink of min(clk / blend_length, 1) takes
-        // the general steps), and pitch < 1/2 (fast_pair's polyBLEP needs the head and tail tests to exclude
-        // each other)
-        bool calm = !done & quiet_ok & (dt > 0.0f) & (clk > (float)(T + 8) * dt) &
-                    (jphase + (float)(T + 1) * jinc < 0.999f) & (room_end - n_out >= (uint32_t)T) & (n_out <= room_end);
-        {
-            const float r_first = (clk - dt) * inv_blend_length;
-            const float r_next = (clk - (float)(T + 5) * dt) * inv_blend_length;
-            // (T + 5, 1.0001: fast_flat_left, asked anywhere in such a tile from the stepped clock, reaches beyond its end)
-            calm = calm & !((r_first > 1.0f) & (r_next < 1.0001f));
-            calm = calm & (__builtin_fmaxf(X.frequency, Y.frequency) + __builtin_fabsf(d_freq) < 0.5f);
-        }
         // shared smoothness: all formants of the utterance, whichever of its L lanes holds them
         auto flavour_now = [&]() __attribute__((always_inline)) -> int {
             if constexpr (L > 1) {
@@ -1997,119 +2049,169 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             }
         };
         int flavour = flavour_now();
-        bool lane_fast = calm;
-        int fast_block = 0;      // a run that could not start (parameters too fast for the guard) is not tried again
-                                 // before this step of the tile
-        const bool starts = calm && fast_have != flavour;          // a run of this lane starts with the tile
-        if (__builtin_amdgcn_ballot_w64(starts) != 0) {
-            if (starts) {
-                const bool ok = flavour ? fast_begin_run(std::true_type(), 0, FAST_TS0) : fast_begin_run(std::false_type(), 0, FAST_TS0);
-                lane_fast = ok;
-                if (!ok) { fast_have = -1; fast_block = FAST_TS0; }
-            }
-        }
-        // the tight loops: every rendering lane fast, one flavour, one sub-tile length, one carrier-noise state
+        const bool ok0 = fast_lane_ok();
+        // the carrier noise of the T steps, lane l taking step l (closed-form skip-ahead of the LCG :36-55), where every
+        // rendering lane begins the tile in the same state (seed 0 in every utterance, :594, and lanes in step: all but
+        // live streams whose utterances waited for their source at different times)
         const uint64_t rendering = __builtin_amdgcn_ballot_w64(!idle);
-        bool uniform = false;
-        int shift_max = 0, flavour_u = 0;
-        uint32_t tile_seed = 0u;
-        if (rendering != 0) {
-            const int first = __builtin_ctzll(rendering);
-            tile_seed = (uint32_t)__builtin_amdgcn_readlane((int)noise_seed, first);
-            flavour_u = __builtin_amdgcn_readlane(flavour, first);
-            const bool fits = idle | (lane_fast & (noise_seed == tile_seed) & (flavour == flavour_u));
-            uniform = __builtin_amdgcn_ballot_w64(!fits) == 0;
-#pragma unroll
-            for (int s_ = 1; s_ <= 4; ++s_)
-                if (__builtin_amdgcn_ballot_w64(!idle & (fast_shift >= s_)) != 0) shift_max = s_;
-        }
-        if (uniform) {
-            // the carrier noise of the T steps, lane l taking step l (closed-form skip-ahead of the LCG :36-55)
-            const uint32_t ahead = (uint32_t)(lane < T ? lane : T - 1) + 1u;
-            const uint32_t sk = tile_seed * LCG_SKIP.mul[ahead] + LCG_SKIP.add[ahead];
-            const float noise_of_lane = (__uint_as_float((sk >> 9) | 0x3F800000u) - 1.5f) * 2.0f;
-            if (flavour_u) fast_tile_uniform(std::true_type(), shift_max, noise_of_lane);
-            else fast_tile_uniform(std::false_type(), shift_max, noise_of_lane);
-            ++fast_tiles;
-            n_out += idle ? 0u : (uint32_t)T;
-            noise_seed = (uint32_t)__builtin_amdgcn_readlane((int)sk, T - 1);
-            return;
-        }
-        // The mixed tile, pair by pair.  A lane in a run renders the pair with fast_pair as long as no event of
-        // its own is due within the pair; where one is, it takes general steps (the reference's control flow;
-        // tolerance-mode formants while its segment pair is inside the safe window) until the event has passed,
-        // and begins a new run at the next pair — its first sub-tile reaching to the next point of its grid.
-        // The wave pays for a general step only while some lane is that close to an event of its own.  All of
-        // it is decided from the lane's own state: a lane that is calm for the whole tile does here exactly what
-        // it does in the tight loops.
-        // The usual pairs even of a mixed tile — every rendering lane inside a sub-tile of its run, events being
-        // rare per pair — go through a tight inner loop of their own (one straight body without lane predicates,
-        // idle lanes riding along; a loop, so that the rarely used code around it does not take its registers).
-        auto plain_pairs = [&](auto su_tag, int &t) __attribute__((always_inline)) {
-            constexpr int FL = decltype(su_tag)::value ? 1 : 0;
+        if (rendering == 0) return;
+        const uint32_t tile_seed = (uint32_t)__builtin_amdgcn_readlane((int)noise_seed, __builtin_ctzll(rendering));
+        const bool seeds_agree = __builtin_amdgcn_ballot_w64(!idle & (noise_seed != tile_seed)) == 0;
+        const uint32_t ahead = (uint32_t)(lane < T ? lane : T - 1) + 1u;
+        const uint32_t sk = tile_seed * LCG_SKIP.mul[ahead] + LCG_SKIP.add[ahead];
+        const float noise_of_lane = (__uint_as_float((sk >> 9) | 0x3F800000u) - 1.5f) * 2.0f;
+        bool any_slow = false;
+        PROF_ADD(9);
+        // One loop, in which the wave either renders a RUN of plain samples or ONE slow sample.
+        // PLAIN RUN: while every rendering lane is inside a sub-tile of its run the wave renders pairs with fast_pair
+        // — tight loops without lane predicates, idle lanes riding along, as many samples at once as every lane's sub-tile
+        // still holds; a lane whose sub-tile has ended takes new slopes at the top of the loop (fast_refresh: one end-point
+        // evaluation under the lane's predicate).  Sub-tiles never reach across an event of their lane, so "inside a
+        // sub-tile" is all there is to test.  SLOW SAMPLE: a lane whose next sample is not certainly free of events —
+        // fast_refresh gave it no sub-tile — or that has no run sends the wave through one sample by the chain part of the
+        // general step (the reference's control flow: a segment advance, a noise wrap, the end of the row happen here and
+        // nowhere else), a new beginning for the lanes that need one (fast_restart, behind their event), and the formants
+        // of all lanes in the one tolerance-mode body.  What the wave pays for an event of one lane is that one sample
+        // and the lane's two end points.
+        // All of it is decided from the lane's own state, and a sample's arithmetic is the same in a pair and alone.
+        // SHARED: the tile's carrier noise is one sequence for all lanes (seeds_agree) and comes from noise_of_lane; the
+        // lanes' own generator states are set where the wave takes a slow sample (seed_at)
+        const float nm1_of_lane = noise_of_lane - 1.0f;
+        auto plain_run = [&](auto su_tag, auto shared_tag, int &t, const int t_end) __attribute__((always_inline)) {
+            constexpr bool SHARED = decltype(shared_tag)::value;
 #pragma unroll 1
-            for (; t < T; t += 2) {
-                const bool plain = fast_pair_calm() && fast_have == FL && fast_sub_left != 0 && flavour_now() == FL;
-                if (__builtin_amdgcn_ballot_w64(!idle & !plain) != 0) break;
-                const float nz0 = lcg_f32(noise_seed), nz1 = lcg_f32(noise_seed);   // :528, the lane's own draws
-                fast_pair(su_tag, t, nz0, nz1, nz0 - 1.0f, nz1 - 1.0f);
-                fast_sub_left -= 2;
-                n_out += idle ? 0u : 2u;
-                if (__builtin_amdgcn_ballot_w64(!idle & (fast_sub_left == 0)) != 0) {
-                    if (fast_sub_left == 0) fast_subtile_end(su_tag);
+            for (; t < t_end; t += 2) {
+                if constexpr (SHARED) {
+                    const float nz0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), t));
+                    const float nz1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), t + 1));
+                    const float nm0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nm1_of_lane), t));
+                    const float nm1_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nm1_of_lane), t + 1));
+                    fast_pair(su_tag, t, nz0, nz1, nm0, nm1_);
+                } else {
+                    const float nz0 = lcg_f32(noise_seed), nz1 = lcg_f32(noise_seed);   // :528, the lane's own draws
+                    fast_pair(su_tag, t, nz0, nz1, nz0 - 1.0f, nz1 - 1.0f);
+                }
+            }
+        };
+        // the generator state of step t of the tile (SHARED)
+        auto seed_at = [&](const int t) __attribute__((always_inline)) -> uint32_t {
+            return t == 0 ? tile_seed : (uint32_t)__builtin_amdgcn_readlane((int)sk, t - 1);
+        };
+        int t = 0;
+        bool ok_lane = ok0;              // fast_lane_ok() and the flavour change in slow samples only
+        // the plain runs of the lanes of one flavour: new slopes for a lane between two sub-tiles whose next samples are
+        // certainly free of events, then as many samples as every rendering lane still has inside its sub-tile — as a
+        // power of two (the sub-tiles sit on power-of-two grids): that many go through without a test
+        auto plain_loop = [&](auto su_tag, int &t) __attribute__((always_inline)) {
+            constexpr int FL = decltype(su_tag)::value ? 1 : 0;
+            const bool idle_now = done && !paused;               // (neither this nor `has_run` changes inside the loop)
+            const bool has_run = ok_lane & (fast_have == FL);
+#pragma unroll 1
+            while (T - t >= 2) {
+                const bool need = has_run & (fast_sub_left == 0);
+                if (__builtin_amdgcn_ballot_w64(need) != 0) {
+                    PROF_CNT(12, 1);
+                    if (need) fast_refresh(su_tag, t);
+                }
+                const int left = idle_now ? 64 : (has_run ? fast_sub_left : 0);
+                if (__builtin_amdgcn_ballot_w64(left < 2) != 0) break;
+                int m = 2;
+                if (__builtin_amdgcn_ballot_w64(left < 4) == 0) {
+                    m = 4;
+                    if (__builtin_amdgcn_ballot_w64(left < 8) == 0) {
+                        m = 8;
+                        if (__builtin_amdgcn_ballot_w64(left < 16) == 0) m = __builtin_amdgcn_ballot_w64(left < 32) == 0 ? 32 : 16;
+                    }
+                }
+                const int room_t = (T - t) & ~1;
+                m = m < room_t ? m : room_t;
+                const int t_end = t + m;
+                if (seeds_agree) plain_run(su_tag, std::true_type(), t, t_end);
+                else plain_run(su_tag, std::false_type(), t, t_end);
+                PROF_CNT(10, m >> 1);
+                fast_sub_left -= m;
+                n_out += idle_now ? 0u : (uint32_t)m;
+                if (__builtin_amdgcn_ballot_w64(!idle_now & (fast_sub_left == 0)) != 0) {
+                    if (!idle_now & (fast_sub_left == 0)) fast_subtile_end(su_tag);
                 }
             }
         };
 #pragma unroll 1
-        for (int t = 0; t < T; t += 2) {
-            if (__builtin_amdgcn_ballot_w64(!idle) != 0) {
-                plain_pairs(std::true_type(), t);
-                plain_pairs(std::false_type(), t);
-                if (t >= T) break;
+        while (t < T) {
+            if (__builtin_amdgcn_ballot_w64(!done) == 0) break;     // nobody renders any more in this launch
+            plain_loop(std::true_type(), t);
+            plain_loop(std::false_type(), t);
+            PROF_ADD(2);
+            if (t >= T) break;
+            // ---- one slow sample
+            PROF_CNT(11, 1);
+            ++general_steps;
+            any_slow = true;
+            if (seeds_agree) {
+                const uint32_t s_ = seed_at(t);
+                if (!done) noise_seed = s_;
             }
+            // the chain part of the general step, every lane; the formant part of the same step for a lane outside the
+            // safe window (before the step, or behind the advance it has just taken): the reference's arithmetic where
+            // it has to be.  (Taken apart for every lane: the whole step in one piece at this place costs the kernel
+            // several hundred bytes of scratch memory — the register allocator's doing, measured.)
+            cv_live = 0;
+            if (!done) general_step(t, std::integral_constant<int, 2>());
+            const bool live = cv_live != 0;
+            const bool ok_after = fast_lane_ok();
+            const bool ok_post = live & ok_lane & ok_after;
+            const bool direct = live & !(ok_lane & ok_after);
+            if (__builtin_amdgcn_ballot_w64(direct) != 0) {
+                if (direct) {
+                    general_step(t, std::integral_constant<int, 3>());
+                    fast_have = -1;
+                }
+            }
+            ok_lane = ok_after;
             flavour = flavour_now();                                // (a segment advance may have changed it)
-            const bool pc = fast_pair_calm();
-            bool run = pc & (fast_have == flavour);
-            // a run between sub-tiles: the next one, to the next point of its grid or to the kink of alpha
-            const int flat_left = fast_flat_left();
-            const bool next_sub = run & (fast_sub_left == 0);
-            if (__builtin_amdgcn_ballot_w64(next_sub) != 0) {
-                if (next_sub) {
-                    if (flat_left < 2) run = false;                 // the kink is due: general steps through it
-                    else if (flavour) fast_subtile_begin_at(std::true_type(), t, flat_left);
-                    else fast_subtile_begin_at(std::false_type(), t, flat_left);
+            PROF_ADD(7);
+            // a new beginning behind the lane's event, or wherever it has no run
+            const bool anew = ok_post & ((fast_have != flavour) | (fast_sub_left == 0));
+            if (__builtin_amdgcn_ballot_w64(anew) != 0) {
+                PROF_CNT(13, 1); PROF_CNT(16, __popcll(__builtin_amdgcn_ballot_w64(anew)));
+                if (anew) {
+                    if (flavour) fast_restart(std::true_type(), t);
+                    else fast_restart(std::false_type(), t);
+#ifdef GRAIL_FAST_PROF
+                    prof_lane_levels += (unsigned long long)fast_shift;
+#endif
                 }
             }
-            // a lane without a run begins one where it can
-            const bool start = pc & !run & (t >= fast_block) & (flat_left >= 2);
-            if (__builtin_amdgcn_ballot_w64(start) != 0) {
-                if (start) {
-                    run = flavour ? fast_begin_run(std::true_type(), t, flat_left) : fast_begin_run(std::false_type(), t, flat_left);
-                    if (!run) fast_block = (t | (FAST_TS0 - 1)) + 1;
-                }
-            }
-            if (!run) fast_have = -1;
-            if (__builtin_amdgcn_ballot_w64(run) != 0) {
-                if (run) {
-                    const float nz0 = lcg_f32(noise_seed), nz1 = lcg_f32(noise_seed);   // :528, the lane's own draws
-                    if (flavour) fast_pair(std::true_type(), t, nz0, nz1, nz0 - 1.0f, nz1 - 1.0f);
-                    else fast_pair(std::false_type(), t, nz0, nz1, nz0 - 1.0f, nz1 - 1.0f);
-                    fast_sub_left -= 2;
+            PROF_ADD(5);
+            // the formants of the sample, every lane in the one body
+            if (__builtin_amdgcn_ballot_w64(ok_post) != 0) {
+                if (ok_post) {
+                    f2 PH, frequency;
+                    PH.x = cv_ph; PH.y = cv_ph;
+                    frequency.x = cv_freq; frequency.y = cv_freq;
+                    const f2 saw2 = fast_saw(PH, frequency);
+                    if constexpr (MID) {
+                        chain_alpha.x = cv_alpha; chain_alpha.y = cv_alpha;
+                        chain_jp.x = jphase; chain_jp.y = jphase;
+                    }
+                    const float nm = cv_noise - 1.0f;
+                    if (flavour) fast_formants(std::true_type(), std::integral_constant<int, 1>(), t, saw2, cv_noise, cv_noise, nm, nm);
+                    else fast_formants(std::false_type(), std::integral_constant<int, 1>(), t, saw2, cv_noise, cv_noise, nm, nm);
+                    fast_sub_left -= 1;
                     if (fast_sub_left == 0) {
                         if (flavour) fast_subtile_end(std::true_type());
                         else fast_subtile_end(std::false_type());
                     }
-                    n_out += 2u;
                 }
             }
-            if (__builtin_amdgcn_ballot_w64(!run & !done) != 0) {
-                general_steps += 2u;
-                if (!run) {
-                    general_step(t, std::false_type());
-                    general_step(t + 1, std::false_type());
-                }
-            }
+            ++t;
+            PROF_ADD(6);
         }
+        if (seeds_agree && t >= T) {
+            const uint32_t s_ = seed_at(T);
+            if (!done) noise_seed = s_;
+        }
+        if (!any_slow) { ++fast_tiles; PROF_CNT(15, 1); }
     };
 
     // ---- SPLIT: fast-forward the exact per-utterance chain to where this chunk's filters start
@@ -2533,6 +2635,19 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     if (emit && lane == 0 && slow_steps) atomicAdd(A.truncated + 1, slow_steps);
     if (emit && lane == 0 && fast_tiles) atomicAdd(A.truncated + 2, fast_tiles);
     if (emit && lane == 0 && general_steps) atomicAdd(A.truncated + 3, general_steps);
+#ifdef GRAIL_FAST_PROF
+    if constexpr (FAST) {
+        unsigned long long *prof = reinterpret_cast<unsigned long long *>(A.truncated + 8);
+        prof_c[0] = clock64() - prof_start;
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k)
+                if (prof_c[k]) atomicAdd(prof + k, prof_c[k]);
+            atomicAdd(prof + 31, 1ull);      // waves
+        }
+        if (prof_lane_levels) atomicAdd(prof + 17, prof_lane_levels);
+    }
+#endif
 }
 
 template <int L, int T, int WAVES, int MINW, bool STREAM, bool HALF, bool ANYBL, int NFA = NF, bool PIPE = false,

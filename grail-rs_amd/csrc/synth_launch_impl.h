@@ -83,7 +83,11 @@ void launch_one_fast(const SynthArgs &args, hipStream_t stream)
     }
     // resumable streams in tolerance mode (chunks concatenate to the one-shot rendering within the
     // tolerance, not bit for bit: the interpolation ends restart with every call)
+#ifdef GRAIL_FAST_STREAM_TF
+    start<L, TF, WAVES, MINW, true, false, true, NF, false, true>(args, grid, block, stream);
+#else
     start<L, T, WAVES, MINW, true, false, true, NF, false, true>(args, grid, block, stream);
+#endif
 }
 
 // time-split fast kernels: one lane per (utterance, chunk), 64-thread workgroups, chunk-major

@@ -5,7 +5,7 @@ Used by bench.py and the parity tests so both sides see identical inputs.
 """
 import numpy as np
 
-from . import (NUM_FORMANTS, PH_A, PH_E, PH_SILENCE, PHONEME_DTYPE, elem_new_phoneme,
+from . import (NUM_FORMANTS, PH_A, PH_E, PH_SILENCE, PH_STOP, PHONEME_DTYPE, elem_new_phoneme,
                elem_resample, shard_range, voice_generic)
 
 SAMPLE_RATE = 48000.0
@@ -47,6 +47,37 @@ def make_batch(n_utt, first_utt=0, n_voices=1, segments=SEGMENTS_PER_UTT, sample
     voice_ids = (u % np.uint32(max(n_voices, 1))).astype(np.uint32)
     jitter_seeds = u.copy()
     return segs.reshape(-1), seg_offsets, voice_ids, jitter_seeds
+
+
+def speech_like_batch(n_utt, rng, n_voices=1, scale=1.0, blend_is_length=False, long_tail=False,
+                      sample_rate=SAMPLE_RATE):
+    """A SPEECH-LIKE corpus next to make_batch's four aligned segments: utterances of 8 - 32 phonemes of 40 - 160 ms
+    (blends of 30 - 80 ms, any length; pitches of 90 - 220 Hz per phoneme; A / E / Silence / Stop 40 / 40 / 12 / 8 %,
+    a leading Silence as .transcribe() emits it, reference src/lib.rs:1201), 2.0 s on average, 0.5 - 3.8 s: the
+    utterances differ in length by a factor of seven and every one has a segment boundary and the kink of
+    alpha = min(time / blend_length, 1) (src/lib.rs:899) every few thousand samples at times of its own.
+    `scale` multiplies every length and blend length (0.1: phonemes of 4 - 16 ms); `blend_is_length`: no flat
+    stretch of alpha and no kink; `long_tail`: one utterance in a hundred of 60 - 80 phonemes among utterances of 4 - 12.
+    `rng`: a numpy Generator (the draws, in this order: counts, phonemes, lengths, blend lengths, pitches).
+    Returns (segs, seg_offsets, voice_ids, jitter_seeds, out_stride)."""
+    counts = rng.integers(8, 33, n_utt)
+    if long_tail:
+        counts = np.where(rng.random(n_utt) < 0.01, rng.integers(60, 81, n_utt), rng.integers(4, 13, n_utt))
+    offs = np.zeros(n_utt + 1, dtype=np.uint32)
+    offs[1:] = np.cumsum(counts)
+    k = int(offs[-1])
+    segs = np.zeros(k, dtype=PHONEME_DTYPE)
+    segs["phoneme"] = rng.choice([PH_A, PH_E, PH_SILENCE, PH_STOP], k, p=[.4, .4, .12, .08])
+    segs["phoneme"][offs[:-1]] = PH_SILENCE
+    segs["length"] = (rng.uniform(0.04, 0.16, k) * scale).astype(np.float32)
+    segs["blend_length"] = (rng.uniform(0.03, 0.08, k) * scale).astype(np.float32)
+    if blend_is_length:
+        segs["blend_length"] = segs["length"]
+    segs["frequency"] = (rng.uniform(90, 220, k) / sample_rate).astype(np.float32)
+    vids = (np.arange(n_utt) % max(n_voices, 1)).astype(np.uint32)
+    seeds = np.arange(n_utt, dtype=np.uint32)
+    stride = (int(int(counts.max()) * 0.16 * scale * sample_rate) + 64 + 63) // 64 * 64
+    return segs, offs, vids, seeds, stride
 
 
 def shard_inputs(utts_per_rank, rank, world, n_voices, **kw):

@@ -31,23 +31,9 @@ rng = np.random.default_rng(7)
 for n_voices in (1, 8):
     voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
     ctx.set_voices(voices)
-    counts = rng.integers(8, 33, n)
-    if "--long-tail" in sys.argv:
-        counts = np.where(rng.random(n) < 0.01, rng.integers(60, 81, n), rng.integers(4, 13, n))
-    offs = np.zeros(n + 1, dtype=np.uint32)
-    offs[1:] = np.cumsum(counts)
-    k = int(offs[-1])
-    segs = np.zeros(k, dtype=G.PHONEME_DTYPE)
-    segs["phoneme"] = rng.choice([G.PH_A, G.PH_E, G.PH_SILENCE, G.PH_STOP], k, p=[.4, .4, .12, .08])
-    segs["phoneme"][offs[:-1]] = G.PH_SILENCE
-    segs["length"] = (rng.uniform(0.04, 0.16, k) * scale).astype(np.float32)
-    segs["blend_length"] = (rng.uniform(0.03, 0.08, k) * scale).astype(np.float32)
-    if "--blend-is-length" in sys.argv:            # (no flat stretch of alpha, no kink: what the kinks cost)
-        segs["blend_length"] = segs["length"]
-    segs["frequency"] = (rng.uniform(90, 220, k) / 48000.0).astype(np.float32)
-    vids = (np.arange(n) % n_voices).astype(np.uint32)
-    seeds = np.arange(n, dtype=np.uint32)
-    stride = (int(int(counts.max()) * 0.16 * scale * 48000) + 64 + 63) // 64 * 64
+    segs, offs, vids, seeds, stride = W.speech_like_batch(n, rng, n_voices=n_voices, scale=scale,
+                                                          blend_is_length="--blend-is-length" in sys.argv,
+                                                          long_tail="--long-tail" in sys.argv)
     batch = ctx.upload(segs, offs, vids, seeds)
     d_out = ctx.device_alloc(n * stride * 4)
     d_len = ctx.device_alloc(n * 4)
