@@ -39,7 +39,7 @@ constexpr double MID_MS_4 = 32.6, MID_MS_8 = 57.2;     // 65 536 x 2 s, the MID 
 static double lane_ms_per_sample(bool fast, bool live4, int L)
 {
     static const double exact4[4] = {40.6, 26.9, 16.3, 18.2}, exact8[4] = {77.1, 43.5, 25.8, 15.7};
-    static const double fast4[4] = {15.6, 13.0, 12.1, 11.7}, fast8[4] = {23.2, 19.9, 13.3, 11.7};
+    static const double fast4[4] = {15.5, 13.6, 12.8, 12.1}, fast8[4] = {23.6, 16.4, 13.3, 12.0};
     const int i = L == 1 ? 0 : L == 2 ? 1 : L == 4 ? 2 : 3;
     return (fast ? (live4 ? fast4 : fast8) : (live4 ? exact4 : exact8))[i] / 96006.0;
 }
@@ -365,12 +365,11 @@ double plan_blocks(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
 // 171.6 / 113.6; fast 87.7 / 73.6 and 145.7 / 88.8; 100 000: 125 -> 94 in ONE launch of the one-lane kernel.  profiles/r04_ragged_plan.txt.)
 // Model: a wave costs its longest row's samples at the mapping's rate plus what its rows' events cost.  Exact: the tiles
 // that hold some lane's segment boundary, tiles x (1 - exp(-boundaries per tile)), at 7 / 8 us per 32 samples (four / eight
-// formants), and 1.5 / 3.7 us per boundary on one lane per utterance.  Fast: a tile is tight with probability
-// exp(-events per tile) (events: boundaries and kinks of alpha) and costs a + b x events per tile otherwise (general steps:
-// the denser the events, the more and the shorter the runs between them).  Waves are handed to the SIMDs in launch order as
-// they fall free.  Fitted on pinned-mapping measurements of the speech-like corpus at 65 536 utterances with phonemes of
-// 40 - 160, 16 - 64 and 4 - 16 ms, L = 1 / 2 / 4, four and eight formants (36 cells within 10 %, three L = 1 cells of the
-// densest corpus 20 - 28 % under) and checked at 16 384 ... 131 072 utterances: profiles/r04_ragged_plan.txt.
+// formants), and 1.5 / 3.7 us per boundary on one lane per utterance.  Fast: the aligned rate x m plus c per event (below).
+// Waves are handed to the SIMDs in launch order as they fall free.  The exact constants were fitted on pinned-mapping
+// measurements of the speech-like corpus at 65 536 utterances with phonemes of 40 - 160, 16 - 64 and 4 - 16 ms, L = 1 / 2 / 4,
+// four and eight formants (within 10 %, three L = 1 cells of the densest corpus 20 - 28 % under) and checked at 16 384 ...
+// 131 072 utterances: profiles/r04_ragged_plan.txt.
 static double ragged_wave_ms(const Family &f, double samples, double segs, double kinks)
 {
     const bool nfa4 = f.live4 != 0;
@@ -383,19 +382,20 @@ static double ragged_wave_ms(const Family &f, double samples, double segs, doubl
         return samples * lane_ms_per_sample(false, nfa4, f.L) + event_tiles * (nfa4 ? 0.007 : 0.008) * (T / 32.0) +
                (f.L == 1 ? segs * (nfa4 ? 0.0015 : 0.0037) : 0.0);
     }
-    const double T = (!nfa4 && f.L == 4) ? 32.0 : 64.0;                  // (tile of the fast kernels)
-    const double tiles = std::fmax(samples / T, 1.0);
-    const double per_tile = std::fmin((segs + kinks) / tiles, T);
-    static const double a4[4] = {0.0325, 0.0325, 0.035, 0.032}, b4[4] = {0.006, 0.0075, 0.010, 0.010};
-    static const double a8[4] = {0.0525, 0.035, 0.025, 0.032}, b8[4] = {0.011, 0.010, 0.009, 0.010};
-    const double fast_tile = lane_ms_per_sample(true, nfa4, f.L) * T;
-    double tight_tile = fast_tile, mixed_tile = (nfa4 ? a4 : a8)[li] + (nfa4 ? b4 : b8)[li] * per_tile;
-    if (f.fast == 2u) {                                                    // second tier: the same events, its own rate
-        tight_tile = mid_ms_per_sample(nfa4) * T;
-        mixed_tile += tight_tile - fast_tile;
-    }
-    const double tight = std::exp(-per_tile);
-    return tiles * (tight * tight_tile + (1.0 - tight) * mixed_tile);
+    // Fast (round 5: sub-tiles that never span an event, one slow sample per event — synth_kernel.h fast_render_tile): a wave
+    // costs its longest row at the mapping's aligned rate x m — while a lane's parameters move (blends of 30 - 80 ms) its
+    // sub-tiles are 8 - 16 samples instead of 32, and the wave takes new slopes at the pace of its busiest lane — plus c
+    // per event of its rows (boundaries and kinks of alpha: the slow sample, the lane's two end points, the shorter runs
+    // around it).  Fitted on pinned-mapping measurements of the speech-like corpus with phonemes of 40 - 160, 16 - 64 and
+    // 4 - 16 ms at 65 536 utterances, one and eight voices, L = 1 / 2 / 4 / 8: all 24 cells within 4 % (tools/ragged_fit.py,
+    // profiles/r05_ragged_fit.txt).  m fades to 1 where events are rare (long segments have long blends: the bench corpora).
+    static const double m4[4] = {1.34, 1.28, 1.22, 1.18}, c4[4] = {0.0055, 0.00575, 0.00825, 0.0115};
+    static const double m8[4] = {1.30, 1.30, 1.24, 1.18}, c8[4] = {0.00775, 0.0065, 0.00675, 0.00975};
+    const double events = segs + kinks;
+    const double density = events / ((64.0 / (double)f.L) * std::fmax(samples, 1.0));        // per lane and sample
+    const double m = 1.0 + ((nfa4 ? m4 : m8)[li] - 1.0) * std::fmin(1.0, density / 3.0e-4);
+    const double rate = f.fast == 2u ? mid_ms_per_sample(nfa4) : lane_ms_per_sample(true, nfa4, f.L);
+    return samples * rate * m + events * (nfa4 ? c4 : c8)[li];
 }
 
 double ragged_cost(const grail_ctx *ctx, const grail_batch *batch, const Family &f, uint32_t slot0, uint32_t rows, double span)

@@ -2139,8 +2139,9 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 #pragma unroll 1
         while (t < T) {
             if (__builtin_amdgcn_ballot_w64(!done) == 0) break;     // nobody renders any more in this launch
-            plain_loop(std::true_type(), t);
-            plain_loop(std::false_type(), t);
+            // (a flavour none of the rendering lanes has a run of: its loop would leave at once)
+            if (__builtin_amdgcn_ballot_w64(!done & ok_lane & (fast_have == 1)) != 0) plain_loop(std::true_type(), t);
+            if (__builtin_amdgcn_ballot_w64(!done & ok_lane & (fast_have == 0)) != 0) plain_loop(std::false_type(), t);
             PROF_ADD(2);
             if (t >= T) break;
             // ---- one slow sample
