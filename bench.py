@@ -256,6 +256,10 @@ def main():
     ap.add_argument("--fast-leg", type=int, default=-1, choices=[-1, 0, 1],
                     help="with --mode exact: also time the same batch in fast mode after the timed "
                          "region and report it as `fast_mode` (default: on at N=1)")
+    ap.add_argument("--other-configs", type=int, default=-1, choices=[-1, 0, 1],
+                    help="after the timed region and the fast leg: BASELINE configs 4 (65 536 utterances x 8 presets) and 2 "
+                         "(4 096 utterances), exact and fast, a few steps each, reported as `other_configs` (default: "
+                         "on for the default config-3 run at N=1)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per utterance (0 = auto)")
     ap.add_argument("--pipeline", type=int, default=1, choices=[0, 1],
                     help="0 disables the small-batch producer/consumer kernels (A/B)")
@@ -624,6 +628,55 @@ def main():
             "roofline_valu": valu_roofline(f_entry, fk),
         }
 
+    # Outside the timed region, rank 0 of a one-GPU run of the headline config only: BASELINE configs 4 and 2 on a context
+    # of their own (the voice table of the timed context stays what it is), exact and fast — the numbers the headline is
+    # quoted beside (config 4: all eight formants live; config 2: a batch that leaves most lanes of the device idle).
+    other_configs = None
+    want_other = (args.other_configs == 1) or (args.other_configs == -1 and world == 1 and args.mode == "exact" and
+                                                 n_utt == 65536 and n_voices == 1 and not args.pcm16 and args.lanes == 0)
+    if want_other and rank == 0 and world == 1:
+        other_configs = {}
+        ctx2 = G.Context(device)
+        try:
+            for name, o_utts, o_voices, o_steps in (("config4", 65536, 8, 5), ("config2", 4096, 1, 10)):
+                o_table = W.single_voice() if o_voices == 1 else W.preset_voices(o_voices)
+                ctx2.set_voices(o_table)
+                o_batch = ctx2.upload(*W.make_batch(o_utts, n_voices=o_voices))
+                legs = {}
+                for o_mode in ("exact", "fast"):
+                    ctx2.set_option("arithmetic", 1 if o_mode == "fast" else 0)
+                    o_batch.synthesize_async(d_out, stride, d_len)      # (d_out / d_len: the timed region's rows, done with)
+                    ctx2.sync()
+                    o_kernel = []
+                    t2 = time.perf_counter()
+                    for _ in range(o_steps):
+                        o_batch.synthesize_async(d_out, stride, d_len)
+                        ctx2.sync()
+                        o_kernel.append(ctx2.last_kernel_ms())
+                    o_elapsed = time.perf_counter() - t2
+                    o_len = np.zeros(o_utts, dtype=np.uint32)
+                    ctx2.d2h(o_len, d_len, o_utts * 4)
+                    o_samples = int(o_len.astype(np.uint64).sum())
+                    o_symbol = ctx2.last_kernel_name()
+                    o_k = float(np.mean(o_kernel))
+                    o_ach = o_samples * ALG_BYTES_PER_SAMPLE / (o_k * 1e-3) / 1e9
+                    o_entry = committed_counters(f"{name}_utts{o_utts}" + ("_fast" if o_mode == "fast" else ""), o_symbol)
+                    legs[o_mode] = {
+                        "value": o_samples * o_steps / o_elapsed, "unit": "samples/s", "steps": o_steps,
+                        "ms_per_step": o_elapsed * 1e3 / o_steps, "kernel_ms": o_k, "kernel": o_symbol,
+                        "launch_blocks": ctx2.get_option("last_launch_blocks"),
+                        "roofline": {"bound": "hbm", "achieved": o_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": o_ach / HBM_PEAK_GBS, "traffic": o_entry.get("hbm_bytes") if o_entry else None,
+                                     "algorithmic_bytes_per_launch": o_samples * ALG_BYTES_PER_SAMPLE},
+                        "roofline_valu": valu_roofline(o_entry, o_k),
+                    }
+                other_configs[name] = {
+                    "workload": f"batch={o_utts} utterances x 2 s (4 segments x 0.5 s), {o_voices} Voice preset(s), 48 kHz, "
+                                f"f32 PCM left in HBM (BASELINE {name})", **legs}
+                o_batch.free()
+        finally:
+            ctx2.close()
+
     my_elapsed = elapsed
     if distributed:
         stats = group.gather_doubles((elapsed, float(samples_per_step), float(np.mean(kernel_ms)), float(device)))
@@ -696,6 +749,8 @@ def main():
             line["verify"] = verify
         if fast_leg is not None:
             line["fast_mode"] = fast_leg
+        if other_configs is not None:
+            line["other_configs"] = other_configs
         if world == 1 and args.cpu_utts > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_utts, voices, W)
             line["speedup_vs_cpu_1thread"] = value / line["cpu_baseline"]["value"]
