@@ -1152,3 +1152,55 @@ def test_time_split_serves_caller_built_elems(gpu_ctx, n_utt, sharp):
     print(f"caller-built elems ({'sharp' if sharp else 'tame'}), {n_utt} utterances: {name} x{chunks} (time_split = 0: {lane_name}); "
           f"worst |fast - oracle| = {worst * 2 ** 23:.1f} * 2^-23")
     assert worst <= G.FAST_TOLERANCE
+
+
+@pytest.mark.parametrize("n_voices", [1, 8])
+@pytest.mark.parametrize("family", ["L1", "L2", "L4", "L8", "split3", "split7", "scan", "mid", "mid split4"])
+def test_every_fast_family_on_a_speech_like_corpus(gpu_ctx, family, n_voices):
+    """Event-dense input — utterances of 8 - 32 phonemes with blends of any length, each lane with a segment boundary, the
+    kink of alpha = min(time / blend_length, 1) and steep parameter ramps every few hundred samples at times of its own
+    (workload.speech_like_batch, phonemes of 10 - 40 and of 4 - 16 ms) — through every kernel family of the tolerance
+    mode against the oracle: the lengths are the reference's, every sample within GRAIL_FAST_TOLERANCE.  This is the
+    input on which a lane's sub-tiles end at its own events and the wave takes slow samples (synth_kernel.h
+    fast_render_tile); the aligned corpora of the tests above hardly ever get there."""
+    voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    worst = 0.0
+    try:
+        for scale, n_utt in ((0.25, 150), (0.1, 200)):
+            segs, offs, vids, seeds, stride = W.speech_like_batch(n_utt, np.random.default_rng(int(scale * 100) + n_voices),
+                                                                  n_voices=n_voices, scale=scale)
+            ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, stride)
+            gpu_ctx.set_option("ragged_plan", 0)
+            if family.startswith("mid"):
+                gpu_ctx.set_option("arithmetic", 2)
+            if "split" in family:
+                _split(gpu_ctx, int(family.split("split")[1]))
+                gpu_ctx.set_option("time_split_min_utterances", 0)
+                gpu_ctx.set_option("time_parallel_scan", 0)
+            elif family == "scan":
+                gpu_ctx.set_option("time_split", 0)
+                gpu_ctx.set_option("time_parallel_scan_max_utterances", 1 << 20)
+            else:
+                gpu_ctx.set_option("time_split", 0)
+                gpu_ctx.set_option("time_parallel_scan", 0)
+            lanes = int(family[1]) if family[0] == "L" else (1 if family == "mid" else 0)
+            if family.startswith("mid"):
+                gpu_ctx.set_option("lanes_per_utterance", lanes)
+                out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+            else:
+                out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride, lanes)
+            name = gpu_ctx.last_kernel_name()
+            assert ("scan" in name) if family == "scan" else ("FAST" in name), name
+            assert ("SPLIT" in name) == ("split" in family) or family == "scan", name
+            assert ("MID" in name) == family.startswith("mid"), name
+            assert np.array_equal(out_len, ref_len)
+            k = _worst(out, ref, ref_len)
+            worst = max(worst, k)
+            assert 0.0 < k * ULP <= TOL, (family, scale, k)
+    finally:
+        for k_, v_ in (("arithmetic", 0), ("lanes_per_utterance", 0), ("ragged_plan", 1), ("time_split", 1), ("time_parallel_scan", 1),
+                       ("time_split_min_utterances", -1), ("time_parallel_scan_max_utterances", -1)):
+            gpu_ctx.set_option(k_, v_)
+        _split(gpu_ctx, 0)
+    print(f"speech-like corpus, {family}, voices={n_voices}: max |d| = {worst:.1f} * 2^-23")
