@@ -22,7 +22,10 @@ int grail_stream_open(grail_ctx *ctx, const grail_batch *batch, grail_stream **o
     s->live4 = batch_live4_any_blend(ctx, batch);      // (the lean resumable kernels exist for every blend length)
     s->voices_epoch = ctx->voices_epoch;
     s->L = ctx->lanes_option ? ctx->lanes_option : auto_lanes_per_utt(batch->n_utt, ctx_simds(ctx));
-    if (s->live4) {
+    if (s->live4 && !ctx->lanes_option && ctx->pipeline_option &&
+        (int64_t)(((uint64_t)batch->n_utt + 15) / 16) <= pipe4_groups(ctx)) {
+        s->L = 4;                            // the pipelined workgroups of four formants (stream_next), 16 utterances each
+    } else if (s->live4) {
         if (s->L == 8) s->live4 = false;     // eight lanes per utterance need eight formants to lay out
         else if (!ctx->lanes_option)         // same rule over four formants: the widest one-wave-per-SIMD mapping
             s->L = ((uint64_t)batch->n_utt * 4 + 63) / 64 <= ctx_simds(ctx) ? 4 : ((uint64_t)batch->n_utt * 2 + 63) / 64 <= ctx_simds(ctx) ? 2 : 1;
@@ -80,6 +83,18 @@ static int stream_next(grail_ctx *ctx, grail_stream *stream, uint32_t max_sample
     // (sharper voices: the second tier has one-lane kernels only — streams on a wider mapping run the exact kernels)
     const int tier = fast_tier(ctx, batch);
     a.fast = tier == 1 ? 1u : (tier == 2 && stream->L == 1) ? 2u : 0u;
+    // A few hundred to a few thousand streams leave most SIMDs idle on the lane kernels: they take the pipelined
+    // workgroups (four waves share 16 / 8 utterances; synth_kernel<..., PIPE>) wherever a one-shot batch of this size
+    // would — same state block as the lane kernels of the stream's mapping, exact arithmetic (a tolerance request is
+    // served by them too: their bits are the reference's, and at these sizes they are the faster kernels)
+    const uint64_t cus = (uint64_t)ctx->cus;
+    if (ctx->pipeline_option && !ctx->lanes_option) {
+        if (stream->live4 && stream->L == 4 && (int64_t)(((uint64_t)batch->n_utt + 15) / 16) <= pipe4_groups(ctx))
+            a.pipe = ctx->pipe_round32 && ((uint64_t)batch->n_utt + 15) / 16 <= cus ? 2u : 1u;
+        else if (!stream->live4 && stream->L == 8 && (int64_t)(((uint64_t)batch->n_utt + 7) / 8) <= pipe8_groups(ctx))
+            a.pipe = ctx->pipe_round32 && ((uint64_t)batch->n_utt + 7) / 8 <= cus ? 2u : 1u;
+        if (a.pipe) a.fast = 0u;
+    }
     a.state = stream->d_state;
     a.state_stride = stream->lanes;
     a.resume = stream->started ? 1u : 0u;
@@ -89,7 +104,7 @@ static int stream_next(grail_ctx *ctx, grail_stream *stream, uint32_t max_sample
     ctx->last_kernel = last_kernel_name();
     ctx->last_formants = a.live4 ? 4 : 8;
     ctx->last_lanes = stream->L;
-    ctx->last_pipe = 0;
+    ctx->last_pipe = a.pipe ? 1 : 0;
     ctx->last_fast = (int)a.fast;
     ctx->last_blocks = 1;
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));

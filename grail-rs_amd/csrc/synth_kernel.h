@@ -445,7 +445,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     static_assert(!MID || FAST, "MID is a flavour of the tolerance kernels");
     static_assert(!SPLIT || (FAST && !STREAM && L == 1 && WAVES == 1 && T == 64), "SPLIT");
     static_assert(NFA == NF || (NFA == 4 && !HALF), "NFA");
-    static_assert(!PIPE || (WAVES == 4 && NFA / L == 1 && L >= 4 && !STREAM && !HALF && T % 4 == 0), "PIPE");
+    static_assert(!PIPE || (WAVES == 4 && NFA / L == 1 && L >= 4 && !HALF && T % 4 == 0), "PIPE");
     constexpr int FPL = NFA / L;         // formants per lane
     constexpr int W = FPL >= 2 ? 2 : 1;  // formants per packed value
     constexpr int NV = FPL / W;          // packed values per lane and field
@@ -698,7 +698,10 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
 
     constexpr bool streaming = STREAM;       // a separate instantiation: the one-shot kernel
                                              // carries none of the state traffic or its registers
-    const size_t state_lane = (size_t)(blockIdx.x * WAVES + wave) * 64 + lane;
+    // (PIPE: the four waves of a workgroup carry ONE set of utterances — every wave loads the set's state, the rendering
+    // wave, whose filters are the live ones, saves it; the block is the lane kernels' of the same L, utterance by utterance:
+    // a stream may take either from call to call)
+    const size_t state_lane = PIPE ? (size_t)blockIdx.x * 64 + lane : (size_t)(blockIdx.x * WAVES + wave) * 64 + lane;
     auto visit_state = [&](auto &io) __attribute__((always_inline)) {
         io(seg_pos);
         io(cur.some); io(cur.elem); io(cur.length); io(cur.blend_length); io(cur.frequency);
@@ -2627,7 +2630,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         if (A.out_len) A.out_len[u] = n_out;
         if (truncated) atomicOr(A.truncated, 1u);
     }
-    if (streaming && A.state && slot_used) {
+    if (streaming && A.state && slot_used && emit) {
         StateIO<false> io{A.state, A.state_stride, state_lane};
         visit_state(io);
         if constexpr (LIVE)

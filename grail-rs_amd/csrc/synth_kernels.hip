@@ -80,7 +80,7 @@ const char *last_kernel_name() { return g_kernel_name; }
 hipError_t launch_synth(const SynthArgs &args, int L, hipStream_t stream)
 {
     if (args.n_utt == 0) return hipSuccess;
-    if (args.pipe && !args.state && !args.fast) {
+    if (args.pipe && !args.fast) {
         if (args.live4) launch_pipe4(args, stream);
         else launch_pipe8(args, stream);
         return hipGetLastError();

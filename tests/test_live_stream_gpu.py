@@ -307,7 +307,8 @@ def test_live_stream_in_fast_arithmetic(gpu_ctx, lanes):
         assert len(got[u]) == n, u
         worst = max(worst, float(np.max(np.abs(got[u].astype(np.float64) - ref.astype(np.float64)))))
     print(f"live stream, fast arithmetic, lanes={lanes}: max |d| = {worst / ULP:.1f} * 2^-23")
-    assert 0.0 < worst <= G.FAST_TOLERANCE
+    # (a few live streams on the library's own mapping take the pipelined exact workgroups: the reference's bits)
+    assert worst <= G.FAST_TOLERANCE and (worst > 0.0 or lanes == 0)
 
 
 def test_live_stream_argument_checks(gpu_ctx):

@@ -59,6 +59,40 @@ def test_chunked_stream_equals_one_shot(gpu_ctx, lanes):
         assert np.array_equal(got[u].view(np.uint32), full[u, :full_len[u]].view(np.uint32)), u
 
 
+@pytest.mark.parametrize("n_voices,n_utt,kernel", [(1, 300, "NFA=4,PIPE,R32"), (1, 5000, "NFA=4,PIPE,R16"),
+                                                    (8, 300, "NFA=8,PIPE,R32"), (8, 3000, "NFA=8,PIPE,R16")])
+def test_mid_size_streams_take_the_pipelined_workgroups(gpu_ctx, n_voices, n_utt, kernel):
+    """A few hundred to a few thousand streams leave most SIMDs idle on the lane kernels; they run the resumable form of
+    the four-wave pipelined workgroups (synth_kernel<..., STREAM, PIPE>: every wave loads the shared utterances' state, the
+    rendering wave saves it).  Chunks of any size — a pause inside a calm run, inside an event tile, at a tile's first
+    sample — concatenate to the oracle's rendering, bit for bit, and a speech-like script (events at every lane's own
+    times) does too."""
+    import oracle_lib as O
+    voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    for corpus in ("aligned", "speech-like"):
+        if corpus == "aligned":
+            segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=n_voices, length=0.03, blend_length=0.03125)
+            total = W.max_samples(length=0.03)
+        else:
+            segs, offs, vids, seeds, total = W.speech_like_batch(n_utt, np.random.default_rng(n_utt), n_voices=n_voices, scale=0.05)
+        b = gpu_ctx.upload(segs, offs, vids, seeds)
+        try:
+            got = stream_all(gpu_ctx, b, n_utt, [1000, 37, 2048, 64, 1, 129], stride=2048)
+            name = gpu_ctx.last_kernel_name()
+        finally:
+            b.free()
+        assert "STREAM" in name and kernel in name, name
+        pick = sorted(set([0, 1, 15, 16, n_utt - 1] + [int(u) for u in np.random.default_rng(1).integers(0, n_utt, 40)]))
+        sub = np.concatenate([segs[offs[u]:offs[u + 1]] for u in pick])
+        sub_offs = np.zeros(len(pick) + 1, dtype=np.uint32)
+        sub_offs[1:] = np.cumsum([offs[u + 1] - offs[u] for u in pick])
+        ref, ref_len = O.synthesize_batch([O.Voice.from_buffer_copy(bytes(v)) for v in voices], sub, sub_offs, vids[pick], seeds[pick], total)
+        for k, u in enumerate(pick):
+            assert len(got[u]) == ref_len[k], (corpus, u)
+            assert np.array_equal(got[u].view(np.uint32), ref[k, :ref_len[k]].view(np.uint32)), (corpus, u)
+
+
 @pytest.mark.parametrize("lanes", [1, 8])
 def test_stream_edge_cases_and_ragged_ends(gpu_ctx, lanes):
     gpu_ctx.set_voices(W.single_voice())

@@ -19,7 +19,7 @@ fast = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 ctx.set_option("arithmetic", fast)
 ctx.set_option("time_parallel_scan", 0)          # compare like with like: lane kernels on both sides
 print("arithmetic:", "fast" if fast else "exact", flush=True)
-for n in (1, 4096, 65536):
+for n in (1, 256, 4096, 65536):
     segs, offs, vids, seeds = W.make_batch(n)
     batch = ctx.upload(segs, offs, vids, seeds)
     full = W.max_samples()
