@@ -553,6 +553,13 @@ def main():
                         fast_pins = {"time_parallel_scan_max_utterances": 1 << 30, "time_split": 0}
                     for k_, v_ in fast_pins.items():
                         ctx.set_option(k_, v_)
+                    if not chunks:
+                        # ... and the batch itself once more on the pinned family: a batch that was cut into several
+                        # blocks (--utts 70000) had rows on other families than its largest block's, and a fast row's
+                        # bits follow its family — the subset must be compared with a rendering on ONE family
+                        batch.synthesize_async(d_out, stride, d_len)
+                        ctx.sync()
+                        sums_family, _, _ = ctx.digest(d_out, stride, d_len, n_utt)
                 pick = np.arange(0, n_utt, 61, dtype=np.int64)
                 _, _, s0, o0, v0, j0 = W.shard_inputs(n_utt, 0, world, len(voices))
                 s0 = s0.reshape(n_utt, -1)[pick].reshape(-1)

@@ -59,6 +59,10 @@ int main(int argc, char **argv)
 {
     const uint32_t chunk = argc > 1 ? (uint32_t)std::strtoul(argv[1], nullptr, 10) : 441;
     const double tail = argc > 2 ? std::strtod(argv[2], nullptr) : 1.0;
+    if (chunk == 0 || !(tail >= 0.0)) {        // (a chunk of 0 samples — or text strtoul makes 0 of — would never feed the stream)
+        std::fprintf(stderr, "usage: grail_interactive [samples per pull >= 1 (default 441)] [seconds of tail >= 0 (default 1)]\n");
+        return 2;
+    }
     try {
         const grail::Voice voice = grail::voices::generic();       // interactive.rs:33-36
         grail::Gpu gpu(0, {voice});

@@ -133,6 +133,14 @@ struct grail_stream {
     float *d_new_elems = nullptr;
     uint32_t *d_new_offs = nullptr;
     size_t new_cap = 0;
+    // ... on the host side two pinned buffers in turn, each with the event behind its last upload: an append returns as
+    // soon as its copies and its scatter kernel are queued, and waits only for the append before last (not for every
+    // kernel queued on the stream) before it writes into a buffer again
+    void *h_stage[2] = {nullptr, nullptr};
+    size_t h_stage_cap[2] = {0, 0};
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
+    bool stage_busy[2] = {false, false};
+    int stage_next = 0;
 };
 
 struct grail_batch {

@@ -155,19 +155,38 @@ int upload_length_order(grail_ctx *ctx, grail_batch *b, const std::vector<RowSta
         }
         b->groups_epoch = ctx->voices_epoch;
     }
-    if (ragged && n_out == 0) {
-        // what ragged_plan() weighs the lane mappings with (batches without row groups: those are planned by size)
-        const size_t n_gran = ((size_t)n_utt + 7) / 8;
-        b->granule_samples.assign(n_gran, 0.0f);
-        b->granule_segs.assign(n_gran, 0u);
-        b->granule_kinks.assign(n_gran, 0u);
-        for (uint32_t s = 0; s < n_utt; ++s) {
+    // What ragged_plan() and ragged_cost() weigh the lane mappings with: per 8 launch slots the longest row and the rows'
+    // segment and kink counts — of the whole batch in launch order, and, where a few rows the lean kernel families cannot take
+    // were put last, of the OTHER rows by themselves too: the first view of the batch is the corpus, and one zero-length
+    // segment among 65 536 speech-like utterances must not cost the rest their plan.  (A view is planned by its rows' lengths
+    // only if they differ THEMSELVES: an aligned batch with a few odd rows is ragged only through those, and its first group
+    // keeps the aligned plan — the model prices every lane's events as its own, which an aligned group's are not.)
+    auto summarise = [&](grail_batch &t, const uint32_t n_rows) {
+        const size_t n_gran = ((size_t)n_rows + 7) / 8;
+        t.granule_samples.assign(n_gran, 0.0f);
+        t.granule_segs.assign(n_gran, 0u);
+        t.granule_kinks.assign(n_gran, 0u);
+        for (uint32_t s = 0; s < n_rows; ++s) {
             const RowStats &r = rows[perm[s]];
             const float samples = key(perm[s]) * ctx->max_rate;
-            if (samples > b->granule_samples[s / 8]) b->granule_samples[s / 8] = samples;
-            b->granule_segs[s / 8] += r.segs;
-            b->granule_kinks[s / 8] += r.kinks;
+            if (samples > t.granule_samples[s / 8]) t.granule_samples[s / 8] = samples;
+            t.granule_segs[s / 8] += r.segs;
+            t.granule_kinks[s / 8] += r.kinks;
         }
+    };
+    if (ragged && n_out) {
+        float llo = INFINITY, lhi = -INFINITY;
+        for (uint32_t u = 0; u < n_utt; ++u)
+            if (!outlier[u]) {
+                llo = std::fmin(llo, rows[u].seconds);
+                lhi = std::fmax(lhi, rows[u].seconds);
+            }
+        if (lhi - llo > 0.002f) {
+            summarise(b->groups[0], n_utt - n_out);
+            summarise(*b, n_utt);
+        }
+    } else if (ragged) {
+        summarise(*b, n_utt);
     }
     return GRAIL_OK;
 }

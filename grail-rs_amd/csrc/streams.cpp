@@ -138,6 +138,10 @@ int grail_stream_close(grail_ctx *ctx, grail_stream *stream)
     if (stream->d_new) (void)hipFree(stream->d_new);
     if (stream->d_new_elems) (void)hipFree(stream->d_new_elems);
     if (stream->d_new_offs) (void)hipFree(stream->d_new_offs);
+    for (int i = 0; i < 2; ++i) {
+        if (stream->h_stage[i]) (void)hipHostFree(stream->h_stage[i]);
+        if (stream->ev_stage[i]) (void)hipEventDestroy(stream->ev_stage[i]);
+    }
     if (stream->own) {
         free_batch_buffers(stream->own);
         delete stream->own;
@@ -238,10 +242,14 @@ static int live_append(grail_ctx *ctx, grail_stream *s, const std::vector<DevSeg
     if (n_new == 0) return GRAIL_OK;
     // The Sequencer holds on to its current and next segment (and their elems in the ring are re-read when a call
     // resumes): a ring keeps the last two segments pulled besides everything pending.
+    uint32_t full_at = 0;
     auto fits = [&]() {
         for (uint32_t u = 0; u < n_utt; ++u) {
             const uint32_t add = seg_offsets[u + 1] - seg_offsets[u];
-            if (add && (uint64_t)s->appended[u] - s->consumed[u] + add + 2u > cap) return false;
+            if (add && (uint64_t)s->appended[u] - s->consumed[u] + add + 2u > cap) {
+                full_at = u;
+                return false;
+            }
         }
         return true;
     };
@@ -249,9 +257,13 @@ static int live_append(grail_ctx *ctx, grail_stream *s, const std::vector<DevSeg
         // what the host knows of the Sequencers' progress is a lower bound: ask the device
         HIP_TRY(hipMemcpyAsync(s->consumed.data(), s->d_consumed, (size_t)n_utt * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (!fits())
-            return fail(GRAIL_ERR_BUFFER_TOO_SMALL, "a segment ring of the live stream is full: pull samples first (or open the "
-                                                    "stream with a larger ring_segments)");
+        if (!fits()) {
+            char msg[200];
+            std::snprintf(msg, sizeof msg, "the segment ring of utterance %u of the live stream is full (%u pending of %u): pull "
+                          "samples first (or open the stream with a larger ring_segments); nothing was appended",
+                          full_at, s->appended[full_at] - s->consumed[full_at], cap);
+            return fail(GRAIL_ERR_BUFFER_TOO_SMALL, msg);
+        }
     }
     for (uint32_t u = 0; u < n_utt; ++u)
         if (seg_offsets[u + 1] > seg_offsets[u] && !s->open[u])
@@ -271,16 +283,41 @@ static int live_append(grail_ctx *ctx, grail_stream *s, const std::vector<DevSeg
         if (e != hipSuccess) return hip_fail(e, "grail_stream_append staging");
         s->new_cap = cap_new;
     }
-    e = hipMemcpyAsync(s->d_new, segs.data(), (size_t)n_new * sizeof(DevSeg), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(s->d_new_offs, seg_offsets, ((size_t)n_utt + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && elems)
-        e = hipMemcpyAsync(s->d_new_elems, elems, (size_t)n_new * ELEM_FLOATS * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    // The caller's (and this function's) buffers go through a pinned buffer of the stream's own, so that the call can return
+    // with its copies queued: with tens of thousands of live streams fed a phoneme at a time a synchronisation per append
+    // — behind every kernel queued so far — was the pace of the whole session.
+    const size_t b_segs = (size_t)n_new * sizeof(DevSeg), b_offs = ((size_t)n_utt + 1) * 4;
+    const size_t b_elems = elems ? (size_t)n_new * ELEM_FLOATS * sizeof(float) : 0;
+    const int slot = s->stage_next;
+    if (s->stage_busy[slot]) {
+        HIP_TRY(hipEventSynchronize(s->ev_stage[slot]));          // the append before last has left this buffer
+        s->stage_busy[slot] = false;
+    }
+    if (s->h_stage_cap[slot] < b_segs + b_offs + b_elems) {
+        if (s->h_stage[slot]) (void)hipHostFree(s->h_stage[slot]);
+        s->h_stage[slot] = nullptr;
+        s->h_stage_cap[slot] = 0;
+        const size_t want = 2 * (b_segs + b_offs + b_elems);
+        e = hipHostMalloc(&s->h_stage[slot], want, hipHostMallocDefault);
+        if (e != hipSuccess) return hip_fail(e, "grail_stream_append pinned staging");
+        s->h_stage_cap[slot] = want;
+    }
+    if (!s->ev_stage[slot]) HIP_TRY(hipEventCreateWithFlags(&s->ev_stage[slot], hipEventDisableTiming));
+    char *h = static_cast<char *>(s->h_stage[slot]);
+    std::memcpy(h, segs.data(), b_segs);
+    std::memcpy(h + b_segs, seg_offsets, b_offs);
+    if (elems) std::memcpy(h + b_segs + b_offs, elems, b_elems);
+    e = hipMemcpyAsync(s->d_new, h, b_segs, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->d_new_offs, h + b_segs, b_offs, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && elems) e = hipMemcpyAsync(s->d_new_elems, h + b_segs + b_offs, b_elems, hipMemcpyHostToDevice, ctx->stream);
     // (stream order: behind every kernel that still reads the rings, ahead of every kernel that will)
     if (e == hipSuccess)
         e = launch_ring_append(s->own->d_segs, s->own->d_elems, s->d_counts, cap, s->d_new, elems ? s->d_new_elems : nullptr,
                                s->d_new_offs, n_utt, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);      // the host buffers are the caller's / locals
+    if (e == hipSuccess) e = hipEventRecord(s->ev_stage[slot], ctx->stream);
     if (e != hipSuccess) return hip_fail(e, "grail_stream_append");
+    s->stage_busy[slot] = true;
+    s->stage_next = slot ^ 1;
     for (uint32_t u = 0; u < n_utt; ++u) s->appended[u] += seg_offsets[u + 1] - seg_offsets[u];
     return GRAIL_OK;
 }

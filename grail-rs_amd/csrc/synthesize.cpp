@@ -1,5 +1,7 @@
 // synthesize.cpp — a batch's rows to kernel launches: the cached block plan of a batch, one launch per block
 // (launch_plan.cpp chose the families), the device-resident entry points.
+#include <mutex>
+
 #include "api_internal.hpp"
 
 using namespace grail;
@@ -93,7 +95,13 @@ int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_dev,
         std::vector<Block> plan;
         const uint64_t key[6] = {rows, out_stride, family_rows, ctx->options_epoch, ctx->voices_epoch,
                                  (uint64_t)(uintptr_t)ctx ^ (view->phoneme_mode ? 0ull : (uint64_t)(view->elems_sharpness * 1024.0))};
-        if (view->plan_cache && std::memcmp(view->plan_cache->key, key, sizeof key) == 0) return view->plan_cache->plan;
+        // (one batch may be rendered by several contexts, each on a thread of its own: the cache is read and replaced
+        // under a lock — the plans are a few dozen bytes, the lock is held for a copy)
+        static std::mutex cache_lock;
+        {
+            std::lock_guard<std::mutex> hold(cache_lock);
+            if (view->plan_cache && std::memcmp(view->plan_cache->key, key, sizeof key) == 0) return view->plan_cache->plan;
+        }
         // one launch when the caller fixes the family (row blocks, a pinned lane mapping or chunk grid) or asks for it
         const bool single = family_rows != 0 || !ctx->composite_option || ctx->lanes_option || ctx->split_chunks >= 2;
         if (single) {
@@ -104,12 +112,17 @@ int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_dev,
             plan_blocks(ctx, view, out_stride, rows, batch_span(ctx, view, out_stride), plan);
             // length-sorted batches: the plan weighed against each lane mapping in as many rounds as it takes, by the
             // lengths and events of the rows (launch_plan.cpp, "Ragged batches")
-            if (use_perm && view == batch) ragged_plan(ctx, view, out_stride, rows, plan);
+            // (the batch itself, or the first of its row groups: those rows hold launch slots 0 .. rows - 1 of the sorted order)
+            if (use_perm && (view == batch || (batch->groups.size() == 2 && view == &batch->groups[0])))
+                ragged_plan(ctx, view, out_stride, rows, plan);
         }
-        if (!view->plan_cache) view->plan_cache = new (std::nothrow) PlanCache();
-        if (view->plan_cache) {
-            std::memcpy(view->plan_cache->key, key, sizeof key);
-            view->plan_cache->plan = plan;
+        {
+            std::lock_guard<std::mutex> hold(cache_lock);
+            if (!view->plan_cache) view->plan_cache = new (std::nothrow) PlanCache();
+            if (view->plan_cache) {
+                std::memcpy(view->plan_cache->key, key, sizeof key);
+                view->plan_cache->plan = plan;
+            }
         }
         return plan;
     };
@@ -125,10 +138,18 @@ int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_dev,
     if (use_perm && family_rows == 0 && ctx->row_groups_option && batch->groups.size() == 2 && batch->groups_epoch == ctx->voices_epoch) {
         // ... where that is cheaper by the cost model: a separate launch for four odd rows behind a full round of the
         // one-lane kernel costs more than it saves (53.7 against 46.7 ms), behind 20 000 rows it does not
+        // (by the rows' own lengths and events where the view has them — a ragged corpus: ragged_cost falls back to the
+        // one-round price of the family otherwise)
         auto cost_of = [&](const std::vector<Part> &parts) {
             double c = 0.0;
-            for (const Part &p : parts)
-                c += family_cost(ctx, p.block.f, p.block.rows, batch_span(ctx, p.view, out_stride)) + 0.05;
+            uint32_t at = 0;
+            const grail_batch *of = nullptr;
+            for (const Part &p : parts) {
+                if (p.view != of) at = 0;        // (a view's blocks follow each other from its first slot)
+                of = p.view;
+                c += ragged_cost(ctx, p.view, p.block.f, at, p.block.rows, batch_span(ctx, p.view, out_stride)) + 0.05;
+                at += p.block.rows;
+            }
             return c;
         };
         std::vector<Part> grouped;

@@ -219,111 +219,50 @@ int grail_device_pci_bus_id(grail_ctx *ctx, char *out, size_t cap);
  * src/lib.rs:1013, 941, 786) to HBM.  Utterances refer to it by voice id. */
 int grail_set_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices);
 int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t *n_voices);
-/* Tuning knobs; with "arithmetic" = 0 none of them ever changes a result bit.
- *   "lanes_per_utterance": 0 = auto, or 1/2/4/8 — how many wavefront lanes share one
- *       utterance's 8 formants.
- *   "skip_silent_formants": 1 (default) / 0 — formants whose amplitude is exactly 0 in both
- *       elems of a segment pair and whose band-pass state is exactly 0 contribute exactly +0.0;
- *       their band-pass filters are skipped (voices::generic() has four such formants,
- *       src/voices/generic.rs:19,31).  When in addition the whole voice table and the batch
- *       guarantee it for every sample (formants 5-8 of every phoneme: amplitude +0, parameters
- *       inside the safe window; no segment shorter than two samples; phoneme batches, and batches of
- *       caller-built elems whose every distinct elem qualifies — checked at upload),
- *       formants 5-8 are not laid out over the lanes at all.  0 forces the literal evaluation
- *       of all eight.
- *   "small_batch_pipeline": 1 (default) / 0 — blocks of at most 32 utterances per compute unit (8192 on
- *       a whole MI355X; 16 per compute unit with eight live formants) run four-wave workgroups (render /
- *       per-utterance chain / 2 x filter coefficients, handed on through LDS) instead of one wave per 8
- *       utterances: 4096 utterances x 2 s in 6.5 ms.
- *   "arithmetic": 0 (default) = exact, every sample bit-identical to the reference's binary32
- *       arithmetic; 1 = fast, the tolerance mode north_star allows: the discontinuous state
- *       (Sequencer clock, jitter phase, carrier phase and its wrap, both LCGs) stays exact; the
- *       per-formant arithmetic uses fused multiply-adds and — first tier — filter coefficients
- *       interpolated across sub-tiles of at most 32 samples whose length an error guard picks per
- *       utterance (parameters that move too fast for two-sample sub-tiles are evaluated directly), or —
- *       second tier, voices sharper than "fast_sharpness_limit" — the reference's own coefficient
- *       sequence at every sample (src/lib.rs:555-562: same bits as the exact kernels).  |fast - exact| <=
- *       GRAIL_FAST_TOLERANCE (DESIGN.md "Fast mode"; tests/test_fast_gpu.py: configs 2 / 3 / 4 at full size,
- *       edge cases, random voice tables of any sharpness).  2 = the second tier whatever the voices.  This is
- *       the ONE knob that changes result bits.
- *   "time_parallel_scan": 1 (default) / 0 — fast arithmetic, first tier: blocks of few utterances (PhonemeElems or
- *       caller-built SequenceElems) whose every parameter is inside the safe window run one workgroup per utterance with the time axis across
- *       the lanes and the filter recurrences solved by parallel scans (csrc/scan_kernels.hip): 256 utterances
- *       x 2 s in 1.15 ms instead of 6.5 ms (exact arithmetic).  A cost model picks between it, the time-split
- *       kernels and the lane kernels: ~1500 utterances of 2 s, ~6000 of 0.25 s (a time-split chunk pays a
- *       warm-up that does not shrink with the utterance); "time_parallel_scan_max_utterances" (-1 = 34 per
- *       compute unit = 8704; 4/7 of that when all eight formants are live) is a hard upper limit.
- *       Up to "time_parallel_scan_split_max_utterances" (-1 = 6 per compute unit = 1536; half with eight live
- *       formants) the workgroups have three pipeline stages (the serial carrier phase on a wave of
- *       its own: lowest time per batch), above it two (more utterances resident per CU: highest
- *       throughput).  Same results either way.
- *   "time_split": 1 (default) / 0 — fast arithmetic, both tiers: blocks of up to half as many utterances as
- *       the device has lanes (32768), of voices whose filters forget their past within 16384 samples, cut every
- *       utterance's time axis into chunks with a wavefront lane each, as many as give every SIMD one wave (a wave
- *       holds 64 utterances at one chunk index: 5000 utterances are 79 waves per chunk and take 12 chunks).  A chunk's
- *       lane fast-forwards the exact per-utterance state to its chunk, starts the filters from zero a warm-up
- *       length earlier (the voice's slowest filter decides: 3904 samples for voices::generic() at 48 kHz,
- *       residual < 2^-21 of the state) and renders its chunk: 4096 utterances x 2 s in 3.3 ms instead of 6.5
- *       (exact).  Caller-built SequenceElems take these kernels too: the warm-up length is computed when the batch is
- *       uploaded, over its distinct elems and the jitter of the voices it names (valid until the voice table changes;
- *       the bench corpus handed over as elems: 4096 utterances in 4.4 ms instead of 11.1).
- *       "time_split_min_utterances" (-1 = the cost model decides; >= 0: smaller batches stay with
- *       the scan kernel whatever their length); "time_split_chunks" (0 = auto, 2..64) and
- *       "time_split_span_samples" (0 = the batch's longest utterance) pin the grid;
- *       "time_split_ff_cost_permille" (default 165) is the cost of a fast-forwarded sample against a rendered
- *       one, which the spacing of the chunks balances.
- *   "fast_sharpness_limit" (default GRAIL_FAST_SHARPNESS_LIMIT = 28): the first tier is served for batches whose
- *       voices (or caller-built elems) have a grail_fast_sharpness() of at most this; sharper resonances amplify
- *       rounding-level differences of the filter coefficients beyond GRAIL_FAST_TOLERANCE (the reference's own
- *       binary32 rendering is then that far from its formulas in double precision).  Raising the limit trades
- *       the tolerance for speed: the deviation grows in proportion (profiles/r03_sharpness.txt).
- *   "fast_exact_coefficients": 1 (default) / 0 — sharper batches, up to
- *       "fast_sharpness_limit_exact_coefficients" (default GRAIL_FAST_SHARPNESS_LIMIT_EXACT_COEFFICIENTS = 1024),
- *       get the second tier (one lane per utterance, or time-split); 0: the exact kernels.  Streams
- *       (grail_stream_*) of such voices run it when they are laid out one lane per utterance (half a machine's
- *       worth of streams, or "lanes_per_utterance" = 1 when the stream is opened), the exact kernels otherwise.
- *       Read-only "fast_arithmetic_served": what "arithmetic" = 1 gets for the current voice table as a whole —
- *       1 first tier, 2 second tier, 0 exact kernels (a batch is judged by the voices IT names);
- *       "last_launch_fast": what the last launch actually ran, same values (0 also when an exact family was the
- *       faster way to render the block).
- *   "composite_launches": 1 (default) / 0 — a batch is cut into blocks with a kernel family each
- *       (grail_plan_blocks): 65537 utterances take one round of the one-lane kernel and one pipelined
- *       workgroup (50 - 52 ms) instead of two rounds (83 ms).  0: one launch per call, whatever it costs.  Read-only
- *       "last_launch_blocks".
- *   "row_groups": 1 (default) / 0 / 2 — utterances the lean kernel families cannot take (a segment shorter than two
- *       samples, a non-finite length, blend length or pitch) are put last in the launch order and planned as a batch of
- *       their own where that is cheaper by the cost model (1), never (0), always (2): a few such rows do not cost the
- *       others their four-formant kernels.  Results never depend on it.  (The groups are a launch order: batches uploaded
- *       with "sort_by_length" = 0, and row-block launches, are planned as one.)
- *   "ragged_plan": 1 (default) / 0 — batches whose utterances differ in length ("sort_by_length" = 1, whole-batch
- *       launches).  The lanes of a wavefront run in lockstep: a wavefront lasts as long as its longest utterance, and
- *       a launch laid out for ONE wavefront per SIMD as long as the longest of all, most SIMDs idle most of that
- *       time.  A wider lane mapping in several rounds keeps them busy (shorter wavefronts, started longest first,
- *       a SIMD that finishes one takes the next) and puts fewer utterances' segment boundaries into a wavefront.  The
- *       plan is therefore weighed against one launch of each lane mapping, by the lengths and the events of the rows
- *       (grail_plan_ragged_blocks); in fast arithmetic the exact mappings — and for small batches the cut exact
- *       arithmetic would get — are candidates too (events of some lane in nearly every tile cost the fast kernels
- *       more than they save; "last_launch_fast" = 0 tells).  Speech-like
- *       corpus — 65 536 utterances of 8 - 32 phonemes, 0.5 - 3.8 s — exact 71 ms instead of 90 (eight live formants:
- *       114 instead of 172), fast asked for 71 instead of 88 (89 instead of 147); phonemes of 4 - 16 ms, fast asked
- *       for: 10.5 instead of 30.8; profiles/r04_ragged_plan.txt.  Exact results never depend on it; fast ones follow
- *       the family (below).
- *   "assume_compute_units": plan for so many compute units instead of what the device reports (0 = the
- *       device's own count; read-only "compute_units" tells what is in force): tests, and callers that share a
- *       device.
- *   "sort_by_length": 1 (default) / 0 — batches uploaded afterwards whose utterances differ in
- *       length fill the launch slots in order of decreasing length (lanes of a wave run in lockstep:
- *       a wave lasts as long as its longest utterance).  Rows stay where the caller put them.
- *   "pipeline_round32": 1 (default) / 0 — the pipelined workgroups hand their work on in rounds of 32 samples
- *       instead of 16 (131 KB of LDS) while one workgroup per CU suffices.
- *   "pipeline4_max_groups", "pipeline8_max_groups" (default -1 = two per compute unit): exact arithmetic, how
- *       many four-wave pipelined workgroups (16 / 8 utterances each, four / eight live formants) a block may
- *       need to still take them.
- * Read-only statistics: "slow_division_wave_steps", "fast_wave_tiles" (wave-tiles rendered in fast
- * arithmetic; scan kernel: 64-sample chain tiles on the closed forms kept from the tile before),
- * "general_wave_steps" (scan kernel: chain tiles whose closed forms were derived afresh),
- * "last_launch_formants" (4 or 8), "last_launch_lanes", "last_launch_pipelined",
- * "last_launch_chunks" (time-split: chunks per utterance, else 0) — of the largest block of the launch. */
+/* Options (grail_set_option / grail_get_option; int64 values).  What each one may change: "bits: fast" = the samples of a
+ * tolerance-mode rendering, within GRAIL_FAST_TOLERANCE; every other option changes time only.  With "arithmetic" = 0 no
+ * option ever changes a result bit.  What each is worth on an MI355X is measured in DESIGN.md section 4, not here.
+ *   "arithmetic"            0 (default) exact: every sample the reference's binary32 bits.  1 fast: the tolerance mode —
+ *                           |fast - reference| <= GRAIL_FAST_TOLERANCE per sample, identical lengths, the discontinuous
+ *                           state (Sequencer clock, jitter phase, carrier phase, both LCGs) exact; served by the tier the
+ *                           voices' sharpness allows (below).  2: the second tier whatever the voices.  THE option that
+ *                           changes result bits.
+ *   "fast_sharpness_limit"  (default GRAIL_FAST_SHARPNESS_LIMIT) first tier (filter coefficients interpolated) for batches
+ *                           whose voices / elems have a grail_fast_sharpness() of at most this.  bits: fast.
+ *   "fast_exact_coefficients" 1 (default) / 0: sharper batches, up to "fast_sharpness_limit_exact_coefficients" (default
+ *                           GRAIL_FAST_SHARPNESS_LIMIT_EXACT_COEFFICIENTS), get the second tier (the reference's own band-pass
+ *                           coefficients at every sample); 0 or beyond: the exact kernels.  bits: fast.
+ *   "lanes_per_utterance"   0 (default) auto, or 1 / 2 / 4 / 8: wavefront lanes that share an utterance's formants; pins the
+ *                           lane kernels (no pipelined workgroups, no composite cut).  bits: fast (the kernel family).
+ *   "skip_silent_formants"  1 (default) / 0: formants that provably contribute exactly +0.0 (amplitude 0 in both elems of a
+ *                           segment pair, band-pass state 0) are skipped, and not laid out at all where the voice table and
+ *                           the batch guarantee it for formants 5-8; 0: all eight evaluated literally.
+ *   "small_batch_pipeline"  1 (default) / 0: small exact blocks run four-wave pipelined workgroups; streams of that size too.
+ *   "pipeline_round32"      1 (default) / 0: ... in rounds of 32 samples while one workgroup per compute unit suffices.
+ *   "pipeline4_max_groups", "pipeline8_max_groups"  (default -1: two per compute unit) workgroups a block may need to take them.
+ *   "time_parallel_scan"    1 (default) / 0: fast, first tier: few utterances run one workgroup each, lanes = time (parallel
+ *                           scans).  "time_parallel_scan_max_utterances" (-1 auto): hard upper limit;
+ *                           "time_parallel_scan_split_max_utterances" (-1 auto): up to here the three-stage flavour.  bits: fast.
+ *   "time_split"            1 (default) / 0: fast, both tiers: up to half a device's lanes' worth of utterances are cut along
+ *                           their time axis, one lane per chunk (filters warmed up from zero: grail_time_split_warmup).
+ *                           "time_split_min_utterances" (-1 auto), "time_split_chunks" (0 auto, 2..64) and
+ *                           "time_split_span_samples" (0: the longest utterance) pin the grid (grail_time_split_grid);
+ *                           "time_split_ff_cost_permille" (default 165): a fast-forwarded sample against a rendered one.  bits: fast.
+ *   "composite_launches"    1 (default) / 0: a batch is cut into blocks with a kernel family each (grail_plan_blocks); 0: one
+ *                           launch per call.  bits: fast (a row follows its block's family).
+ *   "row_groups"            1 (default) / 0 / 2: rows the lean kernel families cannot take (a segment shorter than two samples,
+ *                           a non-finite length, blend length or pitch) are planned apart where cheaper / never / always.
+ *   "ragged_plan"           1 (default) / 0: batches whose utterances differ in length are weighed against one launch of each
+ *                           lane mapping in several rounds, by the rows' lengths and events (grail_plan_ragged_blocks); a fast
+ *                           request may be served by an exact mapping where that is cheaper ("last_launch_fast").  bits: fast.
+ *   "sort_by_length"        1 (default) / 0: batches uploaded afterwards fill the launch slots longest first (rows stay put).
+ *   "assume_compute_units"  0 (default: the device's own) or a count to plan for: tests, callers that share a device.
+ *   "scan_debug"            development builds only.
+ * Read-only (grail_get_option): "compute_units"; "fast_arithmetic_served" (what "arithmetic" = 1 gets for the voice table as
+ *   a whole: 1 / 2 / 0 exact kernels); of the last launch (its largest block): "last_launch_fast" (tier that ran, 0 exact),
+ *   "last_launch_blocks", "last_launch_formants" (4 / 8), "last_launch_lanes", "last_launch_pipelined", "last_launch_chunks";
+ *   statistics: "slow_division_wave_steps", "fast_wave_tiles" (tiles rendered without a slow sample), "general_wave_steps"
+ *   (tolerance mode: slow samples; exact: general steps). */
 int grail_set_option(grail_ctx *ctx, const char *name, int64_t value);
 int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value);
 /* The planning behind "time_split", as pure host functions (no GPU, no context): what a caller needs to
@@ -355,7 +294,7 @@ int grail_time_split_grid(uint32_t span_samples, uint32_t warmup, uint32_t chunk
  * number of utterances (one wavefront per SIMD: 16 / 32 per compute unit for the pipelined workgroups, 256 / L for L
  * lanes per utterance), and one utterance more costs it a whole further round.  A batch is therefore cut into BLOCKS,
  * each rendered by the family that suits the block's size: whole rounds of the one-lane kernels first, the rest with
- * wider mappings (65537 utterances: 65536 on one lane each + 1 on a pipelined workgroup, 50 - 52 ms instead of 83).  The
+ * wider mappings (65537 utterances: 65536 on one lane each + 1 on a pipelined workgroup).  The
  * cut minimises a cost model calibrated on the device (profiles/r04_duration_sweep.txt) that follows the compute-unit
  * count and the utterances' length.  Exact arithmetic is mapping-invariant: the cut never changes a bit.  In fast
  * arithmetic a row's samples follow the family of ITS block, which this function predicts: rows keep batch order

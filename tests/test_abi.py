@@ -29,6 +29,29 @@ def test_library_exports_every_declared_symbol(built):
     assert sorted(G.EXPORTS) == declared
 
 
+def test_header_option_list_equals_what_the_library_accepts():
+    """Option names live in three places — the header's option block (the contract), grail_set_option and
+    grail_get_option (csrc/grail_api.cpp): they must name the same options; what the header calls read-only is exactly
+    what only grail_get_option knows; the block stays a contract (no measured milliseconds, under 60 lines)."""
+    header = open(os.path.join(ROOT, "include", "grail_hip.h")).read()
+    start = header.index("/* Options (grail_set_option / grail_get_option")
+    block = header[start:header.index("*/", start)]
+    settable_text, readonly_text = block.split("Read-only (grail_get_option)")
+    documented_set = set(re.findall(r'"([a-z0-9_]+)"', settable_text))
+    documented_ro = set(re.findall(r'"([a-z0-9_]+)"', readonly_text)) - {"arithmetic"}      # (named in a description)
+    api = open(os.path.join(ROOT, "grail-rs_amd", "csrc", "grail_api.cpp")).read()
+    set_body = api[api.index("int grail_set_option("):api.index("int grail_get_option(")]
+    get_start = api.index("int grail_get_option(")
+    get_body = api[get_start:api.index("\n}\n", get_start)]
+    names = lambda body: set(re.findall(r'strcmp\(name, "([a-z0-9_]+)"\)', body))
+    accepted_set, accepted_get = names(set_body), names(get_body)
+    assert documented_set - {"last_launch_fast"} == accepted_set, (documented_set ^ accepted_set)
+    assert documented_ro == accepted_get - accepted_set, (documented_ro ^ (accepted_get - accepted_set))
+    assert accepted_set <= accepted_get | {"scan_debug"}, accepted_set - accepted_get      # every option can be read back
+    assert len(block.splitlines()) < 60
+    assert not re.search(r"\d\s*(ms|us)\b", block), "measurements belong in DESIGN.md section 4"
+
+
 def test_abi_version_and_status_strings(built):
     lib = G.load()
     assert lib.grail_abi_version() == G.ABI_VERSION == 2

@@ -410,3 +410,27 @@ def test_ragged_batches_take_wider_mappings_in_several_rounds(gpu_ctx, small_mac
             _bit_identical(out, lens, ref, ref_len, f"ragged_plan={ragged_plan}")
     assert seen[0][0] == 1 or "SPLIT" in seen[0][2], seen          # one round: a lane (or a chunk lane) per utterance
     assert seen[1][0] in (2, 4, 8) and seen[1][1] == 1, seen       # several rounds of a wider mapping, one launch
+
+
+def test_one_odd_row_does_not_cost_a_ragged_corpus_its_plan(gpu_ctx, small_machine):
+    """the per-granule summary ragged_plan() needs used to be built only for batches WITHOUT row groups, so a
+    single row the lean kernels cannot take (a zero-length segment) sent a whole speech-like corpus back to the one-round
+    plan.  The rows of the first group now carry their own summary and are planned like the corpus without the odd row:
+    same lane mapping, the odd row in a launch of its own, the oracle's bits for all."""
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
+    n_utt = 1024
+    segs, offs, vids, seeds = _speech_like(n_utt, 1)
+    stride = 24 * 960 + 128
+    small_machine(4, 1)
+    _device_render(gpu_ctx, segs, offs, vids, seeds, stride)
+    want_lanes = gpu_ctx.get_option("last_launch_lanes")
+    assert want_lanes in (2, 4, 8)
+    odd = segs.copy()
+    odd["length"][offs[77] + 1] = 0.0                    # (one segment of one utterance: not "at least two samples long")
+    ref, ref_len = O.synthesize_batch(_ovoices(voices), odd, offs, vids, seeds, stride)
+    out, lens, status = _device_render(gpu_ctx, odd, offs, vids, seeds, stride)
+    assert status == G.OK and np.array_equal(lens, ref_len)
+    assert gpu_ctx.get_option("last_launch_blocks") >= 2            # the odd row apart
+    assert gpu_ctx.get_option("last_launch_lanes") == want_lanes     # ... and the corpus on the plan it had without it
+    _bit_identical(out, lens, ref, ref_len, "one odd row")
