@@ -30,7 +30,7 @@ WORKLOADS = [   # key (as bench.py builds it), bench arguments
     ("config3_utts1024_fast", ["--utts", "1024", "--mode", "fast"]),
 ]
 PASSES = [["WRITE_SIZE"], ["FETCH_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_BUSY_CYCLES"]]
-COMMON = ["--fast-leg", "0", "--cpu-utts", "0", "--steps", "2", "--warmup", "0", "--ramp", "0"]
+COMMON = ["--fast-leg", "0", "--other-configs", "0", "--cpu-utts", "0", "--steps", "2", "--warmup", "0", "--ramp", "0"]
 env = dict(os.environ, TMPDIR="/tmp")
 
 

@@ -3,7 +3,7 @@
 tag=$1; shift; args="$1"; shift
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof/$tag; mkdir -p gpurun_out/prof/$tag
-rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/prof/$tag -- python3 bench.py $args --cpu-utts 0 > gpurun_out/prof/$tag.log 2>&1
+rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/prof/$tag -- python3 bench.py $args --cpu-utts 0 --other-configs 0 > gpurun_out/prof/$tag.log 2>&1
 python3 - <<PY
 import csv,collections,glob
 f=glob.glob('gpurun_out/prof/$tag/*/*counter_collection.csv')

@@ -2,7 +2,7 @@
 # The round's evidence, collected on the GPU box: bench lines, rocprofv3 kernel stats of the default
 # bench command, PMC counters for every reported workload (tools/collect_counters.py), tool outputs.
 # usage (through gpurun): tools/profile_round.sh <tag>     -> gpurun_out/<tag>/
-tag=${1:-r04}
+tag=${1:-r05}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/$tag; mkdir -p $out
 python3 tools/collect_counters.py $out/traffic.json > $out/collect_counters.log 2>&1
@@ -33,6 +33,19 @@ python3 tools/mid_bench.py > $out/mid_bench.txt 2>&1
 python3 tools/small_batch_bench.py > $out/small_batch.txt 2>&1
 python3 tools/stream_latency.py 2>/dev/null | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" > $out/stream_latency.txt
 python3 tools/host_output_bench.py > $out/host_output.txt 2>&1
+python3 tools/live_stream_bench.py 2>/dev/null | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" > $out/live_stream.txt
+python3 tools/stream_latency.py 1 2>/dev/null | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" > $out/stream_latency_fast.txt
+# the speech-like corpus (event-dense input): the library's own plan, the one-round layout, pinned mappings, phonemes of 4 - 16 ms
+( echo "# ---- 65 536 utterances, the library's plan"; python3 tools/speech_like_bench.py 65536
+  echo "# ---- one round, one lane per utterance (option ragged_plan = 0)"; python3 tools/speech_like_bench.py 65536 --no-ragged-plan
+  echo "# ---- pinned: two lanes per utterance"; python3 tools/speech_like_bench.py 65536 --lanes=2
+  echo "# ---- phonemes of 4 - 16 ms (--scale=0.1), the library's plan"; python3 tools/speech_like_bench.py 65536 --scale=0.1
+  echo "# ---- phonemes of 4 - 16 ms, pinned: two lanes per utterance"; python3 tools/speech_like_bench.py 65536 --scale=0.1 --lanes=2
+  echo "# ---- blend_length = length (no kinks)"; python3 tools/speech_like_bench.py 65536 --blend-is-length ) > $out/speech_like.txt 2>&1
+rm -rf gpurun_out/prof/stats6
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats6 -- python3 tools/speech_like_bench.py 65536 > $out/stats6.log 2>&1
+cp gpurun_out/prof/stats6/*/*kernel_stats.csv $out/kernel_stats_speech_like.csv
+python3 -m pytest tests/test_planner_guard_gpu.py -m gpu -q -s 2>&1 | grep -v "^make\|^g++" > $out/planner_guard.txt
 python3 tools/ragged_bench.py 65536 1 0 > $out/ragged.txt 2>&1
 python3 tools/ragged_bench.py 65536 1 1 > $out/ragged_fast.txt 2>&1
 python3 tools/ragged_bench.py 131072 1 0 > $out/ragged_131072.txt 2>&1
