@@ -40,11 +40,10 @@ batch = ctx.upload(segs, offs, vids, seeds)
 d_out = ctx.device_alloc(n * stride * 4)
 d_len = ctx.device_alloc(n * 4)
 ctx.set_option("arithmetic", 1)
-NAMES = {0: "total", 1: "uniform tiles", 2: "plain-pair loops", 3: "slow pair: tests", 4: "slow pair: next sub-tile", 5: "slow pair: run starts",
-         6: "slow pair: fast_pair", 7: "slow pair: general steps", 8: "flush + between tiles", 9: "tile head"}
-CNT = {10: "plain pairs", 11: "slow pairs", 12: "next-sub executions", 13: "run-start executions", 14: "general-step pair executions",
-       15: "uniform tiles", 16: "lanes starting a run", 17: "sum of their levels", 18: "lanes whose run could not start",
-       19: "lane general-step pairs", 20: "lanes taking a next sub-tile (slow path)", 21: "uniform tiles: sub-tile begins", 22: "uniform tiles: sub-tile steps"}
+NAMES = {0: "total", 2: "plain runs (pairs + slope refreshes)", 3: "loop head (refresh test)", 5: "slow sample: new beginnings (fast_restart)",
+         6: "slow sample: formants", 7: "slow sample: chain part of the general step", 8: "flush + between tiles", 9: "tile head"}
+CNT = {10: "plain pairs", 11: "slow samples", 12: "slope-refresh executions (wave level)", 13: "new-beginning executions (wave level)",
+       15: "tiles without a slow sample", 16: "lanes beginning anew", 17: "sum of their levels"}
 
 
 def read():
@@ -69,7 +68,6 @@ for k, name in NAMES.items():
         print(f"  {name:32s} {d[k] / waves:12.0f} cycles  {100.0 * d[k] / max(d[0], 1):5.1f} %")
 for k, name in CNT.items():
     print(f"  {name:44s} {d[k] / waves:10.1f} per wave")
-for a, b, what in ((2, 10, "plain pair"), (4, 12, "next-sub execution"), (5, 13, "run-start execution"), (7, 14, "general-step pair"), (1, 15, "uniform tile"),
-                   (3, 11, "slow-pair tests"), (6, 11, "slow-pair fast_pair")):
+for a, b, what in ((2, 10, "plain pair (incl. refreshes)"), (5, 13, "new-beginning execution"), (7, 11, "slow sample: chain"), (6, 11, "slow sample: formants")):
     if d[b]:
-        print(f"  cycles per {what:24s} {d[a] / d[b]:9.0f}")
+        print(f"  cycles per {what:32s} {d[a] / d[b]:9.0f}")
