@@ -396,6 +396,9 @@ int grail_stream_close(grail_ctx *ctx, grail_stream *stream);
  *   grail_stream_append: utterance u receives segs[seg_offsets[u] .. seg_offsets[u + 1]) behind what it already has
  *     (seg_offsets as in grail_batch_upload: n_utt + 1 non-decreasing entries; an empty range appends nothing).
  *   grail_stream_append_elems: the same for streams opened with caller_built_elems != 0 (SequenceElems, no Selector).
+ *     Both return when the segments are queued on the context's stream, behind the launches before the call and ahead of
+ *     those after it (the caller's arrays have been copied and may be reused at once); a failure of the queued work
+ *     surfaces at the next grail_sync, like a kernel's.
  *   A Sequencer that needs a segment which has not been appended yet PAUSES: the call returns fewer than max_samples
  *     for that row (possibly 0) and the next call after an append carries on from exactly the same state — so the
  *     samples are those of the one-shot rendering of everything appended, bit for bit ("arithmetic" = 0), whatever
