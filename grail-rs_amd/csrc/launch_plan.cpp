@@ -384,13 +384,13 @@ static double ragged_wave_ms(const Family &f, double samples, double segs, doubl
     }
     // Fast (round 5: sub-tiles that never span an event, one slow sample per event — synth_kernel.h fast_render_tile): a wave
     // costs its longest row at the mapping's aligned rate x m — while a lane's parameters move (blends of 30 - 80 ms) its
-    // sub-tiles are 8 - 16 samples instead of 32, and the wave takes new slopes at the pace of its busiest lane — plus c
+    // sub-tiles are 16 samples instead of 32, and the wave takes new slopes at the pace of its busiest lane — plus c
     // per event of its rows (boundaries and kinks of alpha: the slow sample, the lane's two end points, the shorter runs
     // around it).  Fitted on pinned-mapping measurements of the speech-like corpus with phonemes of 40 - 160, 16 - 64 and
-    // 4 - 16 ms at 65 536 utterances, one and eight voices, L = 1 / 2 / 4 / 8: all 24 cells within 4 % (tools/ragged_fit.py,
+    // 4 - 16 ms at 65 536 utterances, one and eight voices, L = 1 / 2 / 4 / 8: all 24 cells within 3.3 % (tools/ragged_fit.py,
     // profiles/r05_ragged_fit.txt).  m fades to 1 where events are rare (long segments have long blends: the bench corpora).
-    static const double m4[4] = {1.34, 1.28, 1.22, 1.18}, c4[4] = {0.0055, 0.00575, 0.00825, 0.0115};
-    static const double m8[4] = {1.30, 1.30, 1.24, 1.18}, c8[4] = {0.00775, 0.0065, 0.00675, 0.00975};
+    static const double m4[4] = {1.16, 1.10, 1.06, 1.02}, c4[4] = {0.00475, 0.0050, 0.00675, 0.00925};
+    static const double m8[4] = {1.08, 1.06, 1.04, 1.02}, c8[4] = {0.00775, 0.00675, 0.0070, 0.0095};
     const double events = segs + kinks;
     const double density = events / ((64.0 / (double)f.L) * std::fmax(samples, 1.0));        // per lane and sample
     const double m = 1.0 + ((nfa4 ? m4 : m8)[li] - 1.0) * std::fmin(1.0, density / 3.0e-4);

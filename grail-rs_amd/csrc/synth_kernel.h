@@ -54,7 +54,12 @@
 #define GRAIL_SCALAR_PACK 1
 #endif
 #ifndef GRAIL_FAST_G_SCALE
-#define GRAIL_FAST_G_SCALE 1048576.0f   // 2^22 / 4: interpolation error of G, H <= 2^-22 (fast_tile's guard)
+// 2^20 / 4: interpolation error of G, H <= 2^-20 (fast_level).  2^-22 until round 5: the products of the amplitude with the
+// amplitude jitter and with the turbulence kept a wave's busiest lane at sub-tiles of 4 - 8 samples through every blend of a
+// speech-like corpus; four times the bound takes 13 % off those batches and moves the largest deviation measured anywhere
+// from 13 to 18 * 2^-23 on such a corpus (25 on random voice tables at the served sharpness, where the resonances decide,
+// unchanged; sixteen times: 57 — too close to the contract's 64).  profiles/r05_guard_scale.txt
+#define GRAIL_FAST_G_SCALE 262144.0f
 #endif
 #ifndef GRAIL_FAST_A_SCALE
 #define GRAIL_FAST_A_SCALE 724.0773439350247f   // 2^9.5: relative change of a1, a2 / a1, 1 - k per sub-tile <= 2^-9.5
@@ -1528,7 +1533,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     //     tan_approx(x) of an x that is linear in time has the curvature of the tangent only, r^2 g^2 / (4 (1 + g^2))
     //     (checked numerically for the reference's rational function, whose own curvature dominates below x = 0.02:
     //     its change is weighed by min(max(2.5 g, 0.1), 2)); G and H are products of linear functions, error
-    //     <= |dA dM| / 4 and |dT dG| / 4 <= 2^-22 absolute.  Faster parameter motion halves TS (error / 4) until it fits,
+    //     <= |dA dM| / 4 and |dT dG| / 4 <= 2^-20 absolute.  Faster parameter motion halves TS (error / 4) until it fits,
     //     down to TS = 1: every sample from its own evaluation.  The reference's own front end always emits 0.5 s blends
     //     (Intonator :1070-1071), for which TS = 32.
     //   * :531 as saw + breath (noise - saw), :538 as fma, :544-550 as a (G + H (noise - 1)), the
@@ -1683,7 +1688,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     ra = __builtin_fmaxf(ra, __builtin_fabsf(vget(FD.om[k], c)) * (float)TS0 *
                                                  __builtin_amdgcn_rcpf(vget(FS.om[k], c)));
         }
-        // halvings needed: r / 2^s <= 2^-9.5 (error ~ r^2 / 16), |.| / 4 / 4^s <= 2^-22
+        // halvings needed: r / 2^s <= 2^-9.5 (error ~ r^2 / 16), |.| / 4 / 4^s <= 2^-20
         const int la = __builtin_amdgcn_frexp_expf(ra * GRAIL_FAST_A_SCALE);
         const int lg = (__builtin_amdgcn_frexp_expf(rg * GRAIL_FAST_G_SCALE) + 1) >> 1;
         int level = la > lg ? la : lg;

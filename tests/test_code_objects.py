@@ -121,13 +121,13 @@ def test_lane_kernels_hold_one_wave_per_simd_by_construction(kernels):
         assert meta["max_flat_workgroup_size"] == 64 * waves, (args, meta)
 
 
-def test_hot_kernels_have_no_scratch(kernels):
-    """The four-formant one-lane kernels (the headline batch, exact and both fast tiers, time-split) keep everything in
-    registers: a private segment would be HBM traffic the roofline does not count."""
+def test_no_kernel_has_a_scratch_segment(kernels):
+    """Every synth_kernel instantiation keeps everything in registers (arch VGPRs + AGPRs): a private segment would be HBM
+    traffic the roofline does not count — and, where the register allocator puts it into the per-tile path, time (the
+    eight-formant one-lane fast kernels held up to 2 KB per lane while the tolerance-mode loop had three code paths, and
+    config 4 fast took 41.9 ms instead of 23; with one path none does: DESIGN.md section 4.3)."""
     checked = 0
     for args, meta in _synth(kernels):
-        L, T, waves, minw, stream, half, anybl, nfa, pipe, fast, pqp, split, mid = args
-        if L == 1 and nfa == 4 and not stream and not pipe:
-            assert meta.get("private_segment_fixed_size", 0) == 0, (args, meta)
-            checked += 1
-    assert checked >= 8, checked
+        assert meta.get("private_segment_fixed_size", 0) == 0, (args, meta)
+        checked += 1
+    assert checked >= 60, checked
