@@ -46,6 +46,26 @@ static double lane_ms_per_sample(bool fast, bool live4, int L)
 // ... of the second tolerance tier (MID, one lane per utterance)
 static double mid_ms_per_sample(bool live4) { return (live4 ? MID_MS_4 : MID_MS_8) / 96006.0; }
 
+// Tolerance-mode lane kernels on two (four live formants), four and eight lanes per utterance keep their state in 256
+// registers: two of their waves share a SIMD, and a launch of more waves than the device has SIMDs takes the instantiations
+// built for that (the lone wave leaves the VALU idle a quarter of the time; 65 536 aligned utterances on two lanes each:
+// 21.5 ms instead of 26.9, on four 38.6 instead of 51.0; profiles/r05_two_waves.txt).  Launches that fit one wave per SIMD
+// keep the one-wave instantiations — which cannot share a SIMD, so where the dispatcher puts their waves cannot matter.
+bool family_cohabits(const grail_ctx *ctx, const Family &f, uint32_t rows)
+{
+    if (!ctx->two_waves_option || f.fast != 1u || f.scan || f.pipe || f.split_k || f.L < 2 || (f.L == 2 && !f.live4)) return false;
+    return ((uint64_t)rows * (uint64_t)f.L + 63u) / 64u > ctx_simds(ctx);
+}
+// What two waves on a SIMD take together, over twice the lone wave's time: 0.76 - 0.80 on aligned batches (the plain pairs of
+// one wave fill three quarters of the issue slots), 0.50 - 0.68 where events are dense — a slow sample is latency (the elems'
+// loads behind a segment advance, branches, end-point evaluations under one lane's predicate), which the other wave fills.
+// `density`: events per lane and sample, as in ragged_wave_ms.  Fitted with tools/ragged_fit.py (profiles/r05_ragged_fit.txt).
+static double cohabit_gain(const Family &f, double density = 0.0)
+{
+    const double aligned = f.L == 2 ? 0.80 : 0.76, dense = f.L == 2 ? 0.52 : f.L == 4 ? 0.65 : 0.68;
+    return aligned - (aligned - dense) * std::fmin(1.0, density / 3.0e-4);
+}
+
 // what launching `rows` rows with family f costs (model milliseconds)
 double family_cost(const grail_ctx *ctx, const Family &f, uint32_t rows, double span)
 {
@@ -79,6 +99,11 @@ double family_cost(const grail_ctx *ctx, const Family &f, uint32_t rows, double 
     // (eight formants laid out, the upper four silent: the half-live loops of the one-lane kernel, 45.7 ms where all
     // eight live take 77.1)
     if (f.half) return rounds * span * 45.7 / 96006.0;
+    if (family_cohabits(ctx, f, rows)) {
+        // (pairs of waves: an odd wave-round at the end runs alone, at the lone wave's rate)
+        const double pairs = std::floor(rounds / 2.0), rest = rounds - 2.0 * pairs;
+        return (2.0 * pairs * cohabit_gain(f) + rest) * span * lane_ms_per_sample(true, f.live4 != 0, f.L);
+    }
     return rounds * span * lane_ms_per_sample(f.fast != 0, f.live4 != 0, f.L);
 }
 
@@ -437,9 +462,7 @@ double ragged_cost(const grail_ctx *ctx, const grail_batch *batch, const Family 
     }
     // waves of 64 / L consecutive slots, handed out in launch order to the SIMD that falls free first
     const size_t per_wave = (size_t)(8 / f.L > 0 ? 8 / f.L : 1);
-    std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
-    double makespan = 0.0;
-    for (size_t g = g0; g < g1; g += per_wave) {
+    auto wave_ms = [&](size_t g) {
         double samples = 0.0, segs = 0.0, kinks = 0.0;
         for (size_t k = g; k < std::min(g + per_wave, g1); ++k) {
             samples = std::fmax(samples, (double)batch->granule_samples[k]);
@@ -447,7 +470,64 @@ double ragged_cost(const grail_ctx *ctx, const grail_batch *batch, const Family 
             kinks += batch->granule_kinks[k];
         }
         samples = std::fmin(samples + 64.0, span);
-        double t = ragged_wave_ms(f, samples, segs, kinks);
+        return ragged_wave_ms(f, samples, segs, kinks);
+    };
+    if (family_cohabits(ctx, f, rows)) {
+        // Two waves per SIMD: while two are resident each advances at 1 / (2 gain) of the lone wave's pace (together
+        // 1 / gain: the 20 - 25 % the second wave adds); the one left behind by a shorter neighbour runs on alone at full
+        // pace.  Waves are handed out in launch order, two per SIMD at first, then to the SIMD that has a slot free first.
+        struct Simd { double t, a, b; };              // time reached; work left (in lone-wave ms) in the two slots, a <= b; < 0: empty
+        double ev_sum = 0.0, lane_samples = 0.0;
+        for (size_t g = g0; g < g1; ++g) {
+            ev_sum += (double)batch->granule_segs[g] + (double)batch->granule_kinks[g];
+            lane_samples += 8.0 * std::fmax((double)batch->granule_samples[g], 1.0);
+        }
+        const double pace2 = 1.0 / (2.0 * cohabit_gain(f, ev_sum / std::fmax(lane_samples, 1.0)));
+        std::vector<Simd> sm(simds, Simd{0.0, -1.0, -1.0});
+        auto next_done = [&](const Simd &m) {         // when the SIMD's next wave ends (it has at least one)
+            return m.a < 0.0 ? m.t + m.b : m.t + m.a / pace2;
+        };
+        typedef std::pair<double, size_t> Ev;
+        std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> done_at;
+        size_t g = g0, filled = 0;
+        for (; g < g1 && filled < 2 * simds; g += per_wave, ++filled) {
+            Simd &m = sm[filled % simds];
+            const double w = wave_ms(g);
+            if (m.b < 0.0) m.b = w;
+            else if (w <= m.b) m.a = w;
+            else { m.a = m.b; m.b = w; }
+        }
+        for (size_t i = 0; i < simds; ++i)
+            if (sm[i].b >= 0.0) done_at.push(Ev(next_done(sm[i]), i));
+        double makespan = 0.0;
+        while (!done_at.empty()) {
+            const Ev ev = done_at.top();
+            done_at.pop();
+            Simd &m = sm[ev.second];
+            if (m.a < 0.0) {                          // the lone wave ends
+                m.t += m.b;
+                m.b = -1.0;
+            } else {                                  // the shorter of two ends; the other has advanced as far
+                m.t += m.a / pace2;
+                m.b -= m.a;
+                m.a = -1.0;
+            }
+            makespan = std::fmax(makespan, m.t);
+            if (g < g1) {                             // the slot takes the next wave of the launch
+                const double w = wave_ms(g);
+                g += per_wave;
+                if (m.b < 0.0) m.b = w;
+                else if (w <= m.b) m.a = w;
+                else { m.a = m.b; m.b = w; }
+            }
+            if (m.b >= 0.0) done_at.push(Ev(next_done(m), ev.second));
+        }
+        return makespan;
+    }
+    std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
+    double makespan = 0.0;
+    for (size_t g = g0; g < g1; g += per_wave) {
+        double t = wave_ms(g);
         if (free_at.size() >= simds) {
             t += free_at.top();
             free_at.pop();

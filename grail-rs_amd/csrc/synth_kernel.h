@@ -466,7 +466,13 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     // the first launch of a process; profiles/r04_dispatch.txt).  A wave that owns more than half of the SIMD's 512
     // registers cannot share it: the one-lane kernels do anyway (256 VGPRs + AGPRs); the others claim accumulation
     // registers they never touch.  (PIPE workgroups are placed by their LDS footprint instead.)
-    if constexpr (L > 1 && !PIPE) asm volatile("" ::: "a127");
+    // TWO WAVES PER SIMD (MIN_WAVES_PER_SIMD = 2; tolerance-mode lane kernels on two, four and eight lanes per utterance
+    // that hold their state in <= 256 registers without a scratch segment): the lone tolerance-mode wave leaves the VALU
+    // idle a quarter of the time, and two of them on a SIMD render 20 - 30 % more per second than one after the other —
+    // where the waves spill (one lane per utterance) they lose 14 % instead (profiles/r04_two_waves.txt).  The host asks for
+    // these instantiations only for launches of more waves than the device has SIMDs, where the dispatcher's placement has
+    // nothing to get wrong.
+    if constexpr (L > 1 && !PIPE && MIN_WAVES_PER_SIMD == 1) asm volatile("" ::: "a127");
 
     // every wave of the block works alone on its own S utterances and its own
     // slice of LDS: there is no inter-wave communication and no block barrier

@@ -54,15 +54,26 @@ template <int L, int T, int WAVES, int MINW>
 void launch_one_fast(const SynthArgs &args, hipStream_t stream)
 {
     const dim3 grid = lane_grid<L, WAVES>(args), block(64 * WAVES);
+    // one-shot launches of more waves than the device has SIMDs (args.cohabit): the instantiations built for two waves per
+    // SIMD — the same operations in the same order, 256 registers instead of 384.  (Two lanes per utterance with eight
+    // formants laid out would spill: those stay as they are.)
+    if constexpr (L >= 2 && MINW == 1) {
+        if (args.cohabit && !args.state && (L > 2 || args.live4)) {
+            launch_one_fast<L, T, WAVES, 2>(args, stream);
+            return;
+        }
+    }
     // one-shot fast kernels at L = 1: 64-step tiles (half as many flushes, calm tests and coefficient end
     // points per sample: 18.1 -> 17.1 ms on the headline batch; the exact kernel measures slower with them,
     // 43.1 against 40.4 ms, same box)
     constexpr int TF = L == 1 ? 64 : T;
     if constexpr (L <= 4) {
-        if (args.state && args.live4) {
-            if (args.any_blend) start<L, T, WAVES, MINW, true, false, true, 4, false, true>(args, grid, block, stream);
-            else start<L, T, WAVES, MINW, true, false, false, 4, false, true>(args, grid, block, stream);
-            return;
+        if constexpr (MINW == 1) {       // (resumable kernels: one wave per SIMD only)
+            if (args.state && args.live4) {
+                if (args.any_blend) start<L, T, WAVES, MINW, true, false, true, 4, false, true>(args, grid, block, stream);
+                else start<L, T, WAVES, MINW, true, false, false, 4, false, true>(args, grid, block, stream);
+                return;
+            }
         }
         if (!args.state && args.live4) {
             // four live formants (any blend length: the host sets live4 for those too in fast mode).  L = 4
@@ -74,20 +85,18 @@ void launch_one_fast(const SynthArgs &args, hipStream_t stream)
             return;
         }
     }
-    if (!args.state) {
-        // (no half-live loops in tolerance mode: which formants a wave skips would be a decision of the wave,
-        // and a lane's samples may not depend on its wave-mates)
-        if (args.any_blend) start<L, TF, WAVES, MINW, false, false, true, NF, false, true>(args, grid, block, stream);
-        else start<L, TF, WAVES, MINW, false, false, false, NF, false, true>(args, grid, block, stream);
-        return;
+    if constexpr (MINW == 1 || L > 2) {     // (two lanes with eight formants laid out: no two-wave instantiation)
+        if (!args.state) {
+            // (no half-live loops in tolerance mode: which formants a wave skips would be a decision of the wave,
+            // and a lane's samples may not depend on its wave-mates)
+            if (args.any_blend) start<L, TF, WAVES, MINW, false, false, true, NF, false, true>(args, grid, block, stream);
+            else start<L, TF, WAVES, MINW, false, false, false, NF, false, true>(args, grid, block, stream);
+            return;
+        }
     }
     // resumable streams in tolerance mode (chunks concatenate to the one-shot rendering within the
     // tolerance, not bit for bit: the interpolation ends restart with every call)
-#ifdef GRAIL_FAST_STREAM_TF
-    start<L, TF, WAVES, MINW, true, false, true, NF, false, true>(args, grid, block, stream);
-#else
-    start<L, T, WAVES, MINW, true, false, true, NF, false, true>(args, grid, block, stream);
-#endif
+    if constexpr (MINW == 1) start<L, T, WAVES, MINW, true, false, true, NF, false, true>(args, grid, block, stream);
 }
 
 // time-split fast kernels: one lane per (utterance, chunk), 64-thread workgroups, chunk-major

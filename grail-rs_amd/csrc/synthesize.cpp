@@ -47,6 +47,7 @@ static int launch_block(grail_ctx *ctx, const grail_batch *batch, const Family &
     a.any_blend = batch->any_blend ? 1u : 0u;
     a.live4 = f.live4;
     a.fast = f.fast;
+    a.cohabit = family_cohabits(ctx, f, count) ? 1u : 0u;
     a.pipe = f.pipe;
     hipError_t e;
     if (f.scan) {

@@ -108,6 +108,7 @@ def test_lane_kernels_hold_one_wave_per_simd_by_construction(kernels):
     """A SIMD has 512 registers per lane (VGPRs + AGPRs, one file on gfx950): a kernel that holds more than 256 cannot
     share a SIMD with a second wave of itself.  Every lane kernel (all but the pipelined four-wave workgroups, which
     are placed by their LDS footprint) must, because the host sizes every launch for exactly that."""
+    two_wave_kernels = []
     for args, meta in _synth(kernels):
         L, T, waves, minw, stream, half, anybl, nfa, pipe = args[:9]
         total = meta["vgpr_count"]          # (the metadata's vgpr_count is the unified total: arch VGPRs + AGPRs)
@@ -117,8 +118,21 @@ def test_lane_kernels_hold_one_wave_per_simd_by_construction(kernels):
             # four waves of a workgroup on the four SIMDs of a CU; LDS decides how many workgroups a CU takes
             assert meta["group_segment_fixed_size"] >= 64 * 1024, (args, meta)
             continue
+        if minw == 2:
+            # the tolerance-mode lane kernels built FOR two waves per SIMD (launches of more waves than the device has SIMDs:
+            # csrc/launch_plan.cpp family_cohabits): one-shot, 2 / 4 / 8 lanes per utterance, and they must really fit twice
+            fast = args[9]
+            assert fast and not stream and L >= 2 and (L > 2 or nfa == 4), args
+            assert total <= 256 and meta["agpr_count"] == 0, ("built for two waves per SIMD, does not fit twice", args, meta)
+            two_wave_kernels.append(args)
+            continue
         assert total > 256, ("two waves of this kernel would fit one SIMD", args, meta)
         assert meta["max_flat_workgroup_size"] == 64 * waves, (args, meta)
+
+
+def test_two_wave_instantiations_exist(kernels):
+    have = {(a[0], a[7]) for a, _ in _synth(kernels) if a[3] == 2}
+    assert have == {(2, 4), (4, 4), (4, 8), (8, 8)}, have
 
 
 def test_no_kernel_has_a_scratch_segment(kernels):

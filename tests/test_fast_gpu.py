@@ -1207,3 +1207,36 @@ def test_every_fast_family_on_a_speech_like_corpus(gpu_ctx, family, n_voices):
             gpu_ctx.set_option(k_, v_)
         _split(gpu_ctx, 0)
     print(f"speech-like corpus, {family}, voices={n_voices}: max |d| = {worst:.1f} * 2^-23")
+
+
+@pytest.mark.parametrize("n_voices,lanes", [(1, 2), (1, 4), (8, 4), (8, 8)])
+def test_two_waves_per_simd_instantiations_give_the_same_bits(gpu_ctx, n_voices, lanes):
+    """A tolerance-mode launch on 2 / 4 / 8 lanes per utterance with more wavefronts than the device has SIMDs takes the
+    instantiations built for two wavefronts per SIMD (256 registers, no AGPR claim: csrc/launch_plan.cpp family_cohabits;
+    the device made small with "assume_compute_units").  Same source, same operations in the same order: the rows are
+    bit-identical to the one-wave kernels' (option "two_waves_per_simd" = 0), and within the tolerance of the oracle."""
+    voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    n_utt = 700
+    segs, offs, vids, seeds, stride = W.speech_like_batch(n_utt, np.random.default_rng(lanes), n_voices=n_voices, scale=0.1)
+    ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, stride)
+    got = {}
+    try:
+        gpu_ctx.set_option("assume_compute_units", 2)          # 8 SIMDs: 700 utterances x L lanes are 22 ... 88 wavefronts
+        gpu_ctx.set_option("ragged_plan", 0)
+        gpu_ctx.set_option("time_split", 0)
+        gpu_ctx.set_option("time_parallel_scan", 0)
+        for two in (1, 0):
+            gpu_ctx.set_option("two_waves_per_simd", two)
+            out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride, lanes)
+            name = gpu_ctx.last_kernel_name()
+            assert "FAST" in name and f"L={lanes}," in name and (",2," in name) == bool(two), name
+            assert np.array_equal(out_len, ref_len)
+            got[two] = out
+    finally:
+        for k_, v_ in (("assume_compute_units", 0), ("ragged_plan", 1), ("time_split", 1), ("time_parallel_scan", 1), ("two_waves_per_simd", 1)):
+            gpu_ctx.set_option(k_, v_)
+    for u in range(n_utt):
+        assert np.array_equal(got[1][u, :ref_len[u]].view(np.uint32), got[0][u, :ref_len[u]].view(np.uint32)), u
+    k = _worst(got[1], ref, ref_len)
+    assert 0.0 < k * ULP <= TOL, k
