@@ -50,6 +50,12 @@
 #include "kernels.h"
 #include "pcm16.h"
 
+#ifndef GRAIL_MIXED_RUNS
+#define GRAIL_MIXED_RUNS 1
+#endif
+#ifndef GRAIL_MIXED_RUNS_L1
+#define GRAIL_MIXED_RUNS_L1 0
+#endif
 #ifndef GRAIL_SCALAR_PACK
 #define GRAIL_SCALAR_PACK 1
 #endif
@@ -86,6 +92,13 @@ extern thread_local char g_kernel_name[96];
 
 namespace {
 
+// min(x, x of the lane the DPP control names); lanes without a source keep their own
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t umin_dpp(const uint32_t x)
+{
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, ROW_MASK, 0xF, false);
+    return o < x ? o : x;
+}
 // lane i takes lane i-1's value (within its row of 16 lanes)
 __device__ __forceinline__ float dpp_from_lane_below(float x)
 {
@@ -2327,6 +2340,18 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             fast_render_tile(0);
             t = T;
         }
+        // MIXED_RUNS: a tile in which some lane has an event still renders the samples between the events by the calm
+        // tile's own loops (packed_run), as many at once as every lane is certain to stay without one; the tile's carrier
+        // noise is then one sequence for all lanes (mixed_shared), drawn once as in a calm tile, and a lane's own generator
+        // state is brought up to date where the wave takes single steps (mixed_stale)
+        // (not the one-lane kernels: the eight-formant ones fill the register file as they are and the second copy of the
+        // loop costs them a scratch segment; the four-formant ones lose 6 % of the headline — 43.6 instead of 40.9 ms, the
+        // calm loop's registers — for nothing: 91.5 against 89.9 ms on the speech-like corpus; profiles/r05_mixed_runs.txt)
+        constexpr bool MIXED_RUNS = GRAIL_MIXED_RUNS && !FAST && !PIPE && GRAIL_SCALAR_PACK && (L > 1 || GRAIL_MIXED_RUNS_L1);
+        bool mixed_shared = false, mixed_stale = false;
+        uint32_t mixed_seed = 0u, mixed_sk = 0u;
+        float mixed_noise = 0.0f;
+        if constexpr (!FAST) PROF_ADD(8);
         while (t < T) {
             // a run of quiet steps: a tight inner loop, so the loop-carried state keeps its
             // registers from one sample to the next.  Two flavours of the same loop: every
@@ -2351,6 +2376,15 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                                 (jphase + (float)(T + 1) * jinc < 0.999f) &
                                 (cap32 - n_out >= (uint32_t)T) & (noise_seed == tile_seed);
                     calm_tile = __builtin_amdgcn_ballot_w64(!(calm | idle)) == 0;
+                    if constexpr (MIXED_RUNS) {
+                        if (!calm_tile && __builtin_amdgcn_ballot_w64(!idle & (noise_seed != tile_seed)) == 0) {
+                            const uint32_t ahead = (uint32_t)(lane < T ? lane : T - 1) + 1u;
+                            mixed_shared = true;
+                            mixed_seed = tile_seed;
+                            mixed_sk = tile_seed * LCG_SKIP.mul[ahead] + LCG_SKIP.add[ahead];
+                            mixed_noise = (__uint_as_float((mixed_sk >> 9) | 0x3F800000u) - 1.5f) * 2.0f;
+                        }
+                    }
                     if constexpr (PIPE) {
                         // how many calm tiles in a row (every wave of the workgroup finds the same number): the
                         // pipeline then runs through them without draining.  The margins of the single tile
@@ -2370,6 +2404,27 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     }
                 }
             }
+            // samples [t0, t1) of the tile by the calm tile's loops (MIXED_RUNS below): nobody has an event among them
+            auto packed_run = [&](auto nlive_tag, auto su_tag, const int t0, const int t1,
+                                  const float noise_of_lane) __attribute__((always_inline)) {
+                if constexpr (PIPE) {
+                } else if constexpr (W == 1 && NV == 1 && FOLD_IN_FLUSH) {
+#pragma unroll 1
+                    for (int tc = t0; tc < t1; tc += 8) time_packed_block(tc, noise_of_lane);
+                } else if constexpr (L >= 4) {
+#pragma unroll 1
+                    for (int tc = t0; tc < t1; tc += 8) scalar_packed_block(nlive_tag, su_tag, tc, noise_of_lane);
+                } else {
+#pragma unroll 1
+                    for (int tc = t0; tc < t1; tc += 2) {
+                        const float nz0 = __builtin_bit_cast(
+                            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc));
+                        const float nz1 = __builtin_bit_cast(
+                            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, noise_of_lane), tc + 1));
+                        scalar_packed_steps(nlive_tag, su_tag, tc, nz0, nz1);
+                    }
+                }
+            };
             auto quiet_run = [&](auto nlive_tag, auto su_tag) __attribute__((always_inline)) {
                 if (calm_tile) {
                     // no lane can have an event before the tile ends: no per-step ballot.  The
@@ -2501,7 +2556,50 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     noise_seed = (uint32_t)__builtin_amdgcn_readlane((int)sk, T - 1);
                     return;
                 }
-                for (; t < T; ++t) {
+                // A tile in which some lane has an event.  MIXED_RUNS: the samples between the events still go through
+                // the calm tile's own loop, as many at once — 2, 4, ... 32 — as every lane is certain to stay without one:
+                // a lane's event-free horizon in steps is min(clk / dt, (1 - jphase) / jinc, room in its row), here from
+                // two v_rcp_f32 with the margins of the calm-tile test (clk > (N + 1) dt leaves > 0.6 dt after N <= 32
+                // steps, each of which lowers the bound by at most 1.01 dt; the phase grows by at most jinc (1 + 2^-23) per
+                // step).  Lanes that will not render again ride along as in a calm tile; a paused stream lane keeps its
+                // state: it is not idle and has no horizon.  A NaN anywhere fails the >= tests: single steps.
+                constexpr int RUN_STEP = L >= 4 ? 8 : 2;
+                while (t < T) {
+                    if constexpr (MIXED_RUNS) {
+                        if (mixed_shared && T - t >= RUN_STEP) {
+                            const bool idle_now = STREAM ? finished : done;
+                            const float by_clock = clk * __builtin_amdgcn_rcpf(dt) - 1.5f;
+                            const float by_phase = (0.9999f - jphase) * __builtin_amdgcn_rcpf(jinc) - 0.5f;
+                            float horizon = __builtin_fminf(__builtin_fminf(by_clock, by_phase), (float)(cap32 - n_out));
+                            const bool lane_ok = !done & quiet_ok & (dt >= 0x1p-50f) & (n_out < cap32);
+                            horizon = idle_now ? 64.0f : (lane_ok ? horizon : 0.0f);
+                            // the wave's horizon: the smallest of the lanes' (max(NaN, 0) is 0; six DPP steps leave the
+                            // minimum over the lanes in lane 63)
+                            uint32_t steps = (uint32_t)__builtin_fminf(__builtin_fmaxf(horizon, 0.0f), 64.0f);
+                            steps = umin_dpp<0x111, 0xF>(steps);    // row_shr:1
+                            steps = umin_dpp<0x112, 0xF>(steps);    // row_shr:2
+                            steps = umin_dpp<0x114, 0xF>(steps);    // row_shr:4
+                            steps = umin_dpp<0x118, 0xF>(steps);    // row_shr:8
+                            steps = umin_dpp<0x142, 0xA>(steps);    // row_bcast:15
+                            steps = umin_dpp<0x143, 0xC>(steps);    // row_bcast:31
+                            const int wave_steps = __builtin_amdgcn_readlane((int)steps, 63) & ~(RUN_STEP - 1);
+                            if (wave_steps > 0) {
+                                const int room_t = (T - t) & ~(RUN_STEP - 1);
+                                const int m = wave_steps < room_t ? wave_steps : room_t;
+                                packed_run(nlive_tag, su_tag, t, t + m, mixed_noise);
+                                PROF_CNT(10, m >> 1);
+                                n_out += idle_now ? 0u : (uint32_t)m;
+                                t += m;
+                                mixed_stale = true;
+                                continue;
+                            }
+                        }
+                        if (mixed_stale) {      // single steps draw from the lane's own generator
+                            const uint32_t s_ = t == 0 ? mixed_seed : (uint32_t)__builtin_amdgcn_readlane((int)mixed_sk, t - 1);
+                            if (!done) noise_seed = s_;
+                            mixed_stale = false;
+                        }
+                    }
                     const float clk_next = clk - dt;
                     const float jphase_next = jphase + jinc;
                     // bitwise on purpose: no short-circuit, so no exec-mask regions
@@ -2512,8 +2610,18 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                                                    (jphase_next > 1.0f) | (n_out >= cap32));
                     if (__builtin_expect(__builtin_amdgcn_ballot_w64(eventful) != 0, 0)) break;
                     quiet_step(nlive_tag, su_tag, std::false_type(), t, clk_next, jphase_next, 0.0f);
+                    PROF_CNT(12, 1);
+                    ++t;
+                }
+                if constexpr (MIXED_RUNS) {
+                    if (mixed_stale && t >= T) {
+                        const uint32_t s_ = (uint32_t)__builtin_amdgcn_readlane((int)mixed_sk, T - 1);
+                        if (!done) noise_seed = s_;
+                        mixed_stale = false;
+                    }
                 }
             };
+            PROF_ADD(9);
             const bool all_su = __builtin_amdgcn_ballot_w64(!done & !smooth_uniform) == 0;
             typedef std::integral_constant<int, NV> FullTag;
             bool half = false;
@@ -2527,11 +2635,14 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 if (all_su) quiet_run(FullTag(), std::true_type());
                 else quiet_run(FullTag(), std::false_type());
             }
+            if (calm_tile) { PROF_ADD(2); PROF_CNT(15, 1); PROF_CNT(16, all_su ? 1 : 0); PROF_CNT(17, half ? 1 : 0); }
+            else { PROF_ADD(3); PROF_CNT(18, all_su ? 1 : 0); PROF_CNT(19, half ? 1 : 0); PROF_CNT(20, 1); }
             if (t < T) {
                 ++general_steps;
                 general_step(t, std::false_type());
                 quiet_ok = pair_safe && (blend_pow2 || blend_div_ok);
                 ++t;
+                PROF_ADD(7); PROF_CNT(11, 1);
             }
         }
 
@@ -2651,7 +2762,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     if (emit && lane == 0 && fast_tiles) atomicAdd(A.truncated + 2, fast_tiles);
     if (emit && lane == 0 && general_steps) atomicAdd(A.truncated + 3, general_steps);
 #ifdef GRAIL_FAST_PROF
-    if constexpr (FAST) {
+    {
         unsigned long long *prof = reinterpret_cast<unsigned long long *>(A.truncated + 8);
         prof_c[0] = clock64() - prof_start;
         if (lane == 0) {

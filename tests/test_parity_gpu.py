@@ -894,3 +894,34 @@ def test_a_batch_is_judged_by_the_voices_it_names(gpu_ctx, n_utt):
     with_narrow = np.where(np.arange(n_utt) % 7 == 0, 5, 0).astype(np.uint32)
     name, formants = check(with_narrow, 1)
     assert "SPLIT" not in name or "scan" in name, name            # (1 Hz of bandwidth: no warm-up within 16 384 samples)
+
+
+@pytest.mark.parametrize("n_voices", [1, 8])
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8])
+def test_runs_between_the_events_of_a_tile(gpu_ctx, lanes, n_voices):
+    """A speech-like corpus: every lane of a wave has segment boundaries at times of its own, so most tiles hold an
+    event of some lane.  The 2 / 4 / 8-lane kernels render the samples between two events by the calm tile's loops,
+    as many at once as every lane's clock, jitter phase and row still allow (synth_kernel.h MIXED_RUNS) — the same
+    bits as the oracle's sample-by-sample chain, with rows that end in the middle of a run (a short out_stride cuts the
+    long ones) and utterances that finish while their wave goes on."""
+    if lanes == 8 and n_voices == 1:
+        pytest.skip("eight lanes per utterance: eight-formant layout only")
+    ctx = gpu_ctx
+    voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
+    rng = np.random.default_rng(100 + lanes)
+    segs, offs, vids, seeds, stride = W.speech_like_batch(200, rng, n_voices=n_voices, scale=0.12)
+    stride = min(stride, 9000 + 4 * 13)        # cuts the longest third of the rows, not at a tile boundary
+    saved = ctx.get_option("small_batch_pipeline")
+    ctx.set_option("small_batch_pipeline", 0)           # (200 utterances would take the pipelined workgroups)
+    try:
+        ctx.set_voices(voices)
+        ctx.set_option("lanes_per_utterance", lanes)
+        out, out_len = ctx.synthesize(segs, offs, vids, seeds, out_stride=stride, allow_truncation=True)
+        assert ("L=%d" % lanes) in ctx.last_kernel_name() and "PIPE" not in ctx.last_kernel_name()
+        ref, ref_len = O.synthesize_batch(ovoices(voices), segs, offs, vids, seeds, stride)
+        ref_len = np.minimum(ref_len, stride)           # (the oracle counts a cut row to its end)
+        assert_bit_identical(out, out_len, ref, ref_len, f"speech-like L={lanes}, {n_voices} voice(s)")
+        assert (out_len == stride).sum() > 20 and (out_len < stride).sum() > 50
+    finally:
+        ctx.set_option("small_batch_pipeline", saved)
+        ctx.set_option("lanes_per_utterance", 0)
