@@ -405,9 +405,10 @@ static double ragged_wave_ms(const Family &f, double samples, double segs, doubl
         const double tiles = std::fmax(samples / T, 1.0);
         const double event_tiles = tiles * (1.0 - std::exp(-segs / tiles));
         // (round 5: the 2 / 4 / 8-lane kernels render the samples between the events of such a tile by the calm tile's loops —
-        // synth_kernel.h MIXED_RUNS — and a tile with an event costs them 0.55 of what it did: profiles/r05_mixed_runs.txt)
-        return samples * lane_ms_per_sample(false, nfa4, f.L) +
-               event_tiles * (nfa4 ? 0.007 : 0.008) * (T / 32.0) * (f.L == 1 ? 1.0 : 0.55) +
+        // synth_kernel.h MIXED_RUNS — and a tile with an event costs them 0.5 - 0.75 of what it did; the four-lane kernel with
+        // eight formants, tiles of 32 in runs of 8, gains nothing: profiles/r05_mixed_runs.txt)
+        const double runs = f.L == 1 ? 1.0 : f.L == 2 ? (nfa4 ? 0.74 : 0.60) : f.L == 4 ? (nfa4 ? 0.51 : 1.0) : 0.58;
+        return samples * lane_ms_per_sample(false, nfa4, f.L) + event_tiles * (nfa4 ? 0.007 : 0.008) * (T / 32.0) * runs +
                (f.L == 1 ? segs * (nfa4 ? 0.0015 : 0.0037) : 0.0);
     }
     // Fast (round 5: sub-tiles that never span an event, one slow sample per event — synth_kernel.h fast_render_tile): a wave

@@ -30,3 +30,31 @@ def gpu_ctx(built):
     ctx = G.Context(0)
     yield ctx
     ctx.close()
+
+
+def _settable_options():
+    """The names of the header's option block that grail_set_option accepts and grail_get_option reads back."""
+    import re
+    header = open(os.path.join(ROOT, "include", "grail_hip.h")).read()
+    start = header.index("/* Options (grail_set_option / grail_get_option")
+    block = header[start:header.index("*/", start)].split("Read-only (grail_get_option)")[0]
+    return sorted(set(re.findall(r'"([a-z0-9_]+)"', block)) - {"last_launch_fast", "scan_debug"})
+
+
+@pytest.fixture(autouse=True)
+def _options_as_found(request):
+    """The GPU tests share one context: a test that leaves an option changed decides which kernels the tests after it
+    exercise (and fails them, or — worse — lets them pass on another family).  Every test must hand the options back
+    as it found them; a leak fails the test that leaked, after the options have been put back for the next one."""
+    if "gpu_ctx" not in request.fixturenames:
+        yield
+        return
+    ctx = request.getfixturevalue("gpu_ctx")
+    names = _settable_options()
+    before = {k: ctx.get_option(k) for k in names}
+    yield
+    after = {k: ctx.get_option(k) for k in names}
+    leaked = {k: (before[k], after[k]) for k in names if before[k] != after[k]}
+    for k, (b, _) in leaked.items():
+        ctx.set_option(k, b)
+    assert not leaked, f"options left changed (was, is): {leaked}"

@@ -140,6 +140,8 @@ def test_random_batches_four_formant_path(gpu_ctx, seed):
     ref, ref_len = O.synthesize_batch(ovoices, segs, offs, vids, seeds, stride)
     assert ref_len.max() < stride
     try:
+        # (segments of 0.5 - 30 ms: weighed by its events the batch would go to a lane mapping — this test wants the pipeline)
+        gpu_ctx.set_option("ragged_plan", 0)
         for lanes in (0, 1, 2, 4):          # 0 = auto: the small-batch pipeline (four-wave workgroups)
             gpu_ctx.set_option("lanes_per_utterance", lanes)
             out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
@@ -151,6 +153,7 @@ def test_random_batches_four_formant_path(gpu_ctx, seed):
                                       ref[u, :ref_len[u]].view(np.uint32)), (lanes, u)
     finally:
         gpu_ctx.set_option("lanes_per_utterance", 0)
+        gpu_ctx.set_option("ragged_plan", 1)
 
 
 def pow2_blend_batch(rng, n_utt, n_voices):
@@ -184,6 +187,7 @@ def test_random_batches_eight_formant_pipeline(gpu_ctx, seed):
     ref, ref_len = O.synthesize_batch(ovoices, segs, offs, vids, seeds, stride)
     assert ref_len.max() < stride
     try:
+        gpu_ctx.set_option("ragged_plan", 0)         # (as above: by its events the batch would go to a lane mapping)
         for round32 in (1, 0):
             gpu_ctx.set_option("pipeline_round32", round32)
             out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
@@ -195,6 +199,7 @@ def test_random_batches_eight_formant_pipeline(gpu_ctx, seed):
                                       ref[u, :ref_len[u]].view(np.uint32)), (round32, u)
     finally:
         gpu_ctx.set_option("pipeline_round32", 1)
+        gpu_ctx.set_option("ragged_plan", 1)
 
 
 @pytest.mark.parametrize("seed", [41, 42] + EXTRA_SEEDS)

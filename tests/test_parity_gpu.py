@@ -33,7 +33,10 @@ def assert_bit_identical(out, out_len, ref, ref_len, what=""):
 def run_both(ctx, voices, segs, offs, vids, seeds, stride, lanes=0):
     ctx.set_voices(voices)
     ctx.set_option("lanes_per_utterance", lanes)
-    out, out_len = ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+    try:
+        out, out_len = ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+    finally:
+        ctx.set_option("lanes_per_utterance", 0)
     ref, ref_len = O.synthesize_batch(ovoices(voices), segs, offs, vids, seeds, stride)
     return out, out_len, ref, ref_len
 
