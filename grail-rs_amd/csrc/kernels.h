@@ -75,8 +75,10 @@ struct SynthArgs {
     uint32_t fast;                // tolerance-mode arithmetic in calm tiles (option "arithmetic" = 1): 1 = coefficients
                                   // interpolated, 2 = the reference's own coefficients at every sample (MID)
     uint32_t any_blend;           // host hint: some segment has a blend length that is not +-2^k
-    uint32_t cohabit;             // tolerance-mode lane kernels on 2 / 4 / 8 lanes per utterance: the instantiation built for two
-                                  // waves per SIMD (launches of more waves than the device has SIMDs)
+    uint32_t cohabit;             // lane kernels on 2 / 4 / 8 lanes per utterance: the instantiation built for two waves per
+                                  // SIMD (launches of more waves than the device has SIMDs; launch_plan.cpp family_cohabits)
+    uint32_t fold_from;           // two waves per SIMD, at most two rounds of the device: workgroups from this index on take the
+                                  // launch slots in reverse order (0: none) — see synth_kernel.h
     uint32_t *state;              // resumable synthesis: state[word][lane] or nullptr (one-shot)
     uint64_t state_stride;        // lanes of the launch (= state_lanes())
     uint32_t resume;              // 1: load the state first (not the first call of a stream)

@@ -46,22 +46,34 @@ static double lane_ms_per_sample(bool fast, bool live4, int L)
 // ... of the second tolerance tier (MID, one lane per utterance)
 static double mid_ms_per_sample(bool live4) { return (live4 ? MID_MS_4 : MID_MS_8) / 96006.0; }
 
-// Tolerance-mode lane kernels on two (four live formants), four and eight lanes per utterance keep their state in 256
-// registers: two of their waves share a SIMD, and a launch of more waves than the device has SIMDs takes the instantiations
-// built for that (the lone wave leaves the VALU idle a quarter of the time; 65 536 aligned utterances on two lanes each:
-// 21.5 ms instead of 26.9, on four 38.6 instead of 51.0; profiles/r05_two_waves.txt).  Launches that fit one wave per SIMD
-// keep the one-wave instantiations — which cannot share a SIMD, so where the dispatcher puts their waves cannot matter.
+// Lane kernels that keep their state in 256 registers — tolerance mode on two (four live formants), four and eight lanes per
+// utterance, exact on two (four live formants) and four — can share a SIMD with a second wave, and a launch of more waves
+// than the device has SIMDs takes the instantiations built for that (tolerance mode: the lone wave leaves the VALU idle a
+// quarter of the time; 65 536 aligned utterances on two lanes each 21.5 ms instead of 26.9, on four 38.6 instead of 51.0.
+// Exact: 49.0 instead of 53.7 and 55.1 instead of 64.6; a speech-like corpus 58.1 instead of 67.0: profiles/r05_two_waves.txt).
+// Launches that fit one wave per SIMD keep the one-wave instantiations — which cannot share a SIMD, so where the dispatcher
+// puts their waves cannot matter.
 bool family_cohabits(const grail_ctx *ctx, const Family &f, uint32_t rows)
 {
-    if (!ctx->two_waves_option || f.fast != 1u || f.scan || f.pipe || f.split_k || f.L < 2 || (f.L == 2 && !f.live4)) return false;
-    return ((uint64_t)rows * (uint64_t)f.L + 63u) / 64u > ctx_simds(ctx);
+    if (!ctx->two_waves_option || f.scan || f.pipe || f.split_k || f.fast > 1u) return false;
+    // (tolerance mode: 2 lanes with four formants laid out, 4 and 8 lanes; exact: 2 lanes with four formants, 4 lanes —
+    // the instantiations that hold their state in 256 registers without a scratch segment)
+    const bool built = f.fast ? (f.L == 4 || f.L == 8 || (f.L == 2 && f.live4)) : (f.L == 4 || (f.L == 2 && f.live4));
+    return built && ((uint64_t)rows * (uint64_t)f.L + 63u) / 64u > ctx_simds(ctx);
 }
-// What two waves on a SIMD take together, over twice the lone wave's time: 0.76 - 0.80 on aligned batches (the plain pairs of
-// one wave fill three quarters of the issue slots), 0.50 - 0.68 where events are dense — a slow sample is latency (the elems'
-// loads behind a segment advance, branches, end-point evaluations under one lane's predicate), which the other wave fills.
+// What two waves on a SIMD take together, over twice the lone wave's time.  Tolerance mode: 0.76 - 0.80 on aligned batches
+// (the plain pairs of one wave fill three quarters of the issue slots), 0.50 - 0.68 where events are dense — a slow sample is
+// latency (the elems' loads behind a segment advance, branches, end-point evaluations under one lane's predicate), which the
+// other wave fills.  Exact: the lone wave issues at 94 % of the best rate this SIMD has shown, yet two
+// resident waves take 0.85 - 0.91 of two in turn on aligned batches — tile heads, flushes and the general steps of the segment
+// boundaries are latency too — and 0.70 on phonemes of 4 - 16 ms (profiles/r05_two_waves.txt).
 // `density`: events per lane and sample, as in ragged_wave_ms.  Fitted with tools/ragged_fit.py (profiles/r05_ragged_fit.txt).
 static double cohabit_gain(const Family &f, double density = 0.0)
 {
+    if (!f.fast) {
+        const double aligned = f.L == 2 ? 0.91 : 0.85, dense = f.L == 2 ? 0.86 : 0.70;
+        return aligned - (aligned - dense) * std::fmin(1.0, density / 3.0e-3);
+    }
     const double aligned = f.L == 2 ? 0.80 : 0.76, dense = f.L == 2 ? 0.52 : f.L == 4 ? 0.65 : 0.68;
     return aligned - (aligned - dense) * std::fmin(1.0, density / 3.0e-4);
 }
@@ -102,7 +114,7 @@ double family_cost(const grail_ctx *ctx, const Family &f, uint32_t rows, double 
     if (family_cohabits(ctx, f, rows)) {
         // (pairs of waves: an odd wave-round at the end runs alone, at the lone wave's rate)
         const double pairs = std::floor(rounds / 2.0), rest = rounds - 2.0 * pairs;
-        return (2.0 * pairs * cohabit_gain(f) + rest) * span * lane_ms_per_sample(true, f.live4 != 0, f.L);
+        return (2.0 * pairs * cohabit_gain(f) + rest) * span * lane_ms_per_sample(f.fast != 0, f.live4 != 0, f.L);
     }
     return rounds * span * lane_ms_per_sample(f.fast != 0, f.live4 != 0, f.L);
 }
@@ -493,10 +505,14 @@ double ragged_cost(const grail_ctx *ctx, const grail_batch *batch, const Family 
         };
         typedef std::pair<double, size_t> Ev;
         std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> done_at;
+        // (a launch of at most two rounds: the waves of the second take their slots in reverse order — synth_kernel.h FOLD —
+        // so that the SIMD with the longest rows of the first round gets the shortest of the second)
+        const size_t n_waves = (g1 - g0 + per_wave - 1) / per_wave;
+        const bool fold = n_waves > simds && n_waves <= 2 * simds;
         size_t g = g0, filled = 0;
         for (; g < g1 && filled < 2 * simds; g += per_wave, ++filled) {
             Simd &m = sm[filled % simds];
-            const double w = wave_ms(g);
+            const double w = wave_ms(fold && filled >= simds ? g0 + (n_waves - 1 - (filled - simds)) * per_wave : g);
             if (m.b < 0.0) m.b = w;
             else if (w <= m.b) m.a = w;
             else { m.a = m.b; m.b = w; }

@@ -479,12 +479,13 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     // the first launch of a process; profiles/r04_dispatch.txt).  A wave that owns more than half of the SIMD's 512
     // registers cannot share it: the one-lane kernels do anyway (256 VGPRs + AGPRs); the others claim accumulation
     // registers they never touch.  (PIPE workgroups are placed by their LDS footprint instead.)
-    // TWO WAVES PER SIMD (MIN_WAVES_PER_SIMD = 2; tolerance-mode lane kernels on two, four and eight lanes per utterance
-    // that hold their state in <= 256 registers without a scratch segment): the lone tolerance-mode wave leaves the VALU
-    // idle a quarter of the time, and two of them on a SIMD render 20 - 30 % more per second than one after the other —
-    // where the waves spill (one lane per utterance) they lose 14 % instead (profiles/r04_two_waves.txt).  The host asks for
-    // these instantiations only for launches of more waves than the device has SIMDs, where the dispatcher's placement has
-    // nothing to get wrong.
+    // TWO WAVES PER SIMD (MIN_WAVES_PER_SIMD = 2; lane kernels on two, four and eight lanes per utterance that hold their
+    // state in <= 256 registers without a scratch segment): the lone tolerance-mode wave leaves the VALU idle a quarter of
+    // the time, and two of them on a SIMD render 20 - 30 % more per second than one after the other (twice as much where
+    // events are dense: a slow sample is latency); the exact kernels gain 9 - 15 % on aligned batches and up to 30 % on
+    // speech-like ones — where the waves spill (one lane per utterance) they lose 14 % instead (profiles/r04_two_waves.txt,
+    // r05_two_waves.txt).  The host asks for these instantiations only for launches of more waves than the device has
+    // SIMDs, where the dispatcher's placement has nothing to get wrong.
     if constexpr (L > 1 && !PIPE && MIN_WAVES_PER_SIMD == 1) asm volatile("" ::: "a127");
 
     // every wave of the block works alone on its own S utterances and its own
@@ -510,8 +511,15 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     // SPLIT: the waves of the last chunk (longest fast-forward) start first
     const uint32_t split_groups = SPLIT ? (A.n_utt + S - 1) / S : 1u;
     const uint32_t chunk = SPLIT ? A.split_chunks - 1u - blockIdx.x / split_groups : 0u;
+    // FOLD (two waves per SIMD, a launch of at most two rounds of the device): every wave is resident from the start, so
+    // nothing evens out the SIMDs' loads afterwards, and the launch slots are filled longest utterances first — the
+    // workgroups of the second round take their slots in reverse order, so that the SIMD with the longest rows of the first
+    // round gets the shortest of the second
+    uint32_t block_id = blockIdx.x;
+    if constexpr (!SPLIT && !PIPE && !STREAM && MIN_WAVES_PER_SIMD == 2)
+        if (A.fold_from != 0u && block_id >= A.fold_from) block_id = gridDim.x - 1u - (block_id - A.fold_from);
     const uint32_t u0 = SPLIT ? (blockIdx.x % split_groups) * S
-                              : PIPE ? blockIdx.x * S : (blockIdx.x * WAVES + wave) * S;
+                              : PIPE ? blockIdx.x * S : (block_id * WAVES + wave) * S;
     // which utterance this slot renders: its position in the launch, or — ragged batches — the host's
     // length-sorted assignment (A.perm), so that the lanes of a wave end together; rows, lengths and
     // per-utterance inputs always belong to utterance `u`.  (A launch may cover a range of the slots only —

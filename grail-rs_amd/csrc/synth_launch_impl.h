@@ -19,13 +19,24 @@ template <int L, int T, int WAVES, int MINW>
 void launch_one_exact(const SynthArgs &args, hipStream_t stream)
 {
     const dim3 grid = lane_grid<L, WAVES>(args), block(64 * WAVES);
-    if constexpr (L <= 4) {
+    // one-shot launches of more waves than the device has SIMDs (args.cohabit): the instantiations built for two waves per
+    // SIMD — two lanes per utterance with four formants laid out, four lanes with either layout; the same operations in the
+    // same order in 256 registers.  (Two lanes with eight formants would spill, eight lanes are never asked for so many waves.)
+    if constexpr ((L == 2 || L == 4) && MINW == 1) {
+        if (args.cohabit && !args.state && (L == 4 || args.live4)) {
+            launch_one_exact<L, T, WAVES, 2>(args, stream);
+            return;
+        }
+    }
+    if constexpr (L <= 4 && MINW == 1) {
         if (args.state && args.live4) {
             // the lean resumable instantiations: four formants laid out, any blend length
             if (args.any_blend) start<L, T, WAVES, MINW, true, false, true, 4>(args, grid, block, stream);
             else start<L, T, WAVES, MINW, true, false, false, 4>(args, grid, block, stream);
             return;
         }
+    }
+    if constexpr (L <= 4) {
         if (!args.state && args.live4) {
             // L = 4 parks 4 floats per sample instead of 8: room for the 64-step tiles of L = 8
             // (any blend length: the four-formant layout does not depend on how alpha is divided out)
@@ -35,19 +46,25 @@ void launch_one_exact(const SynthArgs &args, hipStream_t stream)
             return;
         }
     }
-    if (args.state) {
-        // resumable streams: the lean instantiation when the batch allows it (chosen when the stream is
-        // opened: the state layout follows the formant layout), the general one otherwise
-        if (!args.any_blend && !args.half_capable)
-            start<L, T, WAVES, MINW, true, false, false>(args, grid, block, stream);
+    if constexpr (MINW == 1) {
+        if (args.state) {
+            // resumable streams: the lean instantiation when the batch allows it (chosen when the stream is
+            // opened: the state layout follows the formant layout), the general one otherwise
+            if (!args.any_blend && !args.half_capable)
+                start<L, T, WAVES, MINW, true, false, false>(args, grid, block, stream);
+            else
+                start<L, T, WAVES, MINW, true, true, true>(args, grid, block, stream);
+            return;
+        }
+    }
+    if constexpr (MINW == 1 || L == 4) {
+        if (args.any_blend)
+            start<L, T, WAVES, MINW, false, true, true>(args, grid, block, stream);
+        else if (L == 1 && args.half_capable)
+            start<L, T, WAVES, MINW, false, true, false>(args, grid, block, stream);
         else
-            start<L, T, WAVES, MINW, true, true, true>(args, grid, block, stream);
-    } else if (args.any_blend)
-        start<L, T, WAVES, MINW, false, true, true>(args, grid, block, stream);
-    else if (L == 1 && args.half_capable)
-        start<L, T, WAVES, MINW, false, true, false>(args, grid, block, stream);
-    else
-        start<L, T, WAVES, MINW, false, false, false>(args, grid, block, stream);
+            start<L, T, WAVES, MINW, false, false, false>(args, grid, block, stream);
+    }
 }
 
 template <int L, int T, int WAVES, int MINW>

@@ -48,6 +48,13 @@ static int launch_block(grail_ctx *ctx, const grail_batch *batch, const Family &
     a.live4 = f.live4;
     a.fast = f.fast;
     a.cohabit = family_cohabits(ctx, f, count) ? 1u : 0u;
+    a.fold_from = 0u;
+    if (a.cohabit) {
+        // at most two rounds of the device: the workgroups of the second take their launch slots in reverse order
+        const uint32_t waves_per_block = f.L >= 4 ? 4u : 1u, per_block = (64u / (uint32_t)f.L) * waves_per_block;
+        const uint32_t blocks = (count + per_block - 1u) / per_block, round = (uint32_t)ctx_simds(ctx) / waves_per_block;
+        if (blocks > round && blocks <= 2u * round) a.fold_from = round;
+    }
     a.pipe = f.pipe;
     hipError_t e;
     if (f.scan) {

@@ -255,8 +255,8 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *   "ragged_plan"           1 (default) / 0: batches whose utterances differ in length are weighed against one launch of each
  *                           lane mapping in several rounds, by the rows' lengths and events (grail_plan_ragged_blocks); a fast
  *                           request may be served by an exact mapping where that is cheaper ("last_launch_fast").  bits: fast.
- *   "two_waves_per_simd"    1 (default) / 0: tolerance-mode launches on 2 / 4 / 8 lanes per utterance with more wavefronts than
- *                           the device has SIMDs take instantiations built for two wavefronts per SIMD (same operations, same bits).
+ *   "two_waves_per_simd"    1 (default) / 0: launches of the 2 / 4 / 8-lane kernels with more wavefronts than the device has
+ *                           SIMDs take instantiations built for two wavefronts per SIMD (same operations, same bits).
  *   "sort_by_length"        1 (default) / 0: batches uploaded afterwards fill the launch slots longest first (rows stay put).
  *   "assume_compute_units"  0 (default: the device's own) or a count to plan for: tests, callers that share a device.
  *   "scan_debug"            development builds only.

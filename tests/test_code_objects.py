@@ -119,10 +119,11 @@ def test_lane_kernels_hold_one_wave_per_simd_by_construction(kernels):
             assert meta["group_segment_fixed_size"] >= 64 * 1024, (args, meta)
             continue
         if minw == 2:
-            # the tolerance-mode lane kernels built FOR two waves per SIMD (launches of more waves than the device has SIMDs:
-            # csrc/launch_plan.cpp family_cohabits): one-shot, 2 / 4 / 8 lanes per utterance, and they must really fit twice
+            # the lane kernels built FOR two waves per SIMD (launches of more waves than the device has SIMDs:
+            # csrc/launch_plan.cpp family_cohabits): one-shot, 2 / 4 / 8 lanes per utterance (exact: 2 / 4), and they must
+            # really fit twice
             fast = args[9]
-            assert fast and not stream and L >= 2 and (L > 2 or nfa == 4), args
+            assert not stream and L >= 2 and (L > 2 or nfa == 4) and (fast or L <= 4), args
             assert total <= 256 and meta["agpr_count"] == 0, ("built for two waves per SIMD, does not fit twice", args, meta)
             two_wave_kernels.append(args)
             continue
@@ -131,8 +132,10 @@ def test_lane_kernels_hold_one_wave_per_simd_by_construction(kernels):
 
 
 def test_two_wave_instantiations_exist(kernels):
-    have = {(a[0], a[7]) for a, _ in _synth(kernels) if a[3] == 2}
-    assert have == {(2, 4), (4, 4), (4, 8), (8, 8)}, have
+    fast = {(a[0], a[7]) for a, _ in _synth(kernels) if a[3] == 2 and a[9]}
+    assert fast == {(2, 4), (4, 4), (4, 8), (8, 8)}, fast
+    exact = {(a[0], a[7]) for a, _ in _synth(kernels) if a[3] == 2 and not a[9]}
+    assert exact == {(2, 4), (4, 4), (4, 8)}, exact
 
 
 def test_no_kernel_has_a_scratch_segment(kernels):

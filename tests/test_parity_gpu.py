@@ -906,7 +906,10 @@ def test_runs_between_the_events_of_a_tile(gpu_ctx, lanes, n_voices):
     event of some lane.  The 2 / 4 / 8-lane kernels render the samples between two events by the calm tile's loops,
     as many at once as every lane's clock, jitter phase and row still allow (synth_kernel.h MIXED_RUNS) — the same
     bits as the oracle's sample-by-sample chain, with rows that end in the middle of a run (a short out_stride cuts the
-    long ones) and utterances that finish while their wave goes on."""
+    long ones) and utterances that finish while their wave goes on.
+    ... and on a device of one and of two compute units ("assume_compute_units"): more waves than SIMDs, so the 2- and
+    4-lane mappings take the instantiations built for two waves per SIMD, and where the launch is at most two rounds of
+    the device its second round takes the launch slots in reverse order (synth_kernel.h FOLD)."""
     if lanes == 8 and n_voices == 1:
         pytest.skip("eight lanes per utterance: eight-formant layout only")
     ctx = gpu_ctx
@@ -914,17 +917,26 @@ def test_runs_between_the_events_of_a_tile(gpu_ctx, lanes, n_voices):
     rng = np.random.default_rng(100 + lanes)
     segs, offs, vids, seeds, stride = W.speech_like_batch(200, rng, n_voices=n_voices, scale=0.12)
     stride = min(stride, 9000 + 4 * 13)        # cuts the longest third of the rows, not at a tile boundary
+    ref, ref_len = O.synthesize_batch(ovoices(voices), segs, offs, vids, seeds, stride)
+    ref_len = np.minimum(ref_len, stride)               # (the oracle counts a cut row to its end)
     saved = ctx.get_option("small_batch_pipeline")
     ctx.set_option("small_batch_pipeline", 0)           # (200 utterances would take the pipelined workgroups)
     try:
         ctx.set_voices(voices)
         ctx.set_option("lanes_per_utterance", lanes)
-        out, out_len = ctx.synthesize(segs, offs, vids, seeds, out_stride=stride, allow_truncation=True)
-        assert ("L=%d" % lanes) in ctx.last_kernel_name() and "PIPE" not in ctx.last_kernel_name()
-        ref, ref_len = O.synthesize_batch(ovoices(voices), segs, offs, vids, seeds, stride)
-        ref_len = np.minimum(ref_len, stride)           # (the oracle counts a cut row to its end)
-        assert_bit_identical(out, out_len, ref, ref_len, f"speech-like L={lanes}, {n_voices} voice(s)")
+        two_wave = 0
+        for cus in (0, 1, 2):
+            ctx.set_option("assume_compute_units", cus)
+            out, out_len = ctx.synthesize(segs, offs, vids, seeds, out_stride=stride, allow_truncation=True)
+            name = ctx.last_kernel_name()
+            assert ("L=%d" % lanes) in name and "PIPE" not in name, name
+            two_wave += ",2," in name
+            assert_bit_identical(out, out_len, ref, ref_len, f"speech-like L={lanes}, {n_voices} voice(s), {cus} CUs: {name}")
+        # (two lanes with eight formants laid out have no two-wave instantiation; one and eight lanes never)
+        # 7 waves on two lanes, 13 on four: more than the 4 SIMDs of one compute unit, the 13 more than the 8 of two
+        assert two_wave == (2 if lanes == 4 else 1 if lanes == 2 and n_voices == 1 else 0), (lanes, n_voices, two_wave)
         assert (out_len == stride).sum() > 20 and (out_len < stride).sum() > 50
     finally:
+        ctx.set_option("assume_compute_units", 0)
         ctx.set_option("small_batch_pipeline", saved)
         ctx.set_option("lanes_per_utterance", 0)
