@@ -56,6 +56,9 @@
 #ifndef GRAIL_MIXED_RUNS_L1
 #define GRAIL_MIXED_RUNS_L1 0
 #endif
+#ifndef GRAIL_MIXED_RUNS_PIPE
+#define GRAIL_MIXED_RUNS_PIPE 1
+#endif
 #ifndef GRAIL_SCALAR_PACK
 #define GRAIL_SCALAR_PACK 1
 #endif
@@ -651,7 +654,10 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     // length that is not a power of two: such lanes always take the general step
     bool quiet_ok = false;
 
-    bool finished = false;   // the chain has returned None (persistent); `done` also covers pauses
+    // the chain has returned None (persistent; `done` also covers pauses).  A slot without an utterance counts as finished:
+    // it will not render in this launch or any other, so it rides along in calm tiles and runs like an ended utterance (a
+    // lone stream in a workgroup laid out for sixteen used to keep its wave out of every calm tile)
+    bool finished = !slot_used;
     // one-shot batches: the lane's upper formants have amplitude +0 in every phoneme of the voice table (phoneme
     // batches: looked up here) or in every elem of the batch (caller-built elems: formants 5-8, established by the
     // host at upload — half_capable), so nothing in this launch can ever make them audible
@@ -1171,7 +1177,7 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 st_a[0] = sa;
                 st_b[0] = 2.0f * w1 - sb;                                      // :570
                 st_c[0] = 2.0f * w2 - sc;                                      // :571
-                stage[((tc + h) * S + slot) * NFA + f0] = w1;
+                if (emit) stage[((tc + h) * S + slot) * NFA + f0] = w1;   // (PIPE: the rendering wave's filters are the live ones)
             }
         }
     };
@@ -2356,8 +2362,9 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
         // state is brought up to date where the wave takes single steps (mixed_stale)
         // (not the one-lane kernels: the eight-formant ones fill the register file as they are and the second copy of the
         // loop costs them a scratch segment; the four-formant ones lose 6 % of the headline — 43.6 instead of 40.9 ms, the
-        // calm loop's registers — for nothing: 91.5 against 89.9 ms on the speech-like corpus; profiles/r05_mixed_runs.txt)
-        constexpr bool MIXED_RUNS = GRAIL_MIXED_RUNS && !FAST && !PIPE && GRAIL_SCALAR_PACK && (L > 1 || GRAIL_MIXED_RUNS_L1);
+        // calm loop's registers — for nothing: 91.5 against 89.9 ms on the speech-like corpus; profiles/r05_mixed_runs.txt.
+        // The pipelined workgroups take it too: their four waves render the run redundantly, as they do the single steps)
+        constexpr bool MIXED_RUNS = GRAIL_MIXED_RUNS && !FAST && (!PIPE || GRAIL_MIXED_RUNS_PIPE) && GRAIL_SCALAR_PACK && (L > 1 || GRAIL_MIXED_RUNS_L1);
         bool mixed_shared = false, mixed_stale = false;
         uint32_t mixed_seed = 0u, mixed_sk = 0u;
         float mixed_noise = 0.0f;
@@ -2417,8 +2424,9 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
             // samples [t0, t1) of the tile by the calm tile's loops (MIXED_RUNS below): nobody has an event among them
             auto packed_run = [&](auto nlive_tag, auto su_tag, const int t0, const int t1,
                                   const float noise_of_lane) __attribute__((always_inline)) {
-                if constexpr (PIPE) {
-                } else if constexpr (W == 1 && NV == 1 && FOLD_IN_FLUSH) {
+                // (PIPE: the four waves of the workgroup hold the same utterances and render the run redundantly, as they do
+                // the single steps — the same values parked four times)
+                if constexpr (W == 1 && NV == 1 && FOLD_IN_FLUSH) {
 #pragma unroll 1
                     for (int tc = t0; tc < t1; tc += 8) time_packed_block(tc, noise_of_lane);
                 } else if constexpr (L >= 4) {
@@ -2576,8 +2584,10 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                 constexpr int RUN_STEP = L >= 4 ? 8 : 2;
                 while (t < T) {
                     if constexpr (MIXED_RUNS) {
-                        if (mixed_shared && T - t >= RUN_STEP) {
-                            const bool idle_now = STREAM ? finished : done;
+                        const bool idle_now = STREAM ? finished : done;
+                        // (a lane that has paused, or whose segment pair needs the general step, has no horizon: single steps)
+                        if (mixed_shared && T - t >= RUN_STEP &&
+                            __builtin_amdgcn_ballot_w64(!(idle_now | (!done & quiet_ok))) == 0) {
                             const float by_clock = clk * __builtin_amdgcn_rcpf(dt) - 1.5f;
                             const float by_phase = (0.9999f - jphase) * __builtin_amdgcn_rcpf(jinc) - 0.5f;
                             float horizon = __builtin_fminf(__builtin_fminf(by_clock, by_phase), (float)(cap32 - n_out));

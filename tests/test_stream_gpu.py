@@ -93,6 +93,34 @@ def test_mid_size_streams_take_the_pipelined_workgroups(gpu_ctx, n_voices, n_utt
             assert np.array_equal(got[u].view(np.uint32), ref[k, :ref_len[k]].view(np.uint32)), (corpus, u)
 
 
+def test_a_lone_stream_runs_at_the_pace_of_a_full_workgroup(gpu_ctx):
+    """One stream in a pipelined workgroup laid out for sixteen: the fifteen slots without an utterance count as finished
+    — they ride along in calm tiles like ended utterances — instead of keeping their wave out of every calm tile (a pull of
+    100 ms took 1.67 ms for one stream and 0.40 ms for 256: now 0.37 / 0.38).  Kernel times, best of five pulls."""
+    gpu_ctx.set_voices(W.single_voice())
+    ms = {}
+    for n in (1, 256):
+        segs, offs, vids, seeds = W.make_batch(n)
+        b = gpu_ctx.upload(segs, offs, vids, seeds)
+        st = G.Stream(b)
+        d_out = gpu_ctx.device_alloc(n * 4800 * 4)
+        d_len = gpu_ctx.device_alloc(n * 4)
+        try:
+            t = []
+            for _ in range(6):
+                st.next_async(4800, d_out, 4800, d_len)
+                gpu_ctx.sync()
+                t.append(gpu_ctx.last_kernel_ms())
+            assert "PIPE" in gpu_ctx.last_kernel_name(), gpu_ctx.last_kernel_name()
+            ms[n] = min(t[1:])
+        finally:
+            st.close()
+            gpu_ctx.device_free(d_out)
+            gpu_ctx.device_free(d_len)
+            b.free()
+    assert ms[1] <= 1.5 * ms[256], ms
+
+
 @pytest.mark.parametrize("lanes", [1, 8])
 def test_stream_edge_cases_and_ragged_ends(gpu_ctx, lanes):
     gpu_ctx.set_voices(W.single_voice())
