@@ -258,7 +258,7 @@ def main():
                          "region and report it as `fast_mode` (default: on at N=1)")
     ap.add_argument("--other-configs", type=int, default=-1, choices=[-1, 0, 1],
                     help="after the timed region and the fast leg: BASELINE configs 4 (65 536 utterances x 8 presets) and 2 "
-                         "(4 096 utterances), exact and fast, a few steps each, reported as `other_configs` (default: "
+                         "(4 096 utterances) and the speech-like corpus (65 536), exact and fast, a few steps each, reported as `other_configs` (default: "
                          "on for the default config-3 run at N=1)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per utterance (0 = auto)")
     ap.add_argument("--pipeline", type=int, default=1, choices=[0, 1],
@@ -681,6 +681,48 @@ def main():
                     "workload": f"batch={o_utts} utterances x 2 s (4 segments x 0.5 s), {o_voices} Voice preset(s), 48 kHz, "
                                 f"f32 PCM left in HBM (BASELINE {name})", **legs}
                 o_batch.free()
+            # ... and the headline batch's size on SPEECH-LIKE input (grail_hip/workload.py speech_like_batch: 8 - 32 phonemes of
+            # 40 - 160 ms per utterance, 0.5 - 3.8 s, every lane's segment boundaries at times of its own): what the kernels do
+            # when the events of a wave's lanes do not coincide, and the launch plan by the rows' lengths and events
+            ctx2.set_voices(W.single_voice())
+            s_segs, s_offs, s_vids, s_seeds, s_stride = W.speech_like_batch(65536, np.random.default_rng(7))
+            s_batch = ctx2.upload(s_segs, s_offs, s_vids, s_seeds)
+            s_out, s_len_dev = ctx2.device_alloc(65536 * s_stride * 4), ctx2.device_alloc(65536 * 4)
+            try:
+                legs = {}
+                for o_mode in ("exact", "fast"):
+                    ctx2.set_option("arithmetic", 1 if o_mode == "fast" else 0)
+                    s_batch.synthesize_async(s_out, s_stride, s_len_dev)
+                    ctx2.sync()
+                    o_kernel = []
+                    t2 = time.perf_counter()
+                    for _ in range(3):
+                        s_batch.synthesize_async(s_out, s_stride, s_len_dev)
+                        ctx2.sync()
+                        o_kernel.append(ctx2.last_kernel_ms())
+                    o_elapsed = time.perf_counter() - t2
+                    o_len = np.zeros(65536, dtype=np.uint32)
+                    ctx2.d2h(o_len, s_len_dev, 65536 * 4)
+                    o_samples = int(o_len.astype(np.uint64).sum())
+                    o_k = float(np.mean(o_kernel))
+                    o_ach = o_samples * ALG_BYTES_PER_SAMPLE / (o_k * 1e-3) / 1e9
+                    legs[o_mode] = {
+                        "value": o_samples * 3 / o_elapsed, "unit": "samples/s", "steps": 3, "ms_per_step": o_elapsed * 1e3 / 3,
+                        "kernel_ms": o_k, "kernel": ctx2.last_kernel_name(), "launch_blocks": ctx2.get_option("last_launch_blocks"),
+                        "lanes_per_utterance_used": ctx2.get_option("last_launch_lanes"),
+                        "arithmetic_ran": "fast" if ctx2.get_option("last_launch_fast") else "exact",
+                        "roofline": {"bound": "hbm", "achieved": o_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": o_ach / HBM_PEAK_GBS, "traffic": None,
+                                     "algorithmic_bytes_per_launch": o_samples * ALG_BYTES_PER_SAMPLE},
+                    }
+                other_configs["speech_like"] = {
+                    "workload": "batch=65536 utterances of 8 - 32 phonemes of 40 - 160 ms (0.5 - 3.8 s, 2.0 s on average: the headline "
+                                "batch's samples), blends of 30 - 80 ms, single Voice, 48 kHz, f32 PCM left in HBM (not a BASELINE "
+                                "config: the bench corpus has four aligned segments of 0.5 s)", **legs}
+            finally:
+                ctx2.device_free(s_out)
+                ctx2.device_free(s_len_dev)
+                s_batch.free()
         finally:
             ctx2.close()
 

@@ -445,7 +445,8 @@ double ragged_cost(const grail_ctx *ctx, const grail_batch *batch, const Family 
     if (n_gran == 0 || rows == 0) return family_cost(ctx, f, rows, span);
     const size_t g0 = std::min<size_t>(slot0 / 8, n_gran - 1), g1 = std::min<size_t>(((size_t)slot0 + rows + 7) / 8, n_gran);
     // (families that render an utterance with many lanes: by the block's own longest row.  A pipelined workgroup renders its
-    // 16 / 8 utterances in rounds of 32 samples; a round that holds a segment boundary of one of them costs it ~14 us more:
+    // 16 / 8 utterances in rounds of 32 samples; a round that holds a segment boundary of one of them costs it ~11 us more (14
+    // before the runs between events):
     // 256 utterances with phonemes of 4 - 16 ms take 5.7 ms where their 0.39 s alone would take 1.3)
     if (f.scan || f.pipe) {
         const double longest = std::fmin(span, std::fmax((double)batch->granule_samples[g0], 0.0) + 64.0);
@@ -456,7 +457,7 @@ double ragged_cost(const grail_ctx *ctx, const grail_batch *batch, const Family 
             if (f.live4 && g0 + 1 < g1) segs += batch->granule_segs[g0 + 1];
             const double rounds = std::fmax(longest / 32.0, 1.0);
             const double groups = std::ceil((double)rows / (f.live4 ? 16.0 : 8.0));
-            c += 0.014 * rounds * (1.0 - std::exp(-segs / rounds)) * std::ceil(groups / ((f.pipe == 2 ? 1.0 : 2.0) * (double)ctx->cus));
+            c += 0.011 * rounds * (1.0 - std::exp(-segs / rounds)) * std::ceil(groups / ((f.pipe == 2 ? 1.0 : 2.0) * (double)ctx->cus));
         }
         return c;
     }
