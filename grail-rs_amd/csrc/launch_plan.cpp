@@ -103,7 +103,9 @@ double family_cost(const grail_ctx *ctx, const Family &f, uint32_t rows, double 
         const double groups = std::ceil((double)rows / (f.live4 ? 16.0 : 8.0));
         const double per_cu = std::ceil(groups / cus);
         // rounds of 32: one workgroup per CU; rounds of 16: two per CU are resident together, further ones queue
-        const double ms2s = f.pipe == 2 ? (f.live4 ? 6.5 : 7.3) * per_cu : 11.2 * std::ceil(per_cu / 2.0);
+        // (rounds of 16 with one workgroup per CU: 7.9 ms for config 2 where rounds of 32 take 6.5)
+        const double ms2s = f.pipe == 2 ? (f.live4 ? 6.5 : 7.3) * per_cu
+                                        : per_cu <= 1.0 ? (f.live4 ? 7.9 : 8.8) : 11.2 * std::ceil(per_cu / 2.0);
         return ms2s * span / 96006.0;
     }
     const double rounds = std::ceil((double)rows * f.L / lanes);
@@ -186,9 +188,15 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
                             (int64_t)(((uint64_t)fam + 15) / 16) <= pipe4_groups(ctx);
     const bool want_pipe8 = !batch_live4_any_blend(ctx, batch) && !lanes_option && ctx->pipeline_option &&
                             (int64_t)(((uint64_t)fam + 7) / 8) <= pipe8_groups(ctx);
-    // one workgroup per CU suffices: rounds of 32 samples instead of 16 (pipe = 2)
-    const uint32_t pipe4_kind = ctx->pipe_round32 && ((uint64_t)fam + 15) / 16 <= cus ? 2u : 1u;
-    const uint32_t pipe8_kind = ctx->pipe_round32 && ((uint64_t)fam + 7) / 8 <= cus ? 2u : 1u;
+    // one workgroup per CU suffices: rounds of 32 samples instead of 16 (pipe = 2) — for batches whose rows are aligned.
+    // Rows that differ in length (the upload kept their summary) have their events at times of their own, and a tile with an
+    // event is rendered in whole rounds where nobody has one (synth_kernel.h pipe_rounds): rounds of 16 fit between two events
+    // far more often than rounds of 32 (256 speech-like utterances 18.8 ms against 20.0, with phonemes of 16 - 64 ms 10.0 / 11.2,
+    // 4 - 16 ms 4.6 / 5.3; profiles/r05_mixed_runs.txt)
+    const bool rows_differ = batch != nullptr && !batch->granule_samples.empty() &&
+                             batch->granule_samples.front() != batch->granule_samples.back();
+    const uint32_t pipe4_kind = ctx->pipe_round32 && !rows_differ && ((uint64_t)fam + 15) / 16 <= cus ? 2u : 1u;
+    const uint32_t pipe8_kind = ctx->pipe_round32 && !rows_differ && ((uint64_t)fam + 7) / 8 <= cus ? 2u : 1u;
     if (want_pipe4 && !f.fast) {
         f.pipe = pipe4_kind;
         L = 4;

@@ -59,6 +59,16 @@
 #ifndef GRAIL_MIXED_RUNS_PIPE
 #define GRAIL_MIXED_RUNS_PIPE 1
 #endif
+#ifndef GRAIL_PIPE_PARTIAL
+#define GRAIL_PIPE_PARTIAL 1
+#endif
+// PIPE, rounds of 32 samples: how many of a round's 16 coefficient pairs the chain wave takes (8 / 4 lanes per utterance)
+#ifndef PIPE_CP8_L8
+#define PIPE_CP8_L8 4
+#endif
+#ifndef PIPE_CP8_L4
+#define PIPE_CP8_L4 2
+#endif
 #ifndef GRAIL_SCALAR_PACK
 #define GRAIL_SCALAR_PACK 1
 #endif
@@ -2421,6 +2431,61 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                     }
                 }
             }
+            // PIPE: `n_rounds` rounds of the pipeline from step t0 of the tile — the calm tile's three stages (chain wave two
+            // rounds ahead, coefficient waves one, the rendering wave), one barrier per phase — for a stretch of a tile with an
+            // event in which nobody has one (MIXED_RUNS below).  No tile boundary inside, so no flush; at the end every wave takes
+            // over the clocks the chain wave arrived at, as after a calm tile.
+            auto pipe_rounds = [&](const int t0, const int n_rounds, const float noise_of_lane) __attribute__((always_inline)) {
+                if constexpr (PIPE) {
+                    constexpr int SPR = 4 * QP;
+                    constexpr int CHAIN_PAIRS = QP == 8 ? (L == 4 ? PIPE_CP8_L4 : PIPE_CP8_L8) : QP >= 4 ? QP / 2 : 0;
+                    constexpr int PAIRS_PER_COEF_WAVE = QP >= 4 ? (2 * QP - CHAIN_PAIRS + 1) / 2 : QP;
+                    constexpr int PAIRS_OF_LAST_WAVE = QP >= 4 ? 2 * QP - CHAIN_PAIRS - PAIRS_PER_COEF_WAVE : QP;
+#pragma unroll 1
+                    for (int ph_ = -2; ph_ < n_rounds; ++ph_) {
+                        if (role == 1) {
+                            const int m = ph_ + 2;
+                            if (m < n_rounds) {
+#pragma unroll
+                                for (int g = 0; g < QP / 2; ++g) pipe_chain(chain_all[m & 1][g], noise_of_lane, t0 + SPR * m + 8 * g);
+                            }
+                            if constexpr (CHAIN_PAIRS > 0) {     // and the last pairs of the round before
+                                const int mc = ph_ + 1;
+                                if (mc >= 0 && mc < n_rounds) {
+#pragma unroll
+                                    for (int pair = 2 * QP - CHAIN_PAIRS; pair < 2 * QP; ++pair)
+                                        pipe_coeffs(chain_all[mc & 1][pair / 4], pair % 4, ring_all[mc & 1][pair]);
+                                }
+                            }
+                        } else if (role >= 2) {
+                            const int m = ph_ + 1;
+                            if (m >= 0 && m < n_rounds) {
+#pragma unroll
+                                for (int q = 0; q < PAIRS_PER_COEF_WAVE; ++q) {
+                                    const int pair = QP >= 4 ? PAIRS_PER_COEF_WAVE * (role - 2) + q : 2 * q + (role - 2);
+                                    if (PAIRS_OF_LAST_WAVE == PAIRS_PER_COEF_WAVE || q < PAIRS_OF_LAST_WAVE || role == 2)
+                                        pipe_coeffs(chain_all[m & 1][pair / 4], pair % 4, ring_all[m & 1][pair]);
+                                }
+                            }
+                        } else if (ph_ >= 0) {
+#pragma unroll
+                            for (int q = 0; q < 2 * QP; ++q) pipe_render(ring_all[ph_ & 1][q], t0 + SPR * ph_ + 2 * q);
+                        }
+                        __syncthreads();
+                    }
+                    if (role == 1) {
+                        hand_all[0][lane] = clk;
+                        hand_all[1][lane] = jphase;
+                        hand_all[2][lane] = phase;
+                    }
+                    __syncthreads();
+                    if (role != 1) {
+                        clk = hand_all[0][lane];
+                        jphase = hand_all[1][lane];
+                        phase = hand_all[2][lane];
+                    }
+                }
+            };
             // samples [t0, t1) of the tile by the calm tile's loops (MIXED_RUNS below): nobody has an event among them
             auto packed_run = [&](auto nlive_tag, auto su_tag, const int t0, const int t1,
                                   const float noise_of_lane) __attribute__((always_inline)) {
@@ -2465,12 +2530,6 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                         // pairs, the chain wave, so that the three stages take about the same time
                         // (rounds of 32 samples, 16 pairs: with 4 pairs the chain wave was the slowest stage — 7.39 ms for
                         // config 2 against 6.51 with 2 and 7.26 with none; profiles/r03_pipe_waves.txt)
-#ifndef PIPE_CP8_L8
-#define PIPE_CP8_L8 4
-#endif
-#ifndef PIPE_CP8_L4
-#define PIPE_CP8_L4 2
-#endif
                         constexpr int CHAIN_PAIRS = QP == 8 ? (L == 4 ? PIPE_CP8_L4 : PIPE_CP8_L8) : QP >= 4 ? QP / 2 : 0;
                         // the first coefficient wave takes the odd pair, if there is one
                         constexpr int PAIRS_PER_COEF_WAVE = QP >= 4 ? (2 * QP - CHAIN_PAIRS + 1) / 2 : QP;
@@ -2605,8 +2664,20 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
                             const int wave_steps = __builtin_amdgcn_readlane((int)steps, 63) & ~(RUN_STEP - 1);
                             if (wave_steps > 0) {
                                 const int room_t = (T - t) & ~(RUN_STEP - 1);
-                                const int m = wave_steps < room_t ? wave_steps : room_t;
-                                packed_run(nlive_tag, su_tag, t, t + m, mixed_noise);
+                                int m = wave_steps < room_t ? wave_steps : room_t;
+                                if constexpr (PIPE) {
+                                    // whole rounds go through the pipeline (every wave finds the same count), the rest of
+                                    // the run in the next trip through the loop, redundantly in all four waves
+                                    constexpr int SPR = 4 * QP;
+                                    if (GRAIL_PIPE_PARTIAL && m >= SPR) {
+                                        m = (m / SPR) * SPR;
+                                        pipe_rounds(t, m / SPR, mixed_noise);
+                                    } else {
+                                        packed_run(nlive_tag, su_tag, t, t + m, mixed_noise);
+                                    }
+                                } else {
+                                    packed_run(nlive_tag, su_tag, t, t + m, mixed_noise);
+                                }
                                 PROF_CNT(10, m >> 1);
                                 n_out += idle_now ? 0u : (uint32_t)m;
                                 t += m;

@@ -940,3 +940,30 @@ def test_runs_between_the_events_of_a_tile(gpu_ctx, lanes, n_voices):
         ctx.set_option("assume_compute_units", 0)
         ctx.set_option("small_batch_pipeline", saved)
         ctx.set_option("lanes_per_utterance", 0)
+
+
+@pytest.mark.parametrize("round32", [1, 0])
+@pytest.mark.parametrize("n_voices", [1, 8])
+def test_pipelined_rounds_between_the_events_of_a_tile(gpu_ctx, n_voices, round32):
+    """The same corpus on the pipelined workgroups (a small batch left to the library): in a tile that holds an event of
+    one of the workgroup's utterances, the stretches in which nobody has one go through the pipeline in whole rounds of 32
+    or 16 samples (synth_kernel.h pipe_rounds), what is left of a stretch in 8-sample blocks by all four waves, and only
+    the samples next to an event one by one — bit-identical to the oracle, rows cut in the middle of a round included."""
+    ctx = gpu_ctx
+    voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
+    rng = np.random.default_rng(300 + n_voices)
+    segs, offs, vids, seeds, stride = W.speech_like_batch(200, rng, n_voices=n_voices, scale=0.12)
+    stride = min(stride, 9000 + 4 * 13)
+    ref, ref_len = O.synthesize_batch(ovoices(voices), segs, offs, vids, seeds, stride)
+    ref_len = np.minimum(ref_len, stride)
+    try:
+        ctx.set_voices(voices)
+        ctx.set_option("ragged_plan", 0)            # (by its events the batch might go to a lane mapping)
+        ctx.set_option("pipeline_round32", round32)
+        out, out_len = ctx.synthesize(segs, offs, vids, seeds, out_stride=stride, allow_truncation=True)
+        name = ctx.last_kernel_name()
+        assert "PIPE" in name and ("R32" if round32 else "R16") in name, name
+        assert_bit_identical(out, out_len, ref, ref_len, f"speech-like, pipelined, {n_voices} voice(s): {name}")
+    finally:
+        ctx.set_option("ragged_plan", 1)
+        ctx.set_option("pipeline_round32", 1)

@@ -3,7 +3,7 @@
 contours of 90 - 220 Hz), so that utterances differ in length by a factor of four and every lane of a wave has a segment
 boundary every few thousand samples at a time of its own — next to the bench corpus (4 aligned segments of 0.5 s).
 Reports samples/s over the samples actually rendered.
-usage: speech_like_bench.py [n_utt] [--blend-is-length] [--lanes=L] [--two-waves=0|1] [--no-split] [--no-ragged-plan] [--scale=F] [--long-tail]   (A/B:
+usage: speech_like_bench.py [n_utt] [--blend-is-length] [--lanes=L] [--two-waves=0|1] [--round16] [--no-split] [--no-ragged-plan] [--scale=F] [--long-tail]   (A/B:
 pinned lane mapping, no time-split, the one-round launch policy; every length and blend length times F; one utterance in a hundred
 of 60 - 80 phonemes among utterances of 4 - 12)"""
 import os
@@ -25,6 +25,8 @@ for a in sys.argv[1:]:
         ctx.set_option("lanes_per_utterance", int(a[8:]))
     if a.startswith("--two-waves="):
         ctx.set_option("two_waves_per_simd", int(a[12:]))
+    if a == "--round16":
+        ctx.set_option("pipeline_round32", 0)
     if a == "--no-split":
         ctx.set_option("time_split", 0)
     if a == "--no-ragged-plan":
