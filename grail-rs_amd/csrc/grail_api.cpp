@@ -522,7 +522,8 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         return GRAIL_OK;
     }
     if (std::strcmp(name, "pipeline_round32") == 0) {       // tuning (A/B)
-        ctx->pipe_round32 = value ? 1 : 0;
+        if (value < 0 || value > 2) return fail(GRAIL_ERR_INVALID_ARG, "pipeline_round32 must be 0 (never), 1 (aligned batches) or 2 (any batch)");
+        ctx->pipe_round32 = (int)value;
         return GRAIL_OK;
     }
 #ifdef GRAIL_SCAN_DEBUG

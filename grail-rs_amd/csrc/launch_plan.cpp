@@ -195,8 +195,9 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
     // 4 - 16 ms 4.6 / 5.3; profiles/r05_mixed_runs.txt)
     const bool rows_differ = batch != nullptr && !batch->granule_samples.empty() &&
                              batch->granule_samples.front() != batch->granule_samples.back();
-    const uint32_t pipe4_kind = ctx->pipe_round32 && !rows_differ && ((uint64_t)fam + 15) / 16 <= cus ? 2u : 1u;
-    const uint32_t pipe8_kind = ctx->pipe_round32 && !rows_differ && ((uint64_t)fam + 7) / 8 <= cus ? 2u : 1u;
+    const bool round32 = ctx->pipe_round32 == 2 || (ctx->pipe_round32 == 1 && !rows_differ);      // (2: tests, A/B)
+    const uint32_t pipe4_kind = round32 && ((uint64_t)fam + 15) / 16 <= cus ? 2u : 1u;
+    const uint32_t pipe8_kind = round32 && ((uint64_t)fam + 7) / 8 <= cus ? 2u : 1u;
     if (want_pipe4 && !f.fast) {
         f.pipe = pipe4_kind;
         L = 4;

@@ -238,7 +238,8 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *                           segment pair, band-pass state 0) are skipped, and not laid out at all where the voice table and
  *                           the batch guarantee it for formants 5-8; 0: all eight evaluated literally.
  *   "small_batch_pipeline"  1 (default) / 0: small exact blocks run four-wave pipelined workgroups; streams of that size too.
- *   "pipeline_round32"      1 (default) / 0: ... in rounds of 32 samples while one workgroup per compute unit suffices.
+ *   "pipeline_round32"      1 (default) / 0 / 2: ... in rounds of 32 samples while one workgroup per compute unit suffices and
+ *                           the rows are of one length / never / whatever the rows (rounds of 16 otherwise).
  *   "pipeline4_max_groups", "pipeline8_max_groups"  (default -1: two per compute unit) workgroups a block may need to take them.
  *   "time_parallel_scan"    1 (default) / 0: fast, first tier: few utterances run one workgroup each, lanes = time (parallel
  *                           scans).  "time_parallel_scan_max_utterances" (-1 auto): hard upper limit;

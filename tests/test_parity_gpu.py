@@ -942,7 +942,7 @@ def test_runs_between_the_events_of_a_tile(gpu_ctx, lanes, n_voices):
         ctx.set_option("lanes_per_utterance", 0)
 
 
-@pytest.mark.parametrize("round32", [1, 0])
+@pytest.mark.parametrize("round32", [2, 1, 0])
 @pytest.mark.parametrize("n_voices", [1, 8])
 def test_pipelined_rounds_between_the_events_of_a_tile(gpu_ctx, n_voices, round32):
     """The same corpus on the pipelined workgroups (a small batch left to the library): in a tile that holds an event of
@@ -962,7 +962,8 @@ def test_pipelined_rounds_between_the_events_of_a_tile(gpu_ctx, n_voices, round3
         ctx.set_option("pipeline_round32", round32)
         out, out_len = ctx.synthesize(segs, offs, vids, seeds, out_stride=stride, allow_truncation=True)
         name = ctx.last_kernel_name()
-        assert "PIPE" in name and ("R32" if round32 else "R16") in name, name
+        # (rows that differ in length take rounds of 16 unless the option insists: 2)
+        assert "PIPE" in name and ("R32" if round32 == 2 else "R16") in name, name
         assert_bit_identical(out, out_len, ref, ref_len, f"speech-like, pipelined, {n_voices} voice(s): {name}")
     finally:
         ctx.set_option("ragged_plan", 1)
