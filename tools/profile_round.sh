@@ -45,6 +45,7 @@ python3 tools/stream_latency.py 1 2>/dev/null | grep -v "^RCCL\|^HIP\|^ROCm\|^Ho
 rm -rf gpurun_out/prof/stats6
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats6 -- python3 tools/speech_like_bench.py 65536 > $out/stats6.log 2>&1
 cp gpurun_out/prof/stats6/*/*kernel_stats.csv $out/kernel_stats_speech_like.csv
+bash tools/pmc_speech_like.sh > $out/pmc_speech_like_raw.txt 2>&1
 python3 tools/two_waves_bench.py 2>/dev/null | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" > $out/two_waves.txt
 python3 -m pytest tests/test_planner_guard_gpu.py -m gpu -q -s 2>&1 | grep -v "^make\|^g++" > $out/planner_guard.txt
 python3 tools/ragged_bench.py 65536 1 0 > $out/ragged.txt 2>&1
