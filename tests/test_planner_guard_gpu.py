@@ -104,3 +104,60 @@ def test_the_planners_choice_is_within_ten_percent_of_the_best_pinned_family(gpu
             ctx.set_option(k, v)
     print("\n# kernel ms, min of 2 after a warm-up; the library's choice (auto) against every pinned family\n" + "\n".join(lines))
     assert not failures, "the planner's choice is more than 10 % behind a pinned family:\n" + "\n".join(failures)
+
+
+RAGGED_CELLS = [(65536, 1.0, 1), (65536, 0.1, 1), (32768, 1.0, 1), (65536, 1.0, 8)]
+
+
+def test_the_ragged_planners_choice_is_within_ten_percent_of_the_best_pinned_mapping(gpu_ctx):
+    """The same guard for batches whose rows differ in length (speech-like corpus: phonemes of 40 - 160 ms and of 4 - 16 ms),
+    where the planner weighs lane mappings in several rounds by the rows' lengths and events and by what two waves per SIMD
+    gain (launch_plan.cpp ragged_cost: constants fitted on one box): the library's choice against every pinned lane mapping,
+    exact and tolerance arithmetic.  A fast request served by an exact mapping counts as the library's choice."""
+    ctx = gpu_ctx
+    saved = {k: ctx.get_option(k) for k in DEFAULTS}
+    lines, failures = [], []
+    try:
+        for n, scale, n_voices in RAGGED_CELLS:
+            ctx.set_voices(W.single_voice() if n_voices == 1 else W.preset_voices(8))
+            segs, offs, vids, seeds, stride = W.speech_like_batch(n, np.random.default_rng(7), n_voices=n_voices, scale=scale)
+            batch = ctx.upload(segs, offs, vids, seeds)
+            d_out = ctx.device_alloc(n * stride * 4)
+            d_len = ctx.device_alloc(n * 4)
+            try:
+                for fast in (0, 1):
+                    res = {}
+                    for name, opts in [("auto", {})] + [("L%d" % L, {"lanes_per_utterance": L}) for L in (1, 2, 4, 8)] + [("auto", {})]:
+                        if name == "L8" and n_voices == 1 and not fast:
+                            continue                     # (eight lanes lay out eight formants: twice the work for this voice)
+                        for k, v in DEFAULTS.items():
+                            ctx.set_option(k, v)
+                        ctx.set_option("arithmetic", fast)
+                        for k, v in opts.items():
+                            ctx.set_option(k, v)
+                        ms = []
+                        for rep in range(3):
+                            batch.synthesize_async(d_out, stride, d_len)
+                            ctx.sync()
+                            if rep:
+                                ms.append(ctx.last_kernel_ms())
+                        t = (min(ms), _what(ctx) + (" x2" if ",2," in ctx.last_kernel_name() else ""))
+                        res[name] = t if name not in res or t[0] < res[name][0] else res[name]
+                    best = min(v[0] for v in res.values())
+                    ratio = res["auto"][0] / best
+                    lines.append(f"{n:6d} utterances, phonemes x {scale}, {n_voices} voice(s), {'fast ' if fast else 'exact'}: auto "
+                                 f"{res['auto'][0]:7.2f} ms ({res['auto'][1]}) = {ratio:4.2f} x best | " +
+                                 "  ".join(f"{k} {v[0]:.2f} ({v[1]})" for k, v in res.items() if k != "auto"))
+                    if ratio > 1.10:
+                        failures.append(lines[-1])
+            finally:
+                ctx.device_free(d_out)
+                ctx.device_free(d_len)
+                batch.free()
+    finally:
+        for k, v in saved.items():
+            ctx.set_option(k, v)
+        ctx.set_voices(W.single_voice())
+    print("\n# speech-like corpus, kernel ms, min of 2 after a warm-up; the library's choice (auto) against every pinned lane mapping\n"
+          + "\n".join(lines))
+    assert not failures, "the planner's choice is more than 10 % behind a pinned lane mapping:\n" + "\n".join(failures)
