@@ -150,6 +150,8 @@ struct grail_batch {
     uint32_t *d_voice_ids = nullptr;
     uint32_t *d_seeds = nullptr;
     uint32_t *d_perm = nullptr;   // ragged batches: launch slot -> utterance, longest first
+    uint32_t *d_len_bound = nullptr;   // per utterance: an upper bound of its length in samples (plain batches; time-split kernels)
+    uint64_t len_bound_epoch = 0;      // ... for the voice table of this epoch (its highest sample rate)
     float *d_elems = nullptr;  // elem mode only
     uint32_t n_utt = 0;
     uint32_t n_segs = 0;
@@ -251,6 +253,7 @@ struct Family {
     uint32_t fast = 0;         // tolerance arithmetic
     int split_k = 0;           // time-split kernels: chunks per utterance (0: not time-split)
     uint32_t split_bounds[SPLIT_MAX_CHUNKS + 1] = {};
+    uint32_t split_active = 0; // ... rows that differ in length: how many (wave, chunk) pairs have anything to render (0: all)
     bool scan = false;         // the time-parallel scan kernel
     uint32_t scan_pipe = 0;    // ... its three-stage flavour
 };

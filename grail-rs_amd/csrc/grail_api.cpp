@@ -59,6 +59,7 @@ void free_batch_buffers(grail_batch *b)
     if (b->d_voice_ids) (void)hipFree(b->d_voice_ids);
     if (b->d_seeds) (void)hipFree(b->d_seeds);
     if (b->d_perm) (void)hipFree(b->d_perm);
+    if (b->d_len_bound) (void)hipFree(b->d_len_bound);
     if (b->d_elems) (void)hipFree(b->d_elems);
 }
 
@@ -87,7 +88,29 @@ struct RowStats {
     bool any_blend = false;     // some blend length is not +-2^k
     float min_length = INFINITY, min_pitch = INFINITY, seconds = 0.0f;
     uint32_t segs = 0, kinks = 0;   // segments; those whose alpha = min(clk / blend_length, 1) has a kink (blend_length < length)
+    double bound_seconds = 0.0;     // sum of the positive segment lengths: no utterance lasts longer (every advance adds its
+                                    // segment's length to the clock, :873 / :882; a segment that leaves the clock negative
+                                    // still takes a sample: + segs below)
 };
+
+// An upper bound of every utterance's length in samples, on the device (time-split kernels: a chunk's lane whose utterance
+// ends before the chunk begins has nothing to render and says so at once — batches whose rows differ in length then take
+// more, shorter chunks; launch_plan.cpp).  Sum of the positive lengths at the table's highest sample rate, + 2 % for what
+// the f32 clock's roundings can add up to over a long segment, + two samples per segment + a tile.
+int upload_len_bound(grail_ctx *ctx, grail_batch *b, const std::vector<RowStats> &rows, uint32_t n_utt)
+{
+    if (!b->plain || n_utt == 0 || ctx->voices.empty()) return GRAIL_OK;
+    std::vector<uint32_t> bound(n_utt);
+    for (uint32_t u = 0; u < n_utt; ++u) {
+        const double samples = rows[u].bound_seconds * (double)ctx->max_rate * 1.02 + 2.0 * (double)rows[u].segs + 64.0;
+        bound[u] = samples < 4.0e9 ? (uint32_t)samples : 0xFFFFFFFFu;
+    }
+    int rc = upload(&b->d_len_bound, bound.data(), n_utt, ctx->stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    b->len_bound_epoch = ctx->voices_epoch;
+    return GRAIL_OK;
+}
 
 // Ragged batches: the lanes of a wave run in lockstep, so a wave lasts as long as its longest utterance.
 // Launch slots are therefore filled in order of decreasing length (sum of the segment lengths, in seconds
@@ -728,6 +751,7 @@ int grail_batch_upload(grail_ctx *ctx, const grail_phoneme_elem *segs, const uin
             const float pitch = std::fmin(segs[i].frequency, 0.5f);   // copy_with_frequency :445-450
             if (pitch < r.min_pitch) r.min_pitch = pitch;
             r.seconds += segs[i].length;
+            if (segs[i].length > 0.0f) r.bound_seconds += (double)segs[i].length;
             r.segs += 1u;
             r.kinks += segs[i].blend_length < segs[i].length ? 1u : 0u;
         }
@@ -748,7 +772,7 @@ int grail_batch_upload(grail_ctx *ctx, const grail_phoneme_elem *segs, const uin
     b->n_segs = n_segs;
     if ((rc = upload(&b->d_segs, segs, n_segs, ctx->stream)) ||
         (rc = upload_common(ctx, b, seg_offsets, voice_ids, jitter_seeds, n_utt)) ||
-        (rc = upload_length_order(ctx, b, rows, n_utt))) {
+        (rc = upload_len_bound(ctx, b, rows, n_utt)) || (rc = upload_length_order(ctx, b, rows, n_utt))) {
         free_batch_buffers(b);
         delete b;
         return rc;
@@ -790,6 +814,7 @@ int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
             if (segs[i].length < r.min_length) r.min_length = segs[i].length;
             if (segs[i].elem.frequency < r.min_pitch) r.min_pitch = segs[i].elem.frequency;
             r.seconds += segs[i].length;
+            if (segs[i].length > 0.0f) r.bound_seconds += (double)segs[i].length;
             r.segs += 1u;
             r.kinks += segs[i].blend_length < segs[i].length ? 1u : 0u;
         }
@@ -854,7 +879,7 @@ int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
     if ((rc = upload(&b->d_segs, ds.data(), n_segs, ctx->stream)) ||
         (rc = upload(&b->d_elems, elems.data(), elems.size(), ctx->stream)) ||
         (rc = upload_common(ctx, b, seg_offsets, voice_ids, jitter_seeds, n_utt)) ||
-        (rc = upload_length_order(ctx, b, rows, n_utt))) {
+        (rc = upload_len_bound(ctx, b, rows, n_utt)) || (rc = upload_length_order(ctx, b, rows, n_utt))) {
         free_batch_buffers(b);
         delete b;
         return rc;

@@ -77,6 +77,8 @@ struct SynthArgs {
     uint32_t any_blend;           // host hint: some segment has a blend length that is not +-2^k
     uint32_t cohabit;             // lane kernels on 2 / 4 / 8 lanes per utterance: the instantiation built for two waves per
                                   // SIMD (launches of more waves than the device has SIMDs; launch_plan.cpp family_cohabits)
+    const uint32_t *len_bound;    // time-split kernels: per utterance an upper bound of its length in samples, or nullptr — a
+                                  // chunk's lane whose utterance ends before the chunk begins renders nothing
     uint32_t fold_from;           // two waves per SIMD, at most two rounds of the device: workgroups from this index on take the
                                   // launch slots in reverse order (0: none) — see synth_kernel.h
     uint32_t *state;              // resumable synthesis: state[word][lane] or nullptr (one-shot)

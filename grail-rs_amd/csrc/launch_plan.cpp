@@ -95,7 +95,8 @@ double family_cost(const grail_ctx *ctx, const Family &f, uint32_t rows, double 
     if (f.split_k) {
         // every lane takes as long as the first chunk's, which renders split_bounds[1] samples and nothing else
         // (a wave holds 64 utterances at ONE chunk index: ceil(rows / 64) waves per chunk, whatever rows modulo 64 is)
-        const double rounds = std::ceil(std::ceil((double)rows / 64.0) * f.split_k / (double)ctx_simds(ctx));
+        const double rounds = f.split_active ? std::ceil((double)f.split_active / (double)ctx_simds(ctx))
+                                             : std::ceil(std::ceil((double)rows / 64.0) * f.split_k / (double)ctx_simds(ctx));
         // (+ 0.12 ms: what a launch of chunk lanes costs before any of them renders — short utterances see it)
         if (f.fast == 2u) return rounds * ((double)f.split_bounds[1] * mid_ms_per_sample(f.live4 != 0) + 0.12);
         return rounds * ((double)f.split_bounds[1] * (f.live4 ? 15.7 : 23.3) / 96006.0 + 0.12);
@@ -242,6 +243,22 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
         // per chunk: 12 chunks, not 65 536 / 5 000 = 13, which would be 1 027 waves and a second round for three of them)
         int K = ctx->split_chunks ? (int)ctx->split_chunks
                                   : (int)std::min<uint64_t>(simds / (((uint64_t)fam + 63u) / 64u), SPLIT_MAX_CHUNKS);
+        // Rows that differ in length (whole batch, launched longest first, the upload's length bounds on the device): a
+        // chunk's wave whose utterances all end before the chunk begins is gone at once (synth_kernel.h, SPLIT), so the
+        // grid may hold more (wave, chunk) pairs than the device has SIMDs (a speech-like corpus keeps a third of them: the
+        // grid's chunks are shortest at the far end, where only the longest rows still are)
+        auto active_pairs = [&](const uint32_t *bounds, const int k) {
+            uint64_t pairs = 0;
+            for (size_t g = 0; g < batch->granule_samples.size(); g += 8) {      // 64 launch slots: the first is the longest
+                const double len = (double)batch->granule_samples[g] * 1.02 + 64.0;
+                int c = 1;
+                while (c < k && (double)bounds[c] < len) ++c;
+                pairs += (uint64_t)c;
+            }
+            return pairs;
+        };
+        const bool by_length = !ctx->split_chunks && !ctx->split_span && rows_differ && fam == batch->n_utt &&
+                               batch->d_len_bound != nullptr && batch->len_bound_epoch == ctx->voices_epoch;
         K = (int)std::fmin((double)K, sp / 512.0);
         // (a fast-forwarded sample costs the same whatever is rendered afterwards; a rendered sample of eight live
         // formants costs 1.5 x one of four; 0.8 from a sweep, profiles/r03_small_batch.txt)
@@ -257,8 +274,23 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
             K = lo;
             if (K >= 2) (void)split_grid((uint32_t)sp, warmup, K, ff_cost, split.split_bounds);
         }
+        if (K >= 2 && K <= 4 && by_length) {
+            // (Batches of 16 384 utterances and more, whose grids are coarse — 4 chunks, 2 — and leave SIMDs without a wave:
+            // up to 2 K - 1 chunks while the active pairs fit the device.  The count is an estimate from the upload's summary
+            // — measured 6 % above what the kernel finds — and finer grids of smaller batches gain nothing: a chunk's lane
+            // fast-forwards through everything before it, and on a speech-like corpus that costs more per sample than the
+            // grid is laid out for: 4 096 utterances 15.4 ms on 16 chunks, 14.9 on 24, 19.6 on 34.)
+            const int most = 2 * K - 1;
+            for (int k = K + 1; k <= most && (double)k <= sp / 512.0; ++k) {
+                uint32_t wider[SPLIT_MAX_CHUNKS + 1] = {};
+                if (!split_grid((uint32_t)sp, warmup, k, ff_cost, wider) || active_pairs(wider, k) * 16 > simds * 17) break;
+                K = k;
+                std::memcpy(split.split_bounds, wider, sizeof wider);
+            }
+        }
         if (K >= 2) {
             split.split_k = K;
+            split.split_active = by_length ? (uint32_t)active_pairs(split.split_bounds, K) : 0u;
             split.split_bounds[K] = (uint32_t)out_stride;
             split.live4 = l4ab ? 1u : 0u;
             split.pipe = 0u;
@@ -484,7 +516,8 @@ double ragged_cost(const grail_ctx *ctx, const grail_batch *batch, const Family 
         Family lane = f;
         lane.split_k = 0;
         lane.L = 1;
-        const double rounds = std::ceil(std::ceil((double)rows / 64.0) * f.split_k / (double)simds);
+        const double rounds = f.split_active ? std::ceil((double)f.split_active / (double)simds)
+                                             : std::ceil(std::ceil((double)rows / 64.0) * f.split_k / (double)simds);
         return rounds * (1.2 * ragged_wave_ms(lane, (double)f.split_bounds[1], segs * part, kinks * part) + 0.12);
     }
     // waves of 64 / L consecutive slots, handed out in launch order to the SIMD that falls free first

@@ -59,6 +59,9 @@
 #ifndef GRAIL_MIXED_RUNS_PIPE
 #define GRAIL_MIXED_RUNS_PIPE 1
 #endif
+#ifndef GRAIL_SPLIT_SKIP
+#define GRAIL_SPLIT_SKIP 1
+#endif
 #ifndef GRAIL_PIPE_PARTIAL
 #define GRAIL_PIPE_PARTIAL 1
 #endif
@@ -541,6 +544,19 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     const bool slot_used = u0 + slot < A.n_utt;
     const uint32_t u = !slot_used ? A.n_utt : (A.perm ? A.perm[u0 + slot] : u0 + slot);
     bool done = !slot_used;
+    if constexpr (SPLIT && GRAIL_SPLIT_SKIP) {
+        // a chunk's lane whose utterance ends before the chunk begins (the host's upper bound of its length) has nothing
+        // to render — no fast-forward, no warm-up; a wave of such lanes is gone at once.  Rows that differ in length are
+        // launched longest first, so the waves of the later chunks are the ones that go, and the host lays out more,
+        // shorter chunks than the device has SIMDs for (launch_plan.cpp).
+        if (A.len_bound != nullptr && slot_used && chunk > 0u && A.len_bound[u] <= A.split_bounds[chunk]) done = true;
+        if (__builtin_amdgcn_ballot_w64(!done) == 0) {
+#ifdef GRAIL_FAST_PROF
+            if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(A.truncated + 8) + 30, 1ull);
+#endif
+            return;
+        }
+    }
     const uint32_t uc = done ? 0u : u;
     __shared__ uint32_t rowid_all[PIPE ? 1 : WAVES][S];
     uint32_t *rowid = rowid_all[PIPE ? 0 : wave];

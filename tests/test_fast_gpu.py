@@ -1240,3 +1240,40 @@ def test_two_waves_per_simd_instantiations_give_the_same_bits(gpu_ctx, n_voices,
         assert np.array_equal(got[1][u, :ref_len[u]].view(np.uint32), got[0][u, :ref_len[u]].view(np.uint32)), u
     k = _worst(got[1], ref, ref_len)
     assert 0.0 < k * ULP <= TOL, k
+
+
+@pytest.mark.parametrize("n_voices", [1, 8])
+def test_time_split_lays_out_more_chunks_for_rows_that_differ_in_length(gpu_ctx, n_voices):
+    """Speech-like rows on the time-split kernels: the upload keeps an upper bound of every utterance's length on the device,
+    a chunk's lane whose utterance ends before the chunk begins renders nothing (no fast-forward, no warm-up) and a wave of
+    such lanes is gone at once — so a batch whose grid would be coarse (a device made small here: 3 chunks) gets up to
+    2 K - 1.  Same contract: lengths equal to the oracle's for every row, every sample within the tolerance; and the grid an
+    aligned batch would get, pinned, likewise."""
+    voices = W.single_voice() if n_voices == 1 else W.preset_voices(8)
+    gpu_ctx.set_voices(voices)
+    n = 1500
+    segs, offs, vids, seeds, stride = W.speech_like_batch(n, np.random.default_rng(41), n_voices=n_voices, scale=0.25)
+    try:
+        gpu_ctx.set_option("assume_compute_units", 18)     # 72 SIMDs, 24 waves per chunk: 3 chunks
+        gpu_ctx.set_option("time_parallel_scan", 0)
+        gpu_ctx.set_option("ragged_plan", 0)               # (by its events the batch might go to a lane mapping)
+        gpu_ctx.set_option("time_split_min_utterances", 0)
+        out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
+        name, chunks = gpu_ctx.last_kernel_name(), gpu_ctx.get_option("last_launch_chunks")
+        assert "SPLIT" in name and "FAST" in name, name
+        assert 3 < chunks <= 5, chunks
+        ref, ref_len = O.synthesize_batch(_ovoices(voices), segs, offs, vids, seeds, stride)
+        assert np.array_equal(out_len, ref_len)
+        k = _worst_rel(out, ref, ref_len)
+        assert 0.0 < k <= TOL / ULP, k
+        gpu_ctx.set_option("time_split_chunks", 3)
+        pinned, pinned_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride)
+        assert gpu_ctx.get_option("last_launch_chunks") == 3
+        assert np.array_equal(pinned_len, ref_len) and _worst_rel(pinned, ref, ref_len) <= TOL / ULP
+    finally:
+        gpu_ctx.set_option("time_split_chunks", 0)
+        gpu_ctx.set_option("time_split_min_utterances", -1)
+        gpu_ctx.set_option("ragged_plan", 1)
+        gpu_ctx.set_option("time_parallel_scan", 1)
+        gpu_ctx.set_option("assume_compute_units", 0)
+        gpu_ctx.set_voices(W.single_voice())
