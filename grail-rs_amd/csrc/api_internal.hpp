@@ -152,6 +152,7 @@ struct grail_batch {
     uint32_t *d_perm = nullptr;   // ragged batches: launch slot -> utterance, longest first
     uint32_t *d_len_bound = nullptr;   // per utterance: an upper bound of its length in samples (plain batches; time-split kernels)
     uint64_t len_bound_epoch = 0;      // ... for the voice table of this epoch (its highest sample rate)
+    bool len_bound_known = false;      // (the planner's question; grail_plan_ragged_blocks answers it without a device)
     float *d_elems = nullptr;  // elem mode only
     uint32_t n_utt = 0;
     uint32_t n_segs = 0;

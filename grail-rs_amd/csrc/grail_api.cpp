@@ -109,6 +109,7 @@ int upload_len_bound(grail_ctx *ctx, grail_batch *b, const std::vector<RowStats>
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     b->len_bound_epoch = ctx->voices_epoch;
+    b->len_bound_known = true;
     return GRAIL_OK;
 }
 

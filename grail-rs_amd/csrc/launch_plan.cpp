@@ -258,7 +258,7 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
             return pairs;
         };
         const bool by_length = !ctx->split_chunks && !ctx->split_span && rows_differ && fam == batch->n_utt &&
-                               batch->d_len_bound != nullptr && batch->len_bound_epoch == ctx->voices_epoch;
+                               batch->len_bound_known && batch->len_bound_epoch == ctx->voices_epoch;
         K = (int)std::fmin((double)K, sp / 512.0);
         // (a fast-forwarded sample costs the same whatever is rendered afterwards; a rendered sample of eight live
         // formants costs 1.5 x one of four; 0.8 from a sweep, profiles/r03_small_batch.txt)
@@ -679,6 +679,7 @@ static int plan_preview(uint32_t compute_units, int arithmetic, int live_formant
     batch.min_length = 1e9f;
     batch.min_pitch = 0.25f;
     if (row_samples) {
+        batch.len_bound_known = true;        // (what upload_len_bound keeps)
         // (what upload_length_order keeps of a length-sorted batch)
         const size_t n_gran = ((size_t)rows + 7) / 8;
         batch.granule_samples.assign(n_gran, 0.0f);
