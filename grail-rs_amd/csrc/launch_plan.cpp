@@ -324,9 +324,24 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
         take_split = split.split_k && (int64_t)fam * 6 >= ctx->split_min_utts * (l4ab ? 6 : 5);
         take_scan = !take_split && scan.scan;
     } else {
-        const double c_lane = family_cost(ctx, f, fam, span);
-        const double c_split = split.split_k ? family_cost(ctx, split, fam, span) : INFINITY;
-        const double c_scan = scan.scan ? family_cost(ctx, scan, fam, span) : INFINITY;
+        double c_lane = family_cost(ctx, f, fam, span);
+        double c_split = split.split_k ? family_cost(ctx, split, fam, span) : INFINITY;
+        double c_scan = scan.scan ? family_cost(ctx, scan, fam, span) : INFINITY;
+        if (rows_differ && fam == batch->n_utt) {
+            // Rows that differ in length (the whole batch, its summary from the upload): the three families part ways.  The
+            // scan kernel gives every utterance a workgroup of its own — what a compute unit works off is the SUM of its
+            // utterances' lengths, whatever their spread, and an event costs a workgroup next to nothing (lanes are time) —
+            // while a time-split lane fast-forwards through the events of 64 utterances and waits for the longest of them:
+            // 4 096 speech-like utterances 6.7 ms on the scan kernel, 15.5 time-split (aligned: 6.4 against 3.3); with
+            // phonemes of 16 - 64 ms 3.2 against 11.2.  Priced by the rows: mean length for the scan kernel (plus one
+            // workgroup's way through the longest row), lengths and events (ragged_cost) for the other two.
+            double mean = 0.0;
+            for (const float g : batch->granule_samples) mean += (double)g;
+            mean /= (double)batch->granule_samples.size();
+            if (scan.scan) c_scan = family_cost(ctx, scan, fam, std::fmin(mean + 64.0, span)) + family_cost(ctx, scan, 1u, span);
+            if (split.split_k) c_split = ragged_cost(ctx, batch, split, 0u, fam, span);
+            c_lane = ragged_cost(ctx, batch, f, 0u, fam, span);
+        }
         take_split = c_split <= c_scan && c_split < c_lane;
         take_scan = !take_split && c_scan < c_lane;
     }
@@ -490,7 +505,15 @@ double ragged_cost(const grail_ctx *ctx, const grail_batch *batch, const Family 
     // 16 / 8 utterances in rounds of 32 samples; a round that holds a segment boundary of one of them costs it ~11 us more (14
     // before the runs between events):
     // 256 utterances with phonemes of 4 - 16 ms take 5.7 ms where their 0.39 s alone would take 1.3)
-    if (f.scan || f.pipe) {
+    if (f.scan) {
+        // one workgroup per utterance: a compute unit works off the sum of its utterances' lengths (choose_family)
+        double mean = 0.0;
+        for (size_t g = g0; g < g1; ++g) mean += (double)batch->granule_samples[g];
+        mean /= (double)(g1 - g0);
+        return family_cost(ctx, f, rows, std::fmin(mean + 64.0, span)) +
+               family_cost(ctx, f, 1u, std::fmin(span, (double)batch->granule_samples[g0] + 64.0));
+    }
+    if (f.pipe) {
         const double longest = std::fmin(span, std::fmax((double)batch->granule_samples[g0], 0.0) + 64.0);
         double c = family_cost(ctx, f, rows, longest);
         if (f.pipe) {
@@ -627,6 +650,18 @@ void ragged_plan(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_st
         if (c < best) {
             best = c;
             plan = exact;
+        }
+    }
+    // ... the ONE launch the batch as a whole would get (choose_family weighs scan, time-split and lane kernels by the rows
+    // when it is asked about the whole batch; the cut above was made block by block, by the aligned model: 6 000 speech-like
+    // utterances as 4 096 + 1 904 time-split rows took 26.9 ms, the scan kernel takes 10.9)
+    {
+        Family whole;
+        choose_family(ctx, batch, out_stride, rows, whole, false);
+        const double c = ragged_cost(ctx, batch, whole, 0, rows, span) + Planner::LAUNCH_MS;
+        if (c < best) {
+            best = c;
+            plan.assign(1, Block{rows, whole});
         }
     }
     // ... and ONE launch of each lane mapping in as many rounds as it takes

@@ -1201,9 +1201,21 @@ def test_every_fast_family_on_a_speech_like_corpus(gpu_ctx, family, n_voices):
             k = _worst(out, ref, ref_len)
             worst = max(worst, k)
             assert 0.0 < k * ULP <= TOL, (family, scale, k)
+            if family == "scan" and "SPLIT" in name:
+                # ... and the two-stage flavour, which batches of a few thousand rows that differ in length get (eight live
+                # formants: the only one)
+                gpu_ctx.set_option("time_parallel_scan_split_max_utterances", 0)
+                out, out_len = _render(gpu_ctx, True, segs, offs, vids, seeds, stride, 0)
+                name = gpu_ctx.last_kernel_name()
+                assert "scan" in name and "SPLIT" not in name, name
+                assert np.array_equal(out_len, ref_len)
+                k = _worst(out, ref, ref_len)
+                worst = max(worst, k)
+                assert 0.0 < k * ULP <= TOL, (family, scale, k, name)
     finally:
         for k_, v_ in (("arithmetic", 0), ("lanes_per_utterance", 0), ("ragged_plan", 1), ("time_split", 1), ("time_parallel_scan", 1),
-                       ("time_split_min_utterances", -1), ("time_parallel_scan_max_utterances", -1)):
+                       ("time_split_min_utterances", -1), ("time_parallel_scan_max_utterances", -1),
+                       ("time_parallel_scan_split_max_utterances", -1)):
             gpu_ctx.set_option(k_, v_)
         _split(gpu_ctx, 0)
     print(f"speech-like corpus, {family}, voices={n_voices}: max |d| = {worst:.1f} * 2^-23")

@@ -184,7 +184,7 @@ def test_dense_events_serve_a_fast_request_with_the_exact_cut():
     """Phonemes of 4 - 16 ms: an event of some lane in nearly every tile costs the fast kernels more than they save
     (4 096 utterances: 12.7 ms time-split, 5.1 ms exact; 65 536: 30.7 against 10.5) — the planner prices both and takes the
     exact families, whose bits satisfy the tolerance trivially.  A few utterances keep the scan kernel; the speech-like
-    corpus itself (phonemes of 40 - 160 ms) keeps its time-split kernels at 4 096."""
+    corpus itself (phonemes of 40 - 160 ms) takes the scan kernel at 4 096 and the time-split kernels at 16 384."""
     rng = np.random.default_rng(3)
     def rows(n, scale):
         counts = rng.integers(8, 33, n)
@@ -195,14 +195,23 @@ def test_dense_events_serve_a_fast_request_with_the_exact_cut():
         kinks = np.add.reduceat((blend < length).astype(np.int64), offs[:-1])
         o = np.argsort(-samples, kind="stable")
         return samples[o].astype(np.uint32), counts[o].astype(np.uint32), kinks[o].astype(np.uint32)
-    for n in (4096, 8192, 65536):
+    for n in (12000, 16384, 65536):
         plan = G.plan_ragged_blocks(*rows(n, 0.1), arithmetic=1, live_formants=4)
         assert sum(b.rows for b in plan) == n and all(b.fast == 0 and b.chunks == 0 and b.scan == 0 for b in plan), n
+    # (up to 8 704 utterances the scan kernel is a candidate, and rows of different lengths are its own ground: a workgroup per
+    # utterance, lanes = time — 4 096 such utterances 1.2 ms where the exact kernels take 4.1)
+    for n in (4096, 8192):
+        plan = G.plan_ragged_blocks(*rows(n, 0.1), arithmetic=1, live_formants=4)
+        assert len(plan) == 1 and plan[0].rows == n and plan[0].scan != 0, n
     # (200 000 of them are six waves per SIMD on two lanes per utterance: there the fast kernels' two waves per SIMD draw level
     # with the exact one-lane kernels — 27.6 against 26.2 - 27.2 ms measured — and either plan is a good one)
     plan = G.plan_ragged_blocks(*rows(200000, 0.1), arithmetic=1, live_formants=4)
     assert sum(b.rows for b in plan) == 200000 and all(b.chunks == 0 and b.scan == 0 for b in plan)
     few = G.plan_ragged_blocks(*rows(256, 0.1), arithmetic=1, live_formants=4)
     assert len(few) == 1 and few[0].scan and few[0].fast == 1
+    # the speech-like corpus itself (phonemes of 40 - 160 ms): the scan kernel up to 8 704 utterances (4 096: 6.7 ms, 15.5 on the
+    # time-split kernels, which fast-forward through 64 utterances' events and wait for the longest), time-split beyond
     speech = G.plan_ragged_blocks(*rows(4096, 1.0), arithmetic=1, live_formants=4)
-    assert len(speech) == 1 and speech[0].chunks >= 2 and speech[0].fast == 1
+    assert len(speech) == 1 and speech[0].scan != 0 and speech[0].fast == 1
+    speech = G.plan_ragged_blocks(*rows(16384, 1.0), arithmetic=1, live_formants=4)
+    assert len(speech) == 1 and speech[0].chunks >= 5 and speech[0].fast == 1
