@@ -394,6 +394,12 @@ struct Planner {
         std::pair<Family, double> e;
         choose_family(ctx, batch, out_stride, rows, e.first, exact_only);
         e.second = family_cost(ctx, e.first, rows, span);
+        // (option "ragged_plan" off, rows that differ in length: choose_family has weighed the whole batch's families by the
+        // rows — the price of that one launch is the rows' too, or a cut priced by the aligned model undoes the choice; with
+        // the option on ragged_plan weighs the same launch against whatever cut is made here)
+        if (!ctx->ragged_option && batch != nullptr && rows == batch->n_utt && batch->granule_samples.size() > 1 &&
+            batch->granule_samples.front() != batch->granule_samples.back())
+            e.second = ragged_cost(ctx, batch, e.first, 0u, rows, span);
         return families.emplace(rows, e).first->second;
     }
     const std::pair<double, std::vector<Block>> &plan(uint32_t rows, int depth)
@@ -514,7 +520,15 @@ double ragged_cost(const grail_ctx *ctx, const grail_batch *batch, const Family 
                family_cost(ctx, f, 1u, std::fmin(span, (double)batch->granule_samples[g0] + 64.0));
     }
     if (f.pipe) {
-        const double longest = std::fmin(span, std::fmax((double)batch->granule_samples[g0], 0.0) + 64.0);
+        double longest = std::fmin(span, std::fmax((double)batch->granule_samples[g0], 0.0) + 64.0);
+        // (two workgroups per compute unit: the one with the shorter rows ends early and leaves the unit to the other —
+        // 8 192 speech-like utterances take 19.6 ms where their longest row at the rate of two resident workgroups would
+        // take 21.0; with phonemes of 16 - 64 ms 10.3, of 4 - 16 ms 4.6: profiles/r05_mixed_runs.txt)
+        if (std::ceil((double)rows / (f.live4 ? 16.0 : 8.0)) > (double)ctx->cus) {
+            double mean = 0.0;
+            for (size_t g = g0; g < g1; ++g) mean += (double)batch->granule_samples[g];
+            longest = 0.55 * longest + 0.45 * std::fmin(longest, mean / (double)(g1 - g0) + 64.0);
+        }
         double c = family_cost(ctx, f, rows, longest);
         if (f.pipe) {
             c *= 1.15;      // (ragged corpora measure 15 - 25 % over the aligned rate before any event: pitch contours, stops)
