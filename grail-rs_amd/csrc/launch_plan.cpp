@@ -394,10 +394,10 @@ struct Planner {
         std::pair<Family, double> e;
         choose_family(ctx, batch, out_stride, rows, e.first, exact_only);
         e.second = family_cost(ctx, e.first, rows, span);
-        // (option "ragged_plan" off, rows that differ in length: choose_family has weighed the whole batch's families by the
+        // (option "ragged_plan" off, rows that differ in length, scan or time-split kernels: choose_family has weighed the whole batch's families by the
         // rows — the price of that one launch is the rows' too, or a cut priced by the aligned model undoes the choice; with
         // the option on ragged_plan weighs the same launch against whatever cut is made here)
-        if (!ctx->ragged_option && batch != nullptr && rows == batch->n_utt && batch->granule_samples.size() > 1 &&
+        if (!ctx->ragged_option && (e.first.scan || e.first.split_k) && batch != nullptr && rows == batch->n_utt && batch->granule_samples.size() > 1 &&
             batch->granule_samples.front() != batch->granule_samples.back())
             e.second = ragged_cost(ctx, batch, e.first, 0u, rows, span);
         return families.emplace(rows, e).first->second;
@@ -669,7 +669,7 @@ void ragged_plan(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_st
     // ... the ONE launch the batch as a whole would get (choose_family weighs scan, time-split and lane kernels by the rows
     // when it is asked about the whole batch; the cut above was made block by block, by the aligned model: 6 000 speech-like
     // utterances as 4 096 + 1 904 time-split rows took 26.9 ms, the scan kernel takes 10.9)
-    {
+    if (ctx->fast_option) {       // (exact arithmetic: that launch is one of the lane mappings below)
         Family whole;
         choose_family(ctx, batch, out_stride, rows, whole, false);
         const double c = ragged_cost(ctx, batch, whole, 0, rows, span) + Planner::LAUNCH_MS;
