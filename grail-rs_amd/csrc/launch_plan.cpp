@@ -327,8 +327,9 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
         double c_lane = family_cost(ctx, f, fam, span);
         double c_split = split.split_k ? family_cost(ctx, split, fam, span) : INFINITY;
         double c_scan = scan.scan ? family_cost(ctx, scan, fam, span) : INFINITY;
-        if (rows_differ && fam == batch->n_utt) {
-            // Rows that differ in length (the whole batch, its summary from the upload): the three families part ways.  The
+        if (ctx->ragged_option && rows_differ && fam == batch->n_utt) {
+            // Rows that differ in length (the whole batch, its summary from the upload; part of option "ragged_plan"): the three
+            // families part ways.  The
             // scan kernel gives every utterance a workgroup of its own — what a compute unit works off is the SUM of its
             // utterances' lengths, whatever their spread, and an event costs a workgroup next to nothing (lanes are time) —
             // while a time-split lane fast-forwards through the events of 64 utterances and waits for the longest of them:
@@ -394,12 +395,6 @@ struct Planner {
         std::pair<Family, double> e;
         choose_family(ctx, batch, out_stride, rows, e.first, exact_only);
         e.second = family_cost(ctx, e.first, rows, span);
-        // (option "ragged_plan" off, rows that differ in length, scan or time-split kernels: choose_family has weighed the whole batch's families by the
-        // rows — the price of that one launch is the rows' too, or a cut priced by the aligned model undoes the choice; with
-        // the option on ragged_plan weighs the same launch against whatever cut is made here)
-        if (!ctx->ragged_option && (e.first.scan || e.first.split_k) && batch != nullptr && rows == batch->n_utt && batch->granule_samples.size() > 1 &&
-            batch->granule_samples.front() != batch->granule_samples.back())
-            e.second = ragged_cost(ctx, batch, e.first, 0u, rows, span);
         return families.emplace(rows, e).first->second;
     }
     const std::pair<double, std::vector<Block>> &plan(uint32_t rows, int depth)

@@ -253,9 +253,10 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *                           launch per call.  bits: fast (a row follows its block's family).
  *   "row_groups"            1 (default) / 0 / 2: rows the lean kernel families cannot take (a segment shorter than two samples,
  *                           a non-finite length, blend length or pitch) are planned apart where cheaper / never / always.
- *   "ragged_plan"           1 (default) / 0: batches whose utterances differ in length are weighed against one launch of each
- *                           lane mapping in several rounds, by the rows' lengths and events (grail_plan_ragged_blocks); a fast
- *                           request may be served by an exact mapping where that is cheaper ("last_launch_fast").  bits: fast.
+ *   "ragged_plan"           1 (default) / 0: batches whose utterances differ in length are planned by the rows' lengths and
+ *                           events (grail_plan_ragged_blocks): one launch of each lane mapping in several rounds, and in fast
+ *                           arithmetic the scan and time-split kernels, are weighed against the cut by size; a fast request may
+ *                           be served by an exact mapping where that is cheaper ("last_launch_fast").  bits: fast.
  *   "two_waves_per_simd"    1 (default) / 0: launches of the 2 / 4 / 8-lane kernels with more wavefronts than the device has
  *                           SIMDs take instantiations built for two wavefronts per SIMD (same operations, same bits).
  *   "sort_by_length"        1 (default) / 0: batches uploaded afterwards fill the launch slots longest first (rows stay put).
