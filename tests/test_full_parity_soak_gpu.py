@@ -3,8 +3,9 @@ samples — against the oracle, through per-utterance checksums (sum of the samp
 mod 2^64, computed on the device for the HIP rows and on the host for the oracle's).  The oracle
 renders the batch in chunks on all host cores; a few minutes of CPU, so it is not part of the
 default suite.  GRAIL_SOAK_UTTS picks another batch size (another kernel family), GRAIL_SOAK_FIRST the first
-utterance of the synthetic corpus (k * 65536: shard k of BASELINE config 5, what rank k of an 8-GPU run renders).
-Last runs: profiles/r03_full_parity.txt."""
+utterance of the synthetic corpus (k * 65536: shard k of BASELINE config 5, what rank k of an 8-GPU run renders),
+GRAIL_SOAK_SPEECH=<scale> the speech-like corpus instead of the bench corpus.
+Last runs: profiles/r03_full_parity.txt, r05_full_parity.txt, r05_full_parity_speech_like.txt."""
 import os
 
 import numpy as np
@@ -37,6 +38,11 @@ def test_every_utterance_of_the_full_batch(gpu_ctx, n_voices):
         segs["frequency"] = (rng.choice([70.0, 110.0, 200.0, 400.0], k) / 48000.0).astype(np.float32)
         segs["phoneme"] = rng.choice([G.PH_SILENCE, G.PH_A, G.PH_E, G.PH_A], k)
         stride = 4 * 14400 + 64
+    if os.environ.get("GRAIL_SOAK_SPEECH"):
+        # the speech-like corpus (rows of 0.5 - 3.8 s; GRAIL_SOAK_SPEECH = the scale of its phoneme lengths): the launch plan
+        # by the rows' lengths and events — wider mappings in several rounds, two waves per SIMD, the runs between events
+        segs, offs, vids, seeds, stride = W.speech_like_batch(n_utt, np.random.default_rng(7), n_voices=n_voices,
+                                                              scale=float(os.environ["GRAIL_SOAK_SPEECH"]))
     b = gpu_ctx.upload(segs, offs, vids, seeds)
     d_out = gpu_ctx.device_alloc(n_utt * stride * 4)
     d_len = gpu_ctx.device_alloc(n_utt * 4)
