@@ -88,21 +88,33 @@ struct RowStats {
     bool any_blend = false;     // some blend length is not +-2^k
     float min_length = INFINITY, min_pitch = INFINITY, seconds = 0.0f;
     uint32_t segs = 0, kinks = 0;   // segments; those whose alpha = min(clk / blend_length, 1) has a kink (blend_length < length)
-    double bound_seconds = 0.0;     // sum of the positive segment lengths: no utterance lasts longer (every advance adds its
-                                    // segment's length to the clock, :873 / :882; a segment that leaves the clock negative
-                                    // still takes a sample: + segs below)
+    double bound_samples = 0.0;     // grail_length_bound of the row at the table's highest sample rate (INFINITY: none)
 };
+
+// What one segment can last at most, in samples.  Every advance adds the segment's length to the clock (:873 / :882), every
+// sample takes dt off it in f32 (:861): a step lowers the clock by at least dt - ulp(length) / 2 (the clock is at most the
+// length while the segment lasts), so the segment is over after length / (dt - ulp / 2) steps, + 1 for the step that finds
+// the clock negative, + 1 for a segment that leaves it negative and still takes its sample.  At 192 kHz a segment of 16 s
+// lasts up to 22 % longer than its nominal 3 072 000 samples (ulp(16) / 2 = 0.18 dt) — in the reference as here.
+static double segment_bound(float length, double dt)
+{
+    if (!(length > 0.0f)) return 2.0;
+    int e = 0;
+    (void)std::frexp(length, &e);                       // length = m 2^e, m in [0.5, 1): ulp = 2^(e - 24)
+    const double half_ulp = std::ldexp(1.0, e - 25);
+    if (!(dt > 2.0 * half_ulp)) return INFINITY;        // (the clock may not move at all)
+    return (double)length / (dt - half_ulp) + 2.0;
+}
 
 // An upper bound of every utterance's length in samples, on the device (time-split kernels: a chunk's lane whose utterance
 // ends before the chunk begins has nothing to render and says so at once — batches whose rows differ in length then take
-// more, shorter chunks; launch_plan.cpp).  Sum of the positive lengths at the table's highest sample rate, + 2 % for what
-// the f32 clock's roundings can add up to over a long segment, + two samples per segment + a tile.
+// more, shorter chunks; launch_plan.cpp): grail_length_bound at the table's highest sample rate, + a tile.
 int upload_len_bound(grail_ctx *ctx, grail_batch *b, const std::vector<RowStats> &rows, uint32_t n_utt)
 {
     if (!b->plain || n_utt == 0 || ctx->voices.empty()) return GRAIL_OK;
     std::vector<uint32_t> bound(n_utt);
     for (uint32_t u = 0; u < n_utt; ++u) {
-        const double samples = rows[u].bound_seconds * (double)ctx->max_rate * 1.02 + 2.0 * (double)rows[u].segs + 64.0;
+        const double samples = rows[u].bound_samples + 64.0;
         bound[u] = samples < 4.0e9 ? (uint32_t)samples : 0xFFFFFFFFu;
     }
     int rc = upload(&b->d_len_bound, bound.data(), n_utt, ctx->stream);
@@ -445,6 +457,18 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
     return GRAIL_OK;
 }
 
+uint64_t grail_length_bound(const float *segment_lengths, uint32_t n_segments, float sample_rate)
+{
+    if (!(sample_rate > 0.0f) || (n_segments && !segment_lengths)) return UINT64_MAX;
+    const double dt = (double)(1.0f / sample_rate);
+    double samples = 0.0;
+    for (uint32_t i = 0; i < n_segments; ++i) {
+        if (!std::isfinite(segment_lengths[i])) return UINT64_MAX;
+        samples += segment_bound(segment_lengths[i], dt);
+    }
+    return samples < 1.8e19 ? (uint64_t)samples : UINT64_MAX;
+}
+
 int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
 {
     if (!ctx || !name) return fail(GRAIL_ERR_INVALID_ARG, "NULL argument");
@@ -742,6 +766,8 @@ int grail_batch_upload(grail_ctx *ctx, const grail_phoneme_elem *segs, const uin
             return fail(GRAIL_ERR_INVALID_ARG, "phoneme discriminant out of range");
     // per utterance, then over the batch: what the launch policy asks of the segments
     std::vector<RowStats> rows(n_utt);
+    // (the device's dt of the table's highest sample rate, as the kernels have it: an f32 reciprocal)
+    const double min_dt = ctx->max_rate > 0.0f ? (double)(1.0f / ctx->max_rate) : 0.0;
     for (uint32_t u = 0; u < n_utt; ++u) {
         RowStats &r = rows[u];
         for (uint32_t i = seg_offsets[u]; i < seg_offsets[u + 1]; ++i) {
@@ -752,7 +778,7 @@ int grail_batch_upload(grail_ctx *ctx, const grail_phoneme_elem *segs, const uin
             const float pitch = std::fmin(segs[i].frequency, 0.5f);   // copy_with_frequency :445-450
             if (pitch < r.min_pitch) r.min_pitch = pitch;
             r.seconds += segs[i].length;
-            if (segs[i].length > 0.0f) r.bound_seconds += (double)segs[i].length;
+            r.bound_samples += segment_bound(segs[i].length, min_dt);
             r.segs += 1u;
             r.kinks += segs[i].blend_length < segs[i].length ? 1u : 0u;
         }
@@ -806,6 +832,8 @@ int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
     // (what the launch policy asks of the segments, per utterance and over the batch, as for phoneme batches; a
     // caller-built elem keeps its frequency as it is, copy_with_frequency's min(f, 0.5) :445-450 belongs to the Selector)
     std::vector<RowStats> rows(n_utt);
+    // (the device's dt of the table's highest sample rate, as the kernels have it: an f32 reciprocal)
+    const double min_dt = ctx->max_rate > 0.0f ? (double)(1.0f / ctx->max_rate) : 0.0;
     for (uint32_t u = 0; u < n_utt; ++u) {
         RowStats &r = rows[u];
         for (uint32_t i = seg_offsets[u]; i < seg_offsets[u + 1]; ++i) {
@@ -815,7 +843,7 @@ int grail_batch_upload_elems(grail_ctx *ctx, const grail_sequence_elem *segs,
             if (segs[i].length < r.min_length) r.min_length = segs[i].length;
             if (segs[i].elem.frequency < r.min_pitch) r.min_pitch = segs[i].elem.frequency;
             r.seconds += segs[i].length;
-            if (segs[i].length > 0.0f) r.bound_seconds += (double)segs[i].length;
+            r.bound_samples += segment_bound(segs[i].length, min_dt);
             r.segs += 1u;
             r.kinks += segs[i].blend_length < segs[i].length ? 1u : 0u;
         }

@@ -42,7 +42,7 @@ FAST_TOLERANCE_NOTE = (f"fast mode: max |fast - exact| <= {FAST_TOLERANCE_ULPS} 
                        "full scale vs the oracle (tests/test_fast_gpu.py asserts it on configs 2, 3, 4 "
                        "and a fuzz corpus); clock, phases, wraps and LCGs stay exact")
 UNIQUE_ID_BYTES = 128
-ABI_VERSION = 2                  # GRAIL_ABI_VERSION of the header this binding mirrors
+ABI_VERSION = 3                  # GRAIL_ABI_VERSION of the header this binding mirrors
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRAIL_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib",
@@ -53,7 +53,7 @@ EXPORTS = [
     "grail_abi_version", "grail_status_string", "grail_last_error",
     "grail_elem_silent", "grail_elem_new_phoneme", "grail_elem_new", "grail_elem_resample",
     "grail_elem_blend", "grail_voice_generic", "grail_voice_generic_at", "grail_voice_get",
-    "grail_create", "grail_destroy", "grail_device_count", "grail_device_pci_bus_id", "grail_time_split_warmup",
+    "grail_create", "grail_destroy", "grail_device_count", "grail_device_pci_bus_id", "grail_time_split_warmup", "grail_length_bound",
     "grail_time_split_grid", "grail_fast_sharpness", "grail_plan_blocks", "grail_plan_ragged_blocks", "grail_set_voices",
     "grail_get_voices", "grail_set_option", "grail_get_option",
     "grail_batch_upload", "grail_batch_upload_elems", "grail_batch_free", "grail_batch_size",
@@ -209,6 +209,8 @@ def load():
     L.grail_destroy.argtypes = [vp]
     L.grail_device_count.argtypes = [C.POINTER(C.c_int)]
     L.grail_device_pci_bus_id.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.grail_length_bound.argtypes = [C.POINTER(C.c_float), C.c_uint32, C.c_float]
+    L.grail_length_bound.restype = C.c_uint64
     L.grail_time_split_warmup.argtypes = [C.POINTER(Voice)]
     L.grail_time_split_warmup.restype = C.c_uint32
     L.grail_fast_sharpness.argtypes = [C.POINTER(Voice)]
@@ -402,6 +404,13 @@ def text_to_phoneme_elems(voice, text):
 def wav_write_i16(path, pcm, sample_rate):
     pcm = np.ascontiguousarray(pcm, dtype=np.int16)
     _check(load().grail_wav_write_i16(path.encode(), pcm.ctypes.data, len(pcm), int(sample_rate)))
+
+
+def length_bound(segment_lengths, sample_rate):
+    """An upper bound of an utterance's length in samples (grail_length_bound); None: no bound."""
+    a = np.ascontiguousarray(segment_lengths, dtype=np.float32)
+    v = int(load().grail_length_bound(a.ctypes.data_as(C.POINTER(C.c_float)), len(a), float(sample_rate)))
+    return None if v == 2 ** 64 - 1 else v
 
 
 def time_split_warmup(voice):

@@ -1,4 +1,4 @@
-//! Raw mirror of `include/grail_hip.h` (ABI version 2: `GRAIL_ABI_VERSION`; compare it with
+//! Raw mirror of `include/grail_hip.h` (ABI version 3: `GRAIL_ABI_VERSION`; compare it with
 //! `grail_abi_version()` before the first call, as `grail_hip::Context::new` does).  Field orders follow grail-rs:
 //! `SynthesisElem` src/lib.rs:316-337, `Voice` :696-717, `PhonemeElem` :961-973,
 //! `SequenceElem` :814-824, `Phoneme` :632-649.
@@ -9,7 +9,7 @@ pub const GRAIL_NUM_FORMANTS: usize = 8;
 pub const GRAIL_NUM_VOICED: usize = 2;
 pub const GRAIL_UNIQUE_ID_BYTES: usize = 128;
 
-pub const GRAIL_ABI_VERSION: c_int = 2;
+pub const GRAIL_ABI_VERSION: c_int = 3;
 
 pub const GRAIL_OK: c_int = 0;
 pub const GRAIL_ERR_INVALID_ARG: c_int = -1;
@@ -122,6 +122,7 @@ extern "C" {
     pub fn grail_device_count(count: *mut c_int) -> c_int;
     pub fn grail_device_pci_bus_id(ctx: *mut grail_ctx, out: *mut c_char, cap: usize) -> c_int;
     pub fn grail_time_split_warmup(voice: *const grail_voice) -> u32;
+    pub fn grail_length_bound(segment_lengths: *const f32, n_segments: u32, sample_rate: f32) -> u64;
     pub fn grail_fast_sharpness(voice: *const grail_voice) -> f32;
     pub fn grail_time_split_grid(span_samples: u32, warmup: u32, chunks: u32, ff_cost_permille: u32,
                                  bounds: *mut u32) -> c_int;

@@ -78,8 +78,10 @@ extern "C" {
  * grail_abi_version() of the library it loaded BEFORE its first call (the Python and Rust bindings do).
  *   1: rounds 1-2.   2: round 3-4 — grail_device_pci_bus_id, grail_time_split_warmup / _grid, grail_fast_sharpness,
  *   grail_plan_blocks, grail_stream_open_live / _append / _append_elems / _finish / _pending; option "kernel_variant" removed, "scan_debug" in
- *   development builds only; "arithmetic" = 1 is served up to a sharpness of the voice table. */
-#define GRAIL_ABI_VERSION 2
+ *   development builds only; "arithmetic" = 1 is served up to a sharpness of the voice table.
+ *   3: round 5 — grail_length_bound; options "two_waves_per_simd", "pipeline_round32" = 2; "ragged_plan" also weighs the scan and
+ *   time-split kernels by the rows. */
+#define GRAIL_ABI_VERSION 3
 /* fast mode ("arithmetic" = 1): bound on |fast - exact| per sample, full scale = 1.0; k * 2^-23 */
 #define GRAIL_FAST_TOLERANCE_ULPS 64
 #define GRAIL_FAST_TOLERANCE (GRAIL_FAST_TOLERANCE_ULPS * 1.1920928955078125e-07f)
@@ -280,6 +282,15 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value);
  *   warming up and rendering take every chunk's lane the same time.  GRAIL_ERR_INVALID_ARG when so many chunks
  *   do not fit (a chunk would render fewer than 64 samples). */
 uint32_t grail_time_split_warmup(const grail_voice *voice);
+/* An upper bound of an utterance's length in samples (pure host arithmetic): the lengths of its segments in seconds and the
+ * sample rate of its voice.  Sequencer::next (src/lib.rs:859-888) adds every segment's length to an f32 clock and takes
+ * 1 / sample_rate off it per sample, so a segment lasts length * sample_rate samples only up to the clock's rounding: a step
+ * lowers it by at least dt - ulp(length) / 2, and the bound is the sum of length / (dt - ulp(length) / 2) + 2 over the
+ * segments (a segment of 16 s at 192 kHz may last 22 % longer than its nominal length — in the reference too).  For sizing
+ * out_stride without the device pre-pass (grail_batch_lengths gives the exact lengths); the time-split kernels use it to
+ * skip the chunks an utterance does not reach.  UINT64_MAX: no bound (a length that is not finite, a clock that may not
+ * move: dt <= ulp(length)). */
+uint64_t grail_length_bound(const float *segment_lengths, uint32_t n_segments, float sample_rate);
 /* The sharpness of a voice's resonances as the fast kernels see it: the predicted |fast - reference| in units of
  * 2^-23 of max(1, peak).  Per formant E_i = share_i * (0.0709 / bw_i) * (1 + (f_i / 0.075)^2) — share = the
  * formant's part of the phoneme's amplitudes, f and bw in cycles per sample, each the worst of the voice's

@@ -54,11 +54,11 @@ def test_header_option_list_equals_what_the_library_accepts():
 
 def test_abi_version_and_status_strings(built):
     lib = G.load()
-    assert lib.grail_abi_version() == G.ABI_VERSION == 2
+    assert lib.grail_abi_version() == G.ABI_VERSION == 3
     hdr = open(os.path.join(ROOT, "include", "grail_hip.h")).read()
-    assert re.search(r"#define GRAIL_ABI_VERSION (\d+)", hdr).group(1) == "2"
+    assert re.search(r"#define GRAIL_ABI_VERSION (\d+)", hdr).group(1) == "3"
     sys_rs = open(os.path.join(ROOT, "grail-rs_amd", "rust", "grail-hip-sys", "src", "lib.rs")).read()
-    assert "pub const GRAIL_ABI_VERSION: c_int = 2;" in sys_rs
+    assert "pub const GRAIL_ABI_VERSION: c_int = 3;" in sys_rs
     for st in range(0, -8, -1):
         assert lib.grail_status_string(st)
     assert b"CPU fallback" in lib.grail_status_string(G.ERR_NO_DEVICE)
