@@ -195,3 +195,38 @@ def test_long_segments_cross_the_binades_of_the_clock(gpu_ctx):
         gpu_ctx.set_option("arithmetic", 0)
     print("long segments:", "; ".join(ran))
     assert any("scan_kernel" in r for r in ran) and any("SPLIT" in r for r in ran)
+
+
+def test_mixed_sample_rates_on_the_time_split_grid_of_rows_that_differ(gpu_ctx):
+    """Rows of different lengths AND sample rates on the time-split kernels: the length bound that lets a chunk's lane skip
+    an utterance which ends before the chunk begins is taken at the table's HIGHEST rate (an utterance of a slower voice is
+    shorter in samples than its bound says: it is skipped later than it could be, never too early).  Lengths equal to the
+    oracle's for every row, sampled rows within the tolerance."""
+    rates = RATES[:6]
+    rng = np.random.default_rng(77)
+    voices = _voices(rates)
+    gpu_ctx.set_voices(voices)
+    n_utt = 1500
+    segs, offs, vids, seeds = _batch(rng, n_utt, 0.5, ragged=True, rates=rates)
+    stride = 48128
+    try:
+        gpu_ctx.set_option("assume_compute_units", 18)          # 24 waves per chunk on 72 SIMDs: a coarse grid
+        gpu_ctx.set_option("time_parallel_scan", 0)
+        gpu_ctx.set_option("ragged_plan", 0)
+        gpu_ctx.set_option("time_split_min_utterances", 0)
+        gpu_ctx.set_option("arithmetic", 1)
+        out, out_len = gpu_ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
+        name, chunks = gpu_ctx.last_kernel_name(), gpu_ctx.get_option("last_launch_chunks")
+    finally:
+        for k, v in (("arithmetic", 0), ("time_split_min_utterances", -1), ("ragged_plan", 1), ("time_parallel_scan", 1),
+                     ("assume_compute_units", 0)):
+            gpu_ctx.set_option(k, v)
+    assert "SPLIT" in name and chunks >= 3, (name, chunks)
+    ref, ref_len = _oracle(voices, segs, offs, vids, seeds, stride)
+    assert np.array_equal(out_len, ref_len)
+    worst = 0.0
+    for u in rng.choice(n_utt, size=120, replace=False):
+        n = int(ref_len[u])
+        peak = max(1.0, float(np.abs(ref[u, :n]).max()))
+        worst = max(worst, float(np.abs(out[u, :n] - ref[u, :n]).max()) / peak)
+    assert 0.0 < worst <= G.FAST_TOLERANCE, worst * 2 ** 23
