@@ -301,7 +301,11 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
     // filter recurrences solved by parallel scans (scan_kernels.hip).  Needs every parameter inside the safe window
     // (no IEEE fallback).
     Family scan = f;
-    if (f.fast == 1u && ctx->scan_option && !lanes_option && (int64_t)fam * (l4ab ? 4 : 7) <= 4 * scan_max_utts(ctx) &&
+    // (rows that differ in length, option "ragged_plan": up to 64 workgroups per compute unit — there the cost model decides,
+    // by the rows: 10 000 speech-like utterances 15.3 ms against 19.1 time-split, with phonemes of 16 - 64 ms 7.0 / 13.5)
+    const int64_t scan_limit = ctx->scan_max_utts < 0 && ctx->ragged_option && rows_differ && fam == batch->n_utt
+                                   ? 64 * (int64_t)ctx->cus : scan_max_utts(ctx);
+    if (f.fast == 1u && ctx->scan_option && !lanes_option && (int64_t)fam * (l4ab ? 4 : 7) <= 4 * scan_limit &&
         used_voices_all(ctx, batch, ctx->voices_scan_ok, [](const grail_ctx::VoiceInfo &v) { return v.scan_ok; }) &&
         (batch->phoneme_mode || (batch->elems_scan_ok && batch->elems_warmup_epoch == ctx->voices_epoch)) &&
         batch->plain && batch->min_length >= 2.0f * ctx->max_dt &&
@@ -334,12 +338,12 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
             // utterances' lengths, whatever their spread, and an event costs a workgroup next to nothing (lanes are time) —
             // while a time-split lane fast-forwards through the events of 64 utterances and waits for the longest of them:
             // 4 096 speech-like utterances 6.7 ms on the scan kernel, 15.5 time-split (aligned: 6.4 against 3.3); with
-            // phonemes of 16 - 64 ms 3.2 against 11.2.  Priced by the rows: mean length for the scan kernel (plus one
+            // phonemes of 16 - 64 ms 3.2 against 11.2.  Priced by the rows: mean length for the scan kernel (at least one
             // workgroup's way through the longest row), lengths and events (ragged_cost) for the other two.
             double mean = 0.0;
             for (const float g : batch->granule_samples) mean += (double)g;
             mean /= (double)batch->granule_samples.size();
-            if (scan.scan) c_scan = family_cost(ctx, scan, fam, std::fmin(mean + 64.0, span)) + family_cost(ctx, scan, 1u, span);
+            if (scan.scan) c_scan = std::fmax(family_cost(ctx, scan, fam, std::fmin(mean + 64.0, span)), family_cost(ctx, scan, 1u, span));
             if (split.split_k) c_split = ragged_cost(ctx, batch, split, 0u, fam, span);
             c_lane = ragged_cost(ctx, batch, f, 0u, fam, span);
         }
@@ -511,8 +515,8 @@ double ragged_cost(const grail_ctx *ctx, const grail_batch *batch, const Family 
         double mean = 0.0;
         for (size_t g = g0; g < g1; ++g) mean += (double)batch->granule_samples[g];
         mean /= (double)(g1 - g0);
-        return family_cost(ctx, f, rows, std::fmin(mean + 64.0, span)) +
-               family_cost(ctx, f, 1u, std::fmin(span, (double)batch->granule_samples[g0] + 64.0));
+        return std::fmax(family_cost(ctx, f, rows, std::fmin(mean + 64.0, span)),
+                         family_cost(ctx, f, 1u, std::fmin(span, (double)batch->granule_samples[g0] + 64.0)));
     }
     if (f.pipe) {
         double longest = std::fmin(span, std::fmax((double)batch->granule_samples[g0], 0.0) + 64.0);

@@ -195,12 +195,12 @@ def test_dense_events_serve_a_fast_request_with_the_exact_cut():
         kinks = np.add.reduceat((blend < length).astype(np.int64), offs[:-1])
         o = np.argsort(-samples, kind="stable")
         return samples[o].astype(np.uint32), counts[o].astype(np.uint32), kinks[o].astype(np.uint32)
-    for n in (12000, 16384, 65536):
+    for n in (20000, 65536):
         plan = G.plan_ragged_blocks(*rows(n, 0.1), arithmetic=1, live_formants=4)
         assert sum(b.rows for b in plan) == n and all(b.fast == 0 and b.chunks == 0 and b.scan == 0 for b in plan), n
-    # (up to 8 704 utterances the scan kernel is a candidate, and rows of different lengths are its own ground: a workgroup per
-    # utterance, lanes = time — 4 096 such utterances 1.2 ms where the exact kernels take 4.1)
-    for n in (4096, 8192):
+    # (up to 16 384 utterances of different lengths the scan kernel is a candidate, and such rows are its own ground: a workgroup
+    # per utterance, lanes = time — 4 096 such utterances 1.2 ms where the exact kernels take 4.1)
+    for n in (4096, 8192, 16384):
         plan = G.plan_ragged_blocks(*rows(n, 0.1), arithmetic=1, live_formants=4)
         assert len(plan) == 1 and plan[0].rows == n and plan[0].scan != 0, n
     # (200 000 of them are six waves per SIMD on two lanes per utterance: there the fast kernels' two waves per SIMD draw level
