@@ -66,6 +66,7 @@ struct grail_ctx {
     int64_t scan_max_utts = -1;       // ... up to this many utterances (x 4/7 with eight live formants; -1: 34 per CU = 8704)
     int64_t scan_split_max = -1;      // ... and up to this many with the carrier phase on a wave of its own (-1: 6 per CU = 1536)
     int ragged_option = 1;            // length-sorted batches: lane mappings weighed by the rows' lengths (ragged_plan)
+    int pipe_spread = 1;              // pipelined workgroups on rows that differ in length: few utterances per workgroup (pipe_fill_for)
     int two_waves_option = 1;         // tolerance-mode lane kernels on 2 / 4 / 8 lanes: two waves per SIMD where a launch has more waves than SIMDs
     int composite_option = 1;         // a batch may be cut into blocks with a kernel family each (plan_blocks)
     int row_groups_option = 1;        // rows the lean families cannot take are planned apart: 1 where the cost model says so, 2 always, 0 never
@@ -268,6 +269,8 @@ struct Block {
 int auto_lanes_per_utt(uint32_t n_utt, uint64_t simds);
 double batch_span(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride);
 double family_cost(const grail_ctx *ctx, const Family &f, uint32_t rows, double span);
+// pipelined workgroups, rows that differ in length: utterances per workgroup of a launch of `rows` rows (0: every slot)
+uint32_t pipe_fill_for(const grail_ctx *ctx, const grail_batch *batch, const Family &f, uint32_t rows);
 // a launch of `rows` rows with family f takes the instantiations built for two waves per SIMD (SynthArgs::cohabit)
 bool family_cohabits(const grail_ctx *ctx, const Family &f, uint32_t rows);
 bool batch_half_capable(const grail_ctx *ctx, const grail_batch *batch);

@@ -560,6 +560,10 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         ctx->two_waves_option = value ? 1 : 0;
         return GRAIL_OK;
     }
+    if (std::strcmp(name, "pipeline_spread") == 0) {
+        ctx->pipe_spread = value ? 1 : 0;
+        return GRAIL_OK;
+    }
     if (std::strcmp(name, "row_groups") == 0) {
         if (value < 0 || value > 2) return fail(GRAIL_ERR_INVALID_ARG, "row_groups must be 0 (off), 1 (by cost) or 2 (always)");
         ctx->row_groups_option = (int)value;
@@ -638,6 +642,10 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
     }
     if (std::strcmp(name, "two_waves_per_simd") == 0) {
         *value = ctx->two_waves_option;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "pipeline_spread") == 0) {
+        *value = ctx->pipe_spread;
         return GRAIL_OK;
     }
     if (std::strcmp(name, "pipeline4_max_groups") == 0) {

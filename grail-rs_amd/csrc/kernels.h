@@ -79,6 +79,8 @@ struct SynthArgs {
                                   // SIMD (launches of more waves than the device has SIMDs; launch_plan.cpp family_cohabits)
     const uint32_t *len_bound;    // time-split kernels: per utterance an upper bound of its length in samples, or nullptr — a
                                   // chunk's lane whose utterance ends before the chunk begins renders nothing
+    uint32_t pipe_fill;           // pipelined workgroups, one-shot: utterances per workgroup (0: all 16 / 8 slots) — a small batch
+                                  // of rows that differ in length is spread thinly, so that a workgroup's tiles hold few events
     uint32_t fold_from;           // two waves per SIMD, at most two rounds of the device: workgroups from this index on take the
                                   // launch slots in reverse order (0: none) — see synth_kernel.h
     uint32_t *state;              // resumable synthesis: state[word][lane] or nullptr (one-shot)

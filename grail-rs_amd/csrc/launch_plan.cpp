@@ -79,6 +79,20 @@ static double cohabit_gain(const Family &f, double density = 0.0)
     return aligned - (aligned - dense) * std::fmin(1.0, density / 3.0e-4);
 }
 
+// Pipelined workgroups on rows that differ in length: a tile with an event of ONE of a workgroup's utterances costs the
+// workgroup several calm tiles, so a small batch is spread thinly — as few utterances per workgroup as give every compute
+// unit one workgroup — instead of filling 16 (8) slots of a few workgroups and leaving the other units idle: 256 speech-like
+// utterances, one per workgroup, hold no event but their own (profiles/r05_mixed_runs.txt).
+uint32_t pipe_fill_for(const grail_ctx *ctx, const grail_batch *batch, const Family &f, uint32_t rows)
+{
+    if (!f.pipe || !ctx->pipe_spread || batch == nullptr || batch->granule_samples.size() < 2 ||
+        batch->granule_samples.front() == batch->granule_samples.back())
+        return 0u;
+    const uint32_t slots = f.live4 ? 16u : 8u;
+    const uint32_t fill = (rows + (uint32_t)ctx->cus - 1u) / (uint32_t)ctx->cus;
+    return fill >= slots ? 0u : (fill < 1u ? 1u : fill);
+}
+
 // what launching `rows` rows with family f costs (model milliseconds)
 double family_cost(const grail_ctx *ctx, const Family &f, uint32_t rows, double span)
 {
@@ -533,6 +547,9 @@ double ragged_cost(const grail_ctx *ctx, const grail_batch *batch, const Family 
             c *= 1.15;      // (ragged corpora measure 15 - 25 % over the aligned rate before any event: pitch contours, stops)
             double segs = batch->granule_segs[g0];
             if (f.live4 && g0 + 1 < g1) segs += batch->granule_segs[g0 + 1];
+            // (spread thinly: a workgroup's tiles hold the events of `fill` utterances, not of 16 / 8)
+            const uint32_t fill = pipe_fill_for(ctx, batch, f, rows);
+            if (fill) segs *= (double)fill / (f.live4 ? 16.0 : 8.0);
             const double rounds = std::fmax(longest / 32.0, 1.0);
             const double groups = std::ceil((double)rows / (f.live4 ? 16.0 : 8.0));
             c += 0.011 * rounds * (1.0 - std::exp(-segs / rounds)) * std::ceil(groups / ((f.pipe == 2 ? 1.0 : 2.0) * (double)ctx->cus));

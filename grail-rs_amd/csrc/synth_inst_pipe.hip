@@ -8,7 +8,8 @@ namespace grail {
 // segments possibly in a ring — with the state block of the lane kernels of the same L.
 void launch_pipe4(const SynthArgs &args, hipStream_t stream)
 {
-    const dim3 grid((args.n_utt + 15) / 16), block(256);
+    const uint32_t fill = args.pipe_fill != 0u && !args.state ? args.pipe_fill : 16u;
+    const dim3 grid((args.n_utt + fill - 1) / fill), block(256);
     if (args.state) {
         if (args.pipe == 2) start<4, 64, 4, 1, true, false, true, 4, true, false, 8>(args, grid, block, stream);
         else start<4, 64, 4, 1, true, false, true, 4, true, false, 4>(args, grid, block, stream);
@@ -26,7 +27,8 @@ void launch_pipe4(const SynthArgs &args, hipStream_t stream)
 }
 void launch_pipe8(const SynthArgs &args, hipStream_t stream)
 {
-    const dim3 grid((args.n_utt + 7) / 8), block(256);
+    const uint32_t fill = args.pipe_fill != 0u && !args.state ? args.pipe_fill : 8u;
+    const dim3 grid((args.n_utt + fill - 1) / fill), block(256);
     if (args.state) {
         if (args.pipe == 2) start<8, 64, 4, 1, true, false, true, NF, true, false, 8>(args, grid, block, stream);
         else start<8, 64, 4, 1, true, false, true, NF, true, false, 4>(args, grid, block, stream);

@@ -534,14 +534,16 @@ __global__ __launch_bounds__(64 * WAVES, MIN_WAVES_PER_SIMD) void synth_kernel(c
     uint32_t block_id = blockIdx.x;
     if constexpr (!SPLIT && !PIPE && !STREAM && MIN_WAVES_PER_SIMD == 2)
         if (A.fold_from != 0u && block_id >= A.fold_from) block_id = gridDim.x - 1u - (block_id - A.fold_from);
+    // PIPE, one-shot: a workgroup may hold fewer utterances than it has slots for (SynthArgs::pipe_fill)
+    const uint32_t pipe_fill = PIPE && !STREAM && A.pipe_fill != 0u ? A.pipe_fill : (uint32_t)S;
     const uint32_t u0 = SPLIT ? (blockIdx.x % split_groups) * S
-                              : PIPE ? blockIdx.x * S : (block_id * WAVES + wave) * S;
+                              : PIPE ? blockIdx.x * pipe_fill : (block_id * WAVES + wave) * S;
     // which utterance this slot renders: its position in the launch, or — ragged batches — the host's
     // length-sorted assignment (A.perm), so that the lanes of a wave end together; rows, lengths and
     // per-utterance inputs always belong to utterance `u`.  (A launch may cover a range of the slots only —
     // A.perm then points at the range's first slot and `u` may well exceed A.n_utt: `slot_used` says whether
     // the slot renders, never a comparison of `u`.)
-    const bool slot_used = u0 + slot < A.n_utt;
+    const bool slot_used = (!PIPE || (uint32_t)slot < pipe_fill) && u0 + slot < A.n_utt;
     const uint32_t u = !slot_used ? A.n_utt : (A.perm ? A.perm[u0 + slot] : u0 + slot);
     bool done = !slot_used;
     if constexpr (SPLIT && GRAIL_SPLIT_SKIP) {

@@ -49,6 +49,7 @@ static int launch_block(grail_ctx *ctx, const grail_batch *batch, const Family &
     a.fast = f.fast;
     a.cohabit = family_cohabits(ctx, f, count) ? 1u : 0u;
     a.len_bound = batch->d_len_bound && batch->len_bound_epoch == ctx->voices_epoch ? batch->d_len_bound + row0 : nullptr;
+    a.pipe_fill = pipe_fill_for(ctx, batch, f, count);
     a.fold_from = 0u;
     if (a.cohabit) {
         // at most two rounds of the device: the workgroups of the second take their launch slots in reverse order

@@ -79,7 +79,7 @@ extern "C" {
  *   1: rounds 1-2.   2: round 3-4 — grail_device_pci_bus_id, grail_time_split_warmup / _grid, grail_fast_sharpness,
  *   grail_plan_blocks, grail_stream_open_live / _append / _append_elems / _finish / _pending; option "kernel_variant" removed, "scan_debug" in
  *   development builds only; "arithmetic" = 1 is served up to a sharpness of the voice table.
- *   3: round 5 — grail_length_bound; options "two_waves_per_simd", "pipeline_round32" = 2; "ragged_plan" also weighs the scan and
+ *   3: round 5 — grail_length_bound; options "two_waves_per_simd", "pipeline_spread", "pipeline_round32" = 2; "ragged_plan" also weighs the scan and
  *   time-split kernels by the rows. */
 #define GRAIL_ABI_VERSION 3
 /* fast mode ("arithmetic" = 1): bound on |fast - exact| per sample, full scale = 1.0; k * 2^-23 */
@@ -242,6 +242,8 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *   "small_batch_pipeline"  1 (default) / 0: small exact blocks run four-wave pipelined workgroups; streams of that size too.
  *   "pipeline_round32"      1 (default) / 0 / 2: ... in rounds of 32 samples while one workgroup per compute unit suffices and
  *                           the rows are of one length / never / whatever the rows (rounds of 16 otherwise).
+ *   "pipeline_spread"       1 (default) / 0: ... of rows that differ in length hold as few utterances each as give every compute
+ *                           unit a workgroup (a tile with an event of one utterance costs the whole workgroup).
  *   "pipeline4_max_groups", "pipeline8_max_groups"  (default -1: two per compute unit) workgroups a block may need to take them.
  *   "time_parallel_scan"    1 (default) / 0: fast, first tier: few utterances run one workgroup each, lanes = time (parallel
  *                           scans).  "time_parallel_scan_max_utterances" (-1 auto): hard upper limit;

@@ -960,11 +960,16 @@ def test_pipelined_rounds_between_the_events_of_a_tile(gpu_ctx, n_voices, round3
         ctx.set_voices(voices)
         ctx.set_option("ragged_plan", 0)            # (by its events the batch might go to a lane mapping)
         ctx.set_option("pipeline_round32", round32)
-        out, out_len = ctx.synthesize(segs, offs, vids, seeds, out_stride=stride, allow_truncation=True)
-        name = ctx.last_kernel_name()
-        # (rows that differ in length take rounds of 16 unless the option insists: 2)
-        assert "PIPE" in name and ("R32" if round32 == 2 else "R16") in name, name
-        assert_bit_identical(out, out_len, ref, ref_len, f"speech-like, pipelined, {n_voices} voice(s): {name}")
+        # (spread thinly — 200 utterances on 256 compute units: one per workgroup, whose tiles then hold no event but its
+        # own — and packed sixteen / eight to a workgroup)
+        for spread in (1, 0):
+            ctx.set_option("pipeline_spread", spread)
+            out, out_len = ctx.synthesize(segs, offs, vids, seeds, out_stride=stride, allow_truncation=True)
+            name = ctx.last_kernel_name()
+            # (rows that differ in length take rounds of 16 unless the option insists: 2)
+            assert "PIPE" in name and ("R32" if round32 == 2 else "R16") in name, name
+            assert_bit_identical(out, out_len, ref, ref_len, f"speech-like, pipelined, {n_voices} voice(s), spread {spread}: {name}")
     finally:
         ctx.set_option("ragged_plan", 1)
         ctx.set_option("pipeline_round32", 1)
+        ctx.set_option("pipeline_spread", 1)

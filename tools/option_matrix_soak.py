@@ -27,14 +27,14 @@ DEFAULTS = {"lanes_per_utterance": 0, "small_batch_pipeline": 1, "pipeline_round
             "time_parallel_scan_max_utterances": 1536, "time_parallel_scan_split_max_utterances": 1536, "time_split": 1,
             "time_split_chunks": 0, "time_split_span_samples": 0, "time_split_ff_cost_permille": 165,
             "time_split_min_utterances": 1537, "composite_launches": 1, "row_groups": 1, "ragged_plan": 1,
-            "assume_compute_units": 0, "two_waves_per_simd": 1}
+            "assume_compute_units": 0, "two_waves_per_simd": 1, "pipeline_spread": 1}
 CHOICES = {"lanes_per_utterance": [0, 0, 1, 2, 4, 8], "small_batch_pipeline": [0, 1], "pipeline_round32": [0, 1, 1, 2],
            "pipeline4_max_groups": [0, 2, 512], "pipeline8_max_groups": [0, 3, 512], "skip_silent_formants": [0, 1],
            "sort_by_length": [0, 1], "time_parallel_scan": [0, 1], "time_parallel_scan_max_utterances": [0, 40, 1536],
            "time_parallel_scan_split_max_utterances": [0, 30, 1536], "time_split": [0, 1], "time_split_chunks": [0, 0, 2, 5],
            "time_split_span_samples": [0, 4096, 9000], "time_split_ff_cost_permille": [0, 165, 900],
            "time_split_min_utterances": [0, 50, 1537], "composite_launches": [0, 1, 1], "row_groups": [0, 1, 2],
-           "ragged_plan": [0, 1, 1], "assume_compute_units": [0, 1, 2, 4], "two_waves_per_simd": [0, 1, 1]}
+           "ragged_plan": [0, 1, 1], "assume_compute_units": [0, 1, 2, 4], "two_waves_per_simd": [0, 1, 1], "pipeline_spread": [0, 1, 1]}
 worst, kernels = 0.0, {}
 for trial in range(trials):
     nv = int(rng.choice([1, 2, 8]))

@@ -25,6 +25,10 @@ for a in sys.argv[1:]:
         ctx.set_option("lanes_per_utterance", int(a[8:]))
     if a.startswith("--two-waves="):
         ctx.set_option("two_waves_per_simd", int(a[12:]))
+    if a == "--no-spread":
+        ctx.set_option("pipeline_spread", 0)
+    if a == "--round32":
+        ctx.set_option("pipeline_round32", 2)
     if a == "--round16":
         ctx.set_option("pipeline_round32", 0)
     if a == "--no-split":
