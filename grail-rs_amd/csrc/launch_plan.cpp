@@ -81,7 +81,7 @@ static double cohabit_gain(const Family &f, double density = 0.0)
 
 // Pipelined workgroups on rows that differ in length: a tile with an event of ONE of a workgroup's utterances costs the
 // workgroup several calm tiles, so a small batch is spread thinly — as few utterances per workgroup as give every compute
-// unit one workgroup — instead of filling 16 (8) slots of a few workgroups and leaving the other units idle: 256 speech-like
+// unit two workgroups — instead of filling 16 (8) slots of a few workgroups and leaving the other units idle: 256 speech-like
 // utterances, one per workgroup, hold no event but their own (profiles/r05_mixed_runs.txt).
 uint32_t pipe_fill_for(const grail_ctx *ctx, const grail_batch *batch, const Family &f, uint32_t rows)
 {
@@ -89,7 +89,10 @@ uint32_t pipe_fill_for(const grail_ctx *ctx, const grail_batch *batch, const Fam
         batch->granule_samples.front() == batch->granule_samples.back())
         return 0u;
     const uint32_t slots = f.live4 ? 16u : 8u;
-    const uint32_t fill = (rows + (uint32_t)ctx->cus - 1u) / (uint32_t)ctx->cus;
+    // (two workgroups to a compute unit — what the rounds of 16 samples leave room for: they fill each other's stalls.
+    // 4 096 speech-like utterances, eight to a workgroup: 16.8 ms; sixteen to a workgroup, one per unit: 19.4)
+    const uint32_t units = 2u * (uint32_t)ctx->cus;
+    const uint32_t fill = (rows + units - 1u) / units;
     return fill >= slots ? 0u : (fill < 1u ? 1u : fill);
 }
 

@@ -243,7 +243,7 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *   "pipeline_round32"      1 (default) / 0 / 2: ... in rounds of 32 samples while one workgroup per compute unit suffices and
  *                           the rows are of one length / never / whatever the rows (rounds of 16 otherwise).
  *   "pipeline_spread"       1 (default) / 0: ... of rows that differ in length hold as few utterances each as give every compute
- *                           unit a workgroup (a tile with an event of one utterance costs the whole workgroup).
+ *                           unit two workgroups (a tile with an event of one utterance costs the whole workgroup).
  *   "pipeline4_max_groups", "pipeline8_max_groups"  (default -1: two per compute unit) workgroups a block may need to take them.
  *   "time_parallel_scan"    1 (default) / 0: fast, first tier: few utterances run one workgroup each, lanes = time (parallel
  *                           scans).  "time_parallel_scan_max_utterances" (-1 auto): hard upper limit;
