@@ -9,6 +9,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
@@ -100,7 +101,7 @@ struct grail_ctx {
     int skip_silent_option = 1;       // skip band-pass filters of provably silent formants
     int pipeline_option = 1;          // small qualifying batches: producer/consumer workgroups
     int pipe_round32 = 1;             // ... with rounds of 32 samples while one workgroup per CU suffices (8.20 -> 7.86 ms for config 2)
-    uint64_t voices_epoch = 0;        // bumped by every install_voices
+    uint64_t voices_epoch = 0;        // set by every install_voices: unique in the process, not per context
     uint64_t options_epoch = 0;       // bumped by every grail_set_option (a batch caches its launch plan against both)
     int fast_option = 0;              // "arithmetic": 0 exact (bit-identical), 1 fast (stated tolerance: the tier the voices'
                                       // sharpness allows), 2 fast with the reference's own coefficients (MID) whatever the voices
@@ -152,7 +153,8 @@ struct grail_batch {
     uint32_t *d_seeds = nullptr;
     uint32_t *d_perm = nullptr;   // ragged batches: launch slot -> utterance, longest first
     uint32_t *d_len_bound = nullptr;   // per utterance: an upper bound of its length in samples (plain batches; time-split kernels)
-    uint64_t len_bound_epoch = 0;      // ... for the voice table of this epoch (its highest sample rate)
+    uint64_t len_bound_epoch = 0;      // ... for the voice table of this epoch (its highest sample rate); epochs are unique
+                                       // in the process, so a context other than the uploader never matches
     bool len_bound_known = false;      // (the planner's question; grail_plan_ragged_blocks answers it without a device)
     float *d_elems = nullptr;  // elem mode only
     uint32_t n_utt = 0;
@@ -293,6 +295,11 @@ int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_dev, in
 // host_output.cpp / comm.cpp: what grail_destroy releases
 void pipe_destroy_opaque(void *p);
 void comm_release(grail_ctx *ctx);
+// host_output.cpp: texts -> PhonemeElems (grail_say_batch, grail_node_say_batch)
+int say_segments(const std::vector<grail_voice> &voices, const char *const *texts_utf8, uint32_t n_texts,
+                 const uint32_t *voice_ids, std::vector<grail_phoneme_elem> &segs, std::vector<uint32_t> &offs);
+// comm.cpp: one communicator over the contexts of a node, formed inside the process (ncclCommInitAll)
+int comm_init_all(grail_ctx *const *ctxs, const int *devices, uint32_t n);
 
 }  // namespace host
 }  // namespace grail

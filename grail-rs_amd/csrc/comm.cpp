@@ -12,6 +12,7 @@ struct Rccl {
     void *handle = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t,
                               hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
@@ -40,6 +41,7 @@ Rccl &rccl()
         if (!x.handle) return x;
         x.GetUniqueId = (decltype(x.GetUniqueId))dlsym(x.handle, "ncclGetUniqueId");
         x.CommInitRank = (decltype(x.CommInitRank))dlsym(x.handle, "ncclCommInitRank");
+        x.CommInitAll = (decltype(x.CommInitAll))dlsym(x.handle, "ncclCommInitAll");
         x.Broadcast = (decltype(x.Broadcast))dlsym(x.handle, "ncclBroadcast");
         x.CommDestroy = (decltype(x.CommDestroy))dlsym(x.handle, "ncclCommDestroy");
         x.CommCount = (decltype(x.CommCount))dlsym(x.handle, "ncclCommCount");
@@ -66,6 +68,31 @@ void comm_release(grail_ctx *ctx)
 {
     if (ctx->comm && rccl().ok) rccl().CommDestroy(ctx->comm);
     ctx->comm = nullptr;
+}
+
+// One process, n devices (grail_node): ncclCommInitAll forms the n communicators at once from the calling thread; context i
+// becomes rank i.  RCCL refuses a device list that names a GPU twice (ncclInvalidUsage) — the caller reports that.
+int comm_init_all(grail_ctx *const *ctxs, const int *devices, uint32_t n)
+{
+    if (!ctxs || !devices || n == 0) return fail(GRAIL_ERR_INVALID_ARG, "comm_init_all: no contexts");
+    if (!rccl().ok || !rccl().CommInitAll) return fail(GRAIL_ERR_RCCL, "librccl.so could not be loaded (or lacks ncclCommInitAll)");
+    // (checked here rather than left to the library: an RCCL that did not check would meet itself on one GPU and hang)
+    for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t j = 0; j < i; ++j)
+            if (devices[i] == devices[j])
+                return fail(GRAIL_ERR_RCCL, "RCCL cannot form a communicator that names a GPU twice (device " +
+                                                std::to_string(devices[i]) + " holds slots " + std::to_string(j) + " and " +
+                                                std::to_string(i) + ")");
+    for (uint32_t i = 0; i < n; ++i) comm_release(ctxs[i]);
+    std::vector<ncclComm_t> comms(n, nullptr);
+    ncclResult_t r = rccl().CommInitAll(comms.data(), (int)n, devices);
+    if (r != ncclSuccess) return rccl_fail(r, "ncclCommInitAll");
+    for (uint32_t i = 0; i < n; ++i) {
+        ctxs[i]->comm = comms[i];
+        ctxs[i]->comm_rank = i;
+        ctxs[i]->comm_world = n;
+    }
+    return GRAIL_OK;
 }
 
 }  // namespace host

@@ -19,6 +19,10 @@ namespace host {
 
 namespace {
 thread_local std::string g_last_error;
+// Voice-table epochs are drawn from ONE counter for the whole process: a batch (or a stream) remembers the epoch of the
+// table something was computed against, and a batch may be rendered by another context than the one that uploaded it —
+// two contexts that each installed one table must not both be "epoch 1".
+std::atomic<uint64_t> g_epoch{0};
 }
 
 std::string &last_error() { return g_last_error; }
@@ -284,7 +288,7 @@ int install_voices(grail_ctx *ctx, const grail_voice *voices, uint32_t n_voices)
                            hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // dv / elems are locals
     ctx->voices.assign(voices, voices + n_voices);
-    ++ctx->voices_epoch;
+    ctx->voices_epoch = ++g_epoch;
     bool silent = true;
     for (uint32_t v = 0; v < n_voices; ++v)
         for (int p = 0; p < NUM_VOICED; ++p)

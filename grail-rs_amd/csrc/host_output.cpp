@@ -235,6 +235,29 @@ namespace host {
 
 void pipe_destroy_opaque(void *p) { pipe_destroy((HostPipe *)p); }
 
+// the front of examples/cli.rs:176-179 for n texts: transcribe + intonate with the voice each text names
+int say_segments(const std::vector<grail_voice> &voices, const char *const *texts_utf8, uint32_t n_texts,
+                 const uint32_t *voice_ids, std::vector<grail_phoneme_elem> &segs, std::vector<uint32_t> &offs)
+{
+    if (voices.empty()) return fail(GRAIL_ERR_NO_VOICES, "call grail_set_voices first");
+    if (n_texts && !texts_utf8) return fail(GRAIL_ERR_INVALID_ARG, "texts is NULL");
+    segs.clear();
+    offs.assign(1, 0u);
+    for (uint32_t i = 0; i < n_texts; ++i) {
+        const uint32_t vid = voice_ids ? voice_ids[i] : 0u;
+        if (vid >= voices.size()) return fail(GRAIL_ERR_INVALID_ARG, "voice id out of range");
+        if (!texts_utf8[i]) return fail(GRAIL_ERR_INVALID_ARG, "a text is NULL");
+        uint32_t n = 0;
+        grail_text_to_phoneme_elems(&voices[vid], texts_utf8[i], nullptr, 0, &n);
+        const size_t base = segs.size();
+        segs.resize(base + n);
+        int rc = grail_text_to_phoneme_elems(&voices[vid], texts_utf8[i], segs.data() + base, n, &n);
+        if (rc) return fail(rc, "transcription failed");
+        offs.push_back((uint32_t)segs.size());
+    }
+    return GRAIL_OK;
+}
+
 }  // namespace host
 }  // namespace grail
 
@@ -334,22 +357,10 @@ int grail_say_batch(grail_ctx *ctx, const char *const *texts_utf8, uint32_t n_te
                     uint64_t out_stride, uint32_t *out_len, uint32_t flags)
 {
     if (!ctx) return fail(GRAIL_ERR_INVALID_ARG, "ctx is NULL");
-    if (ctx->voices.empty()) return fail(GRAIL_ERR_NO_VOICES, "call grail_set_voices first");
-    if (n_texts && !texts_utf8) return fail(GRAIL_ERR_INVALID_ARG, "texts is NULL");
     std::vector<grail_phoneme_elem> segs;
-    std::vector<uint32_t> offs(1, 0u);
-    for (uint32_t i = 0; i < n_texts; ++i) {
-        const uint32_t vid = voice_ids ? voice_ids[i] : 0u;
-        if (vid >= ctx->voices.size()) return fail(GRAIL_ERR_INVALID_ARG, "voice id out of range");
-        if (!texts_utf8[i]) return fail(GRAIL_ERR_INVALID_ARG, "a text is NULL");
-        uint32_t n = 0;
-        grail_text_to_phoneme_elems(&ctx->voices[vid], texts_utf8[i], nullptr, 0, &n);
-        const size_t base = segs.size();
-        segs.resize(base + n);
-        int rc = grail_text_to_phoneme_elems(&ctx->voices[vid], texts_utf8[i], segs.data() + base, n, &n);
-        if (rc) return fail(rc, "transcription failed");
-        offs.push_back((uint32_t)segs.size());
-    }
+    std::vector<uint32_t> offs;
+    int rc = say_segments(ctx->voices, texts_utf8, n_texts, voice_ids, segs, offs);
+    if (rc) return rc;
     return grail_synthesize_batch(ctx, segs.data(), offs.data(), voice_ids, jitter_seeds, n_texts, out,
                                   out_stride, out_len, flags);
 }

@@ -315,7 +315,14 @@ static int live_append(grail_ctx *ctx, grail_stream *s, const std::vector<DevSeg
         e = launch_ring_append(s->own->d_segs, s->own->d_elems, s->d_counts, cap, s->d_new, elems ? s->d_new_elems : nullptr,
                                s->d_new_offs, n_utt, ctx->stream);
     if (e == hipSuccess) e = hipEventRecord(s->ev_stage[slot], ctx->stream);
-    if (e != hipSuccess) return hip_fail(e, "grail_stream_append");
+    if (e != hipSuccess) {
+        // some of the copies may be queued and still reading the pinned buffer, which the next append would overwrite (the
+        // slot is not marked busy and stage_next does not move): wait for them before handing the failure back.  Whether
+        // the scatter ran is unknown; `appended` is left alone, so the host's view stays a lower bound and the stream is
+        // best closed by the caller.
+        (void)hipStreamSynchronize(ctx->stream);
+        return hip_fail(e, "grail_stream_append");
+    }
     s->stage_busy[slot] = true;
     s->stage_next = slot ^ 1;
     for (uint32_t u = 0; u < n_utt; ++u) s->appended[u] += seg_offsets[u + 1] - seg_offsets[u];

@@ -42,7 +42,7 @@ FAST_TOLERANCE_NOTE = (f"fast mode: max |fast - exact| <= {FAST_TOLERANCE_ULPS} 
                        "full scale vs the oracle (tests/test_fast_gpu.py asserts it on configs 2, 3, 4 "
                        "and a fuzz corpus); clock, phases, wraps and LCGs stay exact")
 UNIQUE_ID_BYTES = 128
-ABI_VERSION = 3                  # GRAIL_ABI_VERSION of the header this binding mirrors
+ABI_VERSION = 4                  # GRAIL_ABI_VERSION of the header this binding mirrors
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRAIL_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib",
@@ -66,6 +66,10 @@ EXPORTS = [
     "grail_device_alloc", "grail_device_free", "grail_host_alloc", "grail_host_free", "grail_memcpy_d2h", "grail_memcpy_h2d",
     "grail_memset_d", "grail_shard_range", "grail_comm_unique_id", "grail_comm_init",
     "grail_broadcast_voices", "grail_comm_info", "grail_comm_destroy",
+    "grail_node_create", "grail_node_destroy", "grail_node_size", "grail_node_context", "grail_node_set_voices",
+    "grail_node_set_option", "grail_node_get_option", "grail_node_shard_of", "grail_node_synthesize_batch",
+    "grail_node_synthesize_batch_elems", "grail_node_synthesize_batch_pcm16", "grail_node_say_batch",
+    "grail_node_lengths", "grail_node_last_shard_ms", "grail_node_host_alloc", "grail_node_host_free",
 ]
 
 
@@ -150,6 +154,16 @@ class PlanBlock(C.Structure):
         if self.pipelined:
             return f"pipe{self.formants}r{16 * self.pipelined}"
         return ("fast" if self.fast else "exact") + f"L{self.lanes_per_utterance}"
+
+
+class NodeShard(C.Structure):
+    """grail_node_shard: the rows and segments one device of a node renders (grail_node_shard_of)."""
+    _fields_ = [
+        ("first_row", C.c_uint64),
+        ("rows", C.c_uint64),
+        ("first_seg", C.c_uint32),
+        ("n_segs", C.c_uint32),
+    ]
 
 
 class Rule(C.Structure):
@@ -276,6 +290,23 @@ def load():
     L.grail_broadcast_voices.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.grail_comm_info.argtypes = [vp, u32p, u32p]
     L.grail_comm_destroy.argtypes = [vp]
+    L.grail_node_create.argtypes = [C.POINTER(C.c_int), C.c_uint32, C.POINTER(vp)]
+    L.grail_node_destroy.argtypes = [vp]
+    L.grail_node_size.restype = C.c_uint32
+    L.grail_node_size.argtypes = [vp]
+    L.grail_node_context.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
+    L.grail_node_set_voices.argtypes = [vp, vp, C.c_uint32]
+    L.grail_node_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.grail_node_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
+    L.grail_node_shard_of.argtypes = [u32p, u64, C.c_uint32, C.c_uint32, C.POINTER(NodeShard), u32p, u64]
+    L.grail_node_synthesize_batch.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, u64, vp, C.c_uint32]
+    L.grail_node_synthesize_batch_elems.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, u64, vp, C.c_uint32]
+    L.grail_node_synthesize_batch_pcm16.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, u64, vp, C.c_uint32]
+    L.grail_node_say_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.c_uint32, vp, vp, vp, u64, vp, C.c_uint32]
+    L.grail_node_lengths.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp]
+    L.grail_node_last_shard_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_uint32]
+    L.grail_node_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.grail_node_host_free.argtypes = [vp, vp]
     _lib = L
     return L
 
@@ -329,6 +360,20 @@ def shard_range(n_utt, rank, world):
     b, e = C.c_uint64(), C.c_uint64()
     load().grail_shard_range(n_utt, rank, world, C.byref(b), C.byref(e))
     return b.value, e.value
+
+
+def node_shard_of(seg_offsets, index, n_devices):
+    """(NodeShard, rebased seg_offsets) of device slot `index` out of n_devices: the view a node call hands to that
+    device's grail_synthesize_batch (grail_node_shard_of; pure host arithmetic, no GPU)."""
+    offs = np.ascontiguousarray(seg_offsets, dtype=np.uint32)
+    n_utt = len(offs) - 1
+    u32p = C.POINTER(C.c_uint32)
+    sh = NodeShard()
+    _check(load().grail_node_shard_of(offs.ctypes.data_as(u32p), n_utt, index, n_devices, C.byref(sh), None, 0))
+    rebased = np.zeros(sh.rows + 1, dtype=np.uint32)
+    _check(load().grail_node_shard_of(offs.ctypes.data_as(u32p), n_utt, index, n_devices, C.byref(sh),
+                                      rebased.ctypes.data_as(u32p), len(rebased)))
+    return sh, rebased
 
 
 def voices_blob(voices):
@@ -788,3 +833,132 @@ class Context:
         n, r = C.c_uint32(), C.c_uint32()
         _check(load().grail_comm_info(self.handle, C.byref(n), C.byref(r)))
         return n.value, r.value
+
+
+class _BorrowedContext(Context):
+    """A node's context (grail_node_context): owned by the node, never destroyed from here."""
+
+    def __init__(self, handle, device):       # noqa: super().__init__ would create a context
+        self.handle, self.device = handle, device
+
+    def close(self):
+        self.handle = None
+
+
+class Node:
+    """grail_node: one process, several GPUs — a context and a host thread per device; one call renders a batch over all
+    of them (contiguous shards, no data-path collective; the voice table travels by one ncclBroadcast)."""
+
+    def __init__(self, devices, voices_without_rccl=False):
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        _check(load().grail_node_create(arr, len(self.devices), C.byref(h)))
+        self.handle = h
+        if voices_without_rccl:
+            self.set_option("node_voices_without_rccl", 1)
+
+    def close(self):
+        if self.handle:
+            load().grail_node_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def size(self):
+        return int(load().grail_node_size(self.handle))
+
+    def context(self, index):
+        h = C.c_void_p()
+        _check(load().grail_node_context(self.handle, index, C.byref(h)))
+        return _BorrowedContext(h, self.devices[index])
+
+    def set_voices(self, voices):
+        arr = (Voice * len(voices))(*[v.copy() for v in voices])
+        _check(load().grail_node_set_voices(self.handle, C.cast(arr, C.c_void_p), len(voices)))
+
+    def set_option(self, name, value):
+        _check(load().grail_node_set_option(self.handle, name.encode(), value))
+
+    def get_option(self, name):
+        v = C.c_int64()
+        _check(load().grail_node_get_option(self.handle, name.encode(), C.byref(v)))
+        return v.value
+
+    def lengths(self, segs, seg_offsets, voice_ids=None, max_len=0xFFFFFFFF):
+        segs = np.ascontiguousarray(segs, dtype=PHONEME_DTYPE)
+        seg_offsets, n_utt, voice_ids, _ = Context._prep(None, segs, seg_offsets, voice_ids, None)
+        out = np.zeros(max(n_utt, 1), dtype=np.uint32)
+        _check(load().grail_node_lengths(self.handle, segs.ctypes.data, seg_offsets.ctypes.data, _ptr(voice_ids), n_utt,
+                                         max_len, out.ctypes.data))
+        return out[:n_utt]
+
+    def synthesize(self, segs, seg_offsets, voice_ids=None, jitter_seeds=None, out_stride=None, out=None,
+                   allow_truncation=False, pcm16=False):
+        """grail_node_synthesize_batch(_pcm16) over host buffers.  Returns (out[n_utt, out_stride], out_len)."""
+        segs = np.ascontiguousarray(segs, dtype=PHONEME_DTYPE)
+        seg_offsets, n_utt, voice_ids, jitter_seeds = Context._prep(None, segs, seg_offsets, voice_ids, jitter_seeds)
+        if out is not None:
+            out_stride = out.shape[1]
+            assert out.shape[0] >= n_utt and out.flags.c_contiguous
+            pcm16 = out.dtype == np.int16
+        elif out_stride is None:
+            lens = self.lengths(segs, seg_offsets, voice_ids)
+            out_stride = int((max(int(lens.max()) if n_utt else 0, 1) + 63) // 64 * 64)
+        if out is None:
+            out = np.zeros((max(n_utt, 1), out_stride), dtype=np.int16 if pcm16 else np.float32)
+        out_len = np.zeros(max(n_utt, 1), dtype=np.uint32)
+        fn = load().grail_node_synthesize_batch_pcm16 if pcm16 else load().grail_node_synthesize_batch
+        st = fn(self.handle, segs.ctypes.data, seg_offsets.ctypes.data, _ptr(voice_ids), _ptr(jitter_seeds), n_utt,
+                out.ctypes.data, out_stride, out_len.ctypes.data, OUT_HOST)
+        if not (allow_truncation and st == ERR_BUFFER_TOO_SMALL):
+            _check(st)
+        return out[:n_utt], out_len[:n_utt]
+
+    def synthesize_elems(self, seq_elems, seg_offsets, voice_ids=None, jitter_seeds=None, out_stride=4096):
+        arr = (SequenceElem * max(len(seq_elems), 1))(*seq_elems)
+        seg_offsets, n_utt, voice_ids, jitter_seeds = Context._prep(None, None, seg_offsets, voice_ids, jitter_seeds)
+        out = np.zeros((max(n_utt, 1), out_stride), dtype=np.float32)
+        out_len = np.zeros(max(n_utt, 1), dtype=np.uint32)
+        _check(load().grail_node_synthesize_batch_elems(
+            self.handle, C.cast(arr, C.c_void_p), seg_offsets.ctypes.data, _ptr(voice_ids), _ptr(jitter_seeds), n_utt,
+            out.ctypes.data, out_stride, out_len.ctypes.data, OUT_HOST))
+        return out[:n_utt], out_len[:n_utt]
+
+    def say(self, texts, voice_ids=None, jitter_seeds=None, out_stride=4096):
+        n = len(texts)
+        arr = (C.c_char_p * max(n, 1))(*[t.encode("utf-8") for t in texts])
+        if voice_ids is not None:
+            voice_ids = np.ascontiguousarray(voice_ids, dtype=np.uint32)
+        if jitter_seeds is not None:
+            jitter_seeds = np.ascontiguousarray(jitter_seeds, dtype=np.uint32)
+        out = np.zeros((max(n, 1), out_stride), dtype=np.float32)
+        out_len = np.zeros(max(n, 1), dtype=np.uint32)
+        _check(load().grail_node_say_batch(self.handle, arr, n, _ptr(voice_ids), _ptr(jitter_seeds), out.ctypes.data,
+                                           out_stride, out_len.ctypes.data, OUT_HOST))
+        return out[:n], out_len[:n]
+
+    def last_shard_ms(self):
+        ms = (C.c_float * self.size())()
+        _check(load().grail_node_last_shard_ms(self.handle, ms, self.size()))
+        return [float(x) for x in ms]
+
+    def host_alloc(self, shape, dtype):
+        """A numpy array in pinned host memory every device of the node can copy into; free it with host_free(array)."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        _check(load().grail_node_host_alloc(self.handle, n, C.byref(p)))
+        buf = (C.c_char * max(n, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr):
+        p = self._pinned.pop(arr.ctypes.data)
+        _check(load().grail_node_host_free(self.handle, p))

@@ -1,4 +1,4 @@
-//! Raw mirror of `include/grail_hip.h` (ABI version 3: `GRAIL_ABI_VERSION`; compare it with
+//! Raw mirror of `include/grail_hip.h` (ABI version 4: `GRAIL_ABI_VERSION`; compare it with
 //! `grail_abi_version()` before the first call, as `grail_hip::Context::new` does).  Field orders follow grail-rs:
 //! `SynthesisElem` src/lib.rs:316-337, `Voice` :696-717, `PhonemeElem` :961-973,
 //! `SequenceElem` :814-824, `Phoneme` :632-649.
@@ -9,7 +9,7 @@ pub const GRAIL_NUM_FORMANTS: usize = 8;
 pub const GRAIL_NUM_VOICED: usize = 2;
 pub const GRAIL_UNIQUE_ID_BYTES: usize = 128;
 
-pub const GRAIL_ABI_VERSION: c_int = 3;
+pub const GRAIL_ABI_VERSION: c_int = 4;
 
 pub const GRAIL_OK: c_int = 0;
 pub const GRAIL_ERR_INVALID_ARG: c_int = -1;
@@ -86,6 +86,25 @@ pub struct grail_plan_block {
     pub model_ms: f32,
 }
 
+/// The rows and segments one device of a node renders (`grail_node_shard_of`).
+#[repr(C)]
+#[derive(Copy, Clone, Debug, Default, PartialEq)]
+pub struct grail_node_shard {
+    pub first_row: u64,
+    pub rows: u64,
+    pub first_seg: u32,
+    pub n_segs: u32,
+}
+
+// The layouts this crate mirrors, checked at compile time against the C header's (tests/test_abi.py compares these
+// literals with the sizes the C compiler gives the header's structs).
+const _: () = assert!(std::mem::size_of::<grail_synthesis_elem>() == 196);
+const _: () = assert!(std::mem::size_of::<grail_voice>() == 416);
+const _: () = assert!(std::mem::size_of::<grail_phoneme_elem>() == 16);
+const _: () = assert!(std::mem::size_of::<grail_sequence_elem>() == 208);
+const _: () = assert!(std::mem::size_of::<grail_plan_block>() == 32);
+const _: () = assert!(std::mem::size_of::<grail_node_shard>() == 24);
+
 #[repr(C)]
 pub struct grail_ctx {
     _private: [u8; 0],
@@ -96,6 +115,10 @@ pub struct grail_batch {
 }
 #[repr(C)]
 pub struct grail_stream {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct grail_node {
     _private: [u8; 0],
 }
 
@@ -211,4 +234,31 @@ extern "C" {
     pub fn grail_broadcast_voices(ctx: *mut grail_ctx, n_voices: u32, root: u32) -> c_int;
     pub fn grail_comm_info(ctx: *mut grail_ctx, ranks: *mut u32, rank: *mut u32) -> c_int;
     pub fn grail_comm_destroy(ctx: *mut grail_ctx) -> c_int;
+
+    pub fn grail_node_create(devices: *const c_int, n_devices: u32, out: *mut *mut grail_node) -> c_int;
+    pub fn grail_node_destroy(node: *mut grail_node) -> c_int;
+    pub fn grail_node_size(node: *const grail_node) -> u32;
+    pub fn grail_node_context(node: *mut grail_node, index: u32, ctx: *mut *mut grail_ctx) -> c_int;
+    pub fn grail_node_set_voices(node: *mut grail_node, voices: *const grail_voice, n_voices: u32) -> c_int;
+    pub fn grail_node_set_option(node: *mut grail_node, name: *const c_char, value: i64) -> c_int;
+    pub fn grail_node_get_option(node: *mut grail_node, name: *const c_char, value: *mut i64) -> c_int;
+    pub fn grail_node_shard_of(seg_offsets: *const u32, n_utt: u64, index: u32, n_devices: u32,
+        shard: *mut grail_node_shard, rebased_offsets: *mut u32, cap: u64) -> c_int;
+    pub fn grail_node_synthesize_batch(node: *mut grail_node, segs: *const grail_phoneme_elem,
+        seg_offsets: *const u32, voice_ids: *const u32, jitter_seeds: *const u32, n_utt: u32,
+        out: *mut f32, out_stride: u64, out_len: *mut u32, flags: u32) -> c_int;
+    pub fn grail_node_synthesize_batch_elems(node: *mut grail_node, segs: *const grail_sequence_elem,
+        seg_offsets: *const u32, voice_ids: *const u32, jitter_seeds: *const u32, n_utt: u32,
+        out: *mut f32, out_stride: u64, out_len: *mut u32, flags: u32) -> c_int;
+    pub fn grail_node_synthesize_batch_pcm16(node: *mut grail_node, segs: *const grail_phoneme_elem,
+        seg_offsets: *const u32, voice_ids: *const u32, jitter_seeds: *const u32, n_utt: u32,
+        out: *mut i16, out_stride: u64, out_len: *mut u32, flags: u32) -> c_int;
+    pub fn grail_node_say_batch(node: *mut grail_node, texts: *const *const c_char, n_texts: u32,
+        voice_ids: *const u32, jitter_seeds: *const u32, out: *mut f32, out_stride: u64,
+        out_len: *mut u32, flags: u32) -> c_int;
+    pub fn grail_node_lengths(node: *mut grail_node, segs: *const grail_phoneme_elem, seg_offsets: *const u32,
+        voice_ids: *const u32, n_utt: u32, max_len: u32, out_len: *mut u32) -> c_int;
+    pub fn grail_node_last_shard_ms(node: *mut grail_node, ms: *mut f32, cap: u32) -> c_int;
+    pub fn grail_node_host_alloc(node: *mut grail_node, bytes: usize, out: *mut *mut std::ffi::c_void) -> c_int;
+    pub fn grail_node_host_free(node: *mut grail_node, ptr: *mut std::ffi::c_void) -> c_int;
 }

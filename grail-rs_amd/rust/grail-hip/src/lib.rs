@@ -1,4 +1,4 @@
-//! `utterances.synthesize_batch(&gpu)` — the batched counterpart of grail-rs's
+//! `utterances.synthesize_batch(&gpu)` / `utterances.synthesize_batch(&node)` — the batched counterpart of grail-rs's
 //! `.select(v).sequence(v).jitter(seed, v).synthesize()` (reference src/lib.rs:1013, 941, 786,
 //! 587; trait pattern of `IntoSynthesize`, src/lib.rs:582-600).  Per-utterance results are
 //! bit-identical to the CPU iterator chain.  SOURCE ONLY: not compiled in the build image.
@@ -80,32 +80,69 @@ pub struct Utterance {
     pub jitter_seed: u32,
 }
 
-pub trait IntoSynthesizeBatch {
-    fn synthesize_batch(self, gpu: &Gpu) -> Result<Vec<Vec<f32>>, Error>;
+/// A batch in the flat form the C ABI takes (`grail_synthesize_batch`): utterance u is
+/// `segs[offs[u]..offs[u + 1]]` with voice `vids[u]` and jitter seed `seeds[u]`.
+pub struct FlatBatch {
+    segs: Vec<sys::grail_phoneme_elem>,
+    offs: Vec<u32>,
+    vids: Vec<u32>,
+    seeds: Vec<u32>,
 }
 
-impl<I: IntoIterator<Item = Utterance>> IntoSynthesizeBatch for I {
-    fn synthesize_batch(self, gpu: &Gpu) -> Result<Vec<Vec<f32>>, Error> {
-        let (mut segs, mut offs, mut vids, mut seeds) = (vec![], vec![0u32], vec![], vec![]);
-        for u in self {
-            segs.extend(u.phonemes.iter().map(|p| sys::grail_phoneme_elem {
+impl FlatBatch {
+    fn new<I: IntoIterator<Item = Utterance>>(utterances: I) -> Self {
+        let mut b = FlatBatch { segs: vec![], offs: vec![0u32], vids: vec![], seeds: vec![] };
+        for u in utterances {
+            b.segs.extend(u.phonemes.iter().map(|p| sys::grail_phoneme_elem {
                 phoneme: p.phoneme as i32, // Silence=0 Stop=1 Glide=2 A=3 E=4 (src/lib.rs:632-649)
                 length: p.length,
                 blend_length: p.blend_length,
                 frequency: p.frequency,
             }));
-            offs.push(segs.len() as u32);
-            vids.push(u.voice);
-            seeds.push(u.jitter_seed);
+            b.offs.push(b.segs.len() as u32);
+            b.vids.push(u.voice);
+            b.seeds.push(u.jitter_seed);
         }
-        let n = vids.len() as u32;
+        b
+    }
+
+    pub fn len(&self) -> u32 {
+        self.vids.len() as u32
+    }
+}
+
+/// What a batch can be rendered on: one GPU ([`Gpu`]) or every GPU of the node ([`Node`]).
+pub trait SynthesisTarget {
+    fn render(&self, batch: &FlatBatch) -> Result<Vec<Vec<f32>>, Error>;
+}
+
+/// `utterances.synthesize_batch(&gpu)` / `utterances.synthesize_batch(&node)`: the batched counterpart of
+/// `IntoSynthesize` (src/lib.rs:582-600).
+pub trait IntoSynthesizeBatch {
+    fn synthesize_batch<T: SynthesisTarget>(self, target: &T) -> Result<Vec<Vec<f32>>, Error>;
+}
+
+impl<I: IntoIterator<Item = Utterance>> IntoSynthesizeBatch for I {
+    fn synthesize_batch<T: SynthesisTarget>(self, target: &T) -> Result<Vec<Vec<f32>>, Error> {
+        target.render(&FlatBatch::new(self))
+    }
+}
+
+fn rows_of(out: &[f32], stride: usize, lens: &[u32]) -> Vec<Vec<f32>> {
+    lens.iter().enumerate().map(|(u, &l)| out[u * stride..][..l as usize].to_vec()).collect()
+}
+
+impl SynthesisTarget for Gpu {
+    fn render(&self, b: &FlatBatch) -> Result<Vec<Vec<f32>>, Error> {
+        let gpu = self;
+        let n = b.len();
         let mut lens = vec![0u32; n as usize];
         unsafe {
-            let mut b = std::ptr::null_mut();
-            check(sys::grail_batch_upload(gpu.ctx, segs.as_ptr(), offs.as_ptr(), vids.as_ptr(),
-                                          seeds.as_ptr(), n, &mut b))?;
-            let r = check(sys::grail_batch_lengths(gpu.ctx, b, u32::MAX, lens.as_mut_ptr()));
-            sys::grail_batch_free(gpu.ctx, b);
+            let mut h = std::ptr::null_mut();
+            check(sys::grail_batch_upload(gpu.ctx, b.segs.as_ptr(), b.offs.as_ptr(), b.vids.as_ptr(),
+                                          b.seeds.as_ptr(), n, &mut h))?;
+            let r = check(sys::grail_batch_lengths(gpu.ctx, h, u32::MAX, lens.as_mut_ptr()));
+            sys::grail_batch_free(gpu.ctx, h);
             r?;
         }
         let stride = (*lens.iter().max().unwrap_or(&0) as u64 + 63) / 64 * 64;
@@ -125,18 +162,94 @@ impl<I: IntoIterator<Item = Utterance>> IntoSynthesizeBatch for I {
         let mut pageable: Vec<f32> = if have_pinned { Vec::new() } else { vec![0f32; floats] };
         let dst = if have_pinned { pinned as *mut f32 } else { pageable.as_mut_ptr() };
         let r = check(unsafe {
-            sys::grail_synthesize_batch(gpu.ctx, segs.as_ptr(), offs.as_ptr(), vids.as_ptr(),
-                                        seeds.as_ptr(), n, dst, stride,
+            sys::grail_synthesize_batch(gpu.ctx, b.segs.as_ptr(), b.offs.as_ptr(), b.vids.as_ptr(),
+                                        b.seeds.as_ptr(), n, dst, stride,
                                         lens.as_mut_ptr(), sys::GRAIL_OUT_HOST)
         });
-        let result = r.map(|_| {
-            let out = unsafe { std::slice::from_raw_parts(dst as *const f32, floats) };
-            lens.iter().enumerate()
-                .map(|(u, &l)| out[u * stride as usize..][..l as usize].to_vec())
-                .collect()
-        });
+        let result = r.map(|_| rows_of(unsafe { std::slice::from_raw_parts(dst as *const f32, floats) }, stride as usize, &lens));
         if have_pinned {
             unsafe { sys::grail_host_free(gpu.ctx, pinned) };
+        }
+        drop(pageable);
+        result
+    }
+}
+
+/// Every GPU of the node behind the same call (grail_node_*): one context and one host thread per device inside the
+/// library, the voice table carried to the other GPUs' HBM by one ncclBroadcast over xGMI, the batch cut into contiguous
+/// shards (`grail_shard_range`) that render concurrently into slices of one host buffer — the reference's single call
+/// (`examples/cli.rs:175-184`) for a host that holds 524 288 utterances and eight MI355X.  No data-path collective:
+/// per-utterance state is self-contained (src/lib.rs:470-488, 724-748, 839-854).
+pub struct Node {
+    node: *mut sys::grail_node,
+}
+
+impl Node {
+    /// `Node::new(&[0, 1, 2, 3, 4, 5, 6, 7], &[voice])`
+    pub fn new(devices: &[i32], voices: &[Voice]) -> Result<Self, Error> {
+        let have = unsafe { sys::grail_abi_version() };
+        if have != sys::GRAIL_ABI_VERSION {
+            return Err(Error { status: sys::GRAIL_ERR_INVALID_ARG,
+                               message: format!("libgrail_hip.so has ABI version {have}, grail-hip-sys mirrors {}", sys::GRAIL_ABI_VERSION) });
+        }
+        let mut node = std::ptr::null_mut();
+        check(unsafe { sys::grail_node_create(devices.as_ptr(), devices.len() as u32, &mut node) })?;
+        let n = Node { node };
+        let table: Vec<_> = voices.iter().map(voice_to_c).collect();
+        check(unsafe { sys::grail_node_set_voices(n.node, table.as_ptr(), table.len() as u32) })?;
+        Ok(n)
+    }
+
+    pub fn devices(&self) -> u32 {
+        unsafe { sys::grail_node_size(self.node) }
+    }
+
+    /// What RCCL itself reports for the node's communicator (`ncclCommCount`): the number of GPUs that met.
+    pub fn rccl_ranks(&self) -> Result<u32, Error> {
+        let mut v = 0i64;
+        check(unsafe { sys::grail_node_get_option(self.node, b"node_rccl_ranks\0".as_ptr() as *const _, &mut v) })?;
+        Ok(v as u32)
+    }
+
+    pub fn set_arithmetic(&self, a: Arithmetic) -> Result<(), Error> {
+        let v = match a { Arithmetic::Exact => 0, Arithmetic::Fast => 1 };
+        check(unsafe { sys::grail_node_set_option(self.node, b"arithmetic\0".as_ptr() as *const _, v) })
+    }
+}
+
+impl Drop for Node {
+    fn drop(&mut self) {
+        unsafe { sys::grail_node_destroy(self.node) };
+    }
+}
+
+/// `utterances.synthesize_batch(&node)`: the same result as the `Gpu` form, rows in the caller's order.
+impl SynthesisTarget for Node {
+    fn render(&self, b: &FlatBatch) -> Result<Vec<Vec<f32>>, Error> {
+        let node = self;
+        let n = b.len();
+        let mut lens = vec![0u32; n as usize];
+        // the Sequencer clock pre-pass (src/lib.rs:861-888), sharded like the synthesis: sizes the rows
+        check(unsafe { sys::grail_node_lengths(node.node, b.segs.as_ptr(), b.offs.as_ptr(), b.vids.as_ptr(), n, u32::MAX,
+                                               lens.as_mut_ptr()) })?;
+        let stride = (*lens.iter().max().unwrap_or(&0) as u64 + 63) / 64 * 64;
+        let floats = n as usize * stride as usize;
+        // pinned memory every device can copy into (hipHostMallocPortable) while it fits; else a plain Vec, fed through
+        // each context's ring of pinned staging buffers
+        const PINNED_LIMIT: usize = 16 << 30;
+        let mut pinned: *mut std::ffi::c_void = std::ptr::null_mut();
+        let have_pinned = floats * 4 <= PINNED_LIMIT
+            && unsafe { sys::grail_node_host_alloc(node.node, floats * 4, &mut pinned) } == 0
+            && !pinned.is_null();
+        let mut pageable: Vec<f32> = if have_pinned { Vec::new() } else { vec![0f32; floats] };
+        let dst = if have_pinned { pinned as *mut f32 } else { pageable.as_mut_ptr() };
+        let r = check(unsafe {
+            sys::grail_node_synthesize_batch(node.node, b.segs.as_ptr(), b.offs.as_ptr(), b.vids.as_ptr(),
+                                             b.seeds.as_ptr(), n, dst, stride, lens.as_mut_ptr(), sys::GRAIL_OUT_HOST)
+        });
+        let result = r.map(|_| rows_of(unsafe { std::slice::from_raw_parts(dst as *const f32, floats) }, stride as usize, &lens));
+        if have_pinned {
+            unsafe { sys::grail_node_host_free(node.node, pinned) };
         }
         drop(pageable);
         result

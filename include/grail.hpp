@@ -10,6 +10,7 @@
 //       (examples/interactive.rs:31-48)
 //   a chain whose source delivers while it runs         -> grail::LiveStream(gpu, chunk).append(...) / .next()
 //       (repeat_with(|| receiver.try_recv()...), interactive.rs:31)
+//   the same one call over every GPU of the node        -> grail::Node({0, 1, ...}, voices).synthesize({...})
 //
 // No arithmetic lives here; everything forwards to libgrail_hip.so.
 #pragma once
@@ -163,6 +164,75 @@ public:
 
 private:
     grail_ctx *ctx_ = nullptr;
+    std::vector<Voice> voices_;
+};
+
+// Every GPU of the node behind the same call (grail_node_*): one context and one host thread per device, the voice table
+// carried to the others' HBM by one ncclBroadcast, the batch cut into contiguous shards that render concurrently into
+// slices of one host buffer.  Results are those of Gpu::synthesize, row for row, bit for bit (Exact).
+class Node {
+public:
+    // voices_without_rccl: tests on a box whose `devices` name one GPU more than once (RCCL refuses such a communicator)
+    Node(const std::vector<int> &devices, const std::vector<Voice> &voices, bool voices_without_rccl = false) : voices_(voices)
+    {
+        check(grail_node_create(devices.data(), (uint32_t)devices.size(), &node_));
+        int rc = voices_without_rccl ? grail_node_set_option(node_, "node_voices_without_rccl", 1) : GRAIL_OK;
+        if (!rc) rc = grail_node_set_voices(node_, voices_.data(), (uint32_t)voices_.size());
+        if (rc != GRAIL_OK) {
+            grail_node_destroy(node_);
+            check(rc);
+        }
+    }
+    ~Node() { grail_node_destroy(node_); }
+    Node(const Node &) = delete;
+    Node &operator=(const Node &) = delete;
+
+    grail_node *node() const { return node_; }
+    uint32_t size() const { return grail_node_size(node_); }
+    const std::vector<Voice> &voices() const { return voices_; }
+    void set_arithmetic(Gpu::Arithmetic a) const { check(grail_node_set_option(node_, "arithmetic", (int64_t)a)); }
+    // ranks RCCL reports for the node's communicator (ncclCommCount; 0 under voices_without_rccl)
+    uint32_t rccl_ranks() const
+    {
+        int64_t v = 0;
+        check(grail_node_get_option(node_, "node_rccl_ranks", &v));
+        return (uint32_t)v;
+    }
+
+    std::vector<std::vector<float>> synthesize(const std::vector<Utterance> &utts) const
+    {
+        std::vector<PhonemeElem> segs;
+        std::vector<uint32_t> offs(1, 0u), vids, seeds;
+        for (const Utterance &u : utts) {
+            segs.insert(segs.end(), u.phonemes.begin(), u.phonemes.end());
+            offs.push_back((uint32_t)segs.size());
+            vids.push_back(u.voice);
+            seeds.push_back(u.jitter_seed);
+        }
+        const uint32_t n = (uint32_t)utts.size();
+        std::vector<uint32_t> lens(n ? n : 1);
+        check(grail_node_lengths(node_, segs.data(), offs.data(), vids.data(), n, 0xFFFFFFFFu, lens.data()));
+        uint64_t stride = 64;
+        for (uint32_t i = 0; i < n; ++i) stride = lens[i] > stride ? lens[i] : stride;
+        stride = (stride + 63) / 64 * 64;
+        std::vector<float> flat((size_t)n * stride);
+        check(grail_node_synthesize_batch(node_, segs.data(), offs.data(), vids.data(), seeds.data(), n, flat.data(),
+                                          stride, lens.data(), GRAIL_OUT_HOST));
+        std::vector<std::vector<float>> out(n);
+        for (uint32_t i = 0; i < n; ++i)
+            out[i].assign(flat.begin() + (size_t)i * stride, flat.begin() + (size_t)i * stride + lens[i]);
+        return out;
+    }
+
+    std::vector<std::vector<float>> say(const std::vector<std::string> &texts) const
+    {
+        std::vector<Utterance> utts;
+        for (const std::string &t : texts) utts.push_back(Utterance{phoneme_elems(voices_.at(0), t), 0, 0});
+        return synthesize(utts);
+    }
+
+private:
+    grail_node *node_ = nullptr;
     std::vector<Voice> voices_;
 };
 

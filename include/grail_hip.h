@@ -80,8 +80,9 @@ extern "C" {
  *   grail_plan_blocks, grail_stream_open_live / _append / _append_elems / _finish / _pending; option "kernel_variant" removed, "scan_debug" in
  *   development builds only; "arithmetic" = 1 is served up to a sharpness of the voice table.
  *   3: round 5 — grail_length_bound; options "two_waves_per_simd", "pipeline_spread", "pipeline_round32" = 2; "ragged_plan" also weighs the scan and
- *   time-split kernels by the rows. */
-#define GRAIL_ABI_VERSION 3
+ *   time-split kernels by the rows.
+ *   4: round 6 — grail_node_* (one call, every GPU of the node). */
+#define GRAIL_ABI_VERSION 4
 /* fast mode ("arithmetic" = 1): bound on |fast - exact| per sample, full scale = 1.0; k * 2^-23 */
 #define GRAIL_FAST_TOLERANCE_ULPS 64
 #define GRAIL_FAST_TOLERANCE (GRAIL_FAST_TOLERANCE_ULPS * 1.1920928955078125e-07f)
@@ -165,6 +166,7 @@ typedef struct grail_sequence_elem {
 typedef struct grail_ctx   grail_ctx;   /* one per (process, GPU); owns a HIP stream */
 typedef struct grail_batch grail_batch; /* inputs of one batch, resident in HBM */
 typedef struct grail_stream grail_stream; /* resumable synthesis of one batch */
+typedef struct grail_node  grail_node;  /* one process, several GPUs: a grail_ctx and a host thread per GPU */
 
 /* flags of grail_synthesize_batch*() */
 #define GRAIL_OUT_HOST   0u /* `out` is host memory (pageable or pinned) */
@@ -547,6 +549,77 @@ int grail_broadcast_voices(grail_ctx *ctx, uint32_t n_voices, uint32_t root);
  * has been formed), *rank = ncclCommUserRank.  Lets a launcher prove that N ranks really met. */
 int grail_comm_info(grail_ctx *ctx, uint32_t *ranks, uint32_t *rank);
 int grail_comm_destroy(grail_ctx *ctx);
+
+/* ---- one call, the whole node (SURVEY.md §8e "one process, 8 devices") ---------------------------------------------
+ * The reference host makes ONE call for its whole job (examples/cli.rs:175-184: one chain, collected) and the chain's
+ * state is per utterance (src/lib.rs:470-488, 724-748, 839-854), so a batch shards over the GPUs of a node with no
+ * exchange step.  A grail_node is that for a host that stays one process (a Rust binary, say): one grail_ctx and one
+ * host thread per device; a call cuts the batch into the contiguous ranges of grail_shard_range, renders the shards
+ * concurrently and lands every shard in its slice of ONE host buffer.  Utterance u's samples are the same bits as from
+ * grail_synthesize_batch on a single context ("arithmetic" = 0; in fast arithmetic they follow the kernel family of the
+ * shard's size, as with any batch size — pin "lanes_per_utterance" for batch-invariant fast bits).
+ * A node is used from one thread at a time.  Failures: the first failing device's status and message
+ * ("device[i] = d: ..."); GRAIL_ERR_BUFFER_TOO_SMALL when some shard reported it and none failed harder. */
+/* devices[n_devices]: HIP device ordinals, one shard each (NULL: 0 .. n_devices - 1).  A device may be named more than
+ * once (several contexts on it — what the tests on a one-GPU box do); RCCL then cannot form the communicator, see
+ * grail_node_set_voices. */
+int grail_node_create(const int *devices, uint32_t n_devices, grail_node **out);
+int grail_node_destroy(grail_node *node);
+uint32_t grail_node_size(const grail_node *node);
+/* The context of device slot `index` (borrowed; owned by the node): per-device queries — grail_get_option,
+ * grail_device_pci_bus_id, grail_comm_info, grail_get_voices — between node calls. */
+int grail_node_context(grail_node *node, uint32_t index, grail_ctx **ctx);
+/* Installs the voice table on every device: device slot 0 receives it (grail_set_voices) and ONE ncclBroadcast over
+ * xGMI carries it to the HBM of the others, over a communicator formed inside the process (ncclCommInitAll over the
+ * node's devices, on the first call) — the collective of §8e.  RCCL refuses a communicator that names a GPU twice: a
+ * node created with duplicate devices fails here with GRAIL_ERR_RCCL unless option "node_voices_without_rccl" = 1 was
+ * set, which installs the table with one grail_set_voices per context instead (for tests on a one-GPU box; never
+ * chosen silently). */
+int grail_node_set_voices(grail_node *node, const grail_voice *voices, uint32_t n_voices);
+/* "node_voices_without_rccl" (0 default / 1) belongs to the node; every other name is grail_set_option on each of
+ * its contexts.  grail_node_get_option: "node_devices", "node_voices_without_rccl", "node_rccl_ranks" (the smallest
+ * ncclCommCount over the contexts, 0: no communicator); any other name is read from device slot 0. */
+int grail_node_set_option(grail_node *node, const char *name, int64_t value);
+int grail_node_get_option(grail_node *node, const char *name, int64_t *value);
+/* The shard of device slot `index` out of n_devices, as a pure host function (no GPU): rows
+ * [first_row, first_row + rows) = grail_shard_range(n_utt, index, n_devices), their segments
+ * segs[first_seg .. first_seg + n_segs), and — rebased_offsets != NULL, cap >= rows + 1 — the rows' seg_offsets
+ * relative to first_seg.  The node calls below hand exactly this view to grail_synthesize_batch*(): segs + first_seg,
+ * rebased_offsets, voice_ids + first_row, jitter_seeds + first_row, out + first_row * out_stride, out_len + first_row. */
+typedef struct grail_node_shard {
+    uint64_t first_row;
+    uint64_t rows;
+    uint32_t first_seg;
+    uint32_t n_segs;
+} grail_node_shard;
+int grail_node_shard_of(const uint32_t *seg_offsets, uint64_t n_utt, uint32_t index, uint32_t n_devices,
+                        grail_node_shard *shard, uint32_t *rebased_offsets, uint64_t cap);
+/* grail_synthesize_batch / _elems / _pcm16 / grail_say_batch over the node: same arguments and row semantics; `out`
+ * and `out_len` are HOST memory (flags must not hold GRAIL_OUT_DEVICE: there is no one device to leave the rows on).
+ * Every shard goes through its context's overlapped device-to-host pipeline into its slice of `out`; pinned memory
+ * from grail_node_host_alloc receives the copies directly. */
+int grail_node_synthesize_batch(grail_node *node, const grail_phoneme_elem *segs, const uint32_t *seg_offsets,
+                                const uint32_t *voice_ids, const uint32_t *jitter_seeds, uint32_t n_utt, float *out,
+                                uint64_t out_stride, uint32_t *out_len, uint32_t flags);
+int grail_node_synthesize_batch_elems(grail_node *node, const grail_sequence_elem *segs, const uint32_t *seg_offsets,
+                                      const uint32_t *voice_ids, const uint32_t *jitter_seeds, uint32_t n_utt,
+                                      float *out, uint64_t out_stride, uint32_t *out_len, uint32_t flags);
+int grail_node_synthesize_batch_pcm16(grail_node *node, const grail_phoneme_elem *segs, const uint32_t *seg_offsets,
+                                      const uint32_t *voice_ids, const uint32_t *jitter_seeds, uint32_t n_utt,
+                                      int16_t *out, uint64_t out_stride, uint32_t *out_len, uint32_t flags);
+int grail_node_say_batch(grail_node *node, const char *const *texts_utf8, uint32_t n_texts, const uint32_t *voice_ids,
+                         const uint32_t *jitter_seeds, float *out, uint64_t out_stride, uint32_t *out_len,
+                         uint32_t flags);
+/* grail_batch_lengths over the node (the Sequencer clock pre-pass, src/lib.rs:861-888): what a caller sizes out_stride
+ * with.  out_len is host memory [n_utt]. */
+int grail_node_lengths(grail_node *node, const grail_phoneme_elem *segs, const uint32_t *seg_offsets,
+                       const uint32_t *voice_ids, uint32_t n_utt, uint32_t max_len, uint32_t *out_len);
+/* Wall-clock milliseconds each device slot spent in the last node call (host memory [grail_node_size]; 0 for a slot
+ * whose shard was empty): how evenly the shards loaded the node. */
+int grail_node_last_shard_ms(grail_node *node, float *ms, uint32_t cap);
+/* Pinned host memory every device of the node can copy into (hipHostMallocPortable). */
+int grail_node_host_alloc(grail_node *node, size_t bytes, void **out);
+int grail_node_host_free(grail_node *node, void *ptr);
 
 #ifdef __cplusplus
 }

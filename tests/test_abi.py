@@ -54,11 +54,11 @@ def test_header_option_list_equals_what_the_library_accepts():
 
 def test_abi_version_and_status_strings(built):
     lib = G.load()
-    assert lib.grail_abi_version() == G.ABI_VERSION == 3
+    assert lib.grail_abi_version() == G.ABI_VERSION == 4
     hdr = open(os.path.join(ROOT, "include", "grail_hip.h")).read()
-    assert re.search(r"#define GRAIL_ABI_VERSION (\d+)", hdr).group(1) == "3"
+    assert re.search(r"#define GRAIL_ABI_VERSION (\d+)", hdr).group(1) == "4"
     sys_rs = open(os.path.join(ROOT, "grail-rs_amd", "rust", "grail-hip-sys", "src", "lib.rs")).read()
-    assert "pub const GRAIL_ABI_VERSION: c_int = 3;" in sys_rs
+    assert "pub const GRAIL_ABI_VERSION: c_int = 4;" in sys_rs
     for st in range(0, -8, -1):
         assert lib.grail_status_string(st)
     assert b"CPU fallback" in lib.grail_status_string(G.ERR_NO_DEVICE)
@@ -158,11 +158,168 @@ def test_compute_calls_fail_loudly_without_a_device(built):
     assert ei.value.status == G.ERR_NO_DEVICE
 
 
+# ---- the Rust -sys crate against the header, signature by signature --------------------------------------------------
+# There is no rustc in the image, so nothing compiles the crate against the header: this parser is what keeps a swapped
+# u32 / u64 or a dropped parameter out of it.  Types are brought to one canonical form on both sides: a base name and the
+# constness of what each pointer level points to, outermost first ("*const *const c_char" == "const char *const *").
+_C_BASE = {"uint32_t": "u32", "int32_t": "i32", "uint64_t": "u64", "int64_t": "i64", "uint8_t": "u8", "int16_t": "i16",
+           "float": "f32", "double": "f64", "size_t": "usize", "int": "c_int", "char": "c_char", "void": "c_void"}
+
+
+def _c_type(tokens):
+    """['const', 'char', '*', 'const', '*'] -> ('c_char', ('const', 'const')) — pointer levels outermost first."""
+    toks = list(tokens)
+    base_const = False
+    while toks and toks[0] == "const":
+        base_const, toks = True, toks[1:]
+    base, toks = toks[0], toks[1:]
+    if toks and toks[0] == "const":
+        base_const, toks = True, toks[1:]
+    levels, pointee_const = [], base_const
+    while toks:
+        assert toks[0] == "*", tokens
+        levels.append("const" if pointee_const else "mut")
+        toks = toks[1:]
+        pointee_const = bool(toks) and toks[0] == "const"
+        if pointee_const:
+            toks = toks[1:]
+    return _C_BASE.get(base, base), tuple(reversed(levels))
+
+
+def _c_decl(decl):
+    """One C parameter or struct field -> (name, canonical type, array length or None)."""
+    m = re.match(r"^(.*?)(\w+)\s*(?:\[(\w+)\])?$", decl.strip(), re.S)
+    ty, name, arr = m.group(1), m.group(2), m.group(3)
+    return name, _c_type(re.findall(r"\w+|\*", ty)), arr
+
+
+def c_header_model():
+    src = open(os.path.join(ROOT, "include", "grail_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    structs = {}
+    for body, name in re.findall(r"typedef struct \w+ \{(.*?)\}\s*(\w+);", src, flags=re.S):
+        fields = []
+        for f in body.split(";"):
+            if f.strip():
+                fname, ty, arr = _c_decl(f)
+                fields.append((fname, ty, arr))
+        structs[name] = fields
+    src = re.sub(r"typedef (struct|enum) \w+ \{.*?\}\s*\w+;", "", src, flags=re.S)
+    src = re.sub(r"^\s*#.*$", "", src, flags=re.M)                       # preprocessor lines
+    src = re.sub(r"typedef struct \w+\s+\w+;", "", src)                  # the opaque handles
+    src = src.replace('extern "C" {', "")
+    funcs = {}
+    for ret, name, params in re.findall(r"([\w\s\*]+?)\b(grail_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", src):
+        ret_ty = _c_type(re.findall(r"\w+|\*", ret))
+        plist = []
+        if params.strip() != "void":
+            for prm in params.split(","):
+                _, ty, arr = _c_decl(prm)
+                if arr:                                   # an array parameter is a pointer to its element
+                    ty = (ty[0], (("const" if "const" in prm.split() else "mut"),) + ty[1])
+                plist.append(ty)
+        funcs[name] = (None if ret_ty == ("c_void", ()) else ret_ty, plist)
+    return funcs, structs
+
+
+def _rust_type(text):
+    toks = text.replace("std::ffi::c_void", "c_void").split()
+    levels = []
+    while toks[0] in ("*const", "*mut"):
+        levels.append(toks[0][1:])
+        toks = toks[1:]
+    assert len(toks) == 1, text
+    return toks[0], tuple(levels)
+
+
+def rust_sys_model(src):
+    ext = src[src.index('extern "C" {'):]
+    funcs = {}
+    for name, params, ret in re.findall(r"pub fn (grail_[a-z0-9_]+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+?))?\s*;", ext, flags=re.S):
+        plist = [_rust_type(prm.split(":", 1)[1].strip()) for prm in params.split(",") if prm.strip()]
+        funcs[name] = (_rust_type(ret.strip()) if ret else None, plist)
+    structs = {}
+    for name, body in re.findall(r"pub struct (grail_\w+) \{(.*?)\n\}", src, flags=re.S):
+        fields = []
+        for fname, ty in re.findall(r"pub (\w+):\s*([^,\n]+),", body):
+            m = re.match(r"\[(.+);\s*(\w+)\]", ty.strip())
+            fields.append((fname, _rust_type(m.group(1).strip() if m else ty.strip()), m.group(2) if m else None))
+        if fields:
+            structs[name] = fields
+    sizes = {n: int(v) for n, v in re.findall(r"assert!\(std::mem::size_of::<(grail_\w+)>\(\) == (\d+)\)", src)}
+    return funcs, structs, sizes
+
+
+def ffi_differences(rust_src):
+    c_funcs, c_structs = c_header_model()
+    r_funcs, r_structs, _ = rust_sys_model(rust_src)
+    diffs = []
+    for name in sorted(set(c_funcs) | set(r_funcs)):
+        if name not in c_funcs or name not in r_funcs:
+            diffs.append(f"{name}: declared on one side only")
+        elif c_funcs[name] != r_funcs[name]:
+            diffs.append(f"{name}: header {c_funcs[name]} != crate {r_funcs[name]}")
+    for name in sorted(c_structs):
+        if name not in r_structs:
+            diffs.append(f"struct {name}: missing in the crate")
+        elif c_structs[name] != r_structs[name]:
+            diffs.append(f"struct {name}: header {c_structs[name]} != crate {r_structs[name]}")
+    return diffs
+
+
+def _sys_source():
+    return open(os.path.join(ROOT, "grail-rs_amd", "rust", "grail-hip-sys", "src", "lib.rs")).read()
+
+
 def test_rust_sys_crate_mirrors_the_header():
-    """grail-hip-sys (source only: no rustc in the image) declares exactly the header's functions."""
-    src = open(os.path.join(ROOT, "grail-rs_amd", "rust", "grail-hip-sys", "src", "lib.rs")).read()
+    """grail-hip-sys (source only: no rustc in the image) declares exactly the header's functions — names, arity, every
+    parameter type, every return type — and its #[repr(C)] structs have the header's fields in the header's order."""
+    src = _sys_source()
     rust = sorted(set(re.findall(r"pub fn (grail_[a-z0-9_]+)\s*\(", src)))
     assert rust == header_functions()
+    c_funcs, c_structs = c_header_model()
+    assert sorted(c_funcs) == header_functions() and len(c_structs) >= 7
+    assert ffi_differences(src) == []
+
+
+def test_the_signature_check_catches_a_swapped_width_a_dropped_parameter_and_a_lost_const():
+    src = _sys_source()
+    cases = [
+        ("out: *mut f32, out_stride: u64, out_len: *mut u32, flags: u32) -> c_int;",
+         "out: *mut f32, out_stride: u32, out_len: *mut u32, flags: u32) -> c_int;", "grail_synthesize_batch"),
+        ("pub fn grail_shard_range(n_utt: u64, rank: u32, world: u32, begin: *mut u64, end: *mut u64);",
+         "pub fn grail_shard_range(n_utt: u64, rank: u32, begin: *mut u64, end: *mut u64);", "grail_shard_range"),
+        ("pub fn grail_batch_size(batch: *const grail_batch) -> u32;",
+         "pub fn grail_batch_size(batch: *mut grail_batch) -> u32;", "grail_batch_size"),
+        ("pub fn grail_length_bound(segment_lengths: *const f32, n_segments: u32, sample_rate: f32) -> u64;",
+         "pub fn grail_length_bound(segment_lengths: *const f32, n_segments: u32, sample_rate: f32) -> u32;",
+         "grail_length_bound"),
+        ("    pub first_seg: u32,\n    pub n_segs: u32,", "    pub n_segs: u32,\n    pub first_seg: u32,", "struct grail_node_shard"),
+    ]
+    for good, bad, where in cases:
+        assert src.count(good) >= 1, good
+        diffs = ffi_differences(src.replace(good, bad, 1))
+        assert len(diffs) == 1 and diffs[0].startswith(where), (where, diffs)
+
+
+def test_rust_struct_size_asserts_hold_for_the_header(tmp_path):
+    """The crate's `const _: () = assert!(size_of::<T>() == N)` literals against what the C compiler gives the header's
+    structs (and against the ctypes mirrors the GPU tests call through)."""
+    import subprocess
+    _, _, sizes = rust_sys_model(_sys_source())
+    names = ["grail_synthesis_elem", "grail_voice", "grail_phoneme_elem", "grail_sequence_elem", "grail_plan_block",
+             "grail_node_shard"]
+    assert sorted(sizes) == sorted(names)
+    prog = tmp_path / "sizes.c"
+    prog.write_text('#include <stdio.h>\n#include "grail_hip.h"\nint main(void) {\n' +
+                    "".join(f'    printf("{n} %zu\\n", sizeof({n}));\n' for n in names) + "    return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    assert {n: int(v) for n, v in got.items()} == sizes
+    mirrors = {"grail_synthesis_elem": G.SynthesisElem, "grail_voice": G.Voice, "grail_phoneme_elem": G.PhonemeElem,
+               "grail_sequence_elem": G.SequenceElem, "grail_plan_block": G.PlanBlock, "grail_node_shard": G.NodeShard}
+    assert {n: C.sizeof(t) for n, t in mirrors.items()} == sizes
 
 
 def test_cpp_facade_example_builds(built):
