@@ -260,6 +260,10 @@ def main():
                     help="after the timed region and the fast leg: BASELINE configs 4 (65 536 utterances x 8 presets) and 2 "
                          "(4 096 utterances) and the speech-like corpus (65 536), exact and fast, a few steps each, reported as `other_configs` (default: "
                          "on for the default config-3 run at N=1)")
+    ap.add_argument("--corpus", default="aligned", choices=["aligned", "speech"],
+                    help="aligned: the BASELINE corpus (four segments of 0.5 s per utterance, the headline); speech: the "
+                         "speech-like corpus of grail_hip/workload.py (8 - 32 phonemes of 40 - 160 ms, 0.5 - 3.8 s) as the timed "
+                         "batch — N=1 only, not a BASELINE config (counter passes of `other_configs.speech_like`)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per utterance (0 = auto)")
     ap.add_argument("--pipeline", type=int, default=1, choices=[0, 1],
                     help="0 disables the small-batch producer/consumer kernels (A/B)")
@@ -295,6 +299,8 @@ def main():
 
     if args.rccl_diagnose:
         return rccl_diagnose()
+    if args.corpus == "speech" and (args.gpus > 1 or args.verify or args.pcm16):
+        raise SystemExit("--corpus speech is a one-GPU f32 leg (no --gpus N, --verify, --pcm16)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)
 
@@ -438,7 +444,11 @@ def main():
             rccl_info = {"ranks": 0, "broadcast": "file-fallback"}
 
     # ---- this rank's shard of the corpus, resident in HBM ---------------------------------
-    first, last, segs, offs, vids, seeds = W.shard_inputs(n_utt, rank, world, len(voices))
+    if args.corpus == "speech":
+        first, last = 0, n_utt
+        segs, offs, vids, seeds, stride = W.speech_like_batch(n_utt, np.random.default_rng(7), n_voices=len(voices))
+    else:
+        first, last, segs, offs, vids, seeds = W.shard_inputs(n_utt, rank, world, len(voices))
     batch = ctx.upload(segs, offs, vids, seeds)
     ctx.set_option("lanes_per_utterance", args.lanes)
     ctx.set_option("small_batch_pipeline", args.pipeline)
@@ -641,88 +651,97 @@ def main():
     other_configs = None
     want_other = (args.other_configs == 1) or (args.other_configs == -1 and world == 1 and args.mode == "exact" and
                                                  n_utt == 65536 and n_voices == 1 and not args.pcm16 and args.lanes == 0)
-    if want_other and rank == 0 and world == 1:
+    if want_other and rank == 0 and world == 1 and args.corpus == "aligned":
         other_configs = {}
         ctx2 = G.Context(device)
+        # an optional extra must not cost the headline its line: a failure here (a smaller part without room for the
+        # speech-like rows, an upload error) is recorded in `other_configs.error` and the run goes on
         try:
-            for name, o_utts, o_voices, o_steps in (("config4", 65536, 8, 5), ("config2", 4096, 1, 10)):
-                o_table = W.single_voice() if o_voices == 1 else W.preset_voices(o_voices)
-                ctx2.set_voices(o_table)
-                o_batch = ctx2.upload(*W.make_batch(o_utts, n_voices=o_voices))
-                legs = {}
-                for o_mode in ("exact", "fast"):
-                    ctx2.set_option("arithmetic", 1 if o_mode == "fast" else 0)
-                    o_batch.synthesize_async(d_out, stride, d_len)      # (d_out / d_len: the timed region's rows, done with)
-                    ctx2.sync()
-                    o_kernel = []
-                    t2 = time.perf_counter()
-                    for _ in range(o_steps):
-                        o_batch.synthesize_async(d_out, stride, d_len)
-                        ctx2.sync()
-                        o_kernel.append(ctx2.last_kernel_ms())
-                    o_elapsed = time.perf_counter() - t2
-                    o_len = np.zeros(o_utts, dtype=np.uint32)
-                    ctx2.d2h(o_len, d_len, o_utts * 4)
-                    o_samples = int(o_len.astype(np.uint64).sum())
-                    o_symbol = ctx2.last_kernel_name()
-                    o_k = float(np.mean(o_kernel))
-                    o_ach = o_samples * ALG_BYTES_PER_SAMPLE / (o_k * 1e-3) / 1e9
-                    o_entry = committed_counters(f"{name}_utts{o_utts}" + ("_fast" if o_mode == "fast" else ""), o_symbol)
-                    legs[o_mode] = {
-                        "value": o_samples * o_steps / o_elapsed, "unit": "samples/s", "steps": o_steps,
-                        "ms_per_step": o_elapsed * 1e3 / o_steps, "kernel_ms": o_k, "kernel": o_symbol,
-                        "launch_blocks": ctx2.get_option("last_launch_blocks"),
-                        "roofline": {"bound": "hbm", "achieved": o_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": o_ach / HBM_PEAK_GBS, "traffic": o_entry.get("hbm_bytes") if o_entry else None,
-                                     "algorithmic_bytes_per_launch": o_samples * ALG_BYTES_PER_SAMPLE},
-                        "roofline_valu": valu_roofline(o_entry, o_k),
-                    }
-                other_configs[name] = {
-                    "workload": f"batch={o_utts} utterances x 2 s (4 segments x 0.5 s), {o_voices} Voice preset(s), 48 kHz, "
-                                f"f32 PCM left in HBM (BASELINE {name})", **legs}
-                o_batch.free()
-            # ... and the headline batch's size on SPEECH-LIKE input (grail_hip/workload.py speech_like_batch: 8 - 32 phonemes of
-            # 40 - 160 ms per utterance, 0.5 - 3.8 s, every lane's segment boundaries at times of its own): what the kernels do
-            # when the events of a wave's lanes do not coincide, and the launch plan by the rows' lengths and events
-            ctx2.set_voices(W.single_voice())
-            s_segs, s_offs, s_vids, s_seeds, s_stride = W.speech_like_batch(65536, np.random.default_rng(7))
-            s_batch = ctx2.upload(s_segs, s_offs, s_vids, s_seeds)
-            s_out, s_len_dev = ctx2.device_alloc(65536 * s_stride * 4), ctx2.device_alloc(65536 * 4)
-            try:
-                legs = {}
-                for o_mode in ("exact", "fast"):
-                    ctx2.set_option("arithmetic", 1 if o_mode == "fast" else 0)
-                    s_batch.synthesize_async(s_out, s_stride, s_len_dev)
-                    ctx2.sync()
-                    o_kernel = []
-                    t2 = time.perf_counter()
-                    for _ in range(3):
-                        s_batch.synthesize_async(s_out, s_stride, s_len_dev)
-                        ctx2.sync()
-                        o_kernel.append(ctx2.last_kernel_ms())
-                    o_elapsed = time.perf_counter() - t2
-                    o_len = np.zeros(65536, dtype=np.uint32)
-                    ctx2.d2h(o_len, s_len_dev, 65536 * 4)
-                    o_samples = int(o_len.astype(np.uint64).sum())
-                    o_k = float(np.mean(o_kernel))
-                    o_ach = o_samples * ALG_BYTES_PER_SAMPLE / (o_k * 1e-3) / 1e9
-                    legs[o_mode] = {
-                        "value": o_samples * 3 / o_elapsed, "unit": "samples/s", "steps": 3, "ms_per_step": o_elapsed * 1e3 / 3,
-                        "kernel_ms": o_k, "kernel": ctx2.last_kernel_name(), "launch_blocks": ctx2.get_option("last_launch_blocks"),
-                        "lanes_per_utterance_used": ctx2.get_option("last_launch_lanes"),
-                        "arithmetic_ran": "fast" if ctx2.get_option("last_launch_fast") else "exact",
-                        "roofline": {"bound": "hbm", "achieved": o_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": o_ach / HBM_PEAK_GBS, "traffic": None,
-                                     "algorithmic_bytes_per_launch": o_samples * ALG_BYTES_PER_SAMPLE},
-                    }
-                other_configs["speech_like"] = {
-                    "workload": "batch=65536 utterances of 8 - 32 phonemes of 40 - 160 ms (0.5 - 3.8 s, 2.0 s on average: the headline "
-                                "batch's samples), blends of 30 - 80 ms, single Voice, 48 kHz, f32 PCM left in HBM (not a BASELINE "
-                                "config: the bench corpus has four aligned segments of 0.5 s)", **legs}
-            finally:
-                ctx2.device_free(s_out)
-                ctx2.device_free(s_len_dev)
-                s_batch.free()
+          try:
+              for name, o_utts, o_voices, o_steps in (("config4", 65536, 8, 5), ("config2", 4096, 1, 10)):
+                  o_table = W.single_voice() if o_voices == 1 else W.preset_voices(o_voices)
+                  ctx2.set_voices(o_table)
+                  o_batch = ctx2.upload(*W.make_batch(o_utts, n_voices=o_voices))
+                  legs = {}
+                  for o_mode in ("exact", "fast"):
+                      ctx2.set_option("arithmetic", 1 if o_mode == "fast" else 0)
+                      o_batch.synthesize_async(d_out, stride, d_len)      # (d_out / d_len: the timed region's rows, done with)
+                      ctx2.sync()
+                      o_kernel = []
+                      t2 = time.perf_counter()
+                      for _ in range(o_steps):
+                          o_batch.synthesize_async(d_out, stride, d_len)
+                          ctx2.sync()
+                          o_kernel.append(ctx2.last_kernel_ms())
+                      o_elapsed = time.perf_counter() - t2
+                      o_len = np.zeros(o_utts, dtype=np.uint32)
+                      ctx2.d2h(o_len, d_len, o_utts * 4)
+                      o_samples = int(o_len.astype(np.uint64).sum())
+                      o_symbol = ctx2.last_kernel_name()
+                      o_k = float(np.mean(o_kernel))
+                      o_ach = o_samples * ALG_BYTES_PER_SAMPLE / (o_k * 1e-3) / 1e9
+                      o_entry = committed_counters(f"{name}_utts{o_utts}" + ("_fast" if o_mode == "fast" else ""), o_symbol)
+                      legs[o_mode] = {
+                          "value": o_samples * o_steps / o_elapsed, "unit": "samples/s", "steps": o_steps,
+                          "ms_per_step": o_elapsed * 1e3 / o_steps, "kernel_ms": o_k, "kernel": o_symbol,
+                          "launch_blocks": ctx2.get_option("last_launch_blocks"),
+                          "roofline": {"bound": "hbm", "achieved": o_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": o_ach / HBM_PEAK_GBS, "traffic": o_entry.get("hbm_bytes") if o_entry else None,
+                                       "algorithmic_bytes_per_launch": o_samples * ALG_BYTES_PER_SAMPLE},
+                          "roofline_valu": valu_roofline(o_entry, o_k),
+                      }
+                  other_configs[name] = {
+                      "workload": f"batch={o_utts} utterances x 2 s (4 segments x 0.5 s), {o_voices} Voice preset(s), 48 kHz, "
+                                  f"f32 PCM left in HBM (BASELINE {name})", **legs}
+                  o_batch.free()
+              # ... and the headline batch's size on SPEECH-LIKE input (grail_hip/workload.py speech_like_batch: 8 - 32 phonemes of
+              # 40 - 160 ms per utterance, 0.5 - 3.8 s, every lane's segment boundaries at times of its own): what the kernels do
+              # when the events of a wave's lanes do not coincide, and the launch plan by the rows' lengths and events
+              ctx2.set_voices(W.single_voice())
+              s_segs, s_offs, s_vids, s_seeds, s_stride = W.speech_like_batch(65536, np.random.default_rng(7))
+              s_batch = ctx2.upload(s_segs, s_offs, s_vids, s_seeds)
+              s_out, s_len_dev = ctx2.device_alloc(65536 * s_stride * 4), ctx2.device_alloc(65536 * 4)
+              try:
+                  legs = {}
+                  for o_mode in ("exact", "fast"):
+                      ctx2.set_option("arithmetic", 1 if o_mode == "fast" else 0)
+                      s_batch.synthesize_async(s_out, s_stride, s_len_dev)
+                      ctx2.sync()
+                      o_kernel = []
+                      t2 = time.perf_counter()
+                      for _ in range(3):
+                          s_batch.synthesize_async(s_out, s_stride, s_len_dev)
+                          ctx2.sync()
+                          o_kernel.append(ctx2.last_kernel_ms())
+                      o_elapsed = time.perf_counter() - t2
+                      o_len = np.zeros(65536, dtype=np.uint32)
+                      ctx2.d2h(o_len, s_len_dev, 65536 * 4)
+                      o_samples = int(o_len.astype(np.uint64).sum())
+                      o_k = float(np.mean(o_kernel))
+                      o_ach = o_samples * ALG_BYTES_PER_SAMPLE / (o_k * 1e-3) / 1e9
+                      s_symbol = ctx2.last_kernel_name()
+                      # (counters of the same corpus as the timed batch: bench.py --corpus speech, tools/collect_counters.py)
+                      s_entry = committed_counters("speech_like_utts65536" + ("_fast" if o_mode == "fast" else ""), s_symbol)
+                      legs[o_mode] = {
+                          "value": o_samples * 3 / o_elapsed, "unit": "samples/s", "steps": 3, "ms_per_step": o_elapsed * 1e3 / 3,
+                          "kernel_ms": o_k, "kernel": s_symbol, "launch_blocks": ctx2.get_option("last_launch_blocks"),
+                          "lanes_per_utterance_used": ctx2.get_option("last_launch_lanes"),
+                          "arithmetic_ran": "fast" if ctx2.get_option("last_launch_fast") else "exact",
+                          "roofline": {"bound": "hbm", "achieved": o_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": o_ach / HBM_PEAK_GBS, "traffic": s_entry.get("hbm_bytes") if s_entry else None,
+                                       "algorithmic_bytes_per_launch": o_samples * ALG_BYTES_PER_SAMPLE},
+                          "roofline_valu": valu_roofline(s_entry, o_k),
+                      }
+                  other_configs["speech_like"] = {
+                      "workload": "batch=65536 utterances of 8 - 32 phonemes of 40 - 160 ms (0.5 - 3.8 s, 2.0 s on average: the headline "
+                                  "batch's samples), blends of 30 - 80 ms, single Voice, 48 kHz, f32 PCM left in HBM (not a BASELINE "
+                                  "config: the bench corpus has four aligned segments of 0.5 s)", **legs}
+              finally:
+                  ctx2.device_free(s_out)
+                  ctx2.device_free(s_len_dev)
+                  s_batch.free()
+          except Exception as e:                       # noqa: BLE001 — reported in the line
+              other_configs["error"] = f"{type(e).__name__}: {e}"
         finally:
             ctx2.close()
 
@@ -746,8 +765,8 @@ def main():
         alg_bytes = samples_per_step * (ALG_BYTES_PER_SAMPLE - (2.0 if args.pcm16 else 0.0))
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         cfg = "4" if len(voices) > 1 else ("2" if n_utt == 4096 else "3")
-        wl_key = f"config{cfg}_utts{n_utt}" + ("_pcm16" if args.pcm16 else "") + \
-                 ("_fast" if args.mode == "fast" else "_mid" if args.mode == "mid" else "")
+        wl_key = (f"config{cfg}_utts{n_utt}" if args.corpus == "aligned" else f"speech_like_utts{n_utt}") + \
+                 ("_pcm16" if args.pcm16 else "") + ("_fast" if args.mode == "fast" else "_mid" if args.mode == "mid" else "")
         entry = committed_counters(wl_key, kernel_symbol)
         line = {
             "metric": "audio samples/sec (whole node) at 48 kHz, batch=65536 utterances",
@@ -755,9 +774,11 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"batch={n_utt} utterances x 2 s (4 segments x 0.5 s) per GPU, "
-                            f"{len(voices)} Voice preset(s), 48 kHz, {'i16' if args.pcm16 else 'f32'} PCM left in HBM "
-                            f"(BASELINE config {cfg}{'; config 5 sharding' if world > 1 else ''})",
+                "workload": (f"batch={n_utt} utterances x 2 s (4 segments x 0.5 s) per GPU, "
+                             f"{len(voices)} Voice preset(s), 48 kHz, {'i16' if args.pcm16 else 'f32'} PCM left in HBM "
+                             f"(BASELINE config {cfg}{'; config 5 sharding' if world > 1 else ''})") if args.corpus == "aligned" else
+                            (f"batch={n_utt} speech-like utterances (8 - 32 phonemes of 40 - 160 ms, 0.5 - 3.8 s), "
+                             f"{len(voices)} Voice preset(s), 48 kHz, f32 PCM left in HBM (NOT a BASELINE config)"),
                 "arithmetic": args.mode,
                 "utterances_per_gpu": n_utt, "samples_per_utterance": int(out_len[0]),
                 "samples_per_step_per_gpu": samples_per_step, "out_stride": stride,
@@ -803,6 +824,9 @@ def main():
         if world == 1 and args.cpu_utts > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_utts, voices, W)
             line["speedup_vs_cpu_1thread"] = value / line["cpu_baseline"]["value"]
+            # like for like: the CPU baseline evaluates all eight formants; so does config 4 (the headline skips four dead ones)
+            c4 = (other_configs or {}).get("config4", {}).get("exact")
+            line["speedup_vs_cpu_1thread_all_formants"] = (c4["value"] / line["cpu_baseline"]["value"]) if c4 else None
             line["cpu_all_cores"] = cpu_all_cores(voices, W)
         print(json.dumps(line), flush=True)
 

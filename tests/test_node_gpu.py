@@ -210,3 +210,20 @@ def test_failures_name_the_device_slot(built):
     with pytest.raises(G.GrailError) as e:
         G.Node([0, 99])
     assert e.value.status == G.ERR_NO_DEVICE and "device[1] = 99" in str(e.value)
+
+
+def test_cpp_facade_node_example(built):
+    """grail::Node (include/grail.hpp) end to end: examples/grail_node_say.cpp renders its arguments over the node and
+    compares every row with one device's; over RCCL with one device, and over three contexts on it under the option."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "grail-rs_amd", "lib", "grail_node_say")
+    assert os.path.exists(exe)
+    texts = ["a", "ae", "e a e", "aa", "eee a"]
+    r = subprocess.run([exe, "--devices", "0"] + texts, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "5 utterances over 1 device slots (RCCL ranks 1)" in r.stdout and "differ from one device's: 0" in r.stdout
+    r = subprocess.run([exe, "--devices", "0,0,0", "--without-rccl"] + texts, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "5 utterances over 3 device slots (RCCL ranks 0)" in r.stdout and "differ from one device's: 0" in r.stdout
+    r = subprocess.run([exe, "--devices", "0,0"] + texts, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "twice" in r.stderr and "status -6" in r.stderr

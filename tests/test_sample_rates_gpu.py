@@ -230,3 +230,60 @@ def test_mixed_sample_rates_on_the_time_split_grid_of_rows_that_differ(gpu_ctx):
         peak = max(1.0, float(np.abs(ref[u, :n]).max()))
         worst = max(worst, float(np.abs(out[u, :n] - ref[u, :n]).max()) / peak)
     assert 0.0 < worst <= G.FAST_TOLERANCE, worst * 2 ** 23
+
+
+def test_a_batch_uploaded_on_a_48_khz_context_and_rendered_on_a_192_khz_one(built):
+    """One batch, two contexts (a batch may be rendered by several contexts): uploaded where the table's highest rate is
+    48 kHz — the per-utterance length bound of the time-split kernels is computed for THAT rate — and rendered by a context
+    whose table is at 192 kHz, where every utterance is four times as long in samples.  Both contexts have installed
+    exactly one table: a per-context epoch counter would call the bound current ("1 == 1"), the chunks beyond it would be
+    skipped and the rows would come out truncated.  Voice-table epochs are unique in the process, so the second context
+    renders without the bound: lengths equal to the oracle's at 192 kHz, rows within the tolerance."""
+    rng = np.random.default_rng(4242)
+    slow, quick = _voices((48000.0,)), _voices((192000.0,))
+    n_utt = 1500
+    segs, offs, vids, seeds = _batch(rng, n_utt, 0.125, ragged=True, rates=(192000.0,))
+    stride = 48128
+    L = G.load()
+    with G.Context(0) as a, G.Context(0) as b:
+        a.set_voices(slow)
+        b.set_voices(quick)
+        batch = a.upload(segs, offs, vids, seeds)
+        d_out, d_len = b.device_alloc(n_utt * stride * 4), b.device_alloc(n_utt * 4)
+        try:
+            for k, v in (("assume_compute_units", 18), ("time_parallel_scan", 0), ("ragged_plan", 0),
+                         ("time_split_min_utterances", 0), ("arithmetic", 1)):
+                b.set_option(k, v)
+            b.memset(d_out, 0, n_utt * stride * 4)
+            G._check(L.grail_batch_synthesize_async(b.handle, batch.handle, d_out, stride, d_len))
+            b.sync()
+            name, chunks = b.last_kernel_name(), b.get_option("last_launch_chunks")
+            out = np.zeros((n_utt, stride), dtype=np.float32)
+            out_len = np.zeros(n_utt, dtype=np.uint32)
+            b.d2h(out, d_out, out.nbytes)
+            b.d2h(out_len, d_len, out_len.nbytes)
+            # ... and the uploading context still uses its bound, on its own table
+            for k, v in (("assume_compute_units", 18), ("time_parallel_scan", 0), ("ragged_plan", 0),
+                         ("time_split_min_utterances", 0), ("arithmetic", 1)):
+                a.set_option(k, v)
+            own_len = np.zeros(n_utt, dtype=np.uint32)
+            d_out_a, d_len_a = a.device_alloc(n_utt * stride * 4), a.device_alloc(n_utt * 4)
+            batch.synthesize_async(d_out_a, stride, d_len_a)
+            a.sync()
+            a.d2h(own_len, d_len_a, own_len.nbytes)
+            a.device_free(d_out_a)
+            a.device_free(d_len_a)
+        finally:
+            b.device_free(d_out)
+            b.device_free(d_len)
+            batch.free()
+    assert "SPLIT" in name and chunks >= 3, (name, chunks)
+    ref, ref_len = _oracle(quick, segs, offs, vids, seeds, stride)
+    assert np.array_equal(out_len, ref_len)
+    assert np.array_equal(own_len, _oracle(slow, segs, offs, vids, seeds, stride)[1])
+    worst = 0.0
+    for u in rng.choice(n_utt, size=60, replace=False):
+        n = int(ref_len[u])
+        peak = max(1.0, float(np.abs(ref[u, :n]).max()))
+        worst = max(worst, float(np.abs(out[u, :n] - ref[u, :n]).max()) / peak)
+    assert 0.0 < worst <= G.FAST_TOLERANCE, worst * 2 ** 23

@@ -118,6 +118,9 @@ def test_a_lone_stream_runs_at_the_pace_of_a_full_workgroup(gpu_ctx):
             gpu_ctx.device_free(d_out)
             gpu_ctx.device_free(d_len)
             b.free()
+    if ms[1] > 1.5 * ms[256]:
+        from conftest import skip_if_clocks_unstable
+        skip_if_clocks_unstable(gpu_ctx, f"a lone stream took {ms[1]:.3f} ms against {ms[256]:.3f} for 256")
     assert ms[1] <= 1.5 * ms[256], ms
 
 

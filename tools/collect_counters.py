@@ -28,6 +28,9 @@ WORKLOADS = [   # key (as bench.py builds it), bench arguments
     ("config3_utts65536_pcm16", ["--config", "3", "--mode", "exact", "--pcm16"]),
     # the regime the time-parallel scan kernel still serves (fast arithmetic, up to 1 536 utterances)
     ("config3_utts1024_fast", ["--utts", "1024", "--mode", "fast"]),
+    # the speech-like corpus of bench.py's `other_configs.speech_like` (not a BASELINE config), as the timed batch
+    ("speech_like_utts65536", ["--corpus", "speech", "--mode", "exact"]),
+    ("speech_like_utts65536_fast", ["--corpus", "speech", "--mode", "fast"]),
 ]
 PASSES = [["WRITE_SIZE"], ["FETCH_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_BUSY_CYCLES"]]
 COMMON = ["--fast-leg", "0", "--other-configs", "0", "--cpu-utts", "0", "--steps", "2", "--warmup", "0", "--ramp", "0"]

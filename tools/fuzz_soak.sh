@@ -4,7 +4,7 @@
 #   fast mode    the fuzz tests of tests/test_fast_gpu.py (lane kernels; time-split kernels; batch invariance), new seeds
 # usage (through gpurun): tools/fuzz_soak.sh [extra_exact_seeds [fast_seeds [trials_per_seed]]]
 extra=${1:-24}; seeds=${2:-8}; trials=${3:-12}
-cd $GRAFT_REPO_ROOT
+root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; export TMPDIR=/tmp; cd "$root" || exit 1
 echo "# exact mode, $extra extra seeds per test (bit-identical to the oracle, every lane mapping)"
 GRAIL_FUZZ_EXTRA=$extra python3 -m pytest tests/test_fuzz_gpu.py -m gpu -q 2>&1 | tail -1
 echo "# fast mode, $seeds seeds x $trials trials: worst |fast - oracle| relative to max(1, peak), contract 64 * 2^-23"

@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Batches of more than one round of the one-lane kernels whose rows differ in length: what the ORDER of the launch slots is
+worth.  The library fills the slots longest row first; the hardware hands the next workgroup (one wave of 64 rows) to the
+next SIMD that runs dry — greedy list scheduling, "longest processing time first".  With about two waves per SIMD that
+leaves the SIMDs uneven at the end (131 072 speech-like rows: the slowest SIMD holds 1.11 x the mean).  Here the waves are
+PACKED on the host instead (best-fit decreasing under a bisected capacity, per XCD: workgroup b runs on XCD b mod 8) and
+launched in the order of their planned start times, so that the same greedy dispatcher reproduces the packing.
+No kernel change: rows are handed over in the planned order with "sort_by_length" = 0.
+usage: packed_order_experiment.py [n_utt ...] [--voices=8] [--fast] [--no-xcd]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "grail-rs_amd"))
+import numpy as np
+import grail_hip as G
+from grail_hip import workload as W
+
+
+def pack(cost, bins):
+    """jobs (cost descending) -> list of bins, each a list of job indices: best-fit decreasing under the smallest capacity
+    (bisection) that needs no more than `bins` bins."""
+    import bisect
+
+    def fit(cap):
+        rem, who = [], []           # remaining capacities ascending, the bins behind them
+        out = []
+        for j, c in enumerate(cost):
+            i = bisect.bisect_left(rem, c)
+            if i < len(rem):
+                r, b = rem.pop(i), who.pop(i)
+            else:
+                if len(out) == bins:
+                    return None
+                out.append([])
+                r, b = cap, len(out) - 1
+            out[b].append(j)
+            k = bisect.bisect_left(rem, r - c)
+            rem.insert(k, r - c)
+            who.insert(k, b)
+        return out
+
+    lo, hi = max(cost.sum() / bins, cost.max()), None
+    # an upper end that fits: greedy LPT's makespan
+    import heapq
+    loads = [0.0] * bins
+    heapq.heapify(loads)
+    for c in cost:
+        heapq.heappush(loads, heapq.heappop(loads) + c)
+    hi = max(loads)
+    best = fit(hi)
+    for _ in range(24):
+        mid = 0.5 * (lo + hi)
+        got = fit(mid)
+        if got is None:
+            lo = mid
+        else:
+            hi, best = mid, got
+    return best, hi, max(loads)
+
+
+def planned_block_order(job_cost, slots, xcds):
+    """-> order[block] = job; (planned makespan, greedy makespan, ideal) summed over the XCDs' worst."""
+    n_jobs = len(job_cost)
+    order = np.zeros(n_jobs, dtype=np.int64)
+    worst_plan = worst_greedy = 0.0
+    for x in range(xcds):
+        mine = np.arange(x, n_jobs, xcds)                  # the jobs of this XCD, cost descending
+        bins, cap, greedy = pack(job_cost[mine], slots // xcds)
+        worst_plan, worst_greedy = max(worst_plan, cap), max(worst_greedy, greedy)
+        seq = []
+        for b in bins:
+            t = 0.0
+            for j in b:                                     # (descending within a bin: the first round is the longest jobs)
+                seq.append((t, -job_cost[mine[j]], mine[j]))
+                t += job_cost[mine[j]]
+        seq.sort()
+        for k, (_, _, j) in enumerate(seq):
+            order[x + xcds * k] = j
+    return order, worst_plan, worst_greedy, max(job_cost.sum() / slots, job_cost.max())
+
+
+def main():
+    sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [131072]
+    n_voices = 8 if "--voices=8" in sys.argv else 1
+    fast = 1 if "--fast" in sys.argv else 0
+    xcds = 1 if "--no-xcd" in sys.argv else 8
+    ctx = G.Context(0)
+    ctx.set_voices(W.single_voice() if n_voices == 1 else W.preset_voices(8))
+    slots = 4 * ctx.get_option("compute_units")
+    for n in sizes:
+        segs, offs, vids, seeds, stride = W.speech_like_batch(n, np.random.default_rng(7), n_voices=n_voices)
+        d_out, d_len = ctx.device_alloc(n * stride * 4), ctx.device_alloc(n * 4)
+
+        def run(segs_, offs_, vids_, seeds_, sort, lanes):
+            ctx.set_option("sort_by_length", sort)
+            ctx.set_option("lanes_per_utterance", lanes)
+            ctx.set_option("arithmetic", fast)
+            b = ctx.upload(segs_, offs_, vids_, seeds_)
+            ms = []
+            for _ in range(3):
+                b.synthesize_async(d_out, stride, d_len)
+                ctx.sync()
+                ms.append(ctx.last_kernel_ms())
+            what = f"{ctx.last_kernel_name()}, {ctx.get_option('last_launch_blocks')} block(s)"
+            lens = np.zeros(n, dtype=np.uint32)
+            ctx.d2h(lens, d_len, lens.nbytes)
+            b.free()
+            ctx.set_option("sort_by_length", 1)
+            ctx.set_option("lanes_per_utterance", 0)
+            ctx.set_option("arithmetic", 0)
+            return min(ms), what, lens
+
+        auto_ms, auto_what, lens = run(segs, offs, vids, seeds, 1, 0)
+        lpt_ms, lpt_what, _ = run(segs, offs, vids, seeds, 1, 1)
+        # the planned order: rows by length (descending), waves of 64, waves packed and ordered by planned start
+        by_len = np.argsort(-lens.astype(np.int64), kind="stable")
+        n_jobs = (n + 63) // 64
+        job_cost = np.array([lens[by_len[j * 64]] for j in range(n_jobs)], dtype=np.float64)
+        order, plan, greedy, ideal = planned_block_order(job_cost, slots, xcds)
+        rows = np.concatenate([by_len[j * 64:(j + 1) * 64] for j in order])
+        counts = (offs[1:] - offs[:-1])[rows]
+        p_offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint32)
+        p_segs = np.concatenate([segs[offs[u]:offs[u + 1]] for u in rows])
+        packed_ms, packed_what, p_lens = run(p_segs, p_offs, vids[rows], seeds[rows], 0, 1)
+        assert np.array_equal(p_lens, lens[rows])
+        print(f"{n} speech-like rows, {n_voices} voice(s), {'fast' if fast else 'exact'}: library {auto_ms:7.2f} ms ({auto_what}) | one lane, longest "
+              f"first {lpt_ms:7.2f} ms | one lane, packed order {packed_ms:7.2f} ms ({packed_what}) = {packed_ms / lpt_ms:.3f} x   "
+              f"[model, samples of a SIMD's longest rows: ideal {ideal:.0f}, greedy {greedy / ideal:.3f} x, packed {plan / ideal:.3f} x; "
+              f"{'per XCD' if xcds > 1 else 'one pool'}]", flush=True)
+        ctx.device_free(d_out)
+        ctx.device_free(d_len)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/pmc_scan.sh <tag> "<scan_probe_one args>" COUNTER...   (one rocprofv3 --pmc pass over the scan kernel)
 tag=$1; shift; args="$1"; shift
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; export TMPDIR=/tmp; cd "$root" || exit 1
 rm -rf gpurun_out/prof/$tag; mkdir -p gpurun_out/prof/$tag
 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/prof/$tag -- python3 tools/scan_probe_one.py $args > gpurun_out/prof/$tag.log 2>&1
 python3 - <<PY

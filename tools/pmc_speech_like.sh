@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ counters of the kernels the speech-like corpus runs on (the library's plan, 65 536 utterances, one and eight voices, exact
 # and tolerance arithmetic): per-kernel averages per dispatch.   usage (on the GPU box): bash tools/pmc_speech_like.sh > out.txt
-cd /tmp && export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
+root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; export TMPDIR=/tmp; cd "$root" || exit 1
 rm -rf gpurun_out/prof/speech_pmc; mkdir -p gpurun_out/prof/speech_pmc
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_INSTS_LDS \
   --output-format csv -d gpurun_out/prof/speech_pmc -- python3 tools/speech_like_bench.py 65536 > gpurun_out/prof/speech_pmc.log 2>&1

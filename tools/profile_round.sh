@@ -3,7 +3,7 @@
 # bench command, PMC counters for every reported workload (tools/collect_counters.py), tool outputs.
 # usage (through gpurun): tools/profile_round.sh <tag>     -> gpurun_out/<tag>/
 tag=${1:-r05}
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; export TMPDIR=/tmp; cd "$root" || exit 1
 out=gpurun_out/$tag; mkdir -p $out
 python3 tools/collect_counters.py $out/traffic.json > $out/collect_counters.log 2>&1
 cp $out/traffic.json profiles/traffic.json            # so that the bench lines below carry the counters
