@@ -69,6 +69,7 @@ struct grail_ctx {
     int ragged_option = 1;            // length-sorted batches: lane mappings weighed by the rows' lengths (ragged_plan)
     int pipe_spread = 1;              // pipelined workgroups on rows that differ in length: few utterances per workgroup (pipe_fill_for)
     int two_waves_option = 1;         // tolerance-mode lane kernels on 2 / 4 / 8 lanes: two waves per SIMD where a launch has more waves than SIMDs
+    int packed_option = 1;            // launches of more one-wave-per-SIMD workgroups than the device has room for: launch slots in packed order
     int composite_option = 1;         // a batch may be cut into blocks with a kernel family each (plan_blocks)
     int row_groups_option = 1;        // rows the lean families cannot take are planned apart: 1 where the cost model says so, 2 always, 0 never
     double voices_sharpness = INFINITY;   // the largest predicted fast-mode deviation of the table, units of 2^-23
@@ -93,6 +94,7 @@ struct grail_ctx {
     float max_dt = 0.0f;              // largest 1/sample_rate of the table
     float max_pitch_jitter = 0.0f;    // largest |jitter_delta_frequency| of the table
     int last_formants = 8, last_lanes = 0, last_pipe = 0;   // what the last synthesis launch used (statistics)
+    int last_packed = 0;              // ... blocks of it launched in packed order
     uint32_t *d_truncated = nullptr;  // [0] truncation flag, [1] slow-path wave-steps, [2] fast wave-tiles, [3] general wave-steps
     uint64_t slow_steps = 0;          // of the kernels synced so far
     uint64_t fast_tiles = 0, general_steps = 0;
@@ -146,12 +148,25 @@ struct grail_stream {
     int stage_next = 0;
 };
 
+// A block of a ragged batch in PACKED launch order (launch_plan.cpp, "The workgroup dispatcher"): the slot -> utterance table
+// of rows [slot0, slot0 + rows) with its workgroups re-ordered, on the device.  Kept by the batch (never overwritten: a
+// kernel of another context may still be reading it), freed with it.
+struct PackedPerm {
+    const void *view = nullptr;       // the (view of the) batch the block belongs to
+    uint32_t slot0 = 0, rows = 0, per_block = 0, cus = 0;
+    uint32_t family = 0;              // L | fast << 8 | live4 << 16: what the workgroups' costs were priced for
+    uint32_t *d_perm = nullptr;       // [rows]; nullptr: the plain order is as good (remembered, so that it is not packed again)
+    double model_ms = 0.0, plain_ms = 0.0;
+};
+
 struct grail_batch {
     grail::DevSeg *d_segs = nullptr;
     uint32_t *d_offsets = nullptr;
     uint32_t *d_voice_ids = nullptr;
     uint32_t *d_seeds = nullptr;
     uint32_t *d_perm = nullptr;   // ragged batches: launch slot -> utterance, longest first
+    std::vector<uint32_t> perm_host;          // ... its host copy (the root batch only; packed launch orders are cut from it)
+    mutable std::vector<PackedPerm> packed;   // ... blocks of it in packed launch order, made at their first launch
     uint32_t *d_len_bound = nullptr;   // per utterance: an upper bound of its length in samples (plain batches; time-split kernels)
     uint64_t len_bound_epoch = 0;      // ... for the voice table of this epoch (its highest sample rate); epochs are unique
                                        // in the process, so a context other than the uploader never matches
@@ -283,6 +298,11 @@ void choose_family(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_
 // ragged batches: what a block costs given the lengths and events of ITS rows; the whole-batch plan weighed against
 // one launch of each lane mapping with as many rounds as it takes (launch_plan.cpp)
 double ragged_cost(const grail_ctx *ctx, const grail_batch *batch, const Family &f, uint32_t slot0, uint32_t rows, double span);
+// The launch order of the workgroups of such a block (one wave per SIMD, more workgroups than the device holds at once):
+// true and order[position] = workgroup (in the plain, longest-first numbering) when the packed order is worth it by the
+// dispatcher's model; *plain_ms / *packed_ms: the model's makespans.  rows_per_block: what a workgroup renders.
+bool packed_launch_order(const grail_ctx *ctx, const grail_batch *batch, const Family &f, uint32_t slot0, uint32_t rows, double span,
+                         std::vector<uint32_t> *order, uint32_t *rows_per_block, double *plain_ms, double *packed_ms);
 void ragged_plan(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t rows, std::vector<Block> &plan);
 double plan_blocks(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t rows, double span,
                    std::vector<Block> &out, bool exact_only = false);

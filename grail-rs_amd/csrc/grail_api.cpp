@@ -63,6 +63,9 @@ void free_batch_buffers(grail_batch *b)
     if (b->d_voice_ids) (void)hipFree(b->d_voice_ids);
     if (b->d_seeds) (void)hipFree(b->d_seeds);
     if (b->d_perm) (void)hipFree(b->d_perm);
+    for (PackedPerm &pp : b->packed)
+        if (pp.d_perm) (void)hipFree(pp.d_perm);
+    b->packed.clear();
     if (b->d_len_bound) (void)hipFree(b->d_len_bound);
     if (b->d_elems) (void)hipFree(b->d_elems);
 }
@@ -228,6 +231,7 @@ int upload_length_order(grail_ctx *ctx, grail_batch *b, const std::vector<RowSta
     } else if (ragged) {
         summarise(*b, n_utt);
     }
+    b->perm_host.swap(perm);          // (after the views were copied off the batch: they share d_perm, only the root keeps this)
     return GRAIL_OK;
 }
 
@@ -510,6 +514,10 @@ int grail_set_option(grail_ctx *ctx, const char *name, int64_t value)
         ctx->scan_option = value ? 1 : 0;
         return GRAIL_OK;
     }
+    if (std::strcmp(name, "packed_launch_order") == 0) {
+        ctx->packed_option = value ? 1 : 0;
+        return GRAIL_OK;
+    }
     if (std::strcmp(name, "sort_by_length") == 0) {    // applies to batches uploaded afterwards
         ctx->sort_option = value ? 1 : 0;
         return GRAIL_OK;
@@ -662,6 +670,14 @@ int grail_get_option(grail_ctx *ctx, const char *name, int64_t *value)
     }
     if (std::strcmp(name, "pipeline_round32") == 0) {
         *value = ctx->pipe_round32;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "packed_launch_order") == 0) {
+        *value = ctx->packed_option;
+        return GRAIL_OK;
+    }
+    if (std::strcmp(name, "last_launch_packed") == 0) {
+        *value = ctx->last_packed;
         return GRAIL_OK;
     }
     if (std::strcmp(name, "sort_by_length") == 0) {

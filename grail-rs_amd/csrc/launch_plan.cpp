@@ -642,20 +642,190 @@ double ragged_cost(const grail_ctx *ctx, const grail_batch *batch, const Family 
             }
             if (m.b >= 0.0) done_at.push(Ev(next_done(m), ev.second));
         }
-        return makespan;
+        // Against measurements of every pinned mapping on 40 000 ... 200 000 speech-like rows, one and eight voices
+        // (profiles/r06_plan_debug.txt): the exact two-wave kernels run ahead of this simulation — two lanes 0.77 - 0.86 of
+        // it (they got their runs between events after the wave prices were fitted), four lanes 0.86 - 0.95 — at every
+        // size, and the tolerance-mode two-lane kernel falls behind it (1.13 - 1.20) once a launch holds more waves than
+        // are resident at once.  With the one-wave-per-SIMD launches priced by the dispatcher's model (within 0.93 - 1.0
+        // of their measurements), the two-wave prices are brought to the same scale here.
+        const double waves = std::ceil((double)(g1 - g0) / (double)per_wave);
+        const double scale = !f.fast ? (f.L == 2 ? 0.84 : 0.91) : (f.L == 2 && waves > 2.0 * (double)simds ? 1.15 : 1.0);
+        return makespan * scale;
     }
-    std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
-    double makespan = 0.0;
-    for (size_t g = g0; g < g1; g += per_wave) {
-        double t = wave_ms(g);
-        if (free_at.size() >= simds) {
-            t += free_at.top();
-            free_at.pop();
+    // one wave per SIMD: the workgroups of the launch through the dispatcher's model, in the plain (longest rows first) or
+    // in the packed order, whichever the launch will take (packed_launch_order: the same decision)
+    double plain_ms = 0.0, packed_ms = 0.0;
+    const bool packed = packed_launch_order(ctx, batch, f, slot0, rows, span, nullptr, nullptr, &plain_ms, &packed_ms);
+    // (x 0.96: the wave prices of ragged_wave_ms through the dispatcher's model come out 0 - 7 % over the measurements,
+    // uniformly over mappings, sizes and both arithmetics — profiles/r06_plan_debug.txt)
+    return 0.96 * (packed ? packed_ms : plain_ms);
+}
+
+// ---- The workgroup dispatcher, as measured (tools/dispatch_order.hip: workgroups that spin for given times and record
+// where and when they ran; profiles/r06_dispatch_order.txt).  A launch of one-wave workgroups that each hold a SIMD alone:
+//   * workgroup b runs on XCC b mod 8 (8 XCCs of 32 compute units);
+//   * the k-th workgroup of an XCC goes to shader engine pattern[k mod 4] — a STATIC round robin over the XCC's four
+//     engines (8 compute units = 32 SIMDs each), whatever their load;
+//   * it starts when that engine has a SIMD free AND every earlier workgroup of the XCC has started (in order: a full
+//     engine holds up the workgroups behind it that are bound for the others).
+// This model reproduces the makespan of recorded launches of 2 048 - 3 125 workgroups to the microsecond (ten launches,
+// longest first and packed orders).  So workgroup b belongs to pool b mod 32, each pool 32 SIMDs, and "the next wave goes
+// to the SIMD that falls free first" holds within a pool only.  Workgroups of four waves (L >= 4) take a compute unit: 8 per
+// engine.  A device that is not whole XCCs (a test's "assume_compute_units"): one pool.
+struct Dispatcher {
+    uint32_t xcc = 1, se = 1, slots = 1;
+    uint32_t pools() const { return xcc * se; }
+};
+
+static Dispatcher dispatcher_of(const grail_ctx *ctx, const uint32_t waves_per_block)
+{
+    Dispatcher d;
+    const uint32_t cus = (uint32_t)ctx->cus;
+    if (cus >= 32u && cus % 32u == 0u) {
+        d.xcc = cus / 32u;
+        d.se = 4u;
+        d.slots = waves_per_block == 1u ? 32u : 8u;
+    } else {
+        d.slots = std::max(1u, waves_per_block == 1u ? 4u * cus : cus);
+    }
+    return d;
+}
+
+// cost[b]: what workgroup b takes; order (or nullptr: 0, 1, 2 ...): the workgroup at each launch position
+static double dispatch_makespan(const Dispatcher &d, const std::vector<double> &cost, const std::vector<uint32_t> *order)
+{
+    typedef std::priority_queue<double, std::vector<double>, std::greater<double>> Free;
+    const size_t n = order ? order->size() : cost.size();
+    double worst = 0.0;
+    for (uint32_t x = 0; x < d.xcc; ++x) {
+        std::vector<Free> engine(d.se);
+        std::vector<uint32_t> used(d.se, 0u);
+        double prev = 0.0;
+        uint32_t k = 0;
+        for (size_t b = x; b < n; b += d.xcc, ++k) {
+            const uint32_t e = k % d.se;
+            double t = prev;                                     // every earlier workgroup of the XCC has started
+            if (used[e] < d.slots) ++used[e];                    // (a SIMD of the engine that has not run anything yet)
+            else {
+                t = std::fmax(t, engine[e].top());
+                engine[e].pop();
+            }
+            prev = t;
+            const double end = t + cost[order ? (*order)[b] : b];
+            engine[e].push(end);
+            if (end > worst) worst = end;
         }
-        free_at.push(t);
-        if (t > makespan) makespan = t;
     }
-    return makespan;
+    return worst;
+}
+
+// Best-fit decreasing of `jobs` (indices into cost, cost descending) into at most `bins` bins under capacity `cap`:
+// bin_of[i] for jobs[i], or false.
+static bool fit_decreasing(const std::vector<double> &cost, const std::vector<uint32_t> &jobs, const uint32_t bins, const double cap,
+                           std::vector<uint32_t> &bin_of)
+{
+    std::vector<double> room;                                    // remaining capacity of the bins opened so far (a few dozen: scanned)
+    room.reserve(bins);
+    bin_of.resize(jobs.size());
+    for (size_t i = 0; i < jobs.size(); ++i) {
+        const double c = cost[jobs[i]];
+        size_t best = room.size();
+        for (size_t b = 0; b < room.size(); ++b)
+            if (room[b] >= c && (best == room.size() || room[b] < room[best])) best = b;
+        if (best == room.size()) {
+            if (room.size() == bins || c > cap) return false;
+            room.push_back(cap);
+        }
+        bin_of[i] = (uint32_t)best;
+        room[best] -= c;
+    }
+    return true;
+}
+
+// The packed order.  Longest first leaves the SIMDs of a pool uneven at the end when a SIMD gets two or three workgroups
+// (131 072 speech-like rows: the slowest SIMD 1.15 x the mean); packing evens them out, and launching the workgroups in the
+// order of their planned start times makes the dispatcher reproduce the packing.  Workgroups are dealt to the pools in turn
+// (by cost: the pools get alike sets), each pool is packed into its SIMDs under the smallest capacity that fits
+// (bisection), and position p + pools * k of the launch takes the k-th workgroup of pool p by planned start.
+static void pack_order(const Dispatcher &d, const std::vector<double> &cost, const size_t n_jobs, std::vector<uint32_t> &order)
+{
+    const uint32_t P = d.pools();
+    std::vector<uint32_t> by_cost(n_jobs);
+    for (size_t j = 0; j < n_jobs; ++j) by_cost[j] = (uint32_t)j;
+    std::stable_sort(by_cost.begin(), by_cost.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    order.resize(n_jobs);
+    std::vector<uint32_t> jobs, bin_of, best_bin;
+    for (uint32_t p = 0; p < P; ++p) {
+        jobs.clear();
+        for (size_t j = p; j < n_jobs; j += P) jobs.push_back(by_cost[j]);
+        if (jobs.empty()) continue;
+        double sum = 0.0;
+        for (uint32_t j : jobs) sum += cost[j];
+        double lo = std::fmax(sum / (double)d.slots, cost[jobs[0]]), hi = lo;
+        while (!fit_decreasing(cost, jobs, d.slots, hi, best_bin)) hi *= 1.25;       // (terminates: everything fits one bin)
+        for (int it = 0; it < 14 && hi - lo > 5e-4 * hi; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (fit_decreasing(cost, jobs, d.slots, mid, bin_of)) {
+                hi = mid;
+                best_bin.swap(bin_of);
+            } else {
+                lo = mid;
+            }
+        }
+        // planned start of every workgroup: behind the ones before it in its bin (cost descending within a bin)
+        std::vector<double> bin_load(d.slots, 0.0);
+        std::vector<std::pair<double, uint32_t>> seq(jobs.size());                   // (start, rank by cost): stable
+        for (size_t i = 0; i < jobs.size(); ++i) {
+            seq[i] = std::make_pair(bin_load[best_bin[i]], (uint32_t)i);
+            bin_load[best_bin[i]] += cost[jobs[i]];
+        }
+        std::sort(seq.begin(), seq.end());
+        for (size_t k = 0; k < seq.size(); ++k) order[p + (size_t)P * k] = jobs[seq[k].second];
+    }
+}
+
+bool packed_launch_order(const grail_ctx *ctx, const grail_batch *batch, const Family &f, uint32_t slot0, uint32_t rows, double span,
+                         std::vector<uint32_t> *order, uint32_t *rows_per_block, double *plain_ms, double *packed_ms)
+{
+    if (order) order->clear();
+    const size_t n_gran = batch->granule_samples.size();
+    const uint32_t waves_per_block = f.L >= 4 ? 4u : 1u;
+    const uint32_t per_wave_rows = 64u / (uint32_t)f.L, per_block = per_wave_rows * waves_per_block;
+    if (rows_per_block) *rows_per_block = per_block;
+    if (n_gran == 0 || rows == 0 || f.scan || f.pipe || f.split_k || slot0 % 8u != 0u) return false;
+    const size_t g0 = std::min<size_t>(slot0 / 8, n_gran - 1), g1 = std::min<size_t>(((size_t)slot0 + rows + 7) / 8, n_gran);
+    const size_t per_wave = (size_t)(8 / f.L > 0 ? 8 / f.L : 1), per_block_g = per_wave * waves_per_block;
+    // what every workgroup costs: its slowest wave (longest row, the rows' events)
+    std::vector<double> cost;
+    for (size_t g = g0; g < g1; g += per_block_g) {
+        double worst = 0.0;
+        for (size_t w = g; w < std::min(g + per_block_g, g1); w += per_wave) {
+            double samples = 0.0, segs = 0.0, kinks = 0.0;
+            for (size_t k = w; k < std::min(w + per_wave, g1); ++k) {
+                samples = std::fmax(samples, (double)batch->granule_samples[k]);
+                segs += batch->granule_segs[k];
+                kinks += batch->granule_kinks[k];
+            }
+            worst = std::fmax(worst, ragged_wave_ms(f, std::fmin(samples + 64.0, span), segs, kinks));
+        }
+        cost.push_back(worst);
+    }
+    const Dispatcher d = dispatcher_of(ctx, waves_per_block);
+    const double plain = dispatch_makespan(d, cost, nullptr);
+    if (plain_ms) *plain_ms = plain;
+    if (packed_ms) *packed_ms = plain;
+    // more workgroups than the device holds at once, each alone on its SIMDs (two waves per SIMD: the fold of synth_kernel.h),
+    // and only whole workgroups are moved: a last one with fewer rows keeps the last position
+    const size_t n_full = rows / per_block;
+    if (!ctx->packed_option || family_cohabits(ctx, f, rows) || cost.size() <= (size_t)d.pools() * d.slots || n_full < 2) return false;
+    std::vector<uint32_t> o;
+    pack_order(d, cost, n_full, o);
+    for (size_t b = n_full; b < cost.size(); ++b) o.push_back((uint32_t)b);
+    const double packed = dispatch_makespan(d, cost, &o);
+    if (!(packed < 0.985 * plain)) return false;                 // (not worth a table of its own)
+    if (packed_ms) *packed_ms = packed;
+    if (order) order->swap(o);
+    return true;
 }
 
 void ragged_plan(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_stride, uint32_t rows, std::vector<Block> &plan)
@@ -672,7 +842,13 @@ void ragged_plan(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_st
         }
         return c;
     };
-    double best = 0.95 * cost_of(plan);          // (a candidate has to be worth the change)
+    // GRAIL_PLAN_DEBUG=1: the candidates and their prices on stderr (development aid; read once)
+    static const bool debug = [] { const char *e = getenv("GRAIL_PLAN_DEBUG"); return e && *e && *e != '0'; }();
+    // (a candidate has to be worth the change: in tolerance arithmetic a row's bits follow its family, and grail_plan_blocks
+    // predicts the cut by size; exact bits follow nothing, and one launch in packed order beats the same mapping cut in two)
+    const double worth = ctx->fast_option ? 0.95 : 0.98;
+    double best = worth * cost_of(plan);
+    if (debug) std::fprintf(stderr, "[ragged_plan] %u rows: the cut by size (%zu block(s)) %.2f ms\n", rows, plan.size(), best / worth);
     if (ctx->fast_option) {
         // fast arithmetic asked for: the cut exact arithmetic would get stands too (small batches: the pipelined
         // workgroups) — events this dense cost the fast kernels more than they save, and exact bits satisfy the tolerance
@@ -704,6 +880,9 @@ void ragged_plan(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_st
             choose_family(ctx, batch, out_stride, rows, f, exact_only != 0, L);
             if (f.scan || f.pipe || f.split_k) continue;
             const double c = ragged_cost(ctx, batch, f, 0, rows, span) + Planner::LAUNCH_MS;
+            if (debug)
+                std::fprintf(stderr, "[ragged_plan]   one launch on %d lane(s)%s%s: %.2f ms\n", f.L, f.fast ? " fast" : " exact",
+                             family_cohabits(ctx, f, rows) ? ", two waves per SIMD" : "", c);
             if (c < best) {
                 best = c;
                 plan.assign(1, Block{rows, f});
@@ -715,6 +894,40 @@ void ragged_plan(const grail_ctx *ctx, const grail_batch *batch, uint64_t out_st
 }  // namespace grail
 
 extern "C" {
+
+int grail_dispatch_model(uint32_t compute_units, uint32_t waves_per_workgroup, const double *workgroup_ms,
+                         const uint32_t *order, uint32_t n, double *makespan_ms)
+{
+    if (!makespan_ms || (n && !workgroup_ms)) return fail(GRAIL_ERR_INVALID_ARG, "NULL argument");
+    if (compute_units == 0 || compute_units > 4096 || (waves_per_workgroup != 1 && waves_per_workgroup != 4))
+        return fail(GRAIL_ERR_INVALID_ARG, "compute_units must be 1 .. 4096, waves_per_workgroup 1 or 4");
+    grail_ctx ctx;
+    ctx.cus = ctx.device_cus = (int)compute_units;
+    std::vector<double> cost(workgroup_ms, workgroup_ms + n);
+    std::vector<uint32_t> o;
+    if (order) {
+        o.assign(order, order + n);
+        for (uint32_t b : o)
+            if (b >= n) return fail(GRAIL_ERR_INVALID_ARG, "order names a workgroup beyond n");
+    }
+    *makespan_ms = dispatch_makespan(dispatcher_of(&ctx, waves_per_workgroup), cost, order ? &o : nullptr);
+    return GRAIL_OK;
+}
+
+int grail_packed_launch_order(uint32_t compute_units, uint32_t waves_per_workgroup, const double *workgroup_ms, uint32_t n,
+                              uint32_t *order)
+{
+    if (n && (!workgroup_ms || !order)) return fail(GRAIL_ERR_INVALID_ARG, "NULL argument");
+    if (compute_units == 0 || compute_units > 4096 || (waves_per_workgroup != 1 && waves_per_workgroup != 4))
+        return fail(GRAIL_ERR_INVALID_ARG, "compute_units must be 1 .. 4096, waves_per_workgroup 1 or 4");
+    grail_ctx ctx;
+    ctx.cus = ctx.device_cus = (int)compute_units;
+    std::vector<double> cost(workgroup_ms, workgroup_ms + n);
+    std::vector<uint32_t> o;
+    pack_order(dispatcher_of(&ctx, waves_per_workgroup), cost, n, o);
+    std::copy(o.begin(), o.end(), order);
+    return GRAIL_OK;
+}
 
 // grail_plan_blocks / grail_plan_ragged_blocks: row_samples == nullptr is the aligned batch
 static int plan_preview(uint32_t compute_units, int arithmetic, int live_formants, uint32_t warmup, uint32_t rows,

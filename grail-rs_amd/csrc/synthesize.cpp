@@ -19,9 +19,54 @@ namespace host {
 // One launch: `count` launch slots from slot `slot0` of the rows [first, first + n_rows) the caller renders, with
 // family f.  out_dev / out_len_dev point at row `first`.  use_perm: the batch's length-sorted slot order applies
 // (whole-batch calls): slot s renders utterance perm[s], and every per-utterance array is indexed by the utterance.
-static int launch_block(grail_ctx *ctx, const grail_batch *batch, const Family &f, float *out_dev, int16_t *out_pcm16_dev,
-                        uint64_t out_stride, uint32_t *out_len_dev, uint32_t first, uint32_t slot0, uint32_t count,
-                        bool use_perm)
+// The block's slot -> utterance table in PACKED launch order (launch_plan.cpp, "The workgroup dispatcher"), made at the
+// block's first launch and kept by the root batch; nullptr: the plain order (it is as good, or the block does not qualify).
+static const uint32_t *packed_perm_of(grail_ctx *ctx, const grail_batch *root, const grail_batch *view, const Family &f,
+                                      uint64_t out_stride, uint32_t slot0, uint32_t count, int *rc)
+{
+    *rc = GRAIL_OK;
+    if (!ctx->packed_option || root->perm_host.size() < (size_t)slot0 + count) return nullptr;
+    const uint32_t family = (uint32_t)f.L | f.fast << 8 | f.live4 << 16;
+    static std::mutex lock;                    // (one batch may be rendered by several contexts, each on a thread of its own)
+    std::lock_guard<std::mutex> hold(lock);
+    for (const PackedPerm &pp : root->packed)
+        if (pp.view == view && pp.slot0 == slot0 && pp.rows == count && pp.family == family && pp.cus == (uint32_t)ctx->cus)
+            return pp.d_perm;
+    if (root->packed.size() >= 8) return nullptr;      // (a batch launched under ever new plans: stop collecting tables)
+    PackedPerm pp;
+    pp.view = view;
+    pp.slot0 = slot0;
+    pp.rows = count;
+    pp.family = family;
+    pp.cus = (uint32_t)ctx->cus;
+    std::vector<uint32_t> order;
+    // (a view's granules count from ITS first slot: the second row group's slots start behind the first's)
+    const uint32_t view_slot0 = view == root || root->groups.size() != 2 || view == &root->groups[0] ? slot0 : slot0 - root->groups[0].n_utt;
+    if (packed_launch_order(ctx, view, f, view_slot0, count, batch_span(ctx, view, out_stride), &order, &pp.per_block, &pp.plain_ms,
+                            &pp.model_ms)) {
+        std::vector<uint32_t> perm(count);
+        const uint32_t *src = root->perm_host.data() + slot0;
+        size_t at = 0;
+        for (const uint32_t b : order) {
+            const size_t lo = (size_t)b * pp.per_block, hi = std::min<size_t>(lo + pp.per_block, count);
+            for (size_t i = lo; i < hi; ++i) perm[at++] = src[i];
+        }
+        hipError_t e = at == count ? hipMalloc((void **)&pp.d_perm, (size_t)count * sizeof(uint32_t)) : hipErrorInvalidValue;
+        if (e == hipSuccess) e = hipMemcpyAsync(pp.d_perm, perm.data(), (size_t)count * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);      // (`perm` is a local; other contexts may use the table next)
+        if (e != hipSuccess) {
+            if (pp.d_perm) (void)hipFree(pp.d_perm);
+            *rc = hip_fail(e, "packed launch order");
+            return nullptr;
+        }
+    }
+    root->packed.push_back(pp);
+    return pp.d_perm;
+}
+
+static int launch_block(grail_ctx *ctx, const grail_batch *root, const grail_batch *batch, const Family &f, float *out_dev,
+                        int16_t *out_pcm16_dev, uint64_t out_stride, uint32_t *out_len_dev, uint32_t first, uint32_t slot0,
+                        uint32_t count, bool use_perm)
 {
     SynthArgs a{};
     const uint32_t row0 = use_perm ? 0u : first + slot0;      // the utterance that index 0 of the launch's arrays is
@@ -32,6 +77,15 @@ static int launch_block(grail_ctx *ctx, const grail_batch *batch, const Family &
     a.voice_ids = batch->d_voice_ids ? batch->d_voice_ids + row0 : nullptr;
     a.seeds = batch->d_seeds ? batch->d_seeds + row0 : nullptr;
     a.perm = use_perm ? batch->d_perm + slot0 : nullptr;
+    if (use_perm) {
+        int rc = GRAIL_OK;
+        const uint32_t *packed = packed_perm_of(ctx, root, batch, f, out_stride, slot0, count, &rc);
+        if (rc) return rc;
+        if (packed) {
+            a.perm = packed;
+            ++ctx->last_packed;
+        }
+    }
     a.elems = batch->phoneme_mode ? ctx->d_voice_elems : batch->d_elems;
     a.voices = ctx->d_voices;
     a.out = out_dev ? out_dev + out_shift : nullptr;
@@ -175,6 +229,7 @@ int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_dev,
     ctx->last_formants = f0.live4 ? 4 : 8;
     ctx->last_lanes = f0.scan ? 0 : f0.L;
     ctx->last_pipe = f0.pipe && !f0.scan ? 1 : 0;
+    ctx->last_packed = 0;
     ctx->last_fast = 0;
     ctx->last_blocks = (int)plan.size();
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
@@ -182,7 +237,7 @@ int synthesize_rows(grail_ctx *ctx, const grail_batch *batch, float *out_dev,
     std::string first_kernel;
     for (size_t i = 0; i < plan.size(); ++i) {
         const Block &b = plan[i].block;
-        rc = launch_block(ctx, plan[i].view, b.f, out_dev, out_pcm16_dev, out_stride, out_len_dev, first, slot0, b.rows, use_perm);
+        rc = launch_block(ctx, batch, plan[i].view, b.f, out_dev, out_pcm16_dev, out_stride, out_len_dev, first, slot0, b.rows, use_perm);
         if (rc) return rc;
         if (i == main_block) first_kernel = ctx->last_kernel;
         if ((int)b.f.fast > ctx->last_fast) ctx->last_fast = (int)b.f.fast;

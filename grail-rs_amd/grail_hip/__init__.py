@@ -54,7 +54,8 @@ EXPORTS = [
     "grail_elem_silent", "grail_elem_new_phoneme", "grail_elem_new", "grail_elem_resample",
     "grail_elem_blend", "grail_voice_generic", "grail_voice_generic_at", "grail_voice_get",
     "grail_create", "grail_destroy", "grail_device_count", "grail_device_pci_bus_id", "grail_time_split_warmup", "grail_length_bound",
-    "grail_time_split_grid", "grail_fast_sharpness", "grail_plan_blocks", "grail_plan_ragged_blocks", "grail_set_voices",
+    "grail_time_split_grid", "grail_fast_sharpness", "grail_plan_blocks", "grail_plan_ragged_blocks", "grail_dispatch_model",
+    "grail_packed_launch_order", "grail_set_voices",
     "grail_get_voices", "grail_set_option", "grail_get_option",
     "grail_batch_upload", "grail_batch_upload_elems", "grail_batch_free", "grail_batch_size",
     "grail_batch_lengths", "grail_batch_synthesize_async", "grail_sync",
@@ -234,6 +235,8 @@ def load():
                                     C.POINTER(PlanBlock), C.c_uint32, u32p]
     L.grail_plan_ragged_blocks.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_uint32, u32p, u32p, u32p,
                                            C.POINTER(PlanBlock), C.c_uint32, u32p]
+    L.grail_dispatch_model.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_double), u32p, C.c_uint32, C.POINTER(C.c_double)]
+    L.grail_packed_launch_order.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.c_uint32, u32p]
     L.grail_set_voices.argtypes = [vp, vp, C.c_uint32]
     L.grail_get_voices.argtypes = [vp, vp, C.c_uint32, u32p]
     L.grail_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
@@ -498,6 +501,26 @@ def plan_ragged_blocks(row_samples, row_segments=None, row_kinks=None, arithmeti
                                            rs.ctypes.data_as(u32p), None if sg is None else sg.ctypes.data_as(u32p),
                                            None if kk is None else kk.ctypes.data_as(u32p), arr, 16, C.byref(n)))
     return [PlanBlock.from_buffer_copy(bytes(arr[i])) for i in range(min(n.value, 16))]
+
+
+def dispatch_model(workgroup_ms, order=None, compute_units=256, waves_per_workgroup=1):
+    """The makespan of workgroups that take workgroup_ms[b], launched in `order`, by the library's model of the workgroup
+    dispatcher (grail_dispatch_model; pure host arithmetic)."""
+    c = np.ascontiguousarray(workgroup_ms, dtype=np.float64)
+    o = None if order is None else np.ascontiguousarray(order, dtype=np.uint32)
+    out = C.c_double()
+    _check(load().grail_dispatch_model(compute_units, waves_per_workgroup, c.ctypes.data_as(C.POINTER(C.c_double)),
+                                       None if o is None else o.ctypes.data_as(C.POINTER(C.c_uint32)), len(c), C.byref(out)))
+    return out.value
+
+
+def packed_launch_order(workgroup_ms, compute_units=256, waves_per_workgroup=1):
+    """order[position] = workgroup: what option "packed_launch_order" launches such workgroups in (grail_packed_launch_order)."""
+    c = np.ascontiguousarray(workgroup_ms, dtype=np.float64)
+    o = np.zeros(len(c), dtype=np.uint32)
+    _check(load().grail_packed_launch_order(compute_units, waves_per_workgroup, c.ctypes.data_as(C.POINTER(C.c_double)), len(c),
+                                            o.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return o
 
 
 def device_count():

@@ -154,6 +154,10 @@ extern "C" {
     pub fn grail_plan_ragged_blocks(compute_units: u32, arithmetic: c_int, live_formants: c_int, warmup: u32, rows: u32,
                                     row_samples: *const u32, row_segments: *const u32, row_kinks: *const u32,
                                     blocks: *mut grail_plan_block, cap: u32, n_blocks: *mut u32) -> c_int;
+    pub fn grail_dispatch_model(compute_units: u32, waves_per_workgroup: u32, workgroup_ms: *const f64, order: *const u32,
+                                n: u32, makespan_ms: *mut f64) -> c_int;
+    pub fn grail_packed_launch_order(compute_units: u32, waves_per_workgroup: u32, workgroup_ms: *const f64, n: u32,
+                                     order: *mut u32) -> c_int;
     pub fn grail_set_voices(ctx: *mut grail_ctx, voices: *const grail_voice, n: u32) -> c_int;
     pub fn grail_get_voices(ctx: *mut grail_ctx, voices: *mut grail_voice, cap: u32, n: *mut u32) -> c_int;
     pub fn grail_set_option(ctx: *mut grail_ctx, name: *const c_char, value: i64) -> c_int;

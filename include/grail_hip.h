@@ -81,7 +81,7 @@ extern "C" {
  *   development builds only; "arithmetic" = 1 is served up to a sharpness of the voice table.
  *   3: round 5 — grail_length_bound; options "two_waves_per_simd", "pipeline_spread", "pipeline_round32" = 2; "ragged_plan" also weighs the scan and
  *   time-split kernels by the rows.
- *   4: round 6 — grail_node_* (one call, every GPU of the node). */
+ *   4: round 6 — grail_node_* (one call, every GPU of the node); option "packed_launch_order". */
 #define GRAIL_ABI_VERSION 4
 /* fast mode ("arithmetic" = 1): bound on |fast - exact| per sample, full scale = 1.0; k * 2^-23 */
 #define GRAIL_FAST_TOLERANCE_ULPS 64
@@ -265,12 +265,16 @@ int grail_get_voices(grail_ctx *ctx, grail_voice *voices, uint32_t cap, uint32_t
  *                           be served by an exact mapping where that is cheaper ("last_launch_fast").  bits: fast.
  *   "two_waves_per_simd"    1 (default) / 0: launches of the 2 / 4 / 8-lane kernels with more wavefronts than the device has
  *                           SIMDs take instantiations built for two wavefronts per SIMD (same operations, same bits).
+ *   "packed_launch_order"   1 (default) / 0: a launch of more one-wave-per-SIMD workgroups than the device holds at once, of rows
+ *                           that differ in length, takes its workgroups in a packed order (the SIMDs end together) instead of
+ *                           longest first.
  *   "sort_by_length"        1 (default) / 0: batches uploaded afterwards fill the launch slots longest first (rows stay put).
  *   "assume_compute_units"  0 (default: the device's own) or a count to plan for: tests, callers that share a device.
  *   "scan_debug"            development builds only.
  * Read-only (grail_get_option): "compute_units"; "fast_arithmetic_served" (what "arithmetic" = 1 gets for the voice table as
  *   a whole: 1 / 2 / 0 exact kernels); of the last launch (its largest block): "last_launch_fast" (tier that ran, 0 exact),
- *   "last_launch_blocks", "last_launch_formants" (4 / 8), "last_launch_lanes", "last_launch_pipelined", "last_launch_chunks";
+ *   "last_launch_blocks", "last_launch_formants" (4 / 8), "last_launch_lanes", "last_launch_pipelined", "last_launch_chunks",
+ *   "last_launch_packed" (blocks launched in packed order);
  *   statistics: "slow_division_wave_steps", "fast_wave_tiles" (tiles rendered without a slow sample), "general_wave_steps"
  *   (tolerance mode: slow samples; exact: general steps). */
 int grail_set_option(grail_ctx *ctx, const char *name, int64_t value);
@@ -344,6 +348,22 @@ int grail_plan_blocks(uint32_t compute_units, int arithmetic, int live_formants,
 int grail_plan_ragged_blocks(uint32_t compute_units, int arithmetic, int live_formants, uint32_t warmup, uint32_t rows,
                              const uint32_t *row_samples, const uint32_t *row_segments, const uint32_t *row_kinks,
                              grail_plan_block *blocks, uint32_t cap, uint32_t *n_blocks);
+/* The workgroup dispatcher as the library models it, and the packed launch order, as pure host functions (no GPU).  A launch
+ * of workgroups that each hold their SIMDs alone (the one-wave-per-SIMD kernel families), n of them, more than the device
+ * holds at once: workgroup b runs on XCC b mod 8; the k-th workgroup of an XCC goes to shader engine k mod 4 of it, whatever
+ * the engines' load; it starts when that engine has room AND every earlier workgroup of the XCC has started (measured:
+ * tools/dispatch_order.hip, profiles/r06_dispatch_order.txt — the model gives the makespan of recorded launches to the
+ * microsecond).  waves_per_workgroup: 1 (a SIMD each: 32 per engine) or 4 (a compute unit each: 8 per engine);
+ * compute_units that are not whole XCCs of 32: one pool.
+ * grail_dispatch_model: the makespan of workgroups that take workgroup_ms[b], launched in `order` (order[position] =
+ *   workgroup; NULL: 0, 1, 2 ...).
+ * grail_packed_launch_order: the order option "packed_launch_order" launches them in — dealt to the pools by cost, each pool
+ *   packed into its SIMDs (best-fit decreasing under the smallest capacity that fits), launched by planned start time — so
+ *   that the SIMDs end together where "longest first" leaves them uneven (two or three workgroups per SIMD: up to 15 %). */
+int grail_dispatch_model(uint32_t compute_units, uint32_t waves_per_workgroup, const double *workgroup_ms,
+                         const uint32_t *order, uint32_t n, double *makespan_ms);
+int grail_packed_launch_order(uint32_t compute_units, uint32_t waves_per_workgroup, const double *workgroup_ms, uint32_t n,
+                              uint32_t *order);
 
 /* ---- batches ----------------------------------------------------------- */
 /* Uploads the inputs of n_utt utterances: utterance u is

@@ -3,9 +3,9 @@
 launch_plan.cpp ("waves are handed to the SIMDs in launch order as they fall free").  Workgroups spin for the time the waves
 of a speech-like batch would take (scaled), launched (a) longest first and (b) in the packed order of
 tools/packed_order_experiment.py; the records say which XCC / CU / SIMD ran each workgroup, from when to when.
-Reports: workgroup -> XCC mapping; how many workgroups ran per SIMD; the realised makespan against the model's; and for every
-hand-over after the first round, how long the SIMD had been idle and how many workgroups EARLIER in launch order were still
-waiting (a strict in-order greedy dispatcher: none).
+Reports: workgroup -> XCC mapping; how many workgroups ran per SIMD; the realised makespan against the dispatcher model's
+(packed_order_experiment.dispatch_makespan); for every hand-over after the first round how long the SIMD had been idle; how
+many workgroups started out of launch order.  DISPATCH_ORDER_SAVE=dir keeps the records (which XCC / SE / CU / SIMD, when).
 usage (GPU box): python3 tools/dispatch_order.py [n_utt ...]"""
 import heapq
 import importlib.util
@@ -72,9 +72,9 @@ def run(cost_us, tag):
         b = b[np.argsort(start[b])]
         gaps += list(start[b[1:]] - end[b[:-1]])
     gaps = np.array(gaps) if gaps else np.zeros(1)
-    model = max(greedy(np.asarray(cost_us, dtype=np.float64)[x::8], slots // 8) for x in range(8))
+    model = packed.dispatch_makespan(np.asarray(cost_us, dtype=np.float64))
     print(f"{tag}: {n} workgroups on {slots} SIMD slots; workgroup b on XCC b mod 8: {rr}; per SIMD {per_slot.min()} - {per_slot.max()} workgroups; "
-          f"makespan {end.max() / 1e3:.2f} ms, per-XCC greedy model {model / 1e3:.2f} ms ({end.max() / model:.3f} x); hand-over gap median "
+          f"makespan {end.max() / 1e3:.2f} ms, dispatcher model (static shader-engine round robin, in order per XCC) {model / 1e3:.2f} ms ({end.max() / model:.3f} x); hand-over gap median "
           f"{np.median(gaps):.1f} us, 99th percentile {np.percentile(gaps, 99):.1f} us; started out of launch order (by > 5 us): {late}", flush=True)
     return end.max()
 
@@ -89,9 +89,11 @@ def main():
         cost = np.array([L[j * 64] for j in range(n_jobs)])
         us = cost / 10.0                                   # 192 000 samples -> 19.2 ms
         a = run(us, f"{n} rows, longest first")
-        order, plan, greedy_ms, ideal = packed.planned_block_order(cost, 1024, 8)
-        b = run(us[order], f"{n} rows, packed order ")
-        print(f"    packed / longest first = {b / a:.3f}   (model: {plan / greedy_ms:.3f})", flush=True)
+        for pools in (8, 32):
+            order, plan, greedy_ms, ideal = packed.planned_block_order(cost, 1024, pools)
+            b = run(us[order], f"{n} rows, packed in {pools} pools")
+            print(f"    packed / longest first = {b / a:.3f}   (dispatcher model: "
+                  f"{packed.dispatch_makespan(us[order]) / packed.dispatch_makespan(us):.3f})", flush=True)
 
 
 if __name__ == "__main__":
