@@ -691,6 +691,9 @@ static Dispatcher dispatcher_of(const grail_ctx *ctx, const uint32_t waves_per_b
     return d;
 }
 
+// (costs that are not finite, or negative, count as 0 / 1e30: the model's callers hand over sane prices, the C entry points anything)
+static double sane_cost(const double c) { return c > 0.0 ? (c < 1e30 ? c : 1e30) : 0.0; }
+
 // cost[b]: what workgroup b takes; order (or nullptr: 0, 1, 2 ...): the workgroup at each launch position
 static double dispatch_makespan(const Dispatcher &d, const std::vector<double> &cost, const std::vector<uint32_t> *order)
 {
@@ -711,7 +714,7 @@ static double dispatch_makespan(const Dispatcher &d, const std::vector<double> &
                 engine[e].pop();
             }
             prev = t;
-            const double end = t + cost[order ? (*order)[b] : b];
+            const double end = t + sane_cost(cost[order ? (*order)[b] : b]);
             engine[e].push(end);
             if (end > worst) worst = end;
         }
@@ -747,8 +750,10 @@ static bool fit_decreasing(const std::vector<double> &cost, const std::vector<ui
 // order of their planned start times makes the dispatcher reproduce the packing.  Workgroups are dealt to the pools in turn
 // (by cost: the pools get alike sets), each pool is packed into its SIMDs under the smallest capacity that fits
 // (bisection), and position p + pools * k of the launch takes the k-th workgroup of pool p by planned start.
-static void pack_order(const Dispatcher &d, const std::vector<double> &cost, const size_t n_jobs, std::vector<uint32_t> &order)
+static void pack_order(const Dispatcher &d, const std::vector<double> &cost_in, const size_t n_jobs, std::vector<uint32_t> &order)
 {
+    std::vector<double> cost(cost_in.size());
+    for (size_t i = 0; i < cost.size(); ++i) cost[i] = sane_cost(cost_in[i]);
     const uint32_t P = d.pools();
     std::vector<uint32_t> by_cost(n_jobs);
     for (size_t j = 0; j < n_jobs; ++j) by_cost[j] = (uint32_t)j;
@@ -762,7 +767,8 @@ static void pack_order(const Dispatcher &d, const std::vector<double> &cost, con
         double sum = 0.0;
         for (uint32_t j : jobs) sum += cost[j];
         double lo = std::fmax(sum / (double)d.slots, cost[jobs[0]]), hi = lo;
-        while (!fit_decreasing(cost, jobs, d.slots, hi, best_bin)) hi *= 1.25;       // (terminates: everything fits one bin)
+        hi = std::fmax(hi, 1e-300);
+        while (!fit_decreasing(cost, jobs, d.slots, hi, best_bin)) hi *= 1.25;       // (terminates: at hi >= sum everything fits one bin)
         for (int it = 0; it < 14 && hi - lo > 5e-4 * hi; ++it) {
             const double mid = 0.5 * (lo + hi);
             if (fit_decreasing(cost, jobs, d.slots, mid, bin_of)) {

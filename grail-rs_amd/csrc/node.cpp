@@ -347,6 +347,28 @@ int grail_node_synthesize_batch_pcm16(grail_node *node, const grail_phoneme_elem
     }, &skip);
 }
 
+int grail_node_synthesize_batch_device(grail_node *node, const grail_phoneme_elem *segs, const uint32_t *seg_offsets,
+                                       const uint32_t *voice_ids, const uint32_t *jitter_seeds, uint32_t n_utt,
+                                       float *const *out_dev, uint64_t out_stride, uint32_t *out_len)
+{
+    if (!node) return fail(GRAIL_ERR_INVALID_ARG, "node is NULL");
+    if (!out_dev) return fail(GRAIL_ERR_INVALID_ARG, "out_dev is NULL");
+    std::vector<ShardView> v;
+    std::vector<uint8_t> skip;
+    int rc = shard_views(node, seg_offsets, n_utt, v, skip);
+    if (rc) return rc;
+    for (size_t i = 0; i < v.size(); ++i)
+        if (!skip[i] && !out_dev[i] && out_stride)
+            return fail(GRAIL_ERR_INVALID_ARG, "out_dev[" + std::to_string(i) + "] is NULL and the slot has rows to render");
+    return run_all(node, [&](uint32_t i) {
+        const grail_node_shard &s = v[i].s;
+        return grail_synthesize_batch(node->ctxs[i], segs ? segs + s.first_seg : nullptr, v[i].offs.data(),
+                                      voice_ids ? voice_ids + s.first_row : nullptr,
+                                      jitter_seeds ? jitter_seeds + s.first_row : nullptr, (uint32_t)s.rows, out_dev[i],
+                                      out_stride, out_len ? out_len + s.first_row : nullptr, GRAIL_OUT_DEVICE);
+    }, &skip);
+}
+
 int grail_node_say_batch(grail_node *node, const char *const *texts_utf8, uint32_t n_texts, const uint32_t *voice_ids,
                          const uint32_t *jitter_seeds, float *out, uint64_t out_stride, uint32_t *out_len,
                          uint32_t flags)

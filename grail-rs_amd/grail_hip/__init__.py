@@ -69,7 +69,8 @@ EXPORTS = [
     "grail_broadcast_voices", "grail_comm_info", "grail_comm_destroy",
     "grail_node_create", "grail_node_destroy", "grail_node_size", "grail_node_context", "grail_node_set_voices",
     "grail_node_set_option", "grail_node_get_option", "grail_node_shard_of", "grail_node_synthesize_batch",
-    "grail_node_synthesize_batch_elems", "grail_node_synthesize_batch_pcm16", "grail_node_say_batch",
+    "grail_node_synthesize_batch_elems", "grail_node_synthesize_batch_pcm16", "grail_node_synthesize_batch_device",
+    "grail_node_say_batch",
     "grail_node_lengths", "grail_node_last_shard_ms", "grail_node_host_alloc", "grail_node_host_free",
 ]
 
@@ -305,6 +306,7 @@ def load():
     L.grail_node_synthesize_batch.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, u64, vp, C.c_uint32]
     L.grail_node_synthesize_batch_elems.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, u64, vp, C.c_uint32]
     L.grail_node_synthesize_batch_pcm16.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, u64, vp, C.c_uint32]
+    L.grail_node_synthesize_batch_device.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.POINTER(vp), u64, vp]
     L.grail_node_say_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.c_uint32, vp, vp, vp, u64, vp, C.c_uint32]
     L.grail_node_lengths.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp]
     L.grail_node_last_shard_ms.argtypes = [vp, C.POINTER(C.c_float), C.c_uint32]
@@ -941,6 +943,16 @@ class Node:
         if not (allow_truncation and st == ERR_BUFFER_TOO_SMALL):
             _check(st)
         return out[:n_utt], out_len[:n_utt]
+
+    def synthesize_device(self, segs, seg_offsets, voice_ids, jitter_seeds, out_dev, out_stride):
+        """grail_node_synthesize_batch_device: slot i's shard into out_dev[i] (device memory of its GPU).  Returns out_len."""
+        segs = np.ascontiguousarray(segs, dtype=PHONEME_DTYPE)
+        seg_offsets, n_utt, voice_ids, jitter_seeds = Context._prep(None, segs, seg_offsets, voice_ids, jitter_seeds)
+        ptrs = (C.c_void_p * self.size())(*[p if p is None or isinstance(p, C.c_void_p) else C.c_void_p(p) for p in out_dev])
+        out_len = np.zeros(max(n_utt, 1), dtype=np.uint32)
+        _check(load().grail_node_synthesize_batch_device(self.handle, segs.ctypes.data, seg_offsets.ctypes.data, _ptr(voice_ids),
+                                                         _ptr(jitter_seeds), n_utt, ptrs, out_stride, out_len.ctypes.data))
+        return out_len[:n_utt]
 
     def synthesize_elems(self, seq_elems, seg_offsets, voice_ids=None, jitter_seeds=None, out_stride=4096):
         arr = (SequenceElem * max(len(seq_elems), 1))(*seq_elems)

@@ -257,6 +257,9 @@ extern "C" {
     pub fn grail_node_synthesize_batch_pcm16(node: *mut grail_node, segs: *const grail_phoneme_elem,
         seg_offsets: *const u32, voice_ids: *const u32, jitter_seeds: *const u32, n_utt: u32,
         out: *mut i16, out_stride: u64, out_len: *mut u32, flags: u32) -> c_int;
+    pub fn grail_node_synthesize_batch_device(node: *mut grail_node, segs: *const grail_phoneme_elem,
+        seg_offsets: *const u32, voice_ids: *const u32, jitter_seeds: *const u32, n_utt: u32,
+        out_dev: *const *mut f32, out_stride: u64, out_len: *mut u32) -> c_int;
     pub fn grail_node_say_batch(node: *mut grail_node, texts: *const *const c_char, n_texts: u32,
         voice_ids: *const u32, jitter_seeds: *const u32, out: *mut f32, out_stride: u64,
         out_len: *mut u32, flags: u32) -> c_int;

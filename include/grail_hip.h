@@ -627,6 +627,13 @@ int grail_node_synthesize_batch_elems(grail_node *node, const grail_sequence_ele
 int grail_node_synthesize_batch_pcm16(grail_node *node, const grail_phoneme_elem *segs, const uint32_t *seg_offsets,
                                       const uint32_t *voice_ids, const uint32_t *jitter_seeds, uint32_t n_utt,
                                       int16_t *out, uint64_t out_stride, uint32_t *out_len, uint32_t flags);
+/* ... with the rows LEFT IN HBM (what a downstream GPU consumer wants, and what the headline metric measures): slot i's shard is
+ * rendered into out_dev[i] — device memory of slot i's GPU holding its rows x out_stride floats (grail_device_alloc on
+ * grail_node_context(node, i); rows from grail_node_shard_of), row r of the shard at out_dev[i] + r * out_stride; NULL for a slot
+ * whose shard is empty.  out_len: host memory [n_utt] or NULL.  No copy is made; the call returns when every slot has finished. */
+int grail_node_synthesize_batch_device(grail_node *node, const grail_phoneme_elem *segs, const uint32_t *seg_offsets,
+                                       const uint32_t *voice_ids, const uint32_t *jitter_seeds, uint32_t n_utt,
+                                       float *const *out_dev, uint64_t out_stride, uint32_t *out_len);
 int grail_node_say_batch(grail_node *node, const char *const *texts_utf8, uint32_t n_texts, const uint32_t *voice_ids,
                          const uint32_t *jitter_seeds, float *out, uint64_t out_stride, uint32_t *out_len,
                          uint32_t flags);

@@ -142,6 +142,43 @@ int main()
     CHECK(grail_plan_ragged_blocks(256, 0, 4, 0, 10, nullptr, nullptr, nullptr, blocks.data(), 64, &n) == GRAIL_ERR_INVALID_ARG);
     CHECK(ragged == 400);
 
+    // ---- the dispatcher's model and the packed launch order: random, equal, hostile costs; every device shape
+    int orders = 0;
+    std::vector<double> cost;
+    std::vector<uint32_t> order;
+    for (int t = 0; t < 600; ++t) {
+        const uint32_t cus = t % 7 == 0 ? 1u + rnd() % 4096u : (t % 3 == 0 ? 32u * (1u + rnd() % 16u) : 256u);
+        const uint32_t wpw = rnd() & 1u ? 1u : 4u;
+        const uint32_t n_wg = t % 11 == 0 ? rnd() % 3u : 1u + rnd() % 6000u;
+        cost.resize(n_wg);
+        order.assign(n_wg, 0xFFFFFFFFu);
+        for (uint32_t b = 0; b < n_wg; ++b)
+            cost[b] = t % 13 == 0 ? (double)special((int)rnd()) : (t % 5 == 0 ? 1.0 : 0.001 * (double)(1u + rnd() % 100000u));
+        double plain = -1.0, packed = -1.0;
+        CHECK(grail_dispatch_model(cus, wpw, cost.data(), nullptr, n_wg, &plain) == GRAIL_OK);
+        CHECK(grail_packed_launch_order(cus, wpw, cost.data(), n_wg, order.data()) == GRAIL_OK);
+        std::vector<uint8_t> seen(n_wg, 0);
+        for (uint32_t b = 0; b < n_wg; ++b) {
+            CHECK(order[b] < n_wg);
+            if (order[b] < n_wg) {
+                CHECK(!seen[order[b]]);
+                seen[order[b]] = 1;
+            }
+        }
+        CHECK(grail_dispatch_model(cus, wpw, cost.data(), order.data(), n_wg, &packed) == GRAIL_OK);
+        CHECK(plain >= 0.0 && packed >= 0.0 && !std::isnan(plain) && !std::isnan(packed));
+        if (t % 13 != 0 && n_wg) {
+            double sum = 0.0, longest = 0.0;
+            for (double c : cost) { sum += c; longest = std::fmax(longest, c); }
+            CHECK(plain >= longest - 1e-9 && packed >= longest - 1e-9 && packed <= sum + 1e-6);
+        }
+        ++orders;
+    }
+    double ms = 0.0;
+    CHECK(grail_dispatch_model(256, 3, cost.data(), nullptr, 1, &ms) == GRAIL_ERR_INVALID_ARG);
+    CHECK(grail_packed_launch_order(0, 1, cost.data(), 1, order.data()) == GRAIL_ERR_INVALID_ARG);
+    CHECK(orders == 600);
+
     // ---- voice analysis on sane, random and hostile tables
     grail_voice v;
     grail_voice_generic_at(&v, 48000.0f);

@@ -5,7 +5,7 @@ renders the batch in chunks on all host cores; a few minutes of CPU, so it is no
 default suite.  GRAIL_SOAK_UTTS picks another batch size (another kernel family), GRAIL_SOAK_FIRST the first
 utterance of the synthetic corpus (k * 65536: shard k of BASELINE config 5, what rank k of an 8-GPU run renders),
 GRAIL_SOAK_SPEECH=<scale> the speech-like corpus instead of the bench corpus.
-Last runs: profiles/r03_full_parity.txt, r05_full_parity.txt, r05_full_parity_speech_like.txt."""
+Last runs: profiles/r03_full_parity.txt, r05_full_parity.txt, r05_full_parity_speech_like.txt, r06_full_parity_speech_like_131072.txt."""
 import os
 
 import numpy as np
@@ -49,7 +49,7 @@ def test_every_utterance_of_the_full_batch(gpu_ctx, n_voices):
     try:
         b.synthesize_async(d_out, stride, d_len)
         gpu_ctx.sync()
-        kernel = gpu_ctx.last_kernel_name()
+        kernel = gpu_ctx.last_kernel_name() + (", packed launch order" if gpu_ctx.get_option("last_launch_packed") else "")
         out_len = np.zeros(n_utt, dtype=np.uint32)
         gpu_ctx.d2h(out_len, d_len, n_utt * 4)
         sums, _, bad = gpu_ctx.digest(d_out, stride, d_len, n_utt)

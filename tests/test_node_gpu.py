@@ -227,3 +227,49 @@ def test_cpp_facade_node_example(built):
     assert "5 utterances over 3 device slots (RCCL ranks 0)" in r.stdout and "differ from one device's: 0" in r.stdout
     r = subprocess.run([exe, "--devices", "0,0"] + texts, capture_output=True, text=True, timeout=300)
     assert r.returncode == 1 and "twice" in r.stderr and "status -6" in r.stderr
+
+
+def test_rows_left_in_hbm(built, gpu_ctx):
+    """grail_node_synthesize_batch_device: every slot's shard stays on its GPU; the rows' on-device digests are those of one
+    context's rendering, an empty shard needs no buffer."""
+    voices = W.preset_voices(8)
+    n_utt = 1000
+    segs, offs, vids, seeds = W.make_batch(n_utt, n_voices=8, length=0.05, blend_length=0.0625)
+    stride = (W.max_samples(length=0.05) + 63) // 64 * 64
+    gpu_ctx.set_voices(voices)
+    b = gpu_ctx.upload(segs, offs, vids, seeds)
+    d_out, d_len = gpu_ctx.device_alloc(n_utt * stride * 4), gpu_ctx.device_alloc(n_utt * 4)
+    try:
+        b.synthesize_async(d_out, stride, d_len)
+        gpu_ctx.sync()
+        want, _, _ = gpu_ctx.digest(d_out, stride, d_len, n_utt)
+        want_len = np.zeros(n_utt, dtype=np.uint32)
+        gpu_ctx.d2h(want_len, d_len, want_len.nbytes)
+    finally:
+        gpu_ctx.device_free(d_out)
+        gpu_ctx.device_free(d_len)
+        b.free()
+    with G.Node([0, 0, 0], voices_without_rccl=True) as node:
+        node.set_voices(voices)
+        shards = [G.node_shard_of(offs, i, 3)[0] for i in range(3)]
+        ctxs = [node.context(i) for i in range(3)]
+        bufs = [c.device_alloc(int(s.rows) * stride * 4) for c, s in zip(ctxs, shards)]
+        try:
+            out_len = node.synthesize_device(segs, offs, vids, seeds, bufs, stride)
+            assert np.array_equal(out_len, want_len)
+            for c, s, buf in zip(ctxs, shards, bufs):
+                rows = int(s.rows)
+                d_l = c.device_alloc(rows * 4)
+                c.h2d(d_l, np.ascontiguousarray(out_len[s.first_row:s.first_row + rows]), rows * 4)
+                got, _, bad = c.digest(buf, stride, d_l, rows)
+                c.device_free(d_l)
+                assert bad.sum() == 0 and np.array_equal(got, want[s.first_row:s.first_row + rows])
+            # two rows over three slots: the third slot has nothing to render and needs no buffer
+            few = node.synthesize_device(segs[:8], offs[:3], vids[:2], seeds[:2], [bufs[0], bufs[1], None], stride)
+            assert np.array_equal(few, want_len[:2])
+            with pytest.raises(G.GrailError) as e:
+                node.synthesize_device(segs, offs, vids, seeds, [bufs[0], None, bufs[2]], stride)
+            assert e.value.status == G.ERR_INVALID_ARG and "out_dev[1]" in str(e.value)
+        finally:
+            for c, buf in zip(ctxs, bufs):
+                c.device_free(buf)

@@ -2,7 +2,7 @@
 # The round's evidence, collected on the GPU box: bench lines, rocprofv3 kernel stats of the default
 # bench command, PMC counters for every reported workload (tools/collect_counters.py), tool outputs.
 # usage (through gpurun): tools/profile_round.sh <tag>     -> gpurun_out/<tag>/
-tag=${1:-r05}
+tag=${1:-r06}
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; export TMPDIR=/tmp; cd "$root" || exit 1
 out=gpurun_out/$tag; mkdir -p $out
 python3 tools/collect_counters.py $out/traffic.json > $out/collect_counters.log 2>&1
@@ -48,6 +48,13 @@ cp gpurun_out/prof/stats6/*/*kernel_stats.csv $out/kernel_stats_speech_like.csv
 bash tools/pmc_speech_like.sh > $out/pmc_speech_like_raw.txt 2>&1
 python3 tools/two_waves_bench.py 2>/dev/null | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" > $out/two_waves.txt
 python3 -m pytest tests/test_planner_guard_gpu.py -m gpu -q -s 2>&1 | grep -v "^make\|^g++" > $out/planner_guard.txt
+# round 6: the workgroup dispatcher, the packed launch order (option off / on, every row's digest), the planner's prices next to
+# the pinned mappings, the node call on one GPU
+python3 tools/dispatch_order.py 131072 160000 200000 > $out/dispatch_order_raw.txt 2>&1
+python3 tools/packed_order_ab.py --check 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" > $out/packed_order_ab.txt
+( GRAIL_PLAN_DEBUG=1 python3 tools/plan_debug.py 40000 65536 80000 100000 131072 160000 200000 2>&1; GRAIL_PLAN_DEBUG=1 python3 tools/plan_debug.py 40000 65536 80000 100000 131072 160000 200000 --fast 2>&1 ) | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" > $out/plan_debug_raw.txt
+python3 tools/node_bench.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" > $out/node_bench.txt
+python3 -m pytest tests/test_node_gpu.py tests/test_packed_order_gpu.py -m gpu -q 2>&1 | grep -E "passed|failed" > $out/node_tests.txt
 python3 tools/ragged_bench.py 65536 1 0 > $out/ragged.txt 2>&1
 python3 tools/ragged_bench.py 65536 1 1 > $out/ragged_fast.txt 2>&1
 python3 tools/ragged_bench.py 131072 1 0 > $out/ragged_131072.txt 2>&1
@@ -58,5 +65,7 @@ python3 tools/ragged_bench.py 131072 1 0 > $out/ragged_131072.txt 2>&1
   done ) > $out/pmc_sq.txt 2>&1
 # every utterance of full-size batches against the oracle (exact mode), one size per kernel family — the 2 / 4 / 8-lane
 # kernels were rebuilt this round (one wave per SIMD by construction), 70 000 is a composite launch
+# ... and 131 072 speech-like rows (packed launch order), every utterance
+GRAIL_SOAK=1 GRAIL_SOAK_UTTS=131072 GRAIL_SOAK_SPEECH=1.0 python3 -m pytest tests/test_full_parity_soak_gpu.py -m gpu -q -s 2>&1 | grep -E "full parity|passed|failed|skipped" > $out/full_parity_speech_like_131072.txt
 ( for n in 70000 32768 16384 8192 4096; do GRAIL_SOAK=1 GRAIL_SOAK_UTTS=$n python3 -m pytest tests/test_full_parity_soak_gpu.py -m gpu -q -s 2>&1 | grep -E "full parity|passed|failed"; done ) > $out/full_parity.txt 2>&1
 ls -la $out
