@@ -264,8 +264,10 @@ def test_rows_left_in_hbm(built, gpu_ctx):
                 got, _, bad = c.digest(buf, stride, d_l, rows)
                 c.device_free(d_l)
                 assert bad.sum() == 0 and np.array_equal(got, want[s.first_row:s.first_row + rows])
-            # two rows over three slots: the third slot has nothing to render and needs no buffer
-            few = node.synthesize_device(segs[:8], offs[:3], vids[:2], seeds[:2], [bufs[0], bufs[1], None], stride)
+            # two rows over three slots (grail_shard_range: [0, 0), [0, 1), [1, 2)): the first slot has nothing to render
+            # and needs no buffer
+            assert [int(G.node_shard_of(offs[:3], i, 3)[0].rows) for i in range(3)] == [0, 1, 1]
+            few = node.synthesize_device(segs[:8], offs[:3], vids[:2], seeds[:2], [None, bufs[1], bufs[2]], stride)
             assert np.array_equal(few, want_len[:2])
             with pytest.raises(G.GrailError) as e:
                 node.synthesize_device(segs, offs, vids, seeds, [bufs[0], None, bufs[2]], stride)

@@ -114,6 +114,8 @@ def main():
             lanes = int(a[8:])
             rows_per_job = 32 if lanes == 2 else 64
             slots_mult = 2.0 if lanes == 2 else 0.5
+        if a.startswith("--scan"):            # the scan kernel (tolerance arithmetic): one workgroup per utterance, --scan=S workgroups resident per CU
+            lanes, rows_per_job, slots_mult, fast = 0, 1, float(a[7:] or 8) / 4.0, 1
     ctx = G.Context(0)
     ctx.set_voices(W.single_voice() if n_voices == 1 else W.preset_voices(8))
     slots = int(4 * ctx.get_option("compute_units") * slots_mult)
@@ -125,6 +127,9 @@ def main():
             ctx.set_option("sort_by_length", sort)
             ctx.set_option("lanes_per_utterance", lanes)
             ctx.set_option("arithmetic", fast)
+            if rows_per_job == 1:
+                for k, v in (("time_split", 0), ("time_parallel_scan_max_utterances", 1 << 20), ("composite_launches", 0), ("ragged_plan", 0)):
+                    ctx.set_option(k, v)
             b = ctx.upload(segs_, offs_, vids_, seeds_)
             ms = []
             for _ in range(3):
@@ -138,6 +143,9 @@ def main():
             ctx.set_option("sort_by_length", 1)
             ctx.set_option("lanes_per_utterance", 0)
             ctx.set_option("arithmetic", 0)
+            if rows_per_job == 1:
+                for k, v in (("time_split", 1), ("time_parallel_scan_max_utterances", -1), ("composite_launches", 1), ("ragged_plan", 1)):
+                    ctx.set_option(k, v)
             return min(ms), what, lens
 
         auto_ms, auto_what, lens = run(segs, offs, vids, seeds, 1, 0)
