@@ -134,3 +134,50 @@ def test_the_speech_like_corpus_at_full_size(gpu_ctx, n_voices):
         for p in (d_out, d_fast, d_len, d_len_fast):
             gpu_ctx.device_free(p)
         b.free()
+
+
+def test_two_rounds_of_the_device_in_packed_launch_order(gpu_ctx):
+    """131 072 speech-like utterances (phonemes of 10 - 40 ms, rows of 0.12 - 0.95 s) on the REAL device: two one-wave
+    workgroups per SIMD on one lane per utterance, launched in the packed order (launch_plan.cpp, "The workgroup
+    dispatcher").  The order of a launch's workgroups moves no bit: all 131 072 digests equal those of the longest-first
+    order, 40 rows spread over the batch == the oracle; and the packed order is the faster one on this device (kernel
+    time, best of three each; skipped, not failed, where the device's clocks do not hold still)."""
+    from conftest import skip_if_clocks_unstable
+    n = 131072
+    voices = W.single_voice()
+    gpu_ctx.set_voices(voices)
+    segs, offs, vids, seeds, _ = W.speech_like_batch(n, np.random.default_rng(7), scale=0.25)
+    b = gpu_ctx.upload(segs, offs, vids, seeds)
+    stride = (int(b.lengths().max()) + 64 + 63) // 64 * 64
+    d_out = gpu_ctx.device_alloc(n * stride * 4)
+    d_len = gpu_ctx.device_alloc(n * 4)
+    ms = {}
+    try:
+        gpu_ctx.set_option("lanes_per_utterance", 1)
+        for packed in (0, 1):
+            gpu_ctx.set_option("packed_launch_order", packed)
+            t = []
+            for _ in range(3):
+                lens, sums, maxabs, bad = _render(gpu_ctx, b, d_out, stride, d_len, n)
+                t.append(gpu_ctx.last_kernel_ms())
+            assert gpu_ctx.get_option("last_launch_packed") == packed and gpu_ctx.get_option("last_launch_blocks") == 1
+            assert bad.sum() == 0 and maxabs.max() <= 1.0
+            ms[packed] = (min(t), lens, sums)
+        assert np.array_equal(ms[0][1], ms[1][1]) and np.array_equal(ms[0][2], ms[1][2])
+        lens, sums = ms[1][1], ms[1][2]
+        pick = sorted(set([0, 1, 63, 64, 65535, 65536, n - 1, int(np.argmax(lens)), int(np.argmin(lens))] +
+                          [int(u) for u in np.random.default_rng(12).integers(0, n, 32)]))
+        want, want_len = _oracle_digests(voices, segs, offs, vids, seeds, pick, stride)
+        for k, u in enumerate(pick):
+            assert lens[u] == want_len[k] and int(sums[u]) == want[k], u
+        print(f"\n131 072 speech-like rows (phonemes x 0.25), one lane per utterance: longest first {ms[0][0]:.2f} ms, packed order "
+              f"{ms[1][0]:.2f} ms = {ms[1][0] / ms[0][0]:.3f} x")
+        if ms[1][0] > 0.97 * ms[0][0]:
+            skip_if_clocks_unstable(gpu_ctx, f"packed order {ms[1][0]:.2f} ms against {ms[0][0]:.2f} longest first")
+        assert ms[1][0] <= 0.97 * ms[0][0], ms
+    finally:
+        gpu_ctx.set_option("lanes_per_utterance", 0)
+        gpu_ctx.set_option("packed_launch_order", 1)
+        gpu_ctx.device_free(d_out)
+        gpu_ctx.device_free(d_len)
+        b.free()
