@@ -84,3 +84,72 @@ def test_the_plain_order_when_packing_has_nothing_to_gain(gpu_ctx):
         ctx.device_free(d_out)
         ctx.device_free(d_len)
         batch.free()
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_packed_launch_orders_of_random_batches(gpu_ctx, seed):
+    """Random speech-like batches (8 - 32 phonemes per row, phoneme lengths scaled at random, with and without a long tail,
+    a few rows with a zero-length segment among them, two or eight voices) on devices assumed so small that a launch is
+    2 - 2.7 rounds — one pool of SIMDs (1 ... 24 compute units), four pools (32) and eight (64) — on one and two lanes per
+    utterance, one wave per SIMD, with and without the odd rows planned apart: every row == the oracle, bit for bit in exact
+    arithmetic, within the tolerance in fast arithmetic — and several of the launches did take a packed order (a long tail
+    leaves nothing to pack: the longest row is the launch)."""
+    rng = np.random.default_rng(seed)
+    ctx = gpu_ctx
+    saved = {k: ctx.get_option(k) for k in ("assume_compute_units", "lanes_per_utterance", "two_waves_per_simd", "arithmetic",
+                                            "packed_launch_order", "row_groups", "composite_launches")}
+    packed = launches = 0
+    try:
+        for trial in range(4):
+            voices = W.preset_voices(8) if trial % 2 else [G.voice_generic(48000.0), G.voice_generic(44100.0)]
+            ctx.set_voices(voices)
+            lanes = int(rng.choice([1, 2]))
+            pools = trial == 3                                # the last trial: whole XCCs, several pools
+            if pools:
+                lanes, cus = 2, int(rng.choice([32, 64]))
+                n = int(32 * 4 * cus * rng.uniform(2.0, 2.6))
+            else:
+                n = int(rng.integers(900, 3000))
+                cus = max(1, int(round(n * lanes / 64.0 / 4.0 / rng.uniform(2.0, 2.7))))
+                cus += 1 if cus % 32 == 0 else 0
+            segs, offs, vids, seeds, stride = W.speech_like_batch(n, rng, n_voices=len(voices), scale=float(rng.uniform(0.015, 0.04)),
+                                                                  long_tail=trial == 1)
+            seeds = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+            for u in rng.integers(0, n, size=3):              # a few rows the lean kernel families cannot take
+                segs["length"][offs[u] + 1] = 0.0
+            ov = [O.Voice.from_buffer_copy(bytes(v)) for v in voices]
+            ref, ref_len = O.synthesize_batch(ov, segs, offs, vids, seeds, stride)
+            batch = ctx.upload(segs, offs, vids, seeds)
+            d_out, d_len = ctx.device_alloc(n * stride * 4), ctx.device_alloc(n * 4)
+            out, out_len = np.zeros((n, stride), dtype=np.float32), np.zeros(n, dtype=np.uint32)
+            try:
+                ctx.set_option("assume_compute_units", cus)
+                ctx.set_option("lanes_per_utterance", lanes)
+                ctx.set_option("two_waves_per_simd", 0)
+                for fast in (0, 1):
+                    for groups in (1, 0):
+                        ctx.set_option("row_groups", groups)
+                        ctx.set_option("arithmetic", fast)
+                        ctx.memset(d_out, 0, n * stride * 4)
+                        batch.synthesize_async(d_out, stride, d_len)
+                        ctx.sync()
+                        launches += 1
+                        packed += 1 if ctx.get_option("last_launch_packed") else 0
+                        what = (seed, trial, n, cus, lanes, fast, groups, ctx.last_kernel_name(), ctx.get_option("last_launch_packed"))
+                        ctx.d2h(out, d_out, out.nbytes)
+                        ctx.d2h(out_len, d_len, out_len.nbytes)
+                        assert np.array_equal(out_len, ref_len), what
+                        if not fast or ctx.get_option("last_launch_fast") == 0:
+                            assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), what
+                        else:
+                            peak = np.maximum(1.0, np.abs(ref).max(axis=1))
+                            assert (np.abs(out.astype(np.float64) - ref).max(axis=1) / peak).max() <= G.FAST_TOLERANCE, what
+            finally:
+                ctx.device_free(d_out)
+                ctx.device_free(d_len)
+                batch.free()
+    finally:
+        for k, v in saved.items():
+            ctx.set_option(k, v)
+    print(f"\nseed {seed}: {packed} of {launches} launches took a packed order")
+    assert packed >= 3, (packed, launches)

@@ -4,7 +4,7 @@
 ragged segment counts, Silence / Stop / Glide, blend lengths that are powers of two and not), random settings of
 lanes_per_utterance, small_batch_pipeline, pipeline_round32, pipeline4/8_max_groups, skip_silent_formants,
 sort_by_length, time_parallel_scan (+ its two thresholds), time_split (+ chunks, span, cost, minimum), composite_launches,
-row_groups, ragged_plan, two_waves_per_simd and assume_compute_units (1 - 4 compute units: batches of a few hundred utterances are then cut, grouped
+row_groups, ragged_plan, two_waves_per_simd, packed_launch_order and assume_compute_units (1 - 4 compute units: batches of a few hundred utterances are then cut, grouped
 and planned by their rows' lengths the way batches of 100 000 are on the whole device), against the oracle.   usage: option_matrix_soak.py [trials [seed [big]]]"""
 import os
 import sys
@@ -27,15 +27,15 @@ DEFAULTS = {"lanes_per_utterance": 0, "small_batch_pipeline": 1, "pipeline_round
             "time_parallel_scan_max_utterances": 1536, "time_parallel_scan_split_max_utterances": 1536, "time_split": 1,
             "time_split_chunks": 0, "time_split_span_samples": 0, "time_split_ff_cost_permille": 165,
             "time_split_min_utterances": 1537, "composite_launches": 1, "row_groups": 1, "ragged_plan": 1,
-            "assume_compute_units": 0, "two_waves_per_simd": 1, "pipeline_spread": 1}
+            "assume_compute_units": 0, "two_waves_per_simd": 1, "pipeline_spread": 1, "packed_launch_order": 1}
 CHOICES = {"lanes_per_utterance": [0, 0, 1, 2, 4, 8], "small_batch_pipeline": [0, 1], "pipeline_round32": [0, 1, 1, 2],
            "pipeline4_max_groups": [0, 2, 512], "pipeline8_max_groups": [0, 3, 512], "skip_silent_formants": [0, 1],
            "sort_by_length": [0, 1], "time_parallel_scan": [0, 1], "time_parallel_scan_max_utterances": [0, 40, 1536],
            "time_parallel_scan_split_max_utterances": [0, 30, 1536], "time_split": [0, 1], "time_split_chunks": [0, 0, 2, 5],
            "time_split_span_samples": [0, 4096, 9000], "time_split_ff_cost_permille": [0, 165, 900],
            "time_split_min_utterances": [0, 50, 1537], "composite_launches": [0, 1, 1], "row_groups": [0, 1, 2],
-           "ragged_plan": [0, 1, 1], "assume_compute_units": [0, 1, 2, 4], "two_waves_per_simd": [0, 1, 1], "pipeline_spread": [0, 1, 1]}
-worst, kernels = 0.0, {}
+           "ragged_plan": [0, 1, 1], "assume_compute_units": [0, 1, 2, 4], "two_waves_per_simd": [0, 1, 1], "pipeline_spread": [0, 1, 1], "packed_launch_order": [0, 1, 1]}
+worst, kernels, packed_launches = 0.0, {}, 0
 for trial in range(trials):
     nv = int(rng.choice([1, 2, 8]))
     voices = W.single_voice() if nv == 1 else ([G.voice_generic(48000.0), G.voice_generic(44100.0)] if nv == 2 else W.preset_voices(8))
@@ -55,6 +55,7 @@ for trial in range(trials):
         out, out_len = ctx.synthesize(segs, offs, vids, seeds, out_stride=stride)
         name = ctx.last_kernel_name()
         kernels[name] = kernels.get(name, 0) + 1
+        packed_launches += 1 if ctx.get_option("last_launch_packed") else 0
         assert np.array_equal(out_len, ref_len), (trial, opts, fast, name)
         for u in range(n_utt):
             n = int(ref_len[u])
@@ -68,6 +69,6 @@ for trial in range(trials):
         ctx.set_option(k, v)
     ctx.set_option("arithmetic", 0)
 print(f"{trials} random batches x 3 random option settings: exact rows bit-identical to the oracle, fast rows within "
-      f"{worst * 2 ** 23:.1f} * 2^-23; kernels used:")
+      f"{worst * 2 ** 23:.1f} * 2^-23; {packed_launches} of the launches took a packed order; kernels used:")
 for k, v in sorted(kernels.items()):
     print(f"  {v:4d}  {k}")
