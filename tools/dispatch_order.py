@@ -33,7 +33,14 @@ def greedy(seq, slots):
     return max(s)
 
 
+def ensure_built():
+    src = os.path.join(ROOT, "tools", "dispatch_order.hip")
+    if not os.path.exists(BIN) or os.path.getmtime(BIN) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", src, "-o", BIN])
+
+
 def run(cost_us, tag):
+    ensure_built()
     with tempfile.TemporaryDirectory() as d:
         cf, rf = os.path.join(d, "c.u32"), os.path.join(d, "r.u64")
         np.asarray(cost_us, dtype=np.uint32).tofile(cf)
