@@ -3,7 +3,7 @@
 // cost_us[b] microseconds and records where and when it ran: XCC, SE / CU / SIMD (HW_ID), start and end (s_memrealtime,
 // 100 MHz).  tools/dispatch_order.py feeds it launch orders and checks the list-scheduling model of launch_plan.cpp.
 // build: hipcc --offload-arch=gfx950 -O2 tools/dispatch_order.hip -o tools/dispatch_order.bin
-// usage: dispatch_order.bin costs.u32 records.u64   (records: blocks x {start, end, hw_id, xcc_id})
+// usage: dispatch_order.bin costs.u32 records.u64 [waves per workgroup: 1 (default) or 4]   (records: blocks x {start, end, hw_id, xcc_id})
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -19,7 +19,8 @@
         }                                                                              \
     } while (0)
 
-__global__ __launch_bounds__(64) void spin(const uint32_t *cost_us, uint64_t *rec)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void spin(const uint32_t *cost_us, uint64_t *rec)
 {
     // all 512 registers of the wave's budget: one wave per SIMD, as the kernels this stands for
     asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255");
@@ -60,7 +61,8 @@ int main(int argc, char **argv)
     CHECK(hipMalloc((void **)&d_rec, n * 32));
     CHECK(hipMemcpy(d_cost, cost.data(), n * 4, hipMemcpyHostToDevice));
     for (int rep = 0; rep < 2; ++rep) {                     // (the second launch is the one recorded: clocks up)
-        hipLaunchKernelGGL(spin, dim3((unsigned)n), dim3(64), 0, 0, d_cost, d_rec);
+        if (argc > 3 && argv[3][0] == '4') hipLaunchKernelGGL(spin<4>, dim3((unsigned)n), dim3(256), 0, 0, d_cost, d_rec);
+        else hipLaunchKernelGGL(spin<1>, dim3((unsigned)n), dim3(64), 0, 0, d_cost, d_rec);
         CHECK(hipDeviceSynchronize());
     }
     std::vector<uint64_t> rec(n * 4);

@@ -39,12 +39,12 @@ def ensure_built():
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", src, "-o", BIN])
 
 
-def run(cost_us, tag):
+def run(cost_us, tag, waves=1):
     ensure_built()
     with tempfile.TemporaryDirectory() as d:
         cf, rf = os.path.join(d, "c.u32"), os.path.join(d, "r.u64")
         np.asarray(cost_us, dtype=np.uint32).tofile(cf)
-        subprocess.check_call([BIN, cf, rf])
+        subprocess.check_call([BIN, cf, rf, str(waves)])
         rec = np.fromfile(rf, dtype=np.uint64).reshape(-1, 4)
     if os.environ.get("DISPATCH_ORDER_SAVE"):
         np.savez_compressed(os.path.join(os.environ["DISPATCH_ORDER_SAVE"], tag.replace(" ", "_").replace(",", "") + ".npz"),
@@ -55,7 +55,7 @@ def run(cost_us, tag):
     start, end = (t0 - base) / 100.0, (t1 - base) / 100.0            # microseconds
     hw, xcc = rec[:, 2].astype(np.int64), rec[:, 3].astype(np.int64) & 0xF
     simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 0xF, (hw >> 12) & 1, (hw >> 13) & 7
-    slot = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
+    slot = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + (simd if waves == 1 else 0)
     n = len(cost_us)
     slots = len(np.unique(slot))
     by_xcc = [np.flatnonzero(xcc == x) for x in range(8)]
@@ -79,8 +79,8 @@ def run(cost_us, tag):
         b = b[np.argsort(start[b])]
         gaps += list(start[b[1:]] - end[b[:-1]])
     gaps = np.array(gaps) if gaps else np.zeros(1)
-    model = packed.dispatch_makespan(np.asarray(cost_us, dtype=np.float64))
-    print(f"{tag}: {n} workgroups on {slots} SIMD slots; workgroup b on XCC b mod 8: {rr}; per SIMD {per_slot.min()} - {per_slot.max()} workgroups; "
+    model = packed.dispatch_makespan(np.asarray(cost_us, dtype=np.float64), slots=32 if waves == 1 else 8)
+    print(f"{tag}: {n} workgroups on {slots} {'SIMD' if waves == 1 else 'compute-unit'} slots; workgroup b on XCC b mod 8: {rr}; per SIMD {per_slot.min()} - {per_slot.max()} workgroups; "
           f"makespan {end.max() / 1e3:.2f} ms, dispatcher model (static shader-engine round robin, in order per XCC) {model / 1e3:.2f} ms ({end.max() / model:.3f} x); hand-over gap median "
           f"{np.median(gaps):.1f} us, 99th percentile {np.percentile(gaps, 99):.1f} us; started out of launch order (by > 5 us): {late}", flush=True)
     return end.max()
@@ -88,6 +88,20 @@ def run(cost_us, tag):
 
 def main():
     sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [131072, 160000, 200000]
+    if "--waves=4" in sys.argv:
+        # workgroups of four waves that each hold a SIMD alone: one workgroup per compute unit, 8 per shader engine
+        for n in sizes:
+            segs, offs, vids, seeds, stride = W.speech_like_batch(n, np.random.default_rng(7))
+            secs = np.add.reduceat(segs["length"].astype(np.float64), offs[:-1])
+            L = np.sort(secs * 48000.0)[::-1]
+            cost = np.array([L[j * 64] for j in range((n + 63) // 64)])
+            us = cost / 10.0
+            a = run(us, f"{n} rows as workgroups of 4 waves, longest first", waves=4)
+            order, plan, greedy_ms, ideal = packed.planned_block_order(cost, 256, 32)
+            b = run(us[order], f"{n} rows as workgroups of 4 waves, packed in 32 pools", waves=4)
+            print(f"    packed / longest first = {b / a:.3f}   (dispatcher model, 8 slots per engine: "
+                  f"{packed.dispatch_makespan(us[order], slots=8) / packed.dispatch_makespan(us, slots=8):.3f})", flush=True)
+        return
     for n in sizes:
         segs, offs, vids, seeds, stride = W.speech_like_batch(n, np.random.default_rng(7))
         secs = np.add.reduceat(segs["length"].astype(np.float64), offs[:-1])
