@@ -11,6 +11,8 @@ sys.path.insert(0, ROOT)
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: carries a wall-clock assertion (skipped, with the evidence, where the device's clocks "
+                                       "do not hold still; deselect with -m 'gpu and not perf')")
 
 
 @pytest.fixture(scope="session")

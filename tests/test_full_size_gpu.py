@@ -136,6 +136,7 @@ def test_the_speech_like_corpus_at_full_size(gpu_ctx, n_voices):
         b.free()
 
 
+@pytest.mark.perf
 def test_two_rounds_of_the_device_in_packed_launch_order(gpu_ctx):
     """131 072 speech-like utterances (phonemes of 10 - 40 ms, rows of 0.12 - 0.95 s) on the REAL device: two one-wave
     workgroups per SIMD on one lane per utterance, launched in the packed order (launch_plan.cpp, "The workgroup

@@ -11,7 +11,7 @@ import grail_hip as G
 from conftest import skip_if_clocks_unstable
 from grail_hip import workload as W
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.perf]
 
 DEFAULTS = {"arithmetic": 0, "lanes_per_utterance": 0, "time_parallel_scan": 1, "time_split": 1,
             "time_split_min_utterances": -1, "time_parallel_scan_max_utterances": -1, "small_batch_pipeline": 1,

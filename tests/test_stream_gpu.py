@@ -93,6 +93,7 @@ def test_mid_size_streams_take_the_pipelined_workgroups(gpu_ctx, n_voices, n_utt
             assert np.array_equal(got[u].view(np.uint32), ref[k, :ref_len[k]].view(np.uint32)), (corpus, u)
 
 
+@pytest.mark.perf
 def test_a_lone_stream_runs_at_the_pace_of_a_full_workgroup(gpu_ctx):
     """One stream in a pipelined workgroup laid out for sixteen: the fifteen slots without an utterance count as finished
     — they ride along in calm tiles like ended utterances — instead of keeping their wave out of every calm tile (a pull of
